@@ -1,0 +1,87 @@
+"""Pinned synthetic inputs for the benchmark configurations.
+
+target: N i.i.d. uniform float32 points in [-L/2, L/2)^3, L = 0.64 * N^(1/3)
+        (density 3.8147 pt/unit^3 => ~15.98 in-radius candidates at r = 1).
+source: the same points, randomly permuted, moved by the inverse of a known small
+        rigid motion (R_gt: 0.005 rad about (1,2,3)/sqrt(14); t_gt = (0.10,-0.05,0.08)),
+        plus N(0, 0.01^2) noise per coordinate, rounded to float32.
+Seeds: target 1000+cfg, permutation 2000+cfg, noise 3000+cfg; pair p of the batched
+config uses seed + 10*p and (angle, t_gt) scaled by (1 + p/64).
+
+Both the HIP path and the CPU oracle are fed from the arrays this module returns.
+"""
+import numpy as np
+
+GT_ANGLE = 0.005
+GT_AXIS = np.array([1.0, 2.0, 3.0]) / np.sqrt(14.0)
+GT_T = np.array([0.10, -0.05, 0.08])
+
+# BASELINE.json configs -> (N, max_neighbours, dof)
+CONFIGS = {
+    1: dict(n=10_000, max_neighbours=5, dof=5.0, radius=1.0),
+    2: dict(n=100_000, max_neighbours=10, dof=5.0, radius=1.0),
+    3: dict(n=1_000_000, max_neighbours=10, dof=5.0, radius=1.0),
+    4: dict(n=1_000_000, max_neighbours=10, dof=float("inf"), radius=1.0),
+    5: dict(n=250_000, max_neighbours=10, dof=5.0, radius=1.0, pairs=64),
+}
+
+
+def rodrigues(axis, angle):
+    axis = np.asarray(axis, np.float64)
+    axis = axis / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+
+
+def ground_truth(pair=0):
+    s = 1.0 + pair / 64.0
+    return rodrigues(GT_AXIS, GT_ANGLE * s), GT_T * s
+
+
+def make_pair(n, cfg=3, pair=0, stride=4):
+    """-> (source[n,stride] f32, target[n,stride] f32, R_gt, t_gt); T_gt maps source onto target."""
+    off = 10 * pair
+    L = 0.64 * float(n) ** (1.0 / 3.0)
+    rng_t = np.random.Generator(np.random.PCG64(1000 + cfg + off))
+    tgt = ((rng_t.random((n, 3)) - 0.5) * L).astype(np.float32)
+    rng_p = np.random.Generator(np.random.PCG64(2000 + cfg + off))
+    perm = rng_p.permutation(n)
+    rng_n = np.random.Generator(np.random.PCG64(3000 + cfg + off))
+    noise = rng_n.normal(0.0, 0.01, size=(n, 3))
+    R, t = ground_truth(pair)
+    p = tgt[perm].astype(np.float64)
+    src = ((p - t) @ R + noise).astype(np.float32)  # R^T (p - t), row-vector form
+    if stride == 4:
+        src = np.concatenate([src, np.zeros((n, 1), np.float32)], axis=1)
+        tgt = np.concatenate([tgt, np.zeros((n, 1), np.float32)], axis=1)
+    return np.ascontiguousarray(src), np.ascontiguousarray(tgt), R, t
+
+
+def make_config(cfg, pair=0, n=None, stride=4):
+    c = CONFIGS[cfg]
+    return make_pair(n or c["n"], cfg=cfg, pair=pair, stride=stride)
+
+
+def rotation_angle(Ra, Rb):
+    """Angle of Ra * Rb^T in radians."""
+    M = np.asarray(Ra) @ np.asarray(Rb).T
+    c = (np.trace(M) - 1.0) / 2.0
+    # asin of the skew part is accurate for tiny angles where acos is not
+    sk = 0.5 * np.array([M[2, 1] - M[1, 2], M[0, 2] - M[2, 0], M[1, 0] - M[0, 1]])
+    s = np.linalg.norm(sk)
+    return float(np.arctan2(s, c))
+
+
+def grid_test_cloud():
+    """The 30x50 test cloud of the reference's integration tests
+    (test/PointCloudRegistrationTest.cc:12-28): (x, y, sin x + cos y), step 0.5,
+    coordinates accumulated in double then stored as float32."""
+    pts = []
+    x = 0.0
+    for _ in range(30):
+        y = 0.0
+        for _ in range(50):
+            pts.append((x, y, np.sin(x) + np.cos(y)))
+            y += 0.5
+        x += 0.5
+    return np.asarray(pts, dtype=np.float64).astype(np.float32)
