@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the registration hot path on MI355X (contract: see the task statement / DESIGN.md §7).
+
+A "step" is one outer registration iteration over one source/target pair:
+    radius-NN association (K1) -> t/Gaussian weights + weighted moments (K23) -> host 3x3 SVD
+    -> in-place move of the source (K4),
+i.e. BASELINE.json's metric "registration iterations/sec (1M<->1M pts, r=1.0, m=10)" with one inner
+IRLS step per association, early termination disabled (cost_drop_thresh = 0).
+Clouds are resident in HBM before the timed region starts.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank registers its own
+independent 1M<->1M pair (weak scaling, no data-path collective); the only collective is the final
+all_gather of the 3x4 transforms over RCCL, inside the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from probabilistic_point_clouds_registration_amd import _lib, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config number (3 = 1M headline, 4 = Gaussian)")
+    ap.add_argument("--n", type=int, default=None, help="override the cloud size (debugging)")
+    ap.add_argument("--inner-steps", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel pass")
+    return ap.parse_args()
+
+
+def cpu_baseline(src, tgt, cfg, iters, inner_steps):
+    """The oracle (kind 'port': OpenMP-generous variant — grid built per call, all loops parallel) timed on
+    this box's host cores on a bounded sample: `iters` outer iterations of the SAME workload."""
+    from oracle import binding as po  # checker-side import, only on this leg
+    threads = po.num_threads()
+    po.align(src, tgt, cfg["radius"], cfg["max_neighbours"], cfg["dof"], 1, inner_max_steps=inner_steps,
+             threads=threads)  # warm-up (page-in, thread pool)
+    t0 = time.perf_counter()
+    res = po.align(src, tgt, cfg["radius"], cfg["max_neighbours"], cfg["dof"], iters,
+                   inner_max_steps=inner_steps, threads=threads)
+    dt = time.perf_counter() - t0
+    return dict(value=iters / dt, unit="iterations/s", cores=threads, kind="port",
+                sample=f"{iters} outer iterations of the same {src.shape[0]}<->{tgt.shape[0]} workload "
+                       f"(oracle/ppcr_oracle.c, OpenMP x{threads}, grid NN)",
+                seconds=dt), res
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    import torch  # device selection, synchronize, torch.distributed (RCCL)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = dict(synth.CONFIGS[a.config])
+    n = a.n or cfg["n"]
+    # weak scaling: rank r registers its own pair (pair index r of the pinned generator)
+    src, tgt, Rgt, tgt_t = synth.make_pair(n, cfg=a.config, pair=rank)
+
+    ctx = _lib.Context(local_rank)
+    ctx.set_params(cfg["radius"], cfg["max_neighbours"], cfg["dof"], 3)
+    ctx.set_target(tgt)
+    ctx.set_source(src)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # warm-up (also builds the grid and sorts the source once)
+    if a.warmup > 0:
+        ctx.align(a.warmup, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
+    barrier()
+    gathered = None
+    t0 = time.perf_counter()
+    res = ctx.align(a.steps, cost_drop_thresh=0.0, inner_steps=a.inner_steps)
+    if dist is not None:
+        mine = torch.from_numpy(res["history"][-1].reshape(12).copy()).cuda()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)  # RCCL: the only collective — final gather of the transforms
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # per-kernel durations with HIP events on the handle's own stream (separate pass so that the event
+    # records cannot perturb the headline number; same workload, same K)
+    prof = {}
+    nnz = ctx.association_size()[1]
+    if not a.no_profile:
+        ctx.profile_enable(True)
+        tp0 = time.perf_counter()
+        ctx.align(a.steps, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
+        ctx.synchronize()
+        tp = time.perf_counter() - tp0
+        prof = ctx.profile_get()
+        ctx.profile_enable(False)
+        prof["_profiled_pass_ms_per_step"] = 1e3 * tp / a.steps
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ns, nt = src.shape[0], tgt.shape[0]
+    out = {
+        "metric": "registration iterations/sec (1M<->1M pts, r=1.0, m=10)",
+        "value": world * a.steps / dt,
+        "unit": "iterations/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32 distances / f64 weights+moments",
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[{a.config - 1}]: {ns}<->{nt} synthetic clouds, radius={cfg['radius']}, "
+                               f"max_neighbours={cfg['max_neighbours']}, "
+                               f"{'Gaussian' if np.isinf(cfg['dof']) else 't dof=%g' % cfg['dof']}, "
+                               f"{a.inner_steps} inner IRLS step(s)/iteration, cost_drop_thresh=0",
+                   "pairs": world, "parallelism": f"{world} independent pair(s), one per GPU; final RCCL all_gather of transforms"},
+        "nnz": int(nnz),
+    }
+    # roofline of the dominant kernel (K1, nn_topm_kernel): algorithmic bytes B_nn = 16*Ns + 12*Nt + 4*nnz
+    #  / average launch duration measured with HIP events above
+    b_nn = 16.0 * ns + 12.0 * nt + 4.0 * nnz
+    b_iter = 72.0 * ns + 12.0 * nt + 52.0 * nnz + (a.inner_steps - 1) * (32.0 * ns + 48.0 * nnz)
+    if "nn_topm_kernel" in prof:
+        k = prof["nn_topm_kernel"]
+        avg_ms = k["total_ms"] / max(1, k["launches"])
+        ach = b_nn / (avg_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "nn_topm_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "avg_kernel_ms": avg_ms, "algorithmic_bytes_per_launch": b_nn,
+                           "candidate_tests_per_s": 27 * 3.8147 * ns / (avg_ms * 1e-3)}
+    else:
+        out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                           "traffic": None}
+    out["iteration_roofline"] = {"algorithmic_bytes_per_iteration": b_iter,
+                                 "achieved_GBs": b_iter * a.steps / dt / 1e9,
+                                 "frac_of_hbm_peak": b_iter * a.steps / dt / 1e9 / HBM_PEAK_GBS}
+    out["kernels_ms_per_launch"] = {k: v["total_ms"] / max(1, v["launches"]) for k, v in prof.items()
+                                    if isinstance(v, dict)}
+    if "_profiled_pass_ms_per_step" in prof:
+        out["profiled_pass_ms_per_step"] = prof["_profiled_pass_ms_per_step"]
+
+    if world == 1 and not a.no_cpu_baseline:
+        cb, ora = cpu_baseline(src, tgt, cfg, a.cpu_iters, a.inner_steps)
+        out["cpu_baseline"] = cb
+        out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+        # parity attached to the timing: GPU vs oracle after the same number of iterations from the same start
+        chk = _lib.Context(local_rank)
+        chk.set_params(cfg["radius"], cfg["max_neighbours"], cfg["dof"], 3)
+        chk.set_target(tgt)
+        chk.set_source(src)
+        g = chk.align(a.cpu_iters, cost_drop_thresh=0.0, inner_steps=a.inner_steps)
+        chk.close()
+        out["parity"] = {"iterations": a.cpu_iters,
+                         "rot_err_rad": synth.rotation_angle(g["history"][-1][:, :3], ora["history"][-1][:, :3]),
+                         "trans_err_m": float(np.linalg.norm(g["history"][-1][:, 3] - ora["history"][-1][:, 3])),
+                         "vs": "oracle (CPU restatement); the reference itself cannot be built (PCL/Ceres absent)"}
+    elif world > 1:
+        out["gathered_transforms"] = len(gathered) if gathered else 0
+    print(json.dumps(out))
+    sys.stdout.flush()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

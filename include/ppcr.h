@@ -1,0 +1,147 @@
+/*
+ * ppcr.h — C ABI of the MI355X-native probabilistic point-cloud registration hot path.
+ *
+ * This is the drop-in boundary: everything above it (the C++ classes that mirror
+ * prob_point_cloud_registration::*, the CLI, the Python binding) is host code; everything
+ * below it is hand-written HIP for gfx950.  Plain pointers and sizes only.
+ *
+ * The reference (iralabdisco/probabilistic_point_clouds_registration) has no FFI seam of its
+ * own — it is one C++ library — so each entry point below names the reference code it
+ * replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every function returns PPCR_OK (0) or a negative ppcr_status; no exception crosses;
+ *   - the caller owns host buffers, the handle owns device buffers;
+ *   - one handle <-> one device + one HIP stream; a handle is not thread-safe, distinct
+ *     handles are independent;
+ *   - quaternions are (w,x,y,z) (prob_point_cloud_registration_params.hpp:14), need not be
+ *     normalised on input (ceres::QuaternionRotatePoint normalises, error_term.hpp:31);
+ *   - T[12] is the top three rows of a 4x4 rigid transform, row-major: [R|t];
+ *   - clouds are float32 xyz with a byte stride (12 = packed, 16 = pcl::PointXYZ).
+ */
+#ifndef PPCR_H
+#define PPCR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPCR_ABI_VERSION 1
+
+/* number of doubles in the moment vector produced by ppcr_accumulate():
+ *   [0] W=sum w  [1..3] sum w(x-c)  [4..6] sum w(y-c)  [7..15] sum w(x-c)(y-c)^T row-major
+ *   [16] sum w*s  [17] sum w|x-c|^2  [18] sum w|y-c|^2      c = ppcr_get_origin() */
+#define PPCR_NSUMS 19
+
+typedef enum ppcr_status {
+    PPCR_OK = 0,
+    PPCR_ERR_INVALID = -1,  /* bad argument */
+    PPCR_ERR_STATE = -2,    /* call order: e.g. associate before set_target */
+    PPCR_ERR_HIP = -3,      /* a HIP runtime call failed; see ppcr_last_error */
+    PPCR_ERR_NOMEM = -4,
+    PPCR_ERR_NODEVICE = -5  /* no usable GPU: this library has NO CPU fallback */
+} ppcr_status;
+
+typedef struct ppcr_ctx ppcr_ctx;
+
+int ppcr_abi_version(void);
+/* number of visible HIP devices (0 without a GPU; never initialises a context) */
+int ppcr_device_count(int *count);
+
+int ppcr_create(int device_id, ppcr_ctx **out);
+int ppcr_destroy(ppcr_ctx *ctx);
+/* message of the last failing call on this handle (ctx may be NULL for create failures) */
+const char *ppcr_last_error(const ppcr_ctx *ctx);
+
+/* ProbPointCloudRegistrationParams {radius, max_neighbours, dof} and the DIMENSIONS constant
+ * (prob_point_cloud_registration_params.hpp:5-18, ..._iteration.hpp:17,29).
+ * dof = +inf selects the Gaussian model (probabilistic_weights.hpp:35, CLI -u ..._ex.cc:93-97).
+ * max_neighbours <= 0 or >= N_target means unbounded (PCL radiusSearch max_nn rule). */
+int ppcr_set_params(ppcr_ctx *ctx, double radius, int max_neighbours, double dof, int dim);
+
+/* Upload clouds (host pointers).  Replaces the cloud members the reference keeps
+ * (prob_point_cloud_registration.h:50-55) and, for the target, the per-iteration kd-tree
+ * build (src/prob_point_cloud_registration.cc:66-67): the uniform grid over the target is
+ * built once, lazily, at the first ppcr_associate() for the current radius. */
+int ppcr_set_target(ppcr_ctx *ctx, const float *xyz, int64_t n, int64_t stride_bytes);
+int ppcr_set_source(ppcr_ctx *ctx, const float *xyz, int64_t n, int64_t stride_bytes);
+/* Same, from device memory already resident on the handle's GPU (e.g. a torch tensor). */
+int ppcr_set_target_device(ppcr_ctx *ctx, const void *d_xyz, int64_t n, int64_t stride_bytes);
+int ppcr_set_source_device(ppcr_ctx *ctx, const void *d_xyz, int64_t n, int64_t stride_bytes);
+
+/* K1 — radius-NN correspondence search for every source point.  Replaces the radiusSearch
+ * loop + triplet/CSR assembly of src/prob_point_cloud_registration.cc:66-83. */
+int ppcr_associate(ppcr_ctx *ctx);
+int ppcr_association_size(ppcr_ctx *ctx, int64_t *n_rows, int64_t *nnz);
+/* CSR export in the layout Eigen::SparseMatrix<double,RowMajor> would have after
+ * setFromTriplets (cc:82-83): rows = source index, columns ascending = target index.
+ * d2 (nullable) = float squared distance source->target for the CURRENT source positions. */
+int ppcr_get_association(ppcr_ctx *ctx, int32_t *row_ptr, int32_t *col, float *d2);
+/* Install a caller-made association (the data_association argument of
+ * ProbPointCloudRegistrationIteration, ..._iteration.hpp:24-27). */
+int ppcr_set_association(ppcr_ctx *ctx, const int32_t *row_ptr, const int32_t *col, int64_t n_rows);
+
+/* K2 — WeightUpdaterCallback::operator() (weight_updater_callback.hpp:36-63):
+ * s = |y - (R(q)x + t)|^2 per stored pair (ErrorTerm::operator(), error_term.hpp:21-37) and
+ * ProbabilisticWeights::updateWeights (probabilistic_weights.hpp:48-105).  Outputs are in the
+ * CSR order of ppcr_get_association(); either may be NULL. */
+int ppcr_weights(ppcr_ctx *ctx, const double q[4], const double t[3], double *w_out, double *s_out);
+
+/* K2+K3 fused — weights at (q,t) and the weighted moments the closed-form solve needs
+ * (what Ceres would assemble from the residual blocks of ..._iteration.hpp:37-46). */
+int ppcr_accumulate(ppcr_ctx *ctx, const double q[4], const double t[3], double sums[PPCR_NSUMS]);
+int ppcr_get_origin(ppcr_ctx *ctx, double c[3]);
+
+/* Host-side closed-form minimiser (3x3 SVD) of sum w|y - Rx - t|^2 from the moments: replaces
+ * ceres::Solve for fixed weights (..._iteration.hpp:52-57).  Pure host functions. */
+int ppcr_solve_moments(const double sums[PPCR_NSUMS], const double origin[3], double R[9], double t[3]);
+double ppcr_cost_from_moments(const double sums[PPCR_NSUMS], const double origin[3], const double R[9],
+                              const double t[3]);
+
+/* ProbPointCloudRegistrationIteration::solve + transformation() (..._iteration.hpp:52-67) on the
+ * current association: IRLS from (q0,t0) — weights, closed-form solve, repeat — until max_steps
+ * or relative cost decrease <= f_tol (Ceres function_tolerance, cc:97).
+ * cost_out = {initial_cost, final_cost} with Ceres' 1/2 factor; steps_out = solves performed. */
+int ppcr_solve(ppcr_ctx *ctx, const double q0[4], const double t0[3], int max_steps, double f_tol,
+               double T_out[12], double cost_out[2], int *steps_out);
+
+/* K4 — pcl::transformPointCloud(source, source, T) in place: f64 math, f32 store (cc:110-112). */
+int ppcr_apply_transform(ppcr_ctx *ctx, const double T[12]);
+
+/* One outer iteration of ProbPointCloudRegistration::align (cc:65-131), resident on the
+ * device: associate -> solve from (q0,t0) -> move the source by the incremental transform. */
+int ppcr_iterate(ppcr_ctx *ctx, const double q0[4], const double t0[3], int inner_steps, double f_tol,
+                 double T_out[12], double cost_out[2], int *steps_out);
+
+/* The whole align() loop including hasConverged() (cc:63-158).  history (n_iter*12 doubles,
+ * cumulative transforms T_cum <- T_k*T_cum), costs (n_iter*2), steps (n_iter ints) may be NULL.
+ * n_done receives the number of outer iterations performed. */
+int ppcr_align(ppcr_ctx *ctx, int n_iter, double cost_drop_thresh, double n_cost_drop_it,
+               const double q0[4], const double t0[3], int inner_steps, double f_tol, double *history,
+               double *costs, int32_t *steps, int *n_done);
+
+/* current (moved) source in the caller's original point order */
+int ppcr_get_source(ppcr_ctx *ctx, float *xyz, int64_t stride_bytes);
+
+int ppcr_synchronize(ppcr_ctx *ctx);
+
+/* Per-kernel device timing with HIP events recorded on the handle's own stream. */
+typedef struct ppcr_kernel_stat {
+    char name[48];
+    int64_t launches;
+    double total_ms;
+} ppcr_kernel_stat;
+int ppcr_profile_enable(ppcr_ctx *ctx, int enable); /* also clears accumulated stats */
+int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_out);
+
+/* Tuning / debugging knobs (do not change results): key is one of
+ * "sort_source" (1: spatially sort the source once for coherent waves, default 1),
+ * "nn_variant" (0: auto). */
+int ppcr_set_option(ppcr_ctx *ctx, const char *key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPCR_H */

@@ -1,0 +1,275 @@
+"""ctypes binding of the C ABI declared in include/ppcr.h (libppcr_hip.so, built by build.py).
+
+The HIP library is the ONLY compute path: if it is missing or no GPU is visible, loading or
+context creation raises — there is no CPU fallback in this package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libppcr_hip.so")
+NSUMS = 19
+
+# every symbol include/ppcr.h declares (tests check that the built library exports them all)
+SYMBOLS = [
+    "ppcr_abi_version", "ppcr_device_count", "ppcr_create", "ppcr_destroy", "ppcr_last_error",
+    "ppcr_set_params", "ppcr_set_target", "ppcr_set_source", "ppcr_set_target_device",
+    "ppcr_set_source_device", "ppcr_associate", "ppcr_association_size", "ppcr_get_association",
+    "ppcr_set_association", "ppcr_weights", "ppcr_accumulate", "ppcr_get_origin",
+    "ppcr_solve_moments", "ppcr_cost_from_moments", "ppcr_solve", "ppcr_apply_transform",
+    "ppcr_iterate", "ppcr_align", "ppcr_get_source", "ppcr_synchronize", "ppcr_profile_enable",
+    "ppcr_profile_get", "ppcr_set_option",
+]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
+
+
+class PpcrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ppcr error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libppcr_hip.so; raises ImportError loudly when the extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m probabilistic_point_clouds_registration_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, dbl, i32 = C.c_void_p, C.c_int64, C.c_double, C.c_int
+    L.ppcr_abi_version.restype = i32
+    L.ppcr_device_count.argtypes = [C.POINTER(i32)]
+    L.ppcr_create.argtypes = [i32, C.POINTER(vp)]
+    L.ppcr_destroy.argtypes = [vp]
+    L.ppcr_last_error.argtypes = [vp]
+    L.ppcr_last_error.restype = C.c_char_p
+    L.ppcr_set_params.argtypes = [vp, dbl, i32, dbl, i32]
+    for f in (L.ppcr_set_target, L.ppcr_set_source, L.ppcr_set_target_device, L.ppcr_set_source_device):
+        f.argtypes = [vp, vp, i64, i64]
+    L.ppcr_associate.argtypes = [vp]
+    L.ppcr_association_size.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.ppcr_get_association.argtypes = [vp, vp, vp, vp]
+    L.ppcr_set_association.argtypes = [vp, vp, vp, i64]
+    L.ppcr_weights.argtypes = [vp, vp, vp, vp, vp]
+    L.ppcr_accumulate.argtypes = [vp, vp, vp, vp]
+    L.ppcr_get_origin.argtypes = [vp, vp]
+    L.ppcr_solve_moments.argtypes = [vp, vp, vp, vp]
+    L.ppcr_cost_from_moments.argtypes = [vp, vp, vp, vp]
+    L.ppcr_cost_from_moments.restype = dbl
+    L.ppcr_solve.argtypes = [vp, vp, vp, i32, dbl, vp, vp, C.POINTER(i32)]
+    L.ppcr_apply_transform.argtypes = [vp, vp]
+    L.ppcr_iterate.argtypes = [vp, vp, vp, i32, dbl, vp, vp, C.POINTER(i32)]
+    L.ppcr_align.argtypes = [vp, i32, dbl, dbl, vp, vp, i32, dbl, vp, vp, vp, C.POINTER(i32)]
+    L.ppcr_get_source.argtypes = [vp, vp, i64]
+    L.ppcr_synchronize.argtypes = [vp]
+    L.ppcr_profile_enable.argtypes = [vp, i32]
+    L.ppcr_profile_get.argtypes = [vp, C.POINTER(KernelStat), i32, C.POINTER(i32)]
+    L.ppcr_set_option.argtypes = [vp, C.c_char_p, i32]
+    for name in SYMBOLS:
+        f = getattr(L, name)
+        if name not in ("ppcr_last_error", "ppcr_cost_from_moments"):
+            f.restype = i32
+    _lib = L
+    return L
+
+
+def device_count():
+    n = C.c_int(0)
+    load().ppcr_device_count(C.byref(n))
+    return n.value
+
+
+def _f64(a, n):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+    assert a.shape[0] == n
+    return a
+
+
+class Context:
+    """One device-resident source/target pair (thin, 1:1 over the C ABI)."""
+
+    def __init__(self, device_id=0):
+        self._L = load()
+        h = C.c_void_p()
+        rc = self._L.ppcr_create(int(device_id), C.byref(h))
+        if rc != 0:
+            raise PpcrError(rc, self._L.ppcr_last_error(None).decode())
+        self._h = h
+        self.ns = 0
+        self.nt = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ppcr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise PpcrError(rc, self._L.ppcr_last_error(self._h).decode())
+
+    # -- parameters and clouds
+    def set_params(self, radius, max_neighbours, dof=5.0, dim=3):
+        self._ck(self._L.ppcr_set_params(self._h, float(radius), int(max_neighbours), float(dof), int(dim)))
+
+    def set_option(self, key, value):
+        self._ck(self._L.ppcr_set_option(self._h, key.encode(), int(value)))
+
+    @staticmethod
+    def _cloud(a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.ndim != 2 or a.shape[1] not in (3, 4):
+            raise ValueError("cloud must be [n,3] or [n,4] float32")
+        return a
+
+    def set_target(self, xyz):
+        a = self._cloud(xyz)
+        self._ck(self._L.ppcr_set_target(self._h, a.ctypes.data, a.shape[0], a.shape[1] * 4))
+        self.nt = a.shape[0]
+
+    def set_source(self, xyz):
+        a = self._cloud(xyz)
+        self._ck(self._L.ppcr_set_source(self._h, a.ctypes.data, a.shape[0], a.shape[1] * 4))
+        self.ns = a.shape[0]
+
+    def set_target_device(self, ptr, n, stride_bytes):
+        self._ck(self._L.ppcr_set_target_device(self._h, C.c_void_p(int(ptr)), int(n), int(stride_bytes)))
+        self.nt = int(n)
+
+    def set_source_device(self, ptr, n, stride_bytes):
+        self._ck(self._L.ppcr_set_source_device(self._h, C.c_void_p(int(ptr)), int(n), int(stride_bytes)))
+        self.ns = int(n)
+
+    # -- association
+    def associate(self):
+        self._ck(self._L.ppcr_associate(self._h))
+
+    def association_size(self):
+        r, z = C.c_int64(0), C.c_int64(0)
+        self._ck(self._L.ppcr_association_size(self._h, C.byref(r), C.byref(z)))
+        return r.value, z.value
+
+    def get_association(self, want_d2=True):
+        rows, nnz = self.association_size()
+        rp = np.zeros(rows + 1, dtype=np.int32)
+        col = np.zeros(max(nnz, 1), dtype=np.int32)
+        d2 = np.zeros(max(nnz, 1), dtype=np.float32) if want_d2 else None
+        self._ck(self._L.ppcr_get_association(self._h, rp.ctypes.data, col.ctypes.data,
+                                              d2.ctypes.data if want_d2 else None))
+        return rp, col[:nnz], (d2[:nnz] if want_d2 else None)
+
+    def set_association(self, row_ptr, col):
+        rp = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        cl = np.ascontiguousarray(col, dtype=np.int32)
+        self._ck(self._L.ppcr_set_association(self._h, rp.ctypes.data, cl.ctypes.data if cl.size else None,
+                                              rp.shape[0] - 1))
+
+    # -- weights / moments / solve
+    def weights(self, q, t):
+        _, nnz = self.association_size()
+        w = np.zeros(max(nnz, 1))
+        s = np.zeros(max(nnz, 1))
+        q, t = _f64(q, 4), _f64(t, 3)
+        self._ck(self._L.ppcr_weights(self._h, q.ctypes.data, t.ctypes.data, w.ctypes.data, s.ctypes.data))
+        return w[:nnz], s[:nnz]
+
+    def accumulate(self, q, t):
+        sums = np.zeros(NSUMS)
+        q, t = _f64(q, 4), _f64(t, 3)
+        self._ck(self._L.ppcr_accumulate(self._h, q.ctypes.data, t.ctypes.data, sums.ctypes.data))
+        return sums
+
+    def origin(self):
+        o = np.zeros(3)
+        self._ck(self._L.ppcr_get_origin(self._h, o.ctypes.data))
+        return o
+
+    def solve(self, q0=(1, 0, 0, 0), t0=(0, 0, 0), max_steps=100, f_tol=1e-5):
+        T, cost, st = np.zeros(12), np.zeros(2), C.c_int(0)
+        q0, t0 = _f64(q0, 4), _f64(t0, 3)
+        self._ck(self._L.ppcr_solve(self._h, q0.ctypes.data, t0.ctypes.data, int(max_steps), float(f_tol),
+                                    T.ctypes.data, cost.ctypes.data, C.byref(st)))
+        return T.reshape(3, 4), cost, st.value
+
+    def apply_transform(self, T):
+        T = _f64(np.asarray(T, dtype=np.float64)[:3, :4], 12)
+        self._ck(self._L.ppcr_apply_transform(self._h, T.ctypes.data))
+
+    def iterate(self, q0=(1, 0, 0, 0), t0=(0, 0, 0), inner_steps=1, f_tol=1e-5):
+        T, cost, st = np.zeros(12), np.zeros(2), C.c_int(0)
+        q0, t0 = _f64(q0, 4), _f64(t0, 3)
+        self._ck(self._L.ppcr_iterate(self._h, q0.ctypes.data, t0.ctypes.data, int(inner_steps), float(f_tol),
+                                      T.ctypes.data, cost.ctypes.data, C.byref(st)))
+        return T.reshape(3, 4), cost, st.value
+
+    def align(self, n_iter, cost_drop_thresh=0.0, n_cost_drop_it=5, q0=(1, 0, 0, 0), t0=(0, 0, 0),
+              inner_steps=1, f_tol=1e-5, want_history=True):
+        k = max(int(n_iter), 1)
+        hist = np.zeros(k * 12) if want_history else None
+        costs = np.zeros(k * 2) if want_history else None
+        steps = np.zeros(k, dtype=np.int32) if want_history else None
+        done = C.c_int(0)
+        q0, t0 = _f64(q0, 4), _f64(t0, 3)
+        self._ck(self._L.ppcr_align(self._h, int(n_iter), float(cost_drop_thresh), float(n_cost_drop_it),
+                                    q0.ctypes.data, t0.ctypes.data, int(inner_steps), float(f_tol),
+                                    hist.ctypes.data if want_history else None,
+                                    costs.ctypes.data if want_history else None,
+                                    steps.ctypes.data if want_history else None, C.byref(done)))
+        n = done.value
+        if not want_history:
+            return dict(n_iter=n)
+        return dict(n_iter=n, history=hist[:12 * n].reshape(n, 3, 4).copy(), costs=costs[:2 * n].reshape(n, 2).copy(),
+                    inner_steps=steps[:n].copy())
+
+    def get_source(self, stride=3):
+        out = np.zeros((self.ns, stride), dtype=np.float32)
+        self._ck(self._L.ppcr_get_source(self._h, out.ctypes.data, stride * 4))
+        return out
+
+    def synchronize(self):
+        self._ck(self._L.ppcr_synchronize(self._h))
+
+    # -- profiling
+    def profile_enable(self, on=True):
+        self._ck(self._L.ppcr_profile_enable(self._h, 1 if on else 0))
+
+    def profile_get(self):
+        arr = (KernelStat * 32)()
+        n = C.c_int(0)
+        self._ck(self._L.ppcr_profile_get(self._h, arr, 32, C.byref(n)))
+        return {arr[i].name.decode(): dict(launches=arr[i].launches, total_ms=arr[i].total_ms)
+                for i in range(min(n.value, 32))}
+
+
+def solve_moments(sums, origin):
+    R, t = np.zeros(9), np.zeros(3)
+    s, o = _f64(sums, NSUMS), _f64(origin, 3)
+    rc = load().ppcr_solve_moments(s.ctypes.data, o.ctypes.data, R.ctypes.data, t.ctypes.data)
+    return R.reshape(3, 3), t, rc
+
+
+def cost_from_moments(sums, origin, R, t):
+    s, o, R, t = _f64(sums, NSUMS), _f64(origin, 3), _f64(R, 9), _f64(t, 3)
+    return load().ppcr_cost_from_moments(s.ctypes.data, o.ctypes.data, R.ctypes.data, t.ctypes.data)

@@ -1,0 +1,1158 @@
+// C ABI (include/ppcr.h) over the gfx950 kernels of ppcr_kernels.hip.h.
+// One ppcr_ctx = one device + one HIP stream + the device-resident state of one source/target
+// pair.  There is no CPU fallback anywhere in this file: without a GPU ppcr_create() fails with
+// PPCR_ERR_NODEVICE and nothing else can be called.
+#include "ppcr.h"
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "ppcr_host_math.hpp"
+#include "ppcr_kernels.hip.h"
+
+using namespace ppcr;
+using namespace ppcr::dev;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum KernelId {
+    K_REPACK = 0,
+    K_BBOX,
+    K_CELL_KEY,
+    K_RADIX_SORT,
+    K_GATHER,
+    K_CELL_START,
+    K_NN_TOPM,
+    K_NN_COUNT,
+    K_NN_SCAN,
+    K_NN_FILL,
+    K_NN_SELECT,
+    K_NN_COMPACT,
+    K_COUNT_SUM,
+    K_WEIGHTS,
+    K_ACCUMULATE,
+    K_REDUCE,
+    K_TRANSFORM,
+    K_NUM
+};
+const char *const kKernelNames[K_NUM] = {
+    "repack_kernel",   "bbox_kernel",    "cell_key_kernel",   "radix_sort",       "gather_points_kernel",
+    "cell_start_kernel", "nn_topm_kernel", "nn_count_kernel",  "nn_scan",          "nn_fill_kernel",
+    "nn_select_kernel", "csr_compact_kernel", "ell_count_sum_kernel", "weights_kernel", "accumulate_kernel",
+    "reduce_partials_kernel", "transform_kernel"};
+
+constexpr int kEllMaxWidth = 32;   // widest register-list NN variant / widest ELL association
+constexpr int kAccumMaxBlocks = 1024;
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct ProfRec {
+    int id;
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct ppcr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // parameters
+    double radius = 1.0;
+    int max_nb = 20;
+    double dof = 5.0;
+    int dim = 3;
+    int opt_sort_source = 1;
+    int opt_nn_variant = 0;
+
+    // clouds
+    int64_t ns = 0, nt = 0;
+    bool have_src = false, have_tgt = false;
+    DevBuf<unsigned char> staging;
+    DevBuf<float4> tgt_raw, tgt_sorted, src, src_alt;
+    bool grid_valid = false;
+    double grid_radius = -1;
+    bool src_sorted = false;
+    GridDesc grid{};
+    DevBuf<int> cell_start;
+    double origin[3] = {0, 0, 0};
+    bool origin_valid = false;
+
+    // sort scratch
+    DevBuf<unsigned> keys_a, keys_b;
+    DevBuf<int> vals_a, vals_b;
+    DevBuf<unsigned char> cub_tmp;
+    DevBuf<float> bbox_part;
+
+    // association
+    enum { ASSOC_NONE, ASSOC_ELL, ASSOC_CSR } assoc = ASSOC_NONE;
+    int ell_width = 0;
+    DevBuf<int> nbr, cnt, row_ptr;
+    DevBuf<int> gen_counts, gen_row_ptr, gen_pos;
+    DevBuf<unsigned long long> gen_keys;
+    DevBuf<unsigned long long> d_total;
+    int64_t nnz = -1;
+
+    // reductions
+    DevBuf<double> partials, d_sums;
+    double *h_sums = nullptr;          // pinned
+    unsigned long long *h_total = nullptr;  // pinned
+
+    // weights export scratch
+    DevBuf<double> d_w, d_s;
+
+    // host caches for the export / import paths (never touched by the hot loop)
+    bool csr_cache_valid = false;
+    std::vector<int> h_csr_row_ptr, h_csr_col;
+    std::vector<size_t> h_csr_slot;
+
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[K_NUM] = {0};
+    int64_t prof_n[K_NUM] = {0};
+
+    const float4 *tgt_cur() const { return grid_valid ? tgt_sorted.p : tgt_raw.p; }
+};
+
+namespace {
+
+int fail(ppcr_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? PPCR_ERR_NOMEM : PPCR_ERR_HIP,            \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+#define PPCR_TRY(expr)                  \
+    do {                                \
+        int rc_ = (expr);               \
+        if (rc_ != PPCR_OK) return rc_; \
+    } while (0)
+
+inline int nblocks(int64_t n, int block = kBlock) { return (int)((n + block - 1) / block); }
+
+struct ProfScope {
+    ppcr_ctx *c;
+    ProfRec r{};
+    bool active = false;
+    ProfScope(ppcr_ctx *ctx, int id) : c(ctx)
+    {
+        if (!c->prof_on) return;
+        for (int k = 0; k < 2; k++) {
+            hipEvent_t ev;
+            if (!c->prof_pool.empty()) {
+                ev = c->prof_pool.back();
+                c->prof_pool.pop_back();
+            } else if (hipEventCreate(&ev) != hipSuccess) {
+                return;
+            }
+            (k == 0 ? r.start : r.stop) = ev;
+        }
+        r.id = id;
+        active = true;
+        (void)hipEventRecord(r.start, c->stream);
+    }
+    ~ProfScope()
+    {
+        if (!active) return;
+        (void)hipEventRecord(r.stop, c->stream);
+        c->prof_recs.push_back(r);
+    }
+};
+
+int check_launch(ppcr_ctx *c, const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, PPCR_ERR_HIP, std::string(what) + " launch: " + hipGetErrorString(e));
+    return PPCR_OK;
+}
+
+void invalidate_association(ppcr_ctx *c)
+{
+    c->assoc = ppcr_ctx::ASSOC_NONE;
+    c->nnz = -1;
+    c->csr_cache_valid = false;
+}
+
+Model make_model(const ppcr_ctx *c)
+{
+    Model m;
+    m.is_normal = !(c->dof < std::numeric_limits<double>::infinity());
+    m.v = c->dof;
+    m.texp = -(c->dof + c->dim) / 2.0;
+    m.vpd = c->dof + c->dim;
+    return m;
+}
+
+Pose make_pose(const ppcr_ctx *c, const Mat3 &R, const double t[3])
+{
+    Pose P;
+    for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) P.R[3 * a + b] = R.m[a][b];
+        P.t[a] = t[a];
+        P.c[a] = c->origin[a];
+    }
+    return P;
+}
+
+// upload (host or device pointer) + repack into float4 {x,y,z,original index}
+int upload_cloud(ppcr_ctx *c, const void *ptr, bool on_device, int64_t n, int64_t stride, DevBuf<float4> &dst)
+{
+    if (n < 0 || n > (int64_t)INT32_MAX - 1024) return fail(c, PPCR_ERR_INVALID, "cloud size out of range");
+    if (stride < 12 || (stride % 4) != 0) return fail(c, PPCR_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
+    if (n > 0 && ptr == nullptr) return fail(c, PPCR_ERR_INVALID, "null cloud pointer");
+    HIP_TRY(c, dst.reserve((size_t)std::max<int64_t>(n, 1)));
+    if (n == 0) return PPCR_OK;
+    const unsigned char *raw = static_cast<const unsigned char *>(ptr);
+    if (!on_device) {
+        // last point may be packed: copy exactly (n-1)*stride + 12 bytes
+        const size_t bytes = (size_t)(n - 1) * (size_t)stride + 12;
+        HIP_TRY(c, c->staging.reserve(bytes));
+        HIP_TRY(c, hipMemcpyAsync(c->staging.p, ptr, bytes, hipMemcpyHostToDevice, c->stream));
+        raw = c->staging.p;
+    }
+    {
+        ProfScope ps(c, K_REPACK);
+        repack_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(raw, n, stride, dst.p);
+    }
+    PPCR_TRY(check_launch(c, "repack_kernel"));
+    // the caller's host buffer may be freed after return
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PPCR_OK;
+}
+
+// sort `n` points of `in` by grid cell into `out` (stable: ties keep ascending original index)
+int sort_by_cell(ppcr_ctx *c, const float4 *in, int n, float4 *out, bool want_cell_start)
+{
+    HIP_TRY(c, c->keys_a.reserve((size_t)n + 1));
+    HIP_TRY(c, c->keys_b.reserve((size_t)n + 1));
+    HIP_TRY(c, c->vals_a.reserve((size_t)n + 1));
+    HIP_TRY(c, c->vals_b.reserve((size_t)n + 1));
+    if (n > 0) {
+        {
+            ProfScope ps(c, K_CELL_KEY);
+            cell_key_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(in, n, c->grid, c->keys_a.p, c->vals_a.p);
+        }
+        PPCR_TRY(check_launch(c, "cell_key_kernel"));
+        int end_bit = 1;
+        while (end_bit < 32 && (1ll << end_bit) < (long long)c->grid.ncells) end_bit++;
+        size_t tmp_bytes = 0;
+        HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, c->keys_a.p, c->keys_b.p, c->vals_a.p,
+                                                     c->vals_b.p, n, 0, end_bit, c->stream));
+        HIP_TRY(c, c->cub_tmp.reserve(tmp_bytes + 16));
+        {
+            ProfScope ps(c, K_RADIX_SORT);
+            HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp_bytes, c->keys_a.p, c->keys_b.p,
+                                                         c->vals_a.p, c->vals_b.p, n, 0, end_bit, c->stream));
+        }
+        {
+            ProfScope ps(c, K_GATHER);
+            gather_points_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(in, c->vals_b.p, n, out);
+        }
+        PPCR_TRY(check_launch(c, "gather_points_kernel"));
+    }
+    if (want_cell_start) {
+        HIP_TRY(c, c->cell_start.reserve((size_t)c->grid.ncells + 1));
+        {
+            ProfScope ps(c, K_CELL_START);
+            cell_start_kernel<<<nblocks((int64_t)n + 1), kBlock, 0, c->stream>>>(c->keys_b.p, n, c->grid.ncells,
+                                                                                 c->cell_start.p);
+        }
+        PPCR_TRY(check_launch(c, "cell_start_kernel"));
+    }
+    return PPCR_OK;
+}
+
+// K0: bounding box -> cell edge -> cell-sorted target + cell_start
+int ensure_grid(ppcr_ctx *c)
+{
+    if (!c->have_tgt) return fail(c, PPCR_ERR_STATE, "target cloud not set");
+    if (c->grid_valid && c->grid_radius == c->radius) return PPCR_OK;
+    if (!(c->radius > 0) || !std::isfinite(c->radius)) return fail(c, PPCR_ERR_INVALID, "radius must be positive and finite");
+    invalidate_association(c);
+    const int n = (int)c->nt;
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    if (n > 0) {
+        const int nb = std::min(1024, nblocks(n));
+        HIP_TRY(c, c->bbox_part.reserve((size_t)nb * 6));
+        {
+            ProfScope ps(c, K_BBOX);
+            bbox_kernel<<<nb, kBlock, 0, c->stream>>>(c->tgt_raw.p, n, c->bbox_part.p);
+        }
+        PPCR_TRY(check_launch(c, "bbox_kernel"));
+        std::vector<float> part((size_t)nb * 6);
+        HIP_TRY(c, hipMemcpyAsync(part.data(), c->bbox_part.p, part.size() * sizeof(float), hipMemcpyDeviceToHost,
+                                  c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (int a = 0; a < 3; a++) {
+            lo[a] = INFINITY;
+            hi[a] = -INFINITY;
+        }
+        for (int b = 0; b < nb; b++)
+            for (int a = 0; a < 3; a++) {
+                lo[a] = std::min(lo[a], part[(size_t)b * 6 + a]);
+                hi[a] = std::max(hi[a], part[(size_t)b * 6 + 3 + a]);
+            }
+        for (int a = 0; a < 3; a++)
+            if (!(lo[a] <= hi[a])) lo[a] = hi[a] = 0;  // no finite coordinate at all
+    }
+    for (int a = 0; a < 3; a++) c->origin[a] = 0.5 * ((double)lo[a] + (double)hi[a]);
+    c->origin_valid = true;
+    float amax = 0;
+    for (int a = 0; a < 3; a++) amax = std::max(amax, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
+    // cell edge slightly above r: float rounding of the cell index can then never push an
+    // in-radius target outside the query's 27-cell stencil
+    float h = (float)c->radius * 1.001f + 16.0f * FLT_EPSILON * amax;
+    const double max_cells = 4.0 * (double)n + 4096.0;
+    double ext[3];
+    for (int a = 0; a < 3; a++) ext[a] = (double)hi[a] - (double)lo[a];
+    for (;;) {
+        double nc = 1;
+        for (int a = 0; a < 3; a++) nc *= std::floor(ext[a] / h) + 1;
+        if (nc <= max_cells) break;
+        h *= 1.26f;
+    }
+    int64_t ncells = 1;
+    for (int a = 0; a < 3; a++) {
+        c->grid.org[a] = lo[a];
+        c->grid.n[a] = (int)std::floor(ext[a] / h) + 1;
+        ncells *= c->grid.n[a];
+    }
+    c->grid.inv_h = 1.0f / h;
+    c->grid.ncells = (int)ncells;
+    HIP_TRY(c, c->tgt_sorted.reserve((size_t)std::max(n, 1)));
+    PPCR_TRY(sort_by_cell(c, c->tgt_raw.p, n, c->tgt_sorted.p, true));
+    c->grid_valid = true;
+    c->grid_radius = c->radius;
+    c->src_sorted = false;  // re-sort against the new grid at the next associate()
+    return PPCR_OK;
+}
+
+int ensure_source_sorted(ppcr_ctx *c)
+{
+    if (!c->have_src) return fail(c, PPCR_ERR_STATE, "source cloud not set");
+    if (c->src_sorted || !c->opt_sort_source || c->ns == 0) return PPCR_OK;
+    invalidate_association(c);
+    HIP_TRY(c, c->src_alt.reserve((size_t)c->ns));
+    PPCR_TRY(sort_by_cell(c, c->src.p, (int)c->ns, c->src_alt.p, false));
+    std::swap(c->src, c->src_alt);
+    c->src_sorted = true;
+    return PPCR_OK;
+}
+
+template <int M>
+void launch_topm(ppcr_ctx *c, float r2, int m)
+{
+    nn_topm_kernel<M><<<nblocks(c->ns), kBlock, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p,
+                                                                 c->cell_start.p, c->grid, r2, m, c->nbr.p,
+                                                                 c->cnt.p);
+}
+
+int associate_impl(ppcr_ctx *c)
+{
+    PPCR_TRY(ensure_grid(c));
+    PPCR_TRY(ensure_source_sorted(c));
+    invalidate_association(c);
+    const int ns = (int)c->ns;
+    const float r2 = (float)(c->radius * c->radius);  // PCL: static_cast<float>(radius * radius)
+    const bool unbounded = (c->max_nb <= 0 || (int64_t)c->max_nb >= c->nt);
+    if (!unbounded && c->max_nb <= kEllMaxWidth) {
+        const int m = c->max_nb;
+        HIP_TRY(c, c->nbr.reserve((size_t)m * (size_t)std::max(ns, 1)));
+        HIP_TRY(c, c->cnt.reserve((size_t)std::max(ns, 1)));
+        if (ns > 0) {
+            ProfScope ps(c, K_NN_TOPM);
+            if (m <= 4) launch_topm<4>(c, r2, m);
+            else if (m <= 5) launch_topm<5>(c, r2, m);
+            else if (m <= 8) launch_topm<8>(c, r2, m);
+            else if (m <= 10) launch_topm<10>(c, r2, m);
+            else if (m <= 16) launch_topm<16>(c, r2, m);
+            else if (m <= 20) launch_topm<20>(c, r2, m);
+            else launch_topm<32>(c, r2, m);
+        }
+        PPCR_TRY(check_launch(c, "nn_topm_kernel"));
+        c->assoc = ppcr_ctx::ASSOC_ELL;
+        c->ell_width = m;
+        return PPCR_OK;
+    }
+    // generic path: count -> scan -> fill [-> select + compact]
+    HIP_TRY(c, c->gen_counts.reserve((size_t)ns + 1));
+    HIP_TRY(c, c->gen_row_ptr.reserve((size_t)ns + 1));
+    HIP_TRY(c, hipMemsetAsync(c->gen_counts.p, 0, sizeof(int) * ((size_t)ns + 1), c->stream));
+    if (ns > 0) {
+        ProfScope ps(c, K_NN_COUNT);
+        nn_count_kernel<<<nblocks(ns), kBlock, 0, c->stream>>>(c->src.p, ns, c->tgt_sorted.p, c->cell_start.p,
+                                                               c->grid, r2, c->gen_counts.p);
+    }
+    PPCR_TRY(check_launch(c, "nn_count_kernel"));
+    auto scan = [&](int *in, int *out) -> int {
+        size_t tmp_bytes = 0;
+        HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, in, out, ns + 1, c->stream));
+        HIP_TRY(c, c->cub_tmp.reserve(tmp_bytes + 16));
+        ProfScope ps(c, K_NN_SCAN);
+        HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, in, out, ns + 1, c->stream));
+        return PPCR_OK;
+    };
+    // guard int32 CSR offsets: total in-radius pairs must fit
+    HIP_TRY(c, c->d_total.reserve(1));
+    HIP_TRY(c, hipMemsetAsync(c->d_total.p, 0, sizeof(unsigned long long), c->stream));
+    if (ns > 0) {
+        ProfScope ps(c, K_COUNT_SUM);
+        ell_count_sum_kernel<<<std::min(1024, nblocks(ns)), kBlock, 0, c->stream>>>(c->gen_counts.p, ns, c->d_total.p);
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const unsigned long long total_all = *c->h_total;
+    if (total_all > (unsigned long long)INT32_MAX - 1024)
+        return fail(c, PPCR_ERR_INVALID, "association too large for 32-bit CSR offsets (reduce radius or set max_neighbours)");
+    PPCR_TRY(scan(c->gen_counts.p, c->gen_row_ptr.p));
+    HIP_TRY(c, c->gen_keys.reserve((size_t)std::max<unsigned long long>(total_all, 1)));
+    HIP_TRY(c, c->gen_pos.reserve((size_t)std::max<unsigned long long>(total_all, 1)));
+    if (ns > 0) {
+        ProfScope ps(c, K_NN_FILL);
+        nn_fill_kernel<<<nblocks(ns), kBlock, 0, c->stream>>>(c->src.p, ns, c->tgt_sorted.p, c->cell_start.p, c->grid,
+                                                              r2, c->gen_row_ptr.p, c->gen_keys.p, c->gen_pos.p);
+    }
+    PPCR_TRY(check_launch(c, "nn_fill_kernel"));
+    if (unbounded) {
+        std::swap(c->row_ptr, c->gen_row_ptr);
+        std::swap(c->nbr, c->gen_pos);
+        c->nnz = (int64_t)total_all;
+    } else {
+        HIP_TRY(c, hipMemsetAsync(c->gen_counts.p, 0, sizeof(int) * ((size_t)ns + 1), c->stream));
+        if (ns > 0) {
+            ProfScope ps(c, K_NN_SELECT);
+            nn_select_kernel<<<nblocks(ns), kBlock, 0, c->stream>>>(ns, c->gen_row_ptr.p, c->gen_keys.p, c->gen_pos.p,
+                                                                    c->max_nb, c->gen_counts.p);
+        }
+        PPCR_TRY(check_launch(c, "nn_select_kernel"));
+        HIP_TRY(c, c->row_ptr.reserve((size_t)ns + 1));
+        PPCR_TRY(scan(c->gen_counts.p, c->row_ptr.p));
+        HIP_TRY(c, c->nbr.reserve((size_t)std::max<unsigned long long>(total_all, 1)));
+        if (ns > 0) {
+            ProfScope ps(c, K_NN_COMPACT);
+            csr_compact_kernel<<<nblocks(ns), kBlock, 0, c->stream>>>(ns, c->gen_row_ptr.p, c->gen_pos.p, c->row_ptr.p,
+                                                                      c->nbr.p);
+        }
+        PPCR_TRY(check_launch(c, "csr_compact_kernel"));
+        c->nnz = -1;
+    }
+    c->assoc = ppcr_ctx::ASSOC_CSR;
+    return PPCR_OK;
+}
+
+int ensure_nnz(ppcr_ctx *c)
+{
+    if (c->assoc == ppcr_ctx::ASSOC_NONE) return fail(c, PPCR_ERR_STATE, "no association (call ppcr_associate or ppcr_set_association)");
+    if (c->nnz >= 0) return PPCR_OK;
+    const int ns = (int)c->ns;
+    if (c->assoc == ppcr_ctx::ASSOC_CSR) {
+        int last = 0;
+        HIP_TRY(c, hipMemcpyAsync(&last, c->row_ptr.p + ns, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->nnz = last;
+        return PPCR_OK;
+    }
+    HIP_TRY(c, c->d_total.reserve(1));
+    HIP_TRY(c, hipMemsetAsync(c->d_total.p, 0, sizeof(unsigned long long), c->stream));
+    if (ns > 0) {
+        ProfScope ps(c, K_COUNT_SUM);
+        ell_count_sum_kernel<<<std::min(1024, nblocks(ns)), kBlock, 0, c->stream>>>(c->cnt.p, ns, c->d_total.p);
+    }
+    PPCR_TRY(check_launch(c, "ell_count_sum_kernel"));
+    HIP_TRY(c, hipMemcpyAsync(c->h_total, c->d_total.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->nnz = (int64_t)*c->h_total;
+    return PPCR_OK;
+}
+
+// download the w lane (original index) of a float4 cloud
+int download_order(ppcr_ctx *c, const float4 *pts, int64_t n, std::vector<int> &order)
+{
+    std::vector<float4> tmp((size_t)n);
+    if (n > 0) {
+        HIP_TRY(c, hipMemcpyAsync(tmp.data(), pts, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    order.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        int v;
+        std::memcpy(&v, &tmp[(size_t)i].w, sizeof(int));
+        order[(size_t)i] = v;
+    }
+    return PPCR_OK;
+}
+
+// Build the CSR view (original row order, ascending original columns) of a device-made association
+int build_csr_cache(ppcr_ctx *c)
+{
+    if (c->csr_cache_valid) return PPCR_OK;
+    PPCR_TRY(ensure_nnz(c));
+    const int64_t ns = c->ns;
+    std::vector<int> src_order, tgt_order;
+    PPCR_TRY(download_order(c, c->src.p, ns, src_order));
+    PPCR_TRY(download_order(c, c->tgt_cur(), c->nt, tgt_order));
+    std::vector<int> h_nbr, h_cnt, h_rp;
+    if (c->assoc == ppcr_ctx::ASSOC_ELL) {
+        h_nbr.resize((size_t)c->ell_width * (size_t)ns);
+        h_cnt.resize((size_t)ns);
+        if (ns > 0) {
+            HIP_TRY(c, hipMemcpyAsync(h_nbr.data(), c->nbr.p, h_nbr.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(h_cnt.data(), c->cnt.p, h_cnt.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+    } else {
+        h_rp.resize((size_t)ns + 1);
+        h_nbr.resize((size_t)c->nnz);
+        HIP_TRY(c, hipMemcpyAsync(h_rp.data(), c->row_ptr.p, h_rp.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        if (c->nnz > 0)
+            HIP_TRY(c, hipMemcpyAsync(h_nbr.data(), c->nbr.p, h_nbr.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    auto row_count = [&](int64_t r) { return c->assoc == ppcr_ctx::ASSOC_ELL ? h_cnt[(size_t)r] : h_rp[(size_t)r + 1] - h_rp[(size_t)r]; };
+    auto slot_of = [&](int64_t r, int k) -> size_t {
+        return c->assoc == ppcr_ctx::ASSOC_ELL ? (size_t)k * (size_t)ns + (size_t)r : (size_t)h_rp[(size_t)r] + (size_t)k;
+    };
+    c->h_csr_row_ptr.assign((size_t)ns + 1, 0);
+    for (int64_t r = 0; r < ns; r++) c->h_csr_row_ptr[(size_t)src_order[(size_t)r] + 1] = row_count(r);
+    for (int64_t i = 0; i < ns; i++) c->h_csr_row_ptr[(size_t)i + 1] += c->h_csr_row_ptr[(size_t)i];
+    const size_t nnz = (size_t)c->h_csr_row_ptr[(size_t)ns];
+    c->h_csr_col.resize(nnz);
+    c->h_csr_slot.resize(nnz);
+    std::vector<std::pair<int, size_t>> row;
+    for (int64_t r = 0; r < ns; r++) {
+        const int n = row_count(r);
+        row.clear();
+        for (int k = 0; k < n; k++) {
+            const size_t sl = slot_of(r, k);
+            row.emplace_back(tgt_order[(size_t)h_nbr[sl]], sl);
+        }
+        std::sort(row.begin(), row.end());
+        const size_t base = (size_t)c->h_csr_row_ptr[(size_t)src_order[(size_t)r]];
+        for (int k = 0; k < n; k++) {
+            c->h_csr_col[base + k] = row[(size_t)k].first;
+            c->h_csr_slot[base + k] = row[(size_t)k].second;
+        }
+    }
+    c->csr_cache_valid = true;
+    return PPCR_OK;
+}
+
+int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PPCR_NSUMS])
+{
+    if (c->assoc == ppcr_ctx::ASSOC_NONE) return fail(c, PPCR_ERR_STATE, "no association (call ppcr_associate or ppcr_set_association)");
+    if (!c->origin_valid) {
+        // set_association path without a grid: origin = 0 is fine for the exact-association API,
+        // but prefer the target bounding-box centre when a grid has been built
+        c->origin[0] = c->origin[1] = c->origin[2] = 0;
+    }
+    const int ns = (int)c->ns;
+    const Pose P = make_pose(c, R, t);
+    const Model md = make_model(c);
+    const int nb = std::max(1, std::min(kAccumMaxBlocks, nblocks(ns)));
+    HIP_TRY(c, c->partials.reserve((size_t)nb * kNSums));
+    HIP_TRY(c, c->d_sums.reserve(kNSums));
+    {
+        ProfScope ps(c, K_ACCUMULATE);
+        if (c->assoc == ppcr_ctx::ASSOC_ELL) {
+            EllAssoc a{c->nbr.p, c->cnt.p, ns};
+            accumulate_kernel<EllAssoc><<<nb, kBlock, 0, c->stream>>>(a, c->src.p, c->tgt_cur(), ns, P, md, c->partials.p);
+        } else {
+            CsrAssoc a{c->nbr.p, c->row_ptr.p};
+            accumulate_kernel<CsrAssoc><<<nb, kBlock, 0, c->stream>>>(a, c->src.p, c->tgt_cur(), ns, P, md, c->partials.p);
+        }
+    }
+    PPCR_TRY(check_launch(c, "accumulate_kernel"));
+    {
+        ProfScope ps(c, K_REDUCE);
+        reduce_partials_kernel<<<1, kBlock, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p);
+    }
+    PPCR_TRY(check_launch(c, "reduce_partials_kernel"));
+    HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->d_sums.p, sizeof(double) * kNSums, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::memcpy(sums, c->h_sums, sizeof(double) * kNSums);
+    return PPCR_OK;
+}
+
+int apply_transform_impl(ppcr_ctx *c, const double T[12])
+{
+    if (!c->have_src) return fail(c, PPCR_ERR_STATE, "source cloud not set");
+    Pose P;
+    for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) P.R[3 * a + b] = T[4 * a + b];
+        P.t[a] = T[4 * a + 3];
+        P.c[a] = 0;
+    }
+    if (c->ns > 0) {
+        ProfScope ps(c, K_TRANSFORM);
+        transform_kernel<<<nblocks(c->ns), kBlock, 0, c->stream>>>(c->src.p, (int)c->ns, P);
+    }
+    return check_launch(c, "transform_kernel");
+}
+
+// IRLS on the current association (see ppcr_solve in ppcr.h)
+int solve_impl(ppcr_ctx *c, const double q0[4], const double t0[3], int max_steps, double f_tol, double T_out[12],
+               double cost_out[2], int *steps_out)
+{
+    const double qn = q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3];
+    if (!(qn > 0) || !std::isfinite(qn)) return fail(c, PPCR_ERR_INVALID, "initial rotation quaternion has zero or non-finite norm");
+    Mat3 R = quat_to_rot(q0);
+    Vec3 t{{t0[0], t0[1], t0[2]}};
+    double sums[PPCR_NSUMS];
+    PPCR_TRY(run_accumulate(c, R, t.v, sums));
+    double cost_old = 0.5 * sums[16];
+    cost_out[0] = cost_out[1] = cost_old;
+    int steps = 0;
+    if (max_steps < 1) max_steps = 1;
+    for (;;) {
+        const RigidSolve rs = solve_rigid_from_moments(sums, c->origin);
+        const double fc = rs.degenerate ? cost_old : cost_from_moments(sums, c->origin, rs.R, rs.t);
+        steps++;
+        R = rs.R;
+        t = rs.t;
+        cost_out[1] = fc;
+        if (rs.degenerate || steps >= max_steps) break;
+        if ((cost_old - fc) <= f_tol * cost_old) break;
+        PPCR_TRY(run_accumulate(c, R, t.v, sums));
+        cost_old = 0.5 * sums[16];
+    }
+    // transformation(): normalised quaternion -> rotation (..._iteration.hpp:59-67); R is already
+    // orthonormal to rounding so the round trip through a quaternion is not needed here
+    pack_T(R, t, T_out);
+    if (steps_out) *steps_out = steps;
+    return PPCR_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int ppcr_abi_version(void) { return PPCR_ABI_VERSION; }
+
+int ppcr_device_count(int *count)
+{
+    if (!count) return PPCR_ERR_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return PPCR_OK;
+}
+
+const char *ppcr_last_error(const ppcr_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int ppcr_create(int device_id, ppcr_ctx **out)
+{
+    if (!out) return fail(nullptr, PPCR_ERR_INVALID, "out is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, PPCR_ERR_NODEVICE, "no HIP device visible: this library has no CPU fallback");
+    }
+    if (device_id < 0 || device_id >= n) return fail(nullptr, PPCR_ERR_INVALID, "device_id out of range");
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    ppcr_ctx *c = new (std::nothrow) ppcr_ctx();
+    if (!c) return fail(nullptr, PPCR_ERR_NOMEM, "out of host memory");
+    c->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_sums), sizeof(double) * kNSums, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_total), sizeof(unsigned long long), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        std::string msg = std::string("context setup: ") + hipGetErrorString(e);
+        ppcr_destroy(c);
+        return fail(nullptr, PPCR_ERR_HIP, msg);
+    }
+    *out = c;
+    return PPCR_OK;
+}
+
+int ppcr_destroy(ppcr_ctx *c)
+{
+    if (!c) return PPCR_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &r : c->prof_recs) {
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    for (auto ev : c->prof_pool) (void)hipEventDestroy(ev);
+    c->staging.release();
+    c->tgt_raw.release();
+    c->tgt_sorted.release();
+    c->src.release();
+    c->src_alt.release();
+    c->cell_start.release();
+    c->keys_a.release();
+    c->keys_b.release();
+    c->vals_a.release();
+    c->vals_b.release();
+    c->cub_tmp.release();
+    c->bbox_part.release();
+    c->nbr.release();
+    c->cnt.release();
+    c->row_ptr.release();
+    c->gen_counts.release();
+    c->gen_row_ptr.release();
+    c->gen_pos.release();
+    c->gen_keys.release();
+    c->d_total.release();
+    c->partials.release();
+    c->d_sums.release();
+    c->d_w.release();
+    c->d_s.release();
+    if (c->h_sums) (void)hipHostFree(c->h_sums);
+    if (c->h_total) (void)hipHostFree(c->h_total);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PPCR_OK;
+}
+
+#define CTX_ENTER(c)                                  \
+    if (!(c)) return PPCR_ERR_INVALID;                \
+    HIP_TRY(c, hipSetDevice((c)->device))
+
+int ppcr_set_params(ppcr_ctx *c, double radius, int max_neighbours, double dof, int dim)
+{
+    CTX_ENTER(c);
+    if (!(radius > 0) || !std::isfinite(radius)) return fail(c, PPCR_ERR_INVALID, "radius must be positive and finite");
+    if (!(dof > 0)) return fail(c, PPCR_ERR_INVALID, "dof must be > 0 (probabilistic_weights.hpp:34 asserts v > 0)");
+    if (dim <= 0) return fail(c, PPCR_ERR_INVALID, "dim must be > 0 (probabilistic_weights.hpp:33)");
+    if (radius != c->radius || max_neighbours != c->max_nb) invalidate_association(c);
+    c->radius = radius;
+    c->max_nb = max_neighbours;
+    c->dof = dof;
+    c->dim = dim;
+    return PPCR_OK;
+}
+
+int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
+{
+    CTX_ENTER(c);
+    if (!key) return fail(c, PPCR_ERR_INVALID, "null option key");
+    if (std::strcmp(key, "sort_source") == 0) {
+        if (c->have_src && c->src_sorted && !value)
+            return fail(c, PPCR_ERR_STATE, "sort_source can only be switched off before the source has been sorted");
+        c->opt_sort_source = value ? 1 : 0;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "nn_variant") == 0) {
+        c->opt_nn_variant = value;
+        return PPCR_OK;
+    }
+    return fail(c, PPCR_ERR_INVALID, std::string("unknown option: ") + key);
+}
+
+static int set_target_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, int64_t stride)
+{
+    PPCR_TRY(upload_cloud(c, p, dev, n, stride, c->tgt_raw));
+    c->nt = n;
+    c->have_tgt = true;
+    c->grid_valid = false;
+    c->origin_valid = false;
+    invalidate_association(c);
+    return PPCR_OK;
+}
+
+static int set_source_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, int64_t stride)
+{
+    PPCR_TRY(upload_cloud(c, p, dev, n, stride, c->src));
+    c->ns = n;
+    c->have_src = true;
+    c->src_sorted = false;
+    invalidate_association(c);
+    return PPCR_OK;
+}
+
+int ppcr_set_target(ppcr_ctx *c, const float *xyz, int64_t n, int64_t stride_bytes)
+{
+    CTX_ENTER(c);
+    return set_target_common(c, xyz, false, n, stride_bytes);
+}
+int ppcr_set_source(ppcr_ctx *c, const float *xyz, int64_t n, int64_t stride_bytes)
+{
+    CTX_ENTER(c);
+    return set_source_common(c, xyz, false, n, stride_bytes);
+}
+int ppcr_set_target_device(ppcr_ctx *c, const void *d_xyz, int64_t n, int64_t stride_bytes)
+{
+    CTX_ENTER(c);
+    return set_target_common(c, d_xyz, true, n, stride_bytes);
+}
+int ppcr_set_source_device(ppcr_ctx *c, const void *d_xyz, int64_t n, int64_t stride_bytes)
+{
+    CTX_ENTER(c);
+    return set_source_common(c, d_xyz, true, n, stride_bytes);
+}
+
+int ppcr_associate(ppcr_ctx *c)
+{
+    CTX_ENTER(c);
+    if (!c->have_src || !c->have_tgt) return fail(c, PPCR_ERR_STATE, "set source and target before ppcr_associate");
+    return associate_impl(c);
+}
+
+int ppcr_association_size(ppcr_ctx *c, int64_t *n_rows, int64_t *nnz)
+{
+    CTX_ENTER(c);
+    PPCR_TRY(ensure_nnz(c));
+    if (n_rows) *n_rows = c->ns;
+    if (nnz) *nnz = c->nnz;
+    return PPCR_OK;
+}
+
+int ppcr_get_association(ppcr_ctx *c, int32_t *row_ptr, int32_t *col, float *d2)
+{
+    CTX_ENTER(c);
+    PPCR_TRY(build_csr_cache(c));
+    const size_t ns = (size_t)c->ns, nnz = c->h_csr_col.size();
+    if (row_ptr) std::memcpy(row_ptr, c->h_csr_row_ptr.data(), sizeof(int) * (ns + 1));
+    if (col && nnz) std::memcpy(col, c->h_csr_col.data(), sizeof(int) * nnz);
+    if (d2 && nnz) {
+        // recomputed from the CURRENT source positions with the kernel's exact float op order
+        std::vector<float4> hs(ns), ht((size_t)c->nt);
+        HIP_TRY(c, hipMemcpyAsync(hs.data(), c->src.p, sizeof(float4) * ns, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(ht.data(), c->tgt_cur(), sizeof(float4) * (size_t)c->nt, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        std::vector<float4> so(ns), to((size_t)c->nt);
+        for (size_t r = 0; r < ns; r++) { int o; std::memcpy(&o, &hs[r].w, 4); so[(size_t)o] = hs[r]; }
+        for (size_t r = 0; r < (size_t)c->nt; r++) { int o; std::memcpy(&o, &ht[r].w, 4); to[(size_t)o] = ht[r]; }
+        for (size_t i = 0; i < ns; i++)
+            for (int k = c->h_csr_row_ptr[i]; k < c->h_csr_row_ptr[i + 1]; k++) {
+                const float4 a = so[i], b = to[(size_t)c->h_csr_col[(size_t)k]];
+                volatile float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+                volatile float r = dx * dx;
+                volatile float yy = dy * dy;
+                r = r + yy;
+                volatile float zz = dz * dz;
+                r = r + zz;
+                d2[k] = r;
+            }
+    }
+    return PPCR_OK;
+}
+
+int ppcr_set_association(ppcr_ctx *c, const int32_t *row_ptr, const int32_t *col, int64_t n_rows)
+{
+    CTX_ENTER(c);
+    if (!c->have_src || !c->have_tgt) return fail(c, PPCR_ERR_STATE, "set source and target before ppcr_set_association");
+    if (n_rows != c->ns) return fail(c, PPCR_ERR_INVALID, "n_rows must equal the source size");
+    if (!row_ptr) return fail(c, PPCR_ERR_INVALID, "null row_ptr");
+    const int64_t ns = c->ns;
+    if (row_ptr[0] != 0) return fail(c, PPCR_ERR_INVALID, "row_ptr[0] must be 0");
+    int maxlen = 0;
+    for (int64_t i = 0; i < ns; i++) {
+        const int len = row_ptr[i + 1] - row_ptr[i];
+        if (len < 0) return fail(c, PPCR_ERR_INVALID, "row_ptr must be non-decreasing");
+        maxlen = std::max(maxlen, len);
+    }
+    const int64_t nnz = row_ptr[ns];
+    if (nnz > 0 && !col) return fail(c, PPCR_ERR_INVALID, "null col");
+    for (int64_t k = 0; k < nnz; k++)
+        if (col[k] < 0 || col[k] >= c->nt) return fail(c, PPCR_ERR_INVALID, "column index out of range");
+    invalidate_association(c);
+    std::vector<int> src_order, tgt_order;
+    PPCR_TRY(download_order(c, c->src.p, ns, src_order));
+    PPCR_TRY(download_order(c, c->tgt_cur(), c->nt, tgt_order));
+    std::vector<int> src_pos((size_t)ns), tgt_pos((size_t)c->nt);
+    for (int64_t r = 0; r < ns; r++) src_pos[(size_t)src_order[(size_t)r]] = (int)r;
+    for (int64_t r = 0; r < c->nt; r++) tgt_pos[(size_t)tgt_order[(size_t)r]] = (int)r;
+    c->h_csr_row_ptr.assign(row_ptr, row_ptr + ns + 1);
+    c->h_csr_col.assign(col, col + nnz);
+    c->h_csr_slot.resize((size_t)nnz);
+    if (maxlen <= kEllMaxWidth) {
+        const int w = std::max(maxlen, 1);
+        std::vector<int> h_nbr((size_t)w * (size_t)std::max<int64_t>(ns, 1), -1), h_cnt((size_t)std::max<int64_t>(ns, 1), 0);
+        for (int64_t i = 0; i < ns; i++) {
+            const int r = src_pos[(size_t)i];
+            h_cnt[(size_t)r] = row_ptr[i + 1] - row_ptr[i];
+            for (int k = row_ptr[i]; k < row_ptr[i + 1]; k++) {
+                const size_t sl = (size_t)(k - row_ptr[i]) * (size_t)ns + (size_t)r;
+                h_nbr[sl] = tgt_pos[(size_t)col[k]];
+                c->h_csr_slot[(size_t)k] = sl;
+            }
+        }
+        HIP_TRY(c, c->nbr.reserve(h_nbr.size()));
+        HIP_TRY(c, c->cnt.reserve(h_cnt.size()));
+        HIP_TRY(c, hipMemcpyAsync(c->nbr.p, h_nbr.data(), h_nbr.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->cnt.p, h_cnt.data(), h_cnt.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->assoc = ppcr_ctx::ASSOC_ELL;
+        c->ell_width = w;
+    } else {
+        std::vector<int> h_rp((size_t)ns + 1, 0), h_nbr((size_t)std::max<int64_t>(nnz, 1));
+        for (int64_t i = 0; i < ns; i++) h_rp[(size_t)src_pos[(size_t)i] + 1] = row_ptr[i + 1] - row_ptr[i];
+        for (int64_t r = 0; r < ns; r++) h_rp[(size_t)r + 1] += h_rp[(size_t)r];
+        for (int64_t i = 0; i < ns; i++) {
+            const int r = src_pos[(size_t)i];
+            for (int k = row_ptr[i]; k < row_ptr[i + 1]; k++) {
+                const size_t sl = (size_t)h_rp[(size_t)r] + (size_t)(k - row_ptr[i]);
+                h_nbr[sl] = tgt_pos[(size_t)col[k]];
+                c->h_csr_slot[(size_t)k] = sl;
+            }
+        }
+        HIP_TRY(c, c->row_ptr.reserve(h_rp.size()));
+        HIP_TRY(c, c->nbr.reserve(h_nbr.size()));
+        HIP_TRY(c, hipMemcpyAsync(c->row_ptr.p, h_rp.data(), h_rp.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->nbr.p, h_nbr.data(), h_nbr.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->assoc = ppcr_ctx::ASSOC_CSR;
+    }
+    c->nnz = nnz;
+    c->csr_cache_valid = true;
+    return PPCR_OK;
+}
+
+int ppcr_weights(ppcr_ctx *c, const double q[4], const double t[3], double *w_out, double *s_out)
+{
+    CTX_ENTER(c);
+    if (!q || !t) return fail(c, PPCR_ERR_INVALID, "null pose");
+    PPCR_TRY(build_csr_cache(c));
+    const int ns = (int)c->ns;
+    const size_t nnz = c->h_csr_col.size();
+    if (nnz == 0) return PPCR_OK;
+    const size_t slots = (c->assoc == ppcr_ctx::ASSOC_ELL) ? (size_t)c->ell_width * (size_t)ns : (size_t)c->nnz;
+    HIP_TRY(c, c->d_w.reserve(slots));
+    HIP_TRY(c, c->d_s.reserve(slots));
+    const Mat3 R = quat_to_rot(q);
+    const Pose P = make_pose(c, R, t);
+    const Model md = make_model(c);
+    {
+        ProfScope ps(c, K_WEIGHTS);
+        if (c->assoc == ppcr_ctx::ASSOC_ELL) {
+            EllAssoc a{c->nbr.p, c->cnt.p, ns};
+            weights_kernel<EllAssoc><<<nblocks(ns), kBlock, 0, c->stream>>>(a, c->src.p, c->tgt_cur(), ns, P, md, c->d_w.p, c->d_s.p);
+        } else {
+            CsrAssoc a{c->nbr.p, c->row_ptr.p};
+            weights_kernel<CsrAssoc><<<nblocks(ns), kBlock, 0, c->stream>>>(a, c->src.p, c->tgt_cur(), ns, P, md, c->d_w.p, c->d_s.p);
+        }
+    }
+    PPCR_TRY(check_launch(c, "weights_kernel"));
+    std::vector<double> hw(slots), hs(slots);
+    HIP_TRY(c, hipMemcpyAsync(hw.data(), c->d_w.p, slots * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hs.data(), c->d_s.p, slots * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < nnz; k++) {
+        if (w_out) w_out[k] = hw[c->h_csr_slot[k]];
+        if (s_out) s_out[k] = hs[c->h_csr_slot[k]];
+    }
+    return PPCR_OK;
+}
+
+int ppcr_accumulate(ppcr_ctx *c, const double q[4], const double t[3], double sums[PPCR_NSUMS])
+{
+    CTX_ENTER(c);
+    if (!q || !t || !sums) return fail(c, PPCR_ERR_INVALID, "null argument");
+    return run_accumulate(c, quat_to_rot(q), t, sums);
+}
+
+int ppcr_get_origin(ppcr_ctx *c, double o[3])
+{
+    CTX_ENTER(c);
+    if (!o) return fail(c, PPCR_ERR_INVALID, "null argument");
+    for (int a = 0; a < 3; a++) o[a] = c->origin_valid ? c->origin[a] : 0.0;
+    return PPCR_OK;
+}
+
+int ppcr_solve_moments(const double sums[PPCR_NSUMS], const double origin[3], double R[9], double t[3])
+{
+    if (!sums || !origin || !R || !t) return PPCR_ERR_INVALID;
+    const RigidSolve rs = solve_rigid_from_moments(sums, origin);
+    for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) R[3 * a + b] = rs.R.m[a][b];
+        t[a] = rs.t[a];
+    }
+    return rs.degenerate ? 1 : PPCR_OK;
+}
+
+double ppcr_cost_from_moments(const double sums[PPCR_NSUMS], const double origin[3], const double R[9], const double t[3])
+{
+    Mat3 Rm;
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) Rm.m[a][b] = R[3 * a + b];
+    return cost_from_moments(sums, origin, Rm, Vec3{{t[0], t[1], t[2]}});
+}
+
+int ppcr_solve(ppcr_ctx *c, const double q0[4], const double t0[3], int max_steps, double f_tol, double T_out[12],
+               double cost_out[2], int *steps_out)
+{
+    CTX_ENTER(c);
+    if (!q0 || !t0 || !T_out || !cost_out) return fail(c, PPCR_ERR_INVALID, "null argument");
+    return solve_impl(c, q0, t0, max_steps, f_tol, T_out, cost_out, steps_out);
+}
+
+int ppcr_apply_transform(ppcr_ctx *c, const double T[12])
+{
+    CTX_ENTER(c);
+    if (!T) return fail(c, PPCR_ERR_INVALID, "null transform");
+    return apply_transform_impl(c, T);
+}
+
+int ppcr_iterate(ppcr_ctx *c, const double q0[4], const double t0[3], int inner_steps, double f_tol, double T_out[12],
+                 double cost_out[2], int *steps_out)
+{
+    CTX_ENTER(c);
+    if (!q0 || !t0 || !T_out || !cost_out) return fail(c, PPCR_ERR_INVALID, "null argument");
+    if (!c->have_src || !c->have_tgt) return fail(c, PPCR_ERR_STATE, "set source and target before ppcr_iterate");
+    PPCR_TRY(associate_impl(c));
+    PPCR_TRY(solve_impl(c, q0, t0, inner_steps, f_tol, T_out, cost_out, steps_out));
+    return apply_transform_impl(c, T_out);
+}
+
+int ppcr_align(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_drop_it, const double q0[4],
+               const double t0[3], int inner_steps, double f_tol, double *history, double *costs, int32_t *steps,
+               int *n_done)
+{
+    CTX_ENTER(c);
+    if (!q0 || !t0) return fail(c, PPCR_ERR_INVALID, "null argument");
+    if (!c->have_src || !c->have_tgt) return fail(c, PPCR_ERR_STATE, "set source and target before ppcr_align");
+    ConvergenceRule rule;
+    double Tcum[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    while (!rule.has_converged(n_iter, cost_drop_thresh, n_cost_drop_it)) {
+        double Tk[12], cost[2];
+        int st = 0;
+        PPCR_TRY(associate_impl(c));
+        PPCR_TRY(solve_impl(c, q0, t0, inner_steps, f_tol, Tk, cost, &st));
+        PPCR_TRY(apply_transform_impl(c, Tk));
+        compose(Tk, Tcum, Tcum);  // T_cum <- T_k * T_cum (cc:101-107)
+        const int it = rule.current_iteration;
+        if (history) std::memcpy(history + (size_t)it * 12, Tcum, sizeof(Tcum));
+        if (costs) {
+            costs[2 * it] = cost[0];
+            costs[2 * it + 1] = cost[1];
+        }
+        if (steps) steps[it] = st;
+        rule.cost_drop = (cost[0] - cost[1]) / cost[0];  // cc:119
+        rule.current_iteration++;                        // cc:130
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n_done) *n_done = rule.current_iteration;
+    return PPCR_OK;
+}
+
+int ppcr_get_source(ppcr_ctx *c, float *xyz, int64_t stride_bytes)
+{
+    CTX_ENTER(c);
+    if (!c->have_src) return fail(c, PPCR_ERR_STATE, "source cloud not set");
+    if (stride_bytes < 12 || stride_bytes % 4) return fail(c, PPCR_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
+    if (c->ns == 0) return PPCR_OK;
+    if (!xyz) return fail(c, PPCR_ERR_INVALID, "null output");
+    std::vector<float4> h((size_t)c->ns);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->src.p, sizeof(float4) * (size_t)c->ns, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned char *out = reinterpret_cast<unsigned char *>(xyz);
+    for (int64_t r = 0; r < c->ns; r++) {
+        int o;
+        std::memcpy(&o, &h[(size_t)r].w, 4);
+        float *p = reinterpret_cast<float *>(out + (size_t)o * (size_t)stride_bytes);
+        p[0] = h[(size_t)r].x;
+        p[1] = h[(size_t)r].y;
+        p[2] = h[(size_t)r].z;
+    }
+    return PPCR_OK;
+}
+
+int ppcr_synchronize(ppcr_ctx *c)
+{
+    CTX_ENTER(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PPCR_OK;
+}
+
+int ppcr_profile_enable(ppcr_ctx *c, int enable)
+{
+    CTX_ENTER(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto &r : c->prof_recs) {
+        c->prof_pool.push_back(r.start);
+        c->prof_pool.push_back(r.stop);
+    }
+    c->prof_recs.clear();
+    for (int k = 0; k < K_NUM; k++) {
+        c->prof_ms[k] = 0;
+        c->prof_n[k] = 0;
+    }
+    c->prof_on = enable != 0;
+    return PPCR_OK;
+}
+
+int ppcr_profile_get(ppcr_ctx *c, ppcr_kernel_stat *out, int capacity, int *n_out)
+{
+    CTX_ENTER(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto &r : c->prof_recs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+            c->prof_ms[r.id] += ms;
+            c->prof_n[r.id] += 1;
+        }
+        c->prof_pool.push_back(r.start);
+        c->prof_pool.push_back(r.stop);
+    }
+    c->prof_recs.clear();
+    int n = 0;
+    for (int k = 0; k < K_NUM; k++) {
+        if (c->prof_n[k] == 0) continue;
+        if (out && n < capacity) {
+            std::memset(&out[n], 0, sizeof(out[n]));
+            std::snprintf(out[n].name, sizeof(out[n].name), "%s", kKernelNames[k]);
+            out[n].launches = c->prof_n[k];
+            out[n].total_ms = c->prof_ms[k];
+        }
+        n++;
+    }
+    if (n_out) *n_out = n;
+    return PPCR_OK;
+}
+
+}  // extern "C"

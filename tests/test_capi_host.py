@@ -1,0 +1,84 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads, exports every symbol
+include/ppcr.h declares, fails loudly without a GPU, and its host-side closed-form solver agrees
+with the oracle.  No compute kernels are launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import binding as po
+from probabilistic_point_clouds_registration_amd import _lib, build, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "ppcr.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(ppcr_[a-z_0-9]+)\s*\(", header)))
+    assert len(declared) >= 25
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/ppcr.h but not exported"
+    assert sorted(_lib.SYMBOLS) == declared
+    assert lib.ppcr_abi_version() == 1
+
+
+def test_no_silent_cpu_fallback(lib):
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(_lib.PpcrError) as e:
+        _lib.Context(0)
+    assert e.value.code == -5 and "no CPU fallback" in str(e.value)
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libppcr_hip.so")
+    with pytest.raises(ImportError):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    """The shipped package must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "probabilistic_point_clouds_registration_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".cc")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                for needle in ("import oracle", "from oracle", "libppcr_oracle", "ppcr_oracle.c", "po_radius_search"):
+                    assert needle not in txt, (f, needle)
+
+
+def test_host_solver_matches_oracle(lib):
+    rng = np.random.default_rng(1)
+    for trial in range(30):
+        n = 40
+        x = rng.normal(size=(n, 3)) * rng.uniform(0.5, 5) + rng.normal(size=3) * 20
+        Rg = synth.rodrigues(rng.normal(size=3), rng.uniform(0, 3.1))
+        y = x @ Rg.T + rng.normal(size=3) + rng.normal(size=(n, 3)) * 0.02
+        if trial % 5 == 0:
+            x[:, 2] = 1.0                      # planar source: rank-2 cross-covariance
+            y = x @ Rg.T
+        w = rng.uniform(0.1, 1, size=n)
+        c = x.mean(0) + rng.normal(size=3)
+        xc, yc = x - c, y - c
+        S = np.concatenate([[w.sum()], (w[:, None] * xc).sum(0), (w[:, None] * yc).sum(0),
+                            np.einsum("n,na,nb->ab", w, xc, yc).reshape(9), [(w * ((y - x) ** 2).sum(1)).sum()],
+                            [(w * (xc ** 2).sum(1)).sum()], [(w * (yc ** 2).sum(1)).sum()]])
+        R, t, rc = _lib.solve_moments(S, c)
+        Ro, to, rco = po.kabsch(S, c)
+        assert rc == rco == 0
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and np.linalg.det(R) > 0
+        assert synth.rotation_angle(R, Ro) < 1e-10 and np.linalg.norm(t - to) < 1e-9
+        assert abs(_lib.cost_from_moments(S, c, R, t) - po.cost_from_sums(S, c, Ro, to)) < 1e-12 * (S[17] + S[18])
+    R, t, rc = _lib.solve_moments(np.zeros(19), np.zeros(3))
+    assert rc == 1 and np.allclose(R, np.eye(3)) and np.allclose(t, 0)
