@@ -98,6 +98,8 @@ struct ppcr_ctx {
     int dim = 3;
     int opt_sort_source = 1;
     int opt_nn_variant = 0;
+    int opt_stamps = 0;
+    DevBuf<unsigned long long> d_stamps;
 
     // clouds
     int64_t ns = 0, nt = 0;
@@ -225,6 +227,8 @@ Model make_model(const ppcr_ctx *c)
     m.v = c->dof;
     m.texp = -(c->dof + c->dim) / 2.0;
     m.vpd = c->dof + c->dim;
+    m.vpd_int = 0;
+    if (!m.is_normal && m.vpd == std::floor(m.vpd) && m.vpd >= 1 && m.vpd <= 64) m.vpd_int = (int)m.vpd;
     return m;
 }
 
@@ -266,7 +270,7 @@ int upload_cloud(ppcr_ctx *c, const void *ptr, bool on_device, int64_t n, int64_
 }
 
 // sort `n` points of `in` by grid cell into `out` (stable: ties keep ascending original index)
-int sort_by_cell(ppcr_ctx *c, const float4 *in, int n, float4 *out, bool want_cell_start)
+int sort_by_cell(ppcr_ctx *c, const float4 *in, int n, float4 *out, bool want_cell_start, bool brick_order = false)
 {
     HIP_TRY(c, c->keys_a.reserve((size_t)n + 1));
     HIP_TRY(c, c->keys_b.reserve((size_t)n + 1));
@@ -275,11 +279,17 @@ int sort_by_cell(ppcr_ctx *c, const float4 *in, int n, float4 *out, bool want_ce
     if (n > 0) {
         {
             ProfScope ps(c, K_CELL_KEY);
-            cell_key_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(in, n, c->grid, c->keys_a.p, c->vals_a.p);
+            if (brick_order)
+                brick_key_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(in, n, c->grid, c->keys_a.p, c->vals_a.p);
+            else
+                cell_key_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(in, n, c->grid, c->keys_a.p, c->vals_a.p);
         }
         PPCR_TRY(check_launch(c, "cell_key_kernel"));
+        long long nkeys = c->grid.ncells;
+        if (brick_order)
+            nkeys = 64ll * ((c->grid.n[0] + 3) / 4) * ((c->grid.n[1] + 3) / 4) * ((c->grid.n[2] + 3) / 4);
         int end_bit = 1;
-        while (end_bit < 32 && (1ll << end_bit) < (long long)c->grid.ncells) end_bit++;
+        while (end_bit < 32 && (1ll << end_bit) < nkeys) end_bit++;
         size_t tmp_bytes = 0;
         HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, c->keys_a.p, c->keys_b.p, c->vals_a.p,
                                                      c->vals_b.p, n, 0, end_bit, c->stream));
@@ -347,7 +357,8 @@ int ensure_grid(ppcr_ctx *c)
     // cell edge slightly above r: float rounding of the cell index can then never push an
     // in-radius target outside the query's 27-cell stencil
     float h = (float)c->radius * 1.001f + 16.0f * FLT_EPSILON * amax;
-    const double max_cells = 4.0 * (double)n + 4096.0;
+    // table bound: ~4 cells per target point, and small enough that brick-order keys fit 32 bits
+    const double max_cells = std::min(4.0 * (double)n + 4096.0, 67108864.0);
     double ext[3];
     for (int a = 0; a < 3; a++) ext[a] = (double)hi[a] - (double)lo[a];
     for (;;) {
@@ -378,18 +389,39 @@ int ensure_source_sorted(ppcr_ctx *c)
     if (c->src_sorted || !c->opt_sort_source || c->ns == 0) return PPCR_OK;
     invalidate_association(c);
     HIP_TRY(c, c->src_alt.reserve((size_t)c->ns));
-    PPCR_TRY(sort_by_cell(c, c->src.p, (int)c->ns, c->src_alt.p, false));
+    PPCR_TRY(sort_by_cell(c, c->src.p, (int)c->ns, c->src_alt.p, false, c->opt_sort_source == 1));
     std::swap(c->src, c->src_alt);
     c->src_sorted = true;
     return PPCR_OK;
 }
 
+// nn_variant: 0/3 = LDS-tiled halo + med3 selection (default), 2 = per-lane global scan + LDS list,
+// 1 = sorted register list inside the scan loop (first version, kept for A/B measurements)
 template <int M>
 void launch_topm(ppcr_ctx *c, float r2, int m)
 {
-    nn_topm_kernel<M><<<nblocks(c->ns), kBlock, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p,
-                                                                 c->cell_start.p, c->grid, r2, m, c->nbr.p,
-                                                                 c->cnt.p);
+    if (c->opt_nn_variant == 0 || c->opt_nn_variant == 3) {
+        constexpr int C = (M <= 24) ? 32 : 48;
+        nn_tile_kernel<M, C><<<nblocks(c->ns), kBlock, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p,
+                                                                        c->cell_start.p, c->grid, r2, m, c->nbr.p,
+                                                                        c->cnt.p, c->opt_stamps ? c->d_stamps.p : nullptr);
+    } else if (c->opt_nn_variant == 1) {
+        nn_topm_kernel<M><<<nblocks(c->ns), kBlock, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p,
+                                                                     c->cell_start.p, c->grid, r2, m, c->nbr.p,
+                                                                     c->cnt.p);
+    } else {
+        constexpr int C = (M <= 24) ? 32 : 48;
+        nn_list_kernel<M, C><<<nblocks(c->ns), kBlock, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p,
+                                                                        c->cell_start.p, c->grid, r2, m, c->nbr.p,
+                                                                        c->cnt.p);
+    }
+}
+
+template <int W>
+void launch_accumulate_ell(ppcr_ctx *c, int nb, const Pose &P, const Model &md)
+{
+    accumulate_ell_kernel<W><<<nb, kBlock, 0, c->stream>>>(c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md,
+                                                           c->partials.p);
 }
 
 int associate_impl(ppcr_ctx *c)
@@ -598,7 +630,15 @@ int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PP
     HIP_TRY(c, c->d_sums.reserve(kNSums));
     {
         ProfScope ps(c, K_ACCUMULATE);
-        if (c->assoc == ppcr_ctx::ASSOC_ELL) {
+        if (c->assoc == ppcr_ctx::ASSOC_ELL && c->nt > 0) {
+            const int w = c->ell_width;
+            if (w <= 4) launch_accumulate_ell<4>(c, nb, P, md);
+            else if (w <= 8) launch_accumulate_ell<8>(c, nb, P, md);
+            else if (w <= 10) launch_accumulate_ell<10>(c, nb, P, md);
+            else if (w <= 16) launch_accumulate_ell<16>(c, nb, P, md);
+            else if (w <= 20) launch_accumulate_ell<20>(c, nb, P, md);
+            else launch_accumulate_ell<32>(c, nb, P, md);
+        } else if (c->assoc == ppcr_ctx::ASSOC_ELL) {
             EllAssoc a{c->nbr.p, c->cnt.p, ns};
             accumulate_kernel<EllAssoc><<<nb, kBlock, 0, c->stream>>>(a, c->src.p, c->tgt_cur(), ns, P, md, c->partials.p);
         } else {
@@ -609,7 +649,7 @@ int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PP
     PPCR_TRY(check_launch(c, "accumulate_kernel"));
     {
         ProfScope ps(c, K_REDUCE);
-        reduce_partials_kernel<<<1, kBlock, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p);
+        reduce_partials_kernel<<<1, 1024, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p);
     }
     PPCR_TRY(check_launch(c, "reduce_partials_kernel"));
     HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->d_sums.p, sizeof(double) * kNSums, hipMemcpyDeviceToHost, c->stream));
@@ -747,6 +787,7 @@ int ppcr_destroy(ppcr_ctx *c)
     c->gen_pos.release();
     c->gen_keys.release();
     c->d_total.release();
+    c->d_stamps.release();
     c->partials.release();
     c->d_sums.release();
     c->d_w.release();
@@ -783,11 +824,18 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
     if (std::strcmp(key, "sort_source") == 0) {
         if (c->have_src && c->src_sorted && !value)
             return fail(c, PPCR_ERR_STATE, "sort_source can only be switched off before the source has been sorted");
-        c->opt_sort_source = value ? 1 : 0;
+        c->opt_sort_source = value;  // 0 = keep caller order, 1 = brick/snake order (default), 2 = x-fastest cell order
         return PPCR_OK;
     }
     if (std::strcmp(key, "nn_variant") == 0) {
         c->opt_nn_variant = value;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "stamps") == 0) {  // diagnostic: per-phase cycle totals of nn_tile_kernel
+        const size_t nst = (size_t)(nblocks(std::max<int64_t>(c->ns, 1)) * (kBlock / 64)) * 8;
+        HIP_TRY(c, c->d_stamps.reserve(nst));
+        HIP_TRY(c, hipMemsetAsync(c->d_stamps.p, 0, nst * sizeof(unsigned long long), c->stream));
+        c->opt_stamps = value;
         return PPCR_OK;
     }
     return fail(c, PPCR_ERR_INVALID, std::string("unknown option: ") + key);
@@ -1099,6 +1147,20 @@ int ppcr_get_source(ppcr_ctx *c, float *xyz, int64_t stride_bytes)
         p[1] = h[(size_t)r].y;
         p[2] = h[(size_t)r].z;
     }
+    return PPCR_OK;
+}
+
+// diagnostic (tools/exp_stamps.py): out[8] = per-phase cycle totals over all waves of nn_tile_kernel
+int ppcr_debug_get_stamps(ppcr_ctx *c, unsigned long long out[8])
+{
+    CTX_ENTER(c);
+    if (!c->d_stamps.p) return fail(c, PPCR_ERR_STATE, "stamps not enabled");
+    const size_t nst = (size_t)(nblocks(std::max<int64_t>(c->ns, 1)) * (kBlock / 64)) * 8;
+    std::vector<unsigned long long> h(nst);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_stamps.p, nst * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    for (size_t i = 0; i < nst; i++) out[i % 8] += h[i];
     return PPCR_OK;
 }
 

@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <limits.h>
 
 namespace ppcr {
 namespace dev {
@@ -34,6 +35,7 @@ struct Pose {  // y ~ R x + t ; c = fixed origin of the moments
 
 struct Model {  // ProbabilisticWeights constants (probabilistic_weights.hpp:30-46)
     int is_normal;
+    int vpd_int;   // v + dim when that is an integer in [1,64], else 0 (hot-path fast power)
     double v;      // dof
     double texp;   // -(v + dim)/2
     double vpd;    // v + dim
@@ -109,6 +111,29 @@ __global__ void cell_key_kernel(const float4 *__restrict__ pts, int n, GridDesc 
     int cy = clampi(cell_coord(p.y, g.org[1], g.inv_h, g.n[1]), 0, g.n[1] - 1);
     int cz = clampi(cell_coord(p.z, g.org[2], g.inv_h, g.n[2]), 0, g.n[2] - 1);
     keys[i] = (unsigned)((cz * g.n[1] + cy) * g.n[0] + cx);
+    vals[i] = i;
+}
+
+// Source ordering: 4x4x4-cell bricks visited boustrophedon (x snakes per brick row, y snakes per
+// brick plane), cells x-fastest inside a brick.  Any 256 consecutive queries then sit in one or two
+// ADJACENT bricks, so the cell bounding box of a workgroup — and with it the target halo it stages
+// into LDS (nn_tile_kernel) — stays small.  Only the order of the source changes, never a result.
+__global__ void brick_key_kernel(const float4 *__restrict__ pts, int n, GridDesc g,
+                                 unsigned *__restrict__ keys, int *__restrict__ vals)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pts[i];
+    const int cx = clampi(cell_coord(p.x, g.org[0], g.inv_h, g.n[0]), 0, g.n[0] - 1);
+    const int cy = clampi(cell_coord(p.y, g.org[1], g.inv_h, g.n[1]), 0, g.n[1] - 1);
+    const int cz = clampi(cell_coord(p.z, g.org[2], g.inv_h, g.n[2]), 0, g.n[2] - 1);
+    const int nbx = (g.n[0] + 3) >> 2, nby = (g.n[1] + 3) >> 2;
+    const int bx = cx >> 2, by = cy >> 2, bz = cz >> 2;
+    const int byy = (bz & 1) ? nby - 1 - by : by;
+    const int row = bz * nby + byy;
+    const int bxx = (row & 1) ? nbx - 1 - bx : bx;
+    const unsigned brick = (unsigned)(row * nbx + bxx);
+    keys[i] = (brick << 6) | (unsigned)(((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3));
     vals[i] = i;
 }
 
@@ -236,6 +261,449 @@ __global__ __launch_bounds__(kBlock) void nn_topm_kernel(const float4 *__restric
     cnt[i] = c;
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1, list variant (default).  Measured on MI355X: the candidate scan alone costs ~90 us at
+// 1M<->1M while keeping a sorted top-m list inside the scan loop costs another ~320 us (every
+// step some lane of the wave inserts, so the whole wave pays the insertion).  So the scan only
+// APPENDS in-radius candidates to a lane-private list in LDS ([slot][lane]: conflict-free) and
+// the cut-off is applied afterwards:
+//   pass A  threshold T = m-th smallest d2 of the list, by inserting the d2 bit patterns into a
+//           sorted register list with v_med3_u32:  L'_j = med3(L_{j-1}, k, L_j)  — one
+//           instruction per slot and no carry chain (the list stays sorted, duplicates allowed);
+//   pass B  keep the entries with d2 <= T (in place);
+//   ties    only if more entries tie at T than there is room for: keep the tied entries with the
+//           smallest original target index (same med3 trick on the indices) — the oracle's
+//           (d2, index) order, exactly.
+// A list that fills up (C entries) is compacted on the spot and the lane's acceptance
+// threshold drops to T, so dense neighbourhoods cost a few compactions instead of overflowing.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <int M>
+__device__ __forceinline__ void sorted_insert(unsigned (&K)[M], unsigned k)
+{
+#pragma unroll
+    for (int j = M - 1; j >= 1; --j) K[j] = umed3(K[j - 1], k, K[j]);
+    K[0] = min(K[0], k);
+}
+
+template <int M>
+__device__ __forceinline__ unsigned pick(const unsigned (&K)[M], int j)
+{
+    unsigned r = 0;
+#pragma unroll
+    for (int a = 0; a < M; a++) r = (a == j) ? K[a] : r;
+    return r;
+}
+
+template <int M, int C>
+__global__ __launch_bounds__(kBlock) void nn_list_kernel(const float4 *__restrict__ src, int ns,
+                                                         const float4 *__restrict__ tgt,
+                                                         const int *__restrict__ cell_start, GridDesc g,
+                                                         float r2, int m, int *__restrict__ nbr,
+                                                         int *__restrict__ cnt)
+{
+    static_assert(C > M, "a compaction must leave room in the list");
+    __shared__ int lpos[C * kBlock];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kBlock + tid;
+    if (i >= ns) return;  // lists are lane-private: no block-level synchronisation anywhere
+    const float4 q = src[i];
+    int n = 0;
+    unsigned thr = 0xFFFFFFFFu;
+
+    // reduce the lane's list to its top-m by (d2, original index); n > m on entry
+    auto select_top_m = [&]() {
+        unsigned K[M];
+#pragma unroll
+        for (int j = 0; j < M; j++) K[j] = 0xFFFFFFFFu;
+        for (int t = 0; t < n; t++) {
+            const float4 c = tgt[lpos[t * kBlock + tid]];
+            sorted_insert<M>(K, __float_as_uint(dist2_flann(q, c)));
+        }
+        const unsigned T = pick<M>(K, m - 1);
+        int w = 0, c_eq = 0;
+        for (int t = 0; t < n; t++) {
+            const int p = lpos[t * kBlock + tid];
+            const unsigned b = __float_as_uint(dist2_flann(q, tgt[p]));
+            if (b <= T) {
+                lpos[w * kBlock + tid] = p;
+                w++;
+                c_eq += (b == T) ? 1 : 0;
+            }
+        }
+        if (w > m) {  // more ties at the cut-off than room: lowest original indices win
+            const int need = m - (w - c_eq);
+#pragma unroll
+            for (int j = 0; j < M; j++) K[j] = 0xFFFFFFFFu;
+            for (int t = 0; t < w; t++) {
+                const float4 c = tgt[lpos[t * kBlock + tid]];
+                if (__float_as_uint(dist2_flann(q, c)) == T) sorted_insert<M>(K, (unsigned)__float_as_int(c.w));
+            }
+            const unsigned T2 = pick<M>(K, need - 1);
+            int w2 = 0;
+            for (int t = 0; t < w; t++) {
+                const int p = lpos[t * kBlock + tid];
+                const float4 c = tgt[p];
+                const unsigned b = __float_as_uint(dist2_flann(q, c));
+                if (b < T || (unsigned)__float_as_int(c.w) <= T2) {
+                    lpos[w2 * kBlock + tid] = p;
+                    w2++;
+                }
+            }
+            w = w2;
+        }
+        n = w;
+        thr = T;
+    };
+
+    for_each_candidate(q, g, cell_start, tgt, [&](int p, float4 t) {
+        const float d2 = dist2_flann(q, t);
+        if (d2 < r2 && __float_as_uint(d2) <= thr) {
+            lpos[n * kBlock + tid] = p;
+            n++;
+            if (n == C) select_top_m();
+        }
+    });
+    if (n > m) select_top_m();
+    for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = lpos[j * kBlock + tid];
+    cnt[i] = n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1, tiled variant (default).  rocprofv3 on the list variant: the scan is bound by the texture
+// address path (TA busy 79 %, 16 cycles per 64-lane dwordx4 load: every distance test pulls 16 B
+// per lane through L1) and its selection passes re-gather lines L1 has already evicted.  So the
+// candidates are staged in LDS instead:
+//   1. the workgroup's 256 (spatially compact) queries -> bounding box in cells, +-1 cell halo;
+//   2. every halo row (fixed y,z; contiguous in the cell-sorted target) is copied into LDS with
+//      lane-contiguous 16-byte loads — each target point is fetched once per workgroup;
+//   3. each lane walks ITS OWN 27-cell stencil (9 runs) out of LDS (ds_read_b128) — the exact
+//      candidate set, no extra distance tests;
+//   4. in-radius candidates are appended to a lane-private u16 list of LDS indices; the top-m
+//      cut-off is applied afterwards with the v_med3 threshold selection (see nn_list_kernel),
+//      now reading LDS only.
+// A halo that does not fit (sparse or unsorted source) is retried per wave, and as a last resort
+// the wave falls back to scanning global memory with the same selection code.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTileCap = 2048;   // staged candidates per halo (32 KiB)
+constexpr int kTileRows = 128;   // halo rows per staging
+
+struct LdsCands {  // candidate source = staged halo; list entries are LDS indices
+    const float4 *cand;
+    unsigned short *list;  // [slot * kBlock + tid]
+    int tid;
+    __device__ __forceinline__ float4 get(int e) const { return cand[e]; }
+    __device__ __forceinline__ int load(int t) const { return list[t * kBlock + tid]; }
+    __device__ __forceinline__ void store(int t, int e) const { list[t * kBlock + tid] = (unsigned short)e; }
+    __device__ __forceinline__ int pos_of(int e) const { return __float_as_int(cand[e].w); }
+    __device__ __forceinline__ unsigned orig_of(int e, const float4 *__restrict__ tgt) const
+    {
+        return (unsigned)__float_as_int(tgt[__float_as_int(cand[e].w)].w);
+    }
+};
+struct GlobalCands {  // candidate source = global memory; list entries are sorted-target positions
+    const float4 *tgt;
+    int *list;  // [slot * 64 + lane]
+    int lane;
+    __device__ __forceinline__ float4 get(int e) const { return tgt[e]; }
+    __device__ __forceinline__ int load(int t) const { return list[t * 64 + lane]; }
+    __device__ __forceinline__ void store(int t, int e) const { list[t * 64 + lane] = e; }
+    __device__ __forceinline__ int pos_of(int e) const { return e; }
+    __device__ __forceinline__ unsigned orig_of(int e, const float4 *__restrict__) const
+    {
+        return (unsigned)__float_as_int(tgt[e].w);
+    }
+};
+
+// reduce a lane's list (n > m entries) to its top-m by (d2, original index); returns the new n and
+// the threshold T (bit pattern of the m-th smallest d2)
+template <int M, class S>
+__device__ __forceinline__ int select_top_m(const S &src, const float4 *__restrict__ tgt, float4 q, int n, int m,
+                                            unsigned &thr)
+{
+    unsigned K[M];
+#pragma unroll
+    for (int j = 0; j < M; j++) K[j] = 0xFFFFFFFFu;
+    for (int t = 0; t < n; t++) sorted_insert<M>(K, __float_as_uint(dist2_flann(q, src.get(src.load(t)))));
+    const unsigned T = pick<M>(K, m - 1);
+    int w = 0, c_eq = 0;
+    for (int t = 0; t < n; t++) {
+        const int e = src.load(t);
+        const unsigned b = __float_as_uint(dist2_flann(q, src.get(e)));
+        if (b <= T) {
+            src.store(w, e);
+            w++;
+            c_eq += (b == T) ? 1 : 0;
+        }
+    }
+    if (w > m) {  // more ties at the cut-off than room: lowest original target indices win
+        const int need = m - (w - c_eq);
+#pragma unroll
+        for (int j = 0; j < M; j++) K[j] = 0xFFFFFFFFu;
+        for (int t = 0; t < w; t++) {
+            const int e = src.load(t);
+            if (__float_as_uint(dist2_flann(q, src.get(e))) == T) sorted_insert<M>(K, src.orig_of(e, tgt));
+        }
+        const unsigned T2 = pick<M>(K, need - 1);
+        int w2 = 0;
+        for (int t = 0; t < w; t++) {
+            const int e = src.load(t);
+            const unsigned b = __float_as_uint(dist2_flann(q, src.get(e)));
+            if (b < T || src.orig_of(e, tgt) <= T2) {
+                src.store(w2, e);
+                w2++;
+            }
+        }
+        w = w2;
+    }
+    thr = T;
+    return w;
+}
+
+template <int M, int C>
+__global__ __launch_bounds__(kBlock) void nn_tile_kernel(const float4 *__restrict__ src, int ns,
+                                                         const float4 *__restrict__ tgt,
+                                                         const int *__restrict__ cell_start, GridDesc g,
+                                                         float r2, int m, int *__restrict__ nbr,
+                                                         int *__restrict__ cnt,
+                                                         unsigned long long *__restrict__ stamps)
+{
+    static_assert(C > M, "a compaction must leave room in the list");
+    static_assert(C * 64 * 4 <= kTileCap * 16, "the global fallback aliases the candidate buffer");
+    static_assert(kTileRows == 128, "row table: two rows per lane of one wave");
+    constexpr int kWaves = kBlock / 64;
+    constexpr int kStageUnroll = 8;  // halo rows in flight per wave
+    // diagnostic only (stamps == nullptr in every timed run): per-wave, per-phase cycle counts kept in
+    // registers and written once at exit to stamps[(block * waves + wave) * 8 + phase]
+    unsigned long long t_prev = stamps ? clock64() : 0;
+    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int phase) {
+        if (stamps) {
+            const unsigned long long now = clock64();
+#pragma unroll
+            for (int k = 0; k < 8; k++) t_acc[k] += (k == phase) ? now - t_prev : 0ull;
+            t_prev = now;
+        }
+    };
+    auto flush_stamps = [&]() {
+        if (stamps && (threadIdx.x & 63) == 0)
+            for (int k = 0; k < 8; k++) stamps[((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 + k] = t_acc[k];
+    };
+    __shared__ float4 s_cand[kTileCap];
+    __shared__ unsigned short s_list[C * kBlock];
+    __shared__ int s_row_gb[kTileRows];
+    __shared__ int s_row_off[kTileRows + 1];
+    __shared__ int s_wlo[kWaves][3], s_whi[kWaves][3];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = blockIdx.x * kBlock + tid;
+    const bool valid = i < ns;
+    const float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const QueryCells qc = query_cells(q, g);
+
+    // this lane's 9 stencil runs [rb, re) in sorted-target positions: issued now, consumed after the
+    // halo has been staged, so their latency hides behind the staging phase
+    const int x0 = max(qc.cx - 1, 0), x1 = min(qc.cx + 1, g.n[0] - 1);
+    int rb[9], re[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int cz = qc.cz + (k / 3 - 1), cy = qc.cy + (k % 3 - 1);
+        const bool in = valid && x0 <= x1 && (unsigned)cz < (unsigned)g.n[2] && (unsigned)cy < (unsigned)g.n[1];
+        const int base = in ? (cz * g.n[1] + cy) * g.n[0] : 0;
+        rb[k] = in ? cell_start[base + x0] : 0;
+        re[k] = in ? cell_start[base + x1 + 1] : 0;
+    }
+
+    // per-wave bounding box of the query cells
+    {
+        int lo[3] = {valid ? qc.cx : INT_MAX, valid ? qc.cy : INT_MAX, valid ? qc.cz : INT_MAX};
+        int hi[3] = {valid ? qc.cx : INT_MIN, valid ? qc.cy : INT_MIN, valid ? qc.cz : INT_MIN};
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+            for (int off = 32; off > 0; off >>= 1) {
+                lo[a] = min(lo[a], __shfl_xor(lo[a], off));
+                hi[a] = max(hi[a], __shfl_xor(hi[a], off));
+            }
+        if (lane == 0)
+            for (int a = 0; a < 3; a++) {
+                s_wlo[wave][a] = lo[a];
+                s_whi[wave][a] = hi[a];
+            }
+    }
+    __syncthreads();
+    stamp(0);
+
+    int n = 0;
+    bool done = !valid;
+    bool whole_ok = false;
+    // pass 0: the four waves share one halo; passes 1..4 (only if that did not fit): one wave each
+    for (int pass = 0; pass < 1 + kWaves; pass++) {
+        if (pass > 0 && whole_ok) break;
+        const int w0 = (pass == 0) ? 0 : pass - 1, w1 = (pass == 0) ? kWaves : pass;
+        int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+        for (int w = w0; w < w1; w++)
+            for (int a = 0; a < 3; a++) {
+                lo[a] = min(lo[a], s_wlo[w][a]);
+                hi[a] = max(hi[a], s_whi[w][a]);
+            }
+        const bool any = lo[0] <= hi[0];  // at least one valid query among these waves
+        const int hx0 = max(lo[0] - 1, 0), hx1 = min(hi[0] + 1, g.n[0] - 1);
+        const int hy0 = max(lo[1] - 1, 0), hy1 = min(hi[1] + 1, g.n[1] - 1);
+        const int hz0 = max(lo[2] - 1, 0), hz1 = min(hi[2] + 1, g.n[2] - 1);
+        const int ny_h = hy1 - hy0 + 1, nz_h = hz1 - hz0 + 1;
+        const bool empty = !any || hx0 > hx1 || ny_h <= 0 || nz_h <= 0;
+        const long long nrows_ll = empty ? 0 : (long long)ny_h * nz_h;
+        const bool rows_ok = nrows_ll <= kTileRows;
+        const int nrows = rows_ok ? (int)nrows_ll : 0;
+
+        // Row table, built redundantly by every wave in registers (no barrier before the staging):
+        // lane l owns halo rows 2l and 2l+1: global begin, length, exclusive prefix of the lengths.
+        int gbA = 0, gbB = 0, lenA = 0, lenB = 0;
+        {
+            const int rA = 2 * lane, rB = 2 * lane + 1;
+            if (rA < nrows) {
+                const int base = ((hz0 + rA / ny_h) * g.n[1] + hy0 + rA % ny_h) * g.n[0];
+                gbA = cell_start[base + hx0];
+                lenA = cell_start[base + hx1 + 1] - gbA;
+            }
+            if (rB < nrows) {
+                const int base = ((hz0 + rB / ny_h) * g.n[1] + hy0 + rB % ny_h) * g.n[0];
+                gbB = cell_start[base + hx0];
+                lenB = cell_start[base + hx1 + 1] - gbB;
+            }
+        }
+        int incl = lenA + lenB;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        const int offA = incl - lenA - lenB, offB = offA + lenA;
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        const bool ok = rows_ok && total <= kTileCap;
+        if (pass == 0) whole_ok = ok;
+        stamp(1);
+        if (ok) {
+            if (wave == w0) {  // one wave publishes the table for the scan phase
+                s_row_gb[2 * lane] = gbA;
+                s_row_gb[2 * lane + 1] = gbB;
+                s_row_off[2 * lane] = offA;
+                s_row_off[2 * lane + 1] = offB;
+                if (lane == 63) s_row_off[kTileRows] = incl;
+            }
+            // stage the halo: one wave per row, lane-contiguous 16-byte loads, kStageUnroll rows in flight
+            for (int k0 = 0; wave + kWaves * k0 < nrows; k0 += kStageUnroll) {
+                float4 c[kStageUnroll];
+                int so[kStageUnroll], sl[kStageUnroll], sg[kStageUnroll];
+#pragma unroll
+                for (int u = 0; u < kStageUnroll; u++) {
+                    const int r = wave + kWaves * (k0 + u);
+                    const int rr = min(r, kTileRows - 1);
+                    const int gA = __builtin_amdgcn_readlane(gbA, rr >> 1), gB = __builtin_amdgcn_readlane(gbB, rr >> 1);
+                    const int oA = __builtin_amdgcn_readlane(offA, rr >> 1), oB = __builtin_amdgcn_readlane(offB, rr >> 1);
+                    const int lA = __builtin_amdgcn_readlane(lenA, rr >> 1), lB = __builtin_amdgcn_readlane(lenB, rr >> 1);
+                    sg[u] = (rr & 1) ? gB : gA;
+                    so[u] = (rr & 1) ? oB : oA;
+                    sl[u] = (r < nrows) ? ((rr & 1) ? lB : lA) : 0;
+                    c[u] = tgt[(lane < sl[u]) ? sg[u] + lane : 0];  // unconditional load (slot 0 always exists)
+                }
+#pragma unroll
+                for (int u = 0; u < kStageUnroll; u++) {
+                    if (lane < sl[u]) {
+                        c[u].w = __int_as_float(sg[u] + lane);  // sorted-target position travels in the w lane
+                        s_cand[so[u] + lane] = c[u];
+                    }
+                    for (int k = lane + 64; k < sl[u]; k += 64) {  // rows longer than a wave (dense data)
+                        float4 t = tgt[sg[u] + k];
+                        t.w = __int_as_float(sg[u] + k);
+                        s_cand[so[u] + k] = t;
+                    }
+                }
+            }
+            __syncthreads();
+            stamp(2);
+            if (!done && wave >= w0 && wave < w1) {
+                const LdsCands L{s_cand, s_list, tid};
+                unsigned thr = 0xFFFFFFFFu;
+                auto test = [&](int f) {
+                    const float d2 = dist2_flann(q, s_cand[f]);
+                    if (d2 < r2 && __float_as_uint(d2) <= thr) {
+                        L.store(n, f);
+                        n++;
+                        if (n == C) n = select_top_m<M>(L, tgt, q, n, m, thr);
+                    }
+                };
+#pragma unroll 1
+                for (int k = 0; k < 9; k++) {
+                    // take the next prefetched run; rotate the register file instead of indexing it
+                    const int b = rb[0], e = re[0];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        rb[u] = rb[u + 1];
+                        re[u] = re[u + 1];
+                    }
+                    if (b >= e) continue;
+                    const int r = (qc.cz + (k / 3 - 1) - hz0) * ny_h + (qc.cy + (k % 3 - 1) - hy0);
+                    const int fb = s_row_off[r] + (b - s_row_gb[r]), fe = fb + (e - b);
+                    int f = fb;
+                    for (; f + 1 < fe; f += 2) {  // two candidates per trip: both LDS reads in flight
+                        const float4 c0 = s_cand[f], c1 = s_cand[f + 1];
+                        const float d0 = dist2_flann(q, c0), d1 = dist2_flann(q, c1);
+                        if (d0 < r2 && __float_as_uint(d0) <= thr) {
+                            L.store(n, f);
+                            n++;
+                            if (n == C) n = select_top_m<M>(L, tgt, q, n, m, thr);
+                        }
+                        if (d1 < r2 && __float_as_uint(d1) <= thr) {
+                            L.store(n, f + 1);
+                            n++;
+                            if (n == C) n = select_top_m<M>(L, tgt, q, n, m, thr);
+                        }
+                    }
+                    if (f < fe) test(f);
+                }
+                stamp(3);
+                if (n > m) n = select_top_m<M>(L, tgt, q, n, m, thr);
+                stamp(4);
+                for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = L.pos_of(L.load(j));
+                cnt[i] = n;
+                done = true;
+                stamp(5);
+            }
+            if (pass == 0) break;  // common case: nothing left to do, no trailing barrier
+            __syncthreads();       // the halo buffer is reused by the next pass
+            stamp(6);
+        } else if (pass > 0) {
+            // last resort for this wave: scan global memory (list of positions aliases the halo buffer)
+            if (!done && wave == w0) {
+                const GlobalCands G{tgt, reinterpret_cast<int *>(s_cand), lane};
+                unsigned thr = 0xFFFFFFFFu;
+                for_each_candidate(q, g, cell_start, tgt, [&](int p, float4 t) {
+                    const float d2 = dist2_flann(q, t);
+                    if (d2 < r2 && __float_as_uint(d2) <= thr) {
+                        G.store(n, p);
+                        n++;
+                        if (n == C) n = select_top_m<M>(G, tgt, q, n, m, thr);
+                    }
+                });
+                if (n > m) n = select_top_m<M>(G, tgt, q, n, m, thr);
+                for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = G.load(j);
+                cnt[i] = n;
+                done = true;
+            }
+            __syncthreads();
+            stamp(7);
+        }
+    }
+    flush_stamps();
+}
+
 // Generic path (unbounded, or max_neighbours above the register-list variants):
 //   count -> exclusive scan -> fill (keys + positions) [-> per-row select of the m smallest]
 __global__ void nn_count_kernel(const float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt,
@@ -310,10 +778,17 @@ __global__ void csr_compact_kernel(int ns, const int *__restrict__ row_ptr_in, c
 
 __global__ void ell_count_sum_kernel(const int *__restrict__ cnt, int ns, unsigned long long *__restrict__ total)
 {
+    __shared__ unsigned long long sh[kBlock / 64];
     unsigned long long s = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) s += (unsigned)cnt[i];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(total, s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = 0;
+        for (int w = 0; w < kBlock / 64; w++) b += sh[w];
+        if (b) atomicAdd(total, b);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -385,18 +860,78 @@ __global__ void weights_kernel(A a, const float4 *__restrict__ src, const float4
         }
 }
 
-// K23 (hot path): one lane per source row, grid-stride; per row two sweeps over its <= m
-// neighbours (min s, then the softmax sums), per lane 19 f64 accumulators, then wave shuffle
-// reduction -> LDS across the block's waves -> one partial vector per block.  A second tiny
-// kernel folds the per-block partials in a fixed order (deterministic, no float atomics).
+// exp(lp(s) - lp(smin)) for the hot path.  t model: (u_min/u)^((v+d)/2) with u = 1 + s/v; when
+// v + d is an integer (every practical dof) this is an integer power times at most one sqrt — no
+// log1p/exp at all; otherwise the reference's exp(texp * log1p(s/v)) form.  Gaussian: exp(-(s-smin)/2).
+__device__ __forceinline__ double rel_likelihood(const Model &md, double s, double smin, double lp_max)
+{
+    if (md.is_normal) return exp(-0.5 * (s - smin));
+    if (md.vpd_int) {
+        const double rho = (md.v + smin) / (md.v + s);  // = u_min / u  in (0, 1]
+        double r = (md.vpd_int & 1) ? sqrt(rho) : 1.0;
+        double base = rho;
+        for (int k = md.vpd_int >> 1; k; k >>= 1) {     // wave-uniform trip count
+            if (k & 1) r *= base;
+            base *= base;
+        }
+        return r;
+    }
+    return exp(md.texp * log1p(s / md.v) - lp_max);
+}
+
+struct RowAcc {  // per-lane running moments
+    double a[kNSums];
+};
+
+__device__ __forceinline__ void row_finish(RowAcc &acc, const Pose &P, float4 xf, double Z, double G, double Gs,
+                                           double Gyy, const double Gy[3])
+{
+    const double iz = 1.0 / Z;  // w_k = g_k / Z
+    const double Wi = G * iz;
+    const double xc[3] = {(double)xf.x - P.c[0], (double)xf.y - P.c[1], (double)xf.z - P.c[2]};
+    const double wy[3] = {Gy[0] * iz, Gy[1] * iz, Gy[2] * iz};
+    acc.a[0] += Wi;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        acc.a[1 + d] = fma(Wi, xc[d], acc.a[1 + d]);
+        acc.a[4 + d] += wy[d];
+#pragma unroll
+        for (int b = 0; b < 3; b++) acc.a[7 + 3 * d + b] = fma(xc[d], wy[b], acc.a[7 + 3 * d + b]);
+    }
+    acc.a[16] += Gs * iz;
+    acc.a[17] = fma(Wi, xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2], acc.a[17]);
+    acc.a[18] += Gyy * iz;
+}
+
+// wave shuffle reduction -> LDS across the block's waves -> partials[j * nblocks + block]
+__device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__restrict__ partials)
+{
+    __shared__ double sh[kBlock / 64][kNSums];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < kNSums; j++) {
+        double v = acc.a[j];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) sh[wave][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNSums) {
+        double v = sh[0][threadIdx.x];
+        for (int w = 1; w < kBlock / 64; w++) v += sh[w][threadIdx.x];
+        partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
+    }
+}
+
+// K23 (hot path), generic rows (CSR or wide ELL): one lane per source row, grid-stride; two sweeps
+// over the row (min s, then the softmax sums).
 template <class A>
 __global__ __launch_bounds__(kBlock) void accumulate_kernel(A a, const float4 *__restrict__ src,
                                                             const float4 *__restrict__ tgt, int ns, Pose P,
                                                             Model md, double *__restrict__ partials)
 {
-    double acc[kNSums];
+    RowAcc acc;
 #pragma unroll
-    for (int j = 0; j < kNSums; j++) acc[j] = 0.0;
+    for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < ns; i += gridDim.x * kBlock) {
         const int n = a.count(i);
         if (n == 0) continue;
@@ -414,7 +949,7 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(A a, const float4 *_
         for (int k = 0; k < n; k++) {
             const float4 y = tgt[a.nbr[a.slot(i, k)]];
             const double s = sq_residual(y, xr);
-            const double e = exp(log_prob(md, s) - lp_max);
+            const double e = rel_likelihood(md, s, smin, lp_max);
             Z += e;
             const double gk = md.is_normal ? e : e * (md.vpd / (md.v + s));
             const double yc0 = (double)y.x - P.c[0], yc1 = (double)y.y - P.c[1], yc2 = (double)y.z - P.c[2];
@@ -425,54 +960,83 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(A a, const float4 *_
             Gy[2] = fma(gk, yc2, Gy[2]);
             Gyy = fma(gk, yc0 * yc0 + yc1 * yc1 + yc2 * yc2, Gyy);
         }
-        const double iz = 1.0 / Z;  // w_k = g_k / Z
-        const double Wi = G * iz;
-        const double xc[3] = {(double)xf.x - P.c[0], (double)xf.y - P.c[1], (double)xf.z - P.c[2]};
-        const double wy[3] = {Gy[0] * iz, Gy[1] * iz, Gy[2] * iz};
-        acc[0] += Wi;
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            acc[1 + d] = fma(Wi, xc[d], acc[1 + d]);
-            acc[4 + d] += wy[d];
-#pragma unroll
-            for (int b = 0; b < 3; b++) acc[7 + 3 * d + b] = fma(xc[d], wy[b], acc[7 + 3 * d + b]);
-        }
-        acc[16] += Gs * iz;
-        acc[17] = fma(Wi, xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2], acc[17]);
-        acc[18] += Gyy * iz;
+        row_finish(acc, P, xf, Z, G, Gs, Gyy, Gy);
     }
-    __shared__ double sh[kBlock / 64][kNSums];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-    for (int j = 0; j < kNSums; j++) {
-        double v = acc[j];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) sh[wave][j] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < kNSums) {
-        double v = sh[0][threadIdx.x];
-        for (int w = 1; w < kBlock / 64; w++) v += sh[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * kNSums + threadIdx.x] = v;
-    }
+    block_reduce_store(acc, partials);
 }
 
-// fold [nblocks][19] partials -> sums[19]; one block, fixed summation tree
-__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double *__restrict__ partials,
-                                                                 int nblocks, double *__restrict__ sums)
+// K23 (hot path), ELL rows of width <= W: all W neighbour indices are loaded first (coalesced,
+// k-major), then all W target points are gathered with the loads in flight together, and the row
+// is finished from registers in a single sweep — the row is never re-read.
+template <int W>
+__global__ __launch_bounds__(kBlock) void accumulate_ell_kernel(const int *__restrict__ nbr,
+                                                                const int *__restrict__ cnt,
+                                                                const float4 *__restrict__ src,
+                                                                const float4 *__restrict__ tgt, int ns, Pose P,
+                                                                Model md, double *__restrict__ partials)
 {
-    __shared__ double sh[kBlock];
-    for (int j = 0; j < kNSums; j++) {
-        double v = 0;
-        for (int b = threadIdx.x; b < nblocks; b += kBlock) v += partials[(size_t)b * kNSums + j];
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = kBlock / 2; off > 0; off >>= 1) {
-            if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-            __syncthreads();
+    RowAcc acc;
+#pragma unroll
+    for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < ns; i += gridDim.x * kBlock) {
+        const int n = cnt[i];
+        if (n == 0) continue;
+        const float4 xf = src[i];
+        int idx[W];
+#pragma unroll
+        for (int k = 0; k < W; k++) idx[k] = (k < n) ? nbr[(size_t)k * ns + i] : 0;
+        float yx[W], yy[W], yz[W];
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            const float4 y = tgt[idx[k]];  // slot 0 of the target for k >= n: harmless, masked below
+            yx[k] = y.x;
+            yy[k] = y.y;
+            yz[k] = y.z;
         }
-        if (threadIdx.x == 0) sums[j] = sh[0];
-        __syncthreads();
+        double xr[3];
+        rotate_point(P, xf, xr);
+        double s[W];
+        double smin = INFINITY;
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            const double r0 = (double)yx[k] - xr[0], r1 = (double)yy[k] - xr[1], r2 = (double)yz[k] - xr[2];
+            s[k] = r0 * r0 + r1 * r1 + r2 * r2;
+            smin = (k < n && s[k] < smin) ? s[k] : smin;
+        }
+        const double lp_max = (md.is_normal || md.vpd_int) ? 0.0 : log_prob(md, smin);
+        double Z = 0, G = 0, Gs = 0, Gyy = 0, Gy[3] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            if (k < n) {
+                const double e = rel_likelihood(md, s[k], smin, lp_max);
+                Z += e;
+                const double gk = md.is_normal ? e : e * (md.vpd / (md.v + s[k]));
+                const double yc0 = (double)yx[k] - P.c[0], yc1 = (double)yy[k] - P.c[1], yc2 = (double)yz[k] - P.c[2];
+                G += gk;
+                Gs = fma(gk, s[k], Gs);
+                Gy[0] = fma(gk, yc0, Gy[0]);
+                Gy[1] = fma(gk, yc1, Gy[1]);
+                Gy[2] = fma(gk, yc2, Gy[2]);
+                Gyy = fma(gk, yc0 * yc0 + yc1 * yc1 + yc2 * yc2, Gyy);
+            }
+        }
+        row_finish(acc, P, xf, Z, G, Gs, Gyy, Gy);
+    }
+    block_reduce_store(acc, partials);
+}
+
+// fold partials[19][nblocks] -> sums[19]: one 1024-thread block, wave w owns sum j = w (and
+// j = w + 16); every lane adds a fixed strided subset, then a shuffle tree: fixed summation
+// order, no atomics, no block-level barrier.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const double *__restrict__ partials, int nblocks,
+                                                               double *__restrict__ sums)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = wave; j < kNSums; j += 16) {
+        double v = 0;
+        for (int b = lane; b < nblocks; b += 64) v += partials[(size_t)j * nblocks + b];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) sums[j] = v;
     }
 }
 
