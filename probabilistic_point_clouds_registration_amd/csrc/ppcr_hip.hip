@@ -99,6 +99,8 @@ struct ppcr_ctx {
     int opt_sort_source = 1;
     int opt_nn_variant = 0;
     int opt_stamps = 0;
+    int opt_fused = 0;
+    int opt_inkernel_reduce = 0;  // measured slower (serialised agent-scope loads): 102 us vs 80 + 14 us
     DevBuf<unsigned long long> d_stamps;
 
     // clouds
@@ -131,6 +133,8 @@ struct ppcr_ctx {
 
     // reductions
     DevBuf<double> partials, d_sums;
+    DevBuf<unsigned> d_ticket;
+    bool fused_sums_pending = false;  // K1 ran with the fused moments epilogue; d_sums holds them
     double *h_sums = nullptr;          // pinned
     unsigned long long *h_total = nullptr;  // pinned
 
@@ -215,6 +219,7 @@ int check_launch(ppcr_ctx *c, const char *what)
 
 void invalidate_association(ppcr_ctx *c)
 {
+    c->fused_sums_pending = false;
     c->assoc = ppcr_ctx::ASSOC_NONE;
     c->nnz = -1;
     c->csr_cache_valid = false;
@@ -398,13 +403,35 @@ int ensure_source_sorted(ppcr_ctx *c)
 // nn_variant: 0/3 = LDS-tiled halo + med3 selection (default), 2 = per-lane global scan + LDS list,
 // 1 = sorted register list inside the scan loop (first version, kept for A/B measurements)
 template <int M>
-void launch_topm(ppcr_ctx *c, float r2, int m)
+void launch_topm(ppcr_ctx *c, float r2, int m, const FusedMoments &fm)
 {
+    unsigned long long *st = c->opt_stamps ? c->d_stamps.p : nullptr;
+#define PPCR_TILE_F(Cc, B, CAPc, F)                                                                                 \
+    nn_tile_kernel<M, Cc, B, CAPc, F><<<nblocks(c->ns, B), B, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p, \
+                                                                              c->cell_start.p, c->grid, r2, m,      \
+                                                                              c->nbr.p, c->cnt.p, st, fm)
+#define PPCR_TILE(Cc, B, CAPc) PPCR_TILE_F(Cc, B, CAPc, false)
     if (c->opt_nn_variant == 0 || c->opt_nn_variant == 3) {
+        // LDS budget per 256-query block: halo CAP*16 B + list C*512 B (+1.1 KB tables), three blocks per CU.
+        // CAP must hold the halo of two adjacent 4x4x4 bricks AFTER the source has drifted by a cell:
+        // (8+1+2)x(4+1+2)x(4+1+2) cells ~ 2055 candidates at the benchmark density; with 2048 the kernel
+        // slows from 249 to 341 us as the source moves.  Measured at 1M<->1M (fresh / drifted source):
+        // CAP 2048: 249/341 us, 2112: 320/371, 2176: 231/246, 2240: 230/246, 2272: 302/318, 2304: 304/318.
+        // (C below 32 makes list compactions frequent: C = 24 doubled the kernel time.)
         constexpr int C = (M <= 24) ? 32 : 48;
-        nn_tile_kernel<M, C><<<nblocks(c->ns), kBlock, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p,
-                                                                        c->cell_start.p, c->grid, r2, m, c->nbr.p,
-                                                                        c->cnt.p, c->opt_stamps ? c->d_stamps.p : nullptr);
+        constexpr int CAP = (M <= 24) ? 2240 : 2048;
+        if (fm.enabled) {
+            if constexpr (M == 10) PPCR_TILE_F(C, 256, CAP, true);
+        } else {
+            PPCR_TILE(C, 256, CAP);
+        }
+    } else if (c->opt_nn_variant >= 4 && c->opt_nn_variant <= 7) {  // block-shape experiments (M = 10 only)
+        if constexpr (M == 10) {
+            if (c->opt_nn_variant == 4) PPCR_TILE(32, 256, 2048);
+            if (c->opt_nn_variant == 5) PPCR_TILE(32, 256, 2112);
+            if (c->opt_nn_variant == 6) PPCR_TILE(32, 256, 2176);
+            if (c->opt_nn_variant == 7) PPCR_TILE(32, 256, 2240);
+        }
     } else if (c->opt_nn_variant == 1) {
         nn_topm_kernel<M><<<nblocks(c->ns), kBlock, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p,
                                                                      c->cell_start.p, c->grid, r2, m, c->nbr.p,
@@ -421,14 +448,20 @@ template <int W>
 void launch_accumulate_ell(ppcr_ctx *c, int nb, const Pose &P, const Model &md)
 {
     accumulate_ell_kernel<W><<<nb, kBlock, 0, c->stream>>>(c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md,
-                                                           c->partials.p);
+                                                           c->partials.p, c->opt_inkernel_reduce ? c->d_ticket.p : nullptr,
+                                                           c->d_sums.p);
 }
 
-int associate_impl(ppcr_ctx *c)
+bool tile_variant(const ppcr_ctx *c) { return c->opt_nn_variant == 0 || c->opt_nn_variant == 3; }
+
+// fused_theta (nullable): {R, t} of the state the first IRLS half-step is evaluated at; when given and
+// the tiled kernel runs, K1 also produces the moments (c->fused_sums_pending) and K23 is skipped once
+int associate_impl(ppcr_ctx *c, const Mat3 *fused_R = nullptr, const double *fused_t = nullptr)
 {
     PPCR_TRY(ensure_grid(c));
     PPCR_TRY(ensure_source_sorted(c));
     invalidate_association(c);
+    c->fused_sums_pending = false;
     const int ns = (int)c->ns;
     const float r2 = (float)(c->radius * c->radius);  // PCL: static_cast<float>(radius * radius)
     const bool unbounded = (c->max_nb <= 0 || (int64_t)c->max_nb >= c->nt);
@@ -436,17 +469,35 @@ int associate_impl(ppcr_ctx *c)
         const int m = c->max_nb;
         HIP_TRY(c, c->nbr.reserve((size_t)m * (size_t)std::max(ns, 1)));
         HIP_TRY(c, c->cnt.reserve((size_t)std::max(ns, 1)));
+        FusedMoments fm;
+        std::memset(&fm, 0, sizeof(fm));
+        if (fused_R && c->opt_fused && m > 8 && m <= 10 && ns > 0 && c->nt > 0 && tile_variant(c)) {  // experiment: M = 10 only
+            const int nb = nblocks(ns);
+            HIP_TRY(c, c->partials.reserve((size_t)nb * kNSums));
+            HIP_TRY(c, c->d_sums.reserve(kNSums));
+            if (!c->d_ticket.p) {
+                HIP_TRY(c, c->d_ticket.reserve(1));
+                HIP_TRY(c, hipMemsetAsync(c->d_ticket.p, 0, sizeof(unsigned), c->stream));
+            }
+            fm.enabled = 1;
+            fm.P = make_pose(c, *fused_R, fused_t);
+            fm.md = make_model(c);
+            fm.partials = c->partials.p;
+            fm.ticket = c->d_ticket.p;
+            fm.sums = c->d_sums.p;
+        }
         if (ns > 0) {
             ProfScope ps(c, K_NN_TOPM);
-            if (m <= 4) launch_topm<4>(c, r2, m);
-            else if (m <= 5) launch_topm<5>(c, r2, m);
-            else if (m <= 8) launch_topm<8>(c, r2, m);
-            else if (m <= 10) launch_topm<10>(c, r2, m);
-            else if (m <= 16) launch_topm<16>(c, r2, m);
-            else if (m <= 20) launch_topm<20>(c, r2, m);
-            else launch_topm<32>(c, r2, m);
+            if (m <= 4) launch_topm<4>(c, r2, m, fm);
+            else if (m <= 5) launch_topm<5>(c, r2, m, fm);
+            else if (m <= 8) launch_topm<8>(c, r2, m, fm);
+            else if (m <= 10) launch_topm<10>(c, r2, m, fm);
+            else if (m <= 16) launch_topm<16>(c, r2, m, fm);
+            else if (m <= 20) launch_topm<20>(c, r2, m, fm);
+            else launch_topm<32>(c, r2, m, fm);
         }
         PPCR_TRY(check_launch(c, "nn_topm_kernel"));
+        c->fused_sums_pending = fm.enabled != 0;
         c->assoc = ppcr_ctx::ASSOC_ELL;
         c->ell_width = m;
         return PPCR_OK;
@@ -628,6 +679,11 @@ int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PP
     const int nb = std::max(1, std::min(kAccumMaxBlocks, nblocks(ns)));
     HIP_TRY(c, c->partials.reserve((size_t)nb * kNSums));
     HIP_TRY(c, c->d_sums.reserve(kNSums));
+    if (!c->d_ticket.p) {
+        HIP_TRY(c, c->d_ticket.reserve(1));
+        HIP_TRY(c, hipMemsetAsync(c->d_ticket.p, 0, sizeof(unsigned), c->stream));
+    }
+    const bool ell_fast = c->opt_inkernel_reduce && c->assoc == ppcr_ctx::ASSOC_ELL && c->nt > 0;  // reduce inside the kernel
     {
         ProfScope ps(c, K_ACCUMULATE);
         if (c->assoc == ppcr_ctx::ASSOC_ELL && c->nt > 0) {
@@ -647,7 +703,7 @@ int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PP
         }
     }
     PPCR_TRY(check_launch(c, "accumulate_kernel"));
-    {
+    if (!ell_fast) {
         ProfScope ps(c, K_REDUCE);
         reduce_partials_kernel<<<1, 1024, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p);
     }
@@ -683,7 +739,15 @@ int solve_impl(ppcr_ctx *c, const double q0[4], const double t0[3], int max_step
     Mat3 R = quat_to_rot(q0);
     Vec3 t{{t0[0], t0[1], t0[2]}};
     double sums[PPCR_NSUMS];
-    PPCR_TRY(run_accumulate(c, R, t.v, sums));
+    if (c->fused_sums_pending) {
+        // K1's epilogue already evaluated the weights and moments at (q0, t0)
+        c->fused_sums_pending = false;
+        HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->d_sums.p, sizeof(double) * kNSums, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        std::memcpy(sums, c->h_sums, sizeof(sums));
+    } else {
+        PPCR_TRY(run_accumulate(c, R, t.v, sums));
+    }
     double cost_old = 0.5 * sums[16];
     cost_out[0] = cost_out[1] = cost_old;
     int steps = 0;
@@ -790,6 +854,7 @@ int ppcr_destroy(ppcr_ctx *c)
     c->d_stamps.release();
     c->partials.release();
     c->d_sums.release();
+    c->d_ticket.release();
     c->d_w.release();
     c->d_s.release();
     if (c->h_sums) (void)hipHostFree(c->h_sums);
@@ -831,8 +896,16 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
         c->opt_nn_variant = value;
         return PPCR_OK;
     }
+    if (std::strcmp(key, "inkernel_reduce") == 0) {
+        c->opt_inkernel_reduce = value ? 1 : 0;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "fused") == 0) {  // 1: K1 also evaluates the first weights+moments step (default)
+        c->opt_fused = value ? 1 : 0;
+        return PPCR_OK;
+    }
     if (std::strcmp(key, "stamps") == 0) {  // diagnostic: per-phase cycle totals of nn_tile_kernel
-        const size_t nst = (size_t)(nblocks(std::max<int64_t>(c->ns, 1)) * (kBlock / 64)) * 8;
+        const size_t nst = (size_t)(nblocks(std::max<int64_t>(c->ns, 1)) * (kBlock / 64) + 64) * 8;
         HIP_TRY(c, c->d_stamps.reserve(nst));
         HIP_TRY(c, hipMemsetAsync(c->d_stamps.p, 0, nst * sizeof(unsigned long long), c->stream));
         c->opt_stamps = value;
@@ -1092,7 +1165,12 @@ int ppcr_iterate(ppcr_ctx *c, const double q0[4], const double t0[3], int inner_
     CTX_ENTER(c);
     if (!q0 || !t0 || !T_out || !cost_out) return fail(c, PPCR_ERR_INVALID, "null argument");
     if (!c->have_src || !c->have_tgt) return fail(c, PPCR_ERR_STATE, "set source and target before ppcr_iterate");
-    PPCR_TRY(associate_impl(c));
+    {
+        const double qn = q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3];
+        if (!(qn > 0) || !std::isfinite(qn)) return fail(c, PPCR_ERR_INVALID, "initial rotation quaternion has zero or non-finite norm");
+    }
+    const Mat3 R0 = quat_to_rot(q0);
+    PPCR_TRY(associate_impl(c, &R0, t0));
     PPCR_TRY(solve_impl(c, q0, t0, inner_steps, f_tol, T_out, cost_out, steps_out));
     return apply_transform_impl(c, T_out);
 }
@@ -1104,12 +1182,17 @@ int ppcr_align(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_d
     CTX_ENTER(c);
     if (!q0 || !t0) return fail(c, PPCR_ERR_INVALID, "null argument");
     if (!c->have_src || !c->have_tgt) return fail(c, PPCR_ERR_STATE, "set source and target before ppcr_align");
+    {
+        const double qn = q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3];
+        if (!(qn > 0) || !std::isfinite(qn)) return fail(c, PPCR_ERR_INVALID, "initial rotation quaternion has zero or non-finite norm");
+    }
+    const Mat3 R0 = quat_to_rot(q0);
     ConvergenceRule rule;
     double Tcum[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     while (!rule.has_converged(n_iter, cost_drop_thresh, n_cost_drop_it)) {
         double Tk[12], cost[2];
         int st = 0;
-        PPCR_TRY(associate_impl(c));
+        PPCR_TRY(associate_impl(c, &R0, t0));
         PPCR_TRY(solve_impl(c, q0, t0, inner_steps, f_tol, Tk, cost, &st));
         PPCR_TRY(apply_transform_impl(c, Tk));
         compose(Tk, Tcum, Tcum);  // T_cum <- T_k * T_cum (cc:101-107)

@@ -375,6 +375,181 @@ __global__ __launch_bounds__(kBlock) void nn_list_kernel(const float4 *__restric
     cnt[i] = n;
 }
 
+__device__ __forceinline__ double log_prob(const Model &md, double s)
+{
+    // additive constants cancel in the row softmax (probabilistic_weights.hpp:39-41,44,69,71-72)
+    return md.is_normal ? -0.5 * s : md.texp * log1p(s / md.v);
+}
+
+__device__ __forceinline__ double sq_residual(const float4 y, const double xr[3])
+{
+    const double r0 = (double)y.x - xr[0], r1 = (double)y.y - xr[1], r2 = (double)y.z - xr[2];
+    return r0 * r0 + r1 * r1 + r2 * r2;
+}
+
+__device__ __forceinline__ void rotate_point(const Pose &P, float4 xf, double xr[3])
+{
+    const double px = xf.x, py = xf.y, pz = xf.z;
+    xr[0] = (P.R[0] * px + P.R[1] * py + P.R[2] * pz) + P.t[0];
+    xr[1] = (P.R[3] * px + P.R[4] * py + P.R[5] * pz) + P.t[1];
+    xr[2] = (P.R[6] * px + P.R[7] * py + P.R[8] * pz) + P.t[2];
+}
+
+// 1/x to ~1 ulp without the IEEE division sequence: v_rcp_f64 seed + two Newton steps (x finite, > 0)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// exp(lp(s) - lp(smin)) for the hot path.  t model: (u_min/u)^((v+d)/2) with u = 1 + s/v; when
+// v + d is an integer (every practical dof) this is an integer power times at most one sqrt — no
+// log1p/exp at all; otherwise the reference's exp(texp * log1p(s/v)) form.  Gaussian: exp(-(s-smin)/2).
+// inv_vs = 1/(v + s) (shared with the expected-weight factor; unused by the Gaussian model)
+__device__ __forceinline__ double rel_likelihood(const Model &md, double s, double smin, double lp_max, double inv_vs)
+{
+    if (md.is_normal) return exp(-0.5 * (s - smin));
+    if (md.vpd_int) {
+        const double rho = (md.v + smin) * inv_vs;  // = u_min / u  in (0, 1]
+        double r = (md.vpd_int & 1) ? sqrt(rho) : 1.0;
+        double base = rho;
+        for (int k = md.vpd_int >> 1; k; k >>= 1) {     // wave-uniform trip count
+            if (k & 1) r *= base;
+            base *= base;
+        }
+        return r;
+    }
+    return exp(md.texp * log1p(s / md.v) - lp_max);
+}
+
+struct RowAcc {  // per-lane running moments
+    double a[kNSums];
+};
+
+__device__ __forceinline__ void row_finish(RowAcc &acc, const Pose &P, float4 xf, double Z, double G, double Gs,
+                                           double Gyy, const double Gy[3])
+{
+    const double iz = fast_rcp(Z);  // w_k = g_k / Z
+    const double Wi = G * iz;
+    const double xc[3] = {(double)xf.x - P.c[0], (double)xf.y - P.c[1], (double)xf.z - P.c[2]};
+    const double wy[3] = {Gy[0] * iz, Gy[1] * iz, Gy[2] * iz};
+    acc.a[0] += Wi;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        acc.a[1 + d] = fma(Wi, xc[d], acc.a[1 + d]);
+        acc.a[4 + d] += wy[d];
+#pragma unroll
+        for (int b = 0; b < 3; b++) acc.a[7 + 3 * d + b] = fma(xc[d], wy[b], acc.a[7 + 3 * d + b]);
+    }
+    acc.a[16] += Gs * iz;
+    acc.a[17] = fma(Wi, xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2], acc.a[17]);
+    acc.a[18] += Gyy * iz;
+}
+
+// wave shuffle reduction -> LDS across the block's waves -> partials[j * nblocks + block]
+template <int BLOCK = kBlock>
+__device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__restrict__ partials)
+{
+    __shared__ double sh[BLOCK / 64][kNSums];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < kNSums; j++) {
+        double v = acc.a[j];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) sh[wave][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNSums) {
+        double v = sh[0][threadIdx.x];
+        for (int w = 1; w < BLOCK / 64; w++) v += sh[w][threadIdx.x];
+        partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
+    }
+}
+
+
+// Arguments of the fused first IRLS half-step (weights at theta0 + moments) that nn_tile_kernel<FUSED>
+// can run as an epilogue while the winners are still in LDS.  MEASURED NEGATIVE on MI355X (1M<->1M):
+// the 19 f64 accumulators + division code push the kernel to 226 VGPRs (2 waves/SIMD) and the per-block
+// 19-value reduction + agent release cost more than the separate K23 launch saves (797 us fused vs
+// 260 + 80 + 14 us separate).  Kept (option "fused", off by default) so the experiment is repeatable.
+struct FusedMoments {
+    int enabled;
+    Pose P;
+    Model md;
+    double *partials;        // [kNSums][gridDim.x]
+    unsigned *ticket;        // arrival counter (zero before the launch; reset by the last block)
+    double *sums;            // [kNSums] final moments, written by the last block to arrive
+};
+
+// moments of one source row from its (<= m) winners; src.get(e) yields the target point of entry e
+template <class S>
+__device__ __forceinline__ void row_moments(const S &src, int n, float4 xf, const Pose &P, const Model &md, RowAcc &acc)
+{
+    if (n == 0) return;
+    double xr[3];
+    rotate_point(P, xf, xr);
+    double smin = INFINITY;
+    for (int j = 0; j < n; j++) {
+        const double sj = sq_residual(src.get(src.load(j)), xr);
+        smin = sj < smin ? sj : smin;
+    }
+    const double lp_max = (md.is_normal || md.vpd_int) ? 0.0 : log_prob(md, smin);
+    double Z = 0, G = 0, Gs = 0, Gyy = 0, Gy[3] = {0, 0, 0};
+    for (int j = 0; j < n; j++) {
+        const float4 y = src.get(src.load(j));
+        const double sj = sq_residual(y, xr);
+        const double inv_vs = md.is_normal ? 0.0 : fast_rcp(md.v + sj);
+            const double e = rel_likelihood(md, sj, smin, lp_max, inv_vs);
+        Z += e;
+        const double gk = md.is_normal ? e : e * (md.vpd * inv_vs);
+        const double yc0 = (double)y.x - P.c[0], yc1 = (double)y.y - P.c[1], yc2 = (double)y.z - P.c[2];
+        G += gk;
+        Gs = fma(gk, sj, Gs);
+        Gy[0] = fma(gk, yc0, Gy[0]);
+        Gy[1] = fma(gk, yc1, Gy[1]);
+        Gy[2] = fma(gk, yc2, Gy[2]);
+        Gyy = fma(gk, yc0 * yc0 + yc1 * yc1 + yc2 * yc2, Gyy);
+    }
+    row_finish(acc, P, xf, Z, G, Gs, Gyy, Gy);
+}
+
+// Last-block final reduction.  Every block has stored its partial vector; the block that draws the
+// last ticket folds partials[j][0..nblocks) in a fixed order (deterministic, no float atomics).
+// Inter-workgroup visibility per the CDNA4 rules: every storing wave drains its stores, barrier,
+// one lane releases at agent scope, explicit vmcnt(0), then the relaxed ticket; the last block
+// acquires at agent scope before it reads.
+template <int BLOCK>
+__device__ __forceinline__ void last_block_reduce(const double *__restrict__ partials, unsigned *ticket,
+                                                  double *__restrict__ sums)
+{
+    __shared__ unsigned s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nb = gridDim.x;
+    for (int j = wave; j < kNSums; j += BLOCK / 64) {
+        double v = 0;
+        for (int b = lane; b < nb; b += 64) v += partials[(size_t)j * nb + b];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) sums[j] = v;
+    }
+    if (threadIdx.x == 0) *ticket = 0;  // ready for the next launch on this stream
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1, tiled variant (default).  rocprofv3 on the list variant: the scan is bound by the texture
 // address path (TA busy 79 %, 16 cycles per 64-lane dwordx4 load: every distance test pulls 16 B
@@ -391,16 +566,16 @@ __global__ __launch_bounds__(kBlock) void nn_list_kernel(const float4 *__restric
 // A halo that does not fit (sparse or unsorted source) is retried per wave, and as a last resort
 // the wave falls back to scanning global memory with the same selection code.
 // ---------------------------------------------------------------------------------------------
-constexpr int kTileCap = 2048;   // staged candidates per halo (32 KiB)
 constexpr int kTileRows = 128;   // halo rows per staging
 
+template <int BLOCK>
 struct LdsCands {  // candidate source = staged halo; list entries are LDS indices
     const float4 *cand;
-    unsigned short *list;  // [slot * kBlock + tid]
+    unsigned short *list;  // [slot * BLOCK + tid]
     int tid;
     __device__ __forceinline__ float4 get(int e) const { return cand[e]; }
-    __device__ __forceinline__ int load(int t) const { return list[t * kBlock + tid]; }
-    __device__ __forceinline__ void store(int t, int e) const { list[t * kBlock + tid] = (unsigned short)e; }
+    __device__ __forceinline__ int load(int t) const { return list[t * BLOCK + tid]; }
+    __device__ __forceinline__ void store(int t, int e) const { list[t * BLOCK + tid] = (unsigned short)e; }
     __device__ __forceinline__ int pos_of(int e) const { return __float_as_int(cand[e].w); }
     __device__ __forceinline__ unsigned orig_of(int e, const float4 *__restrict__ tgt) const
     {
@@ -466,18 +641,18 @@ __device__ __forceinline__ int select_top_m(const S &src, const float4 *__restri
     return w;
 }
 
-template <int M, int C>
-__global__ __launch_bounds__(kBlock) void nn_tile_kernel(const float4 *__restrict__ src, int ns,
+template <int M, int C, int BLOCK, int CAP, bool FUSED>
+__global__ __launch_bounds__(BLOCK) void nn_tile_kernel(const float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt,
                                                          const int *__restrict__ cell_start, GridDesc g,
                                                          float r2, int m, int *__restrict__ nbr,
                                                          int *__restrict__ cnt,
-                                                         unsigned long long *__restrict__ stamps)
+                                                         unsigned long long *__restrict__ stamps, FusedMoments fm)
 {
     static_assert(C > M, "a compaction must leave room in the list");
-    static_assert(C * 64 * 4 <= kTileCap * 16, "the global fallback aliases the candidate buffer");
+    static_assert(CAP <= 65536 && C * 64 * 4 <= CAP * 16, "the global fallback aliases the candidate buffer");
     static_assert(kTileRows == 128, "row table: two rows per lane of one wave");
-    constexpr int kWaves = kBlock / 64;
+    constexpr int kWaves = BLOCK / 64;
     constexpr int kStageUnroll = 8;  // halo rows in flight per wave
     // diagnostic only (stamps == nullptr in every timed run): per-wave, per-phase cycle counts kept in
     // registers and written once at exit to stamps[(block * waves + wave) * 8 + phase]
@@ -493,17 +668,17 @@ __global__ __launch_bounds__(kBlock) void nn_tile_kernel(const float4 *__restric
     };
     auto flush_stamps = [&]() {
         if (stamps && (threadIdx.x & 63) == 0)
-            for (int k = 0; k < 8; k++) stamps[((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 + k] = t_acc[k];
+            for (int k = 0; k < 8; k++) stamps[((size_t)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8 + k] = t_acc[k];
     };
-    __shared__ float4 s_cand[kTileCap];
-    __shared__ unsigned short s_list[C * kBlock];
+    __shared__ float4 s_cand[CAP];
+    __shared__ unsigned short s_list[C * BLOCK];
     __shared__ int s_row_gb[kTileRows];
     __shared__ int s_row_off[kTileRows + 1];
     __shared__ int s_wlo[kWaves][3], s_whi[kWaves][3];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = blockIdx.x * kBlock + tid;
+    const int i = blockIdx.x * BLOCK + tid;
     const bool valid = i < ns;
     const float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const QueryCells qc = query_cells(q, g);
@@ -542,11 +717,21 @@ __global__ __launch_bounds__(kBlock) void nn_tile_kernel(const float4 *__restric
 
     int n = 0;
     bool done = !valid;
-    bool whole_ok = false;
-    // pass 0: the four waves share one halo; passes 1..4 (only if that did not fit): one wave each
-    for (int pass = 0; pass < 1 + kWaves; pass++) {
-        if (pass > 0 && whole_ok) break;
-        const int w0 = (pass == 0) ? 0 : pass - 1, w1 = (pass == 0) ? kWaves : pass;
+    RowAcc acc;  // only live in the FUSED instantiation
+    if constexpr (FUSED) {
+#pragma unroll
+        for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
+    }
+    // Halo passes, coarse to fine: all waves together; if that halo does not fit, halves, then single
+    // waves (binary subdivision of the wave range).  done_mask (uniform over the block) has a bit per
+    // finished wave; a pass whose waves are all finished is skipped.
+    unsigned done_mask = 0;
+    for (int span = kWaves; span >= 1; span >>= 1)
+      for (int w0 = 0; w0 < kWaves; w0 += span) {
+        const int w1 = w0 + span;
+        const unsigned pass_mask = ((1u << span) - 1u) << w0;
+        if ((done_mask & pass_mask) == pass_mask) continue;
+        const bool last_level = span == 1;
         int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
         for (int w = w0; w < w1; w++)
             for (int a = 0; a < 3; a++) {
@@ -586,8 +771,7 @@ __global__ __launch_bounds__(kBlock) void nn_tile_kernel(const float4 *__restric
         }
         const int offA = incl - lenA - lenB, offB = offA + lenA;
         const int total = __builtin_amdgcn_readlane(incl, 63);
-        const bool ok = rows_ok && total <= kTileCap;
-        if (pass == 0) whole_ok = ok;
+        const bool ok = rows_ok && total <= CAP;
         stamp(1);
         if (ok) {
             if (wave == w0) {  // one wave publishes the table for the scan phase
@@ -629,7 +813,7 @@ __global__ __launch_bounds__(kBlock) void nn_tile_kernel(const float4 *__restric
             __syncthreads();
             stamp(2);
             if (!done && wave >= w0 && wave < w1) {
-                const LdsCands L{s_cand, s_list, tid};
+                const LdsCands<BLOCK> L{s_cand, s_list, tid};
                 unsigned thr = 0xFFFFFFFFu;
                 auto test = [&](int f) {
                     const float d2 = dist2_flann(q, s_cand[f]);
@@ -674,12 +858,14 @@ __global__ __launch_bounds__(kBlock) void nn_tile_kernel(const float4 *__restric
                 for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = L.pos_of(L.load(j));
                 cnt[i] = n;
                 done = true;
+                if constexpr (FUSED) row_moments(L, n, q, fm.P, fm.md, acc);  // winners are still in LDS
                 stamp(5);
             }
-            if (pass == 0) break;  // common case: nothing left to do, no trailing barrier
-            __syncthreads();       // the halo buffer is reused by the next pass
+            done_mask |= pass_mask;
+            if (done_mask == (1u << kWaves) - 1u) break;  // common case: nothing left, no trailing barrier
+            __syncthreads();                              // the halo buffer is reused by the next pass
             stamp(6);
-        } else if (pass > 0) {
+        } else if (last_level) {
             // last resort for this wave: scan global memory (list of positions aliases the halo buffer)
             if (!done && wave == w0) {
                 const GlobalCands G{tgt, reinterpret_cast<int *>(s_cand), lane};
@@ -696,10 +882,17 @@ __global__ __launch_bounds__(kBlock) void nn_tile_kernel(const float4 *__restric
                 for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = G.load(j);
                 cnt[i] = n;
                 done = true;
+                if constexpr (FUSED) row_moments(G, n, q, fm.P, fm.md, acc);
             }
+            done_mask |= pass_mask;
             __syncthreads();
             stamp(7);
         }
+      }
+    if constexpr (FUSED) {
+        block_reduce_store<BLOCK>(acc, fm.partials);
+        last_block_reduce<BLOCK>(fm.partials, fm.ticket, fm.sums);
+        stamp(6);
     }
     flush_stamps();
 }
@@ -809,26 +1002,6 @@ struct CsrAssoc {
     __device__ __forceinline__ size_t slot(int i, int k) const { return (size_t)row_ptr[i] + k; }
 };
 
-__device__ __forceinline__ double log_prob(const Model &md, double s)
-{
-    // additive constants cancel in the row softmax (probabilistic_weights.hpp:39-41,44,69,71-72)
-    return md.is_normal ? -0.5 * s : md.texp * log1p(s / md.v);
-}
-
-__device__ __forceinline__ double sq_residual(const float4 y, const double xr[3])
-{
-    const double r0 = (double)y.x - xr[0], r1 = (double)y.y - xr[1], r2 = (double)y.z - xr[2];
-    return r0 * r0 + r1 * r1 + r2 * r2;
-}
-
-__device__ __forceinline__ void rotate_point(const Pose &P, float4 xf, double xr[3])
-{
-    const double px = xf.x, py = xf.y, pz = xf.z;
-    xr[0] = (P.R[0] * px + P.R[1] * py + P.R[2] * pz) + P.t[0];
-    xr[1] = (P.R[3] * px + P.R[4] * py + P.R[5] * pz) + P.t[1];
-    xr[2] = (P.R[6] * px + P.R[7] * py + P.R[8] * pz) + P.t[2];
-}
-
 // K2 (API path): materialise s and w per stored pair with the reference's exact formula:
 //   lp, row max, mll = log(sum exp(lp - max)) + max, w = exp(lp - mll) [* (v+d)/(v+s)]
 template <class A>
@@ -860,53 +1033,16 @@ __global__ void weights_kernel(A a, const float4 *__restrict__ src, const float4
         }
 }
 
-// exp(lp(s) - lp(smin)) for the hot path.  t model: (u_min/u)^((v+d)/2) with u = 1 + s/v; when
-// v + d is an integer (every practical dof) this is an integer power times at most one sqrt — no
-// log1p/exp at all; otherwise the reference's exp(texp * log1p(s/v)) form.  Gaussian: exp(-(s-smin)/2).
-__device__ __forceinline__ double rel_likelihood(const Model &md, double s, double smin, double lp_max)
+// Partial vectors handed to the last-arriving block WITHOUT fences: every partial is stored
+// write-through at agent scope (sc1), the storing waves drain vmcnt, a barrier, then one relaxed
+// agent-scope ticket; the block that draws the last ticket re-reads all partials with agent-scope
+// (sc1) loads and folds them in a fixed order (deterministic; no float atomics, no L2 write-back).
+template <int BLOCK>
+__device__ __forceinline__ void block_reduce_finish(const RowAcc &acc, double *__restrict__ partials,
+                                                    unsigned *__restrict__ ticket, double *__restrict__ sums)
 {
-    if (md.is_normal) return exp(-0.5 * (s - smin));
-    if (md.vpd_int) {
-        const double rho = (md.v + smin) / (md.v + s);  // = u_min / u  in (0, 1]
-        double r = (md.vpd_int & 1) ? sqrt(rho) : 1.0;
-        double base = rho;
-        for (int k = md.vpd_int >> 1; k; k >>= 1) {     // wave-uniform trip count
-            if (k & 1) r *= base;
-            base *= base;
-        }
-        return r;
-    }
-    return exp(md.texp * log1p(s / md.v) - lp_max);
-}
-
-struct RowAcc {  // per-lane running moments
-    double a[kNSums];
-};
-
-__device__ __forceinline__ void row_finish(RowAcc &acc, const Pose &P, float4 xf, double Z, double G, double Gs,
-                                           double Gyy, const double Gy[3])
-{
-    const double iz = 1.0 / Z;  // w_k = g_k / Z
-    const double Wi = G * iz;
-    const double xc[3] = {(double)xf.x - P.c[0], (double)xf.y - P.c[1], (double)xf.z - P.c[2]};
-    const double wy[3] = {Gy[0] * iz, Gy[1] * iz, Gy[2] * iz};
-    acc.a[0] += Wi;
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        acc.a[1 + d] = fma(Wi, xc[d], acc.a[1 + d]);
-        acc.a[4 + d] += wy[d];
-#pragma unroll
-        for (int b = 0; b < 3; b++) acc.a[7 + 3 * d + b] = fma(xc[d], wy[b], acc.a[7 + 3 * d + b]);
-    }
-    acc.a[16] += Gs * iz;
-    acc.a[17] = fma(Wi, xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2], acc.a[17]);
-    acc.a[18] += Gyy * iz;
-}
-
-// wave shuffle reduction -> LDS across the block's waves -> partials[j * nblocks + block]
-__device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__restrict__ partials)
-{
-    __shared__ double sh[kBlock / 64][kNSums];
+    __shared__ double sh[BLOCK / 64][kNSums];
+    __shared__ unsigned s_last;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int j = 0; j < kNSums; j++) {
@@ -917,9 +1053,27 @@ __device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__
     __syncthreads();
     if (threadIdx.x < kNSums) {
         double v = sh[0][threadIdx.x];
-        for (int w = 1; w < kBlock / 64; w++) v += sh[w][threadIdx.x];
-        partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
+        for (int w = 1; w < BLOCK / 64; w++) v += sh[w][threadIdx.x];
+        __hip_atomic_store(&partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x], v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int nb = gridDim.x;
+    for (int j = wave; j < kNSums; j += BLOCK / 64) {
+        double v = 0;
+        for (int b = lane; b < nb; b += 64)
+            v += __hip_atomic_load(&partials[(size_t)j * nb + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) sums[j] = v;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // K23 (hot path), generic rows (CSR or wide ELL): one lane per source row, grid-stride; two sweeps
@@ -949,9 +1103,10 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(A a, const float4 *_
         for (int k = 0; k < n; k++) {
             const float4 y = tgt[a.nbr[a.slot(i, k)]];
             const double s = sq_residual(y, xr);
-            const double e = rel_likelihood(md, s, smin, lp_max);
+            const double inv_vs = md.is_normal ? 0.0 : fast_rcp(md.v + s);
+            const double e = rel_likelihood(md, s, smin, lp_max, inv_vs);
             Z += e;
-            const double gk = md.is_normal ? e : e * (md.vpd / (md.v + s));
+            const double gk = md.is_normal ? e : e * (md.vpd * inv_vs);
             const double yc0 = (double)y.x - P.c[0], yc1 = (double)y.y - P.c[1], yc2 = (double)y.z - P.c[2];
             G += gk;
             Gs = fma(gk, s, Gs);
@@ -973,7 +1128,9 @@ __global__ __launch_bounds__(kBlock) void accumulate_ell_kernel(const int *__res
                                                                 const int *__restrict__ cnt,
                                                                 const float4 *__restrict__ src,
                                                                 const float4 *__restrict__ tgt, int ns, Pose P,
-                                                                Model md, double *__restrict__ partials)
+                                                                Model md, double *__restrict__ partials,
+                                                                unsigned *__restrict__ ticket,
+                                                                double *__restrict__ sums)
 {
     RowAcc acc;
 #pragma unroll
@@ -1008,9 +1165,10 @@ __global__ __launch_bounds__(kBlock) void accumulate_ell_kernel(const int *__res
 #pragma unroll
         for (int k = 0; k < W; k++) {
             if (k < n) {
-                const double e = rel_likelihood(md, s[k], smin, lp_max);
+                const double inv_vs = md.is_normal ? 0.0 : fast_rcp(md.v + s[k]);
+            const double e = rel_likelihood(md, s[k], smin, lp_max, inv_vs);
                 Z += e;
-                const double gk = md.is_normal ? e : e * (md.vpd / (md.v + s[k]));
+                const double gk = md.is_normal ? e : e * (md.vpd * inv_vs);
                 const double yc0 = (double)yx[k] - P.c[0], yc1 = (double)yy[k] - P.c[1], yc2 = (double)yz[k] - P.c[2];
                 G += gk;
                 Gs = fma(gk, s[k], Gs);
@@ -1022,7 +1180,8 @@ __global__ __launch_bounds__(kBlock) void accumulate_ell_kernel(const int *__res
         }
         row_finish(acc, P, xf, Z, G, Gs, Gyy, Gy);
     }
-    block_reduce_store(acc, partials);
+    if (ticket) block_reduce_finish<kBlock>(acc, partials, ticket, sums);  // experiment (uniform branch)
+    else block_reduce_store<kBlock>(acc, partials);
 }
 
 // fold partials[19][nblocks] -> sums[19]: one 1024-thread block, wave w owns sum j = w (and

@@ -390,5 +390,5 @@ def test_profile_reports_kernels(ctx):
     ctx.align(3, inner_steps=1)
     st = ctx.profile_get()
     ctx.profile_enable(False)
-    assert st["nn_topm_kernel"]["launches"] == 3 and st["accumulate_kernel"]["launches"] == 3
+    assert st["nn_topm_kernel"]["launches"] == 3 and st["accumulate_kernel"]["launches"] == 3, st
     assert st["transform_kernel"]["launches"] == 3 and st["nn_topm_kernel"]["total_ms"] > 0

@@ -9,14 +9,16 @@ m = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 src, tgt, _, _ = synth.make_pair(n, cfg=3)
 c = _lib.Context(0)
 c.set_params(1.0, m, 5.0, 3); c.set_target(tgt); c.set_source(src)
-c.associate(); c.synchronize()
+fused = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+c.set_option("fused", fused)
+c.iterate(); c.synchronize()
 c.set_option("stamps", 1)
-c.associate(); c.synchronize()
+c.iterate(); c.synchronize()
 out = (C.c_ulonglong * 8)()
 L = _lib.load(); L.ppcr_debug_get_stamps.argtypes = [C.c_void_p, C.c_void_p]
 assert L.ppcr_debug_get_stamps(c._h, out) == 0
 v = np.array(list(out), dtype=np.float64)
-names = ["bbox", "rowtable", "stage", "scan", "select", "emit", "tail-sync", "fallback"]
+names = ["bbox", "rowtable", "stage", "scan", "select", "emit+moments", "reduce/tail", "fallback"]
 tot = v[:8].sum()
 for k in range(8):
     print(f"{names[k]:10s} {v[k]:14.0f} ticks  {100*v[k]/tot:5.1f}%")
