@@ -89,6 +89,12 @@ int ppcr_set_association(ppcr_ctx *ctx, const int32_t *row_ptr, const int32_t *c
  * CSR order of ppcr_get_association(); either may be NULL. */
 int ppcr_weights(ppcr_ctx *ctx, const double q[4], const double t[3], double *w_out, double *s_out);
 
+/* ProbabilisticWeights(dof, dim, max_nb).updateWeights(data_association, squared_errors)
+ * (probabilistic_weights.hpp:30-105) as a stateless call: caller-supplied squared errors in CSR
+ * order, weights out in the same order.  (max_neighbours only sizes a reserve() in the reference.) */
+int ppcr_update_weights(int device_id, const int32_t *row_ptr, int64_t n_rows, const double *sq_errors,
+                        double dof, int dim, double *w_out);
+
 /* K2+K3 fused — weights at (q,t) and the weighted moments the closed-form solve needs
  * (what Ceres would assemble from the residual blocks of ..._iteration.hpp:37-46). */
 int ppcr_accumulate(ppcr_ctx *ctx, const double q[4], const double t[3], double sums[PPCR_NSUMS]);

@@ -17,7 +17,7 @@ SYMBOLS = [
     "ppcr_abi_version", "ppcr_device_count", "ppcr_create", "ppcr_destroy", "ppcr_last_error",
     "ppcr_set_params", "ppcr_set_target", "ppcr_set_source", "ppcr_set_target_device",
     "ppcr_set_source_device", "ppcr_associate", "ppcr_association_size", "ppcr_get_association",
-    "ppcr_set_association", "ppcr_weights", "ppcr_accumulate", "ppcr_get_origin",
+    "ppcr_set_association", "ppcr_weights", "ppcr_update_weights", "ppcr_accumulate", "ppcr_get_origin",
     "ppcr_solve_moments", "ppcr_cost_from_moments", "ppcr_solve", "ppcr_apply_transform",
     "ppcr_iterate", "ppcr_align", "ppcr_get_source", "ppcr_synchronize", "ppcr_profile_enable",
     "ppcr_profile_get", "ppcr_set_option",
@@ -63,6 +63,7 @@ def load():
     L.ppcr_set_association.argtypes = [vp, vp, vp, i64]
     L.ppcr_weights.argtypes = [vp, vp, vp, vp, vp]
     L.ppcr_accumulate.argtypes = [vp, vp, vp, vp]
+    L.ppcr_update_weights.argtypes = [i32, vp, i64, vp, dbl, i32, vp]
     L.ppcr_get_origin.argtypes = [vp, vp]
     L.ppcr_solve_moments.argtypes = [vp, vp, vp, vp]
     L.ppcr_cost_from_moments.argtypes = [vp, vp, vp, vp]
@@ -261,6 +262,19 @@ class Context:
         self._ck(self._L.ppcr_profile_get(self._h, arr, 32, C.byref(n)))
         return {arr[i].name.decode(): dict(launches=arr[i].launches, total_ms=arr[i].total_ms)
                 for i in range(min(n.value, 32))}
+
+
+def update_weights(row_ptr, sq_errors, dof, dim, device_id=0):
+    """ProbabilisticWeights(dof, dim, .).updateWeights on caller-supplied squared errors (CSR order)."""
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    s = np.ascontiguousarray(sq_errors, dtype=np.float64)
+    w = np.zeros(max(1, s.shape[0]))
+    L = load()
+    rc = L.ppcr_update_weights(int(device_id), rp.ctypes.data, rp.shape[0] - 1, s.ctypes.data if s.size else None,
+                               float(dof), int(dim), w.ctypes.data)
+    if rc != 0:
+        raise PpcrError(rc, L.ppcr_last_error(None).decode())
+    return w[:s.shape[0]]
 
 
 def solve_moments(sums, origin):

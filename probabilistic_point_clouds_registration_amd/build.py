@@ -46,5 +46,30 @@ def build(force=False, verbose=False):
     return LIB
 
 
+CPP = os.path.join(CSRC, "cpp")
+CLI = os.path.join(PKG, "probabilistic_point_cloud_registration")   # the reference's executable name
+CPP_TEST = os.path.join(PKG, "ppcr_cpp_api_test")
+CPP_SOURCES = [os.path.join(CPP, "src", "prob_point_cloud_registration.cc"), os.path.join(CPP, "src", "pcd_io.cc")]
+
+
+def build_host_programs(force=False, verbose=False):
+    """C++ host layer above the C ABI: the CLI and the C++ API test program (plain g++, links libppcr_hip.so)."""
+    build()
+    common = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(CPP, "include")]
+    link = ["-L", PKG, "-lppcr_hip", "-Wl,-rpath,$ORIGIN"]
+    jobs = [(CLI, CPP_SOURCES + [os.path.join(CPP, "src", "prob_point_cloud_registration_ex.cc")]),
+            (CPP_TEST, CPP_SOURCES + [os.path.join(ROOT, "tests", "cpp", "test_api.cc")])]
+    for out, srcs in jobs:
+        hdrs = [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(CPP, "include")) for f in fs]
+        stale = force or not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in srcs + hdrs + [LIB])
+        if stale:
+            cmd = common + srcs + link + ["-o", out]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+    return CLI, CPP_TEST
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host_programs(force="--force" in sys.argv, verbose=True))

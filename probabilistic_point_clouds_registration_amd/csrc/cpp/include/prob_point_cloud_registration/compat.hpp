@@ -1,0 +1,223 @@
+// Minimal stand-ins for the third-party types on the reference's public surface (PCL point clouds,
+// Eigen Affine3d / row-major sparse matrix, ceres::Solver::Options/Summary).  None of PCL, Eigen or
+// Ceres is needed to build or use this library; the names, members and semantics below are the subset
+// the reference's API touches.  When the real libraries are present, define
+// PPCR_NO_COMPAT_TYPES before including any header of this directory and provide equivalent aliases.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#ifndef PPCR_NO_COMPAT_TYPES
+
+namespace pcl {
+
+struct alignas(16) PointXYZ {  // same 16-byte layout as pcl::PointXYZ
+    float x = 0, y = 0, z = 0, pad = 1.0f;
+    PointXYZ() = default;
+    PointXYZ(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
+};
+
+template <class PointT>
+class PointCloud {
+public:
+    using Ptr = std::shared_ptr<PointCloud<PointT>>;
+    using ConstPtr = std::shared_ptr<const PointCloud<PointT>>;
+    std::vector<PointT> points;
+    std::size_t size() const { return points.size(); }
+    bool empty() const { return points.empty(); }
+    void reserve(std::size_t n) { points.reserve(n); }
+    void resize(std::size_t n) { points.resize(n); }
+    void clear() { points.clear(); }
+    void push_back(const PointT &p) { points.push_back(p); }
+    PointT &operator[](std::size_t i) { return points[i]; }
+    const PointT &operator[](std::size_t i) const { return points[i]; }
+    PointT &at(std::size_t i) { return points.at(i); }
+    const PointT &at(std::size_t i) const { return points.at(i); }
+    auto begin() { return points.begin(); }
+    auto end() { return points.end(); }
+    auto begin() const { return points.begin(); }
+    auto end() const { return points.end(); }
+};
+
+inline double rad2deg(double r) { return r * 57.29577951308232; }
+
+}  // namespace pcl
+
+namespace Eigen {
+
+struct Vector3d {
+    double v[3] = {0, 0, 0};
+    Vector3d() = default;
+    Vector3d(double a, double b, double c) : v{a, b, c} {}
+    double x() const { return v[0]; }
+    double y() const { return v[1]; }
+    double z() const { return v[2]; }
+    double &operator()(int i) { return v[i]; }
+    double operator()(int i) const { return v[i]; }
+    double operator()(int i, int) const { return v[i]; }
+};
+
+struct Matrix3d {
+    double m[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    double &operator()(int r, int c) { return m[r][c]; }
+    double operator()(int r, int c) const { return m[r][c]; }
+    // Eigen::Matrix3d::eulerAngles(0,1,2): R = Rx(a) * Ry(b) * Rz(c), a in [0, pi]
+    Vector3d eulerAngles(int a0, int a1, int a2) const;
+};
+
+struct Quaterniond {
+    double qw = 1, qx = 0, qy = 0, qz = 0;
+    Quaterniond() = default;
+    Quaterniond(double w, double x, double y, double z) : qw(w), qx(x), qy(y), qz(z) {}
+    explicit Quaterniond(const Matrix3d &R);
+    double w() const { return qw; }
+    double x() const { return qx; }
+    double y() const { return qy; }
+    double z() const { return qz; }
+    void normalize()
+    {
+        const double n = std::sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+        qw /= n, qx /= n, qy /= n, qz /= n;
+    }
+    Matrix3d toRotationMatrix() const;
+};
+
+// rigid transform [R|t]; operator* composes (this applied after rhs), like Eigen::Affine3d
+class Affine3d {
+public:
+    Matrix3d R;
+    Vector3d t;
+    static Affine3d Identity() { return Affine3d(); }
+    const Matrix3d &rotation() const { return R; }
+    const Vector3d &translation() const { return t; }
+    Affine3d operator*(const Affine3d &o) const
+    {
+        Affine3d r;
+        for (int a = 0; a < 3; a++) {
+            for (int b = 0; b < 3; b++) {
+                double acc = 0;
+                for (int k = 0; k < 3; k++) acc += R.m[a][k] * o.R.m[k][b];
+                r.R.m[a][b] = acc;
+            }
+            r.t.v[a] = R.m[a][0] * o.t.v[0] + R.m[a][1] * o.t.v[1] + R.m[a][2] * o.t.v[2] + t.v[a];
+        }
+        return r;
+    }
+    // row-major top three rows of the 4x4 (the C ABI's T[12])
+    void to_rows(double T[12]) const
+    {
+        for (int a = 0; a < 3; a++) {
+            for (int b = 0; b < 3; b++) T[4 * a + b] = R.m[a][b];
+            T[4 * a + 3] = t.v[a];
+        }
+    }
+    static Affine3d from_rows(const double T[12])
+    {
+        Affine3d r;
+        for (int a = 0; a < 3; a++) {
+            for (int b = 0; b < 3; b++) r.R.m[a][b] = T[4 * a + b];
+            r.t.v[a] = T[4 * a + 3];
+        }
+        return r;
+    }
+};
+
+template <class T>
+struct Triplet {
+    int r = 0, c = 0;
+    T v = T();
+    Triplet() = default;
+    Triplet(int row, int col, T val = T()) : r(row), c(col), v(val) {}
+    int row() const { return r; }
+    int col() const { return c; }
+    T value() const { return v; }
+};
+
+struct RowMajorTag {};
+constexpr int RowMajor = 1;
+
+// compressed row-major sparse matrix with the members the reference uses: rows/cols/outerSize,
+// setFromTriplets (ascending columns per row, explicit zeros kept), InnerIterator, coeff
+template <class T, int Options = RowMajor>
+class SparseMatrix {
+public:
+    SparseMatrix() = default;
+    SparseMatrix(long rows, long cols) : rows_(rows), cols_(cols), outer_(static_cast<std::size_t>(rows) + 1, 0) {}
+    long rows() const { return rows_; }
+    long cols() const { return cols_; }
+    long outerSize() const { return rows_; }
+    long nonZeros() const { return static_cast<long>(inner_.size()); }
+    template <class It>
+    void setFromTriplets(It first, It last);
+    void makeCompressed() {}
+    T coeff(long r, long c) const
+    {
+        for (int k = outer_[r]; k < outer_[r + 1]; k++)
+            if (inner_[k] == c) return values_[k];
+        return T();
+    }
+    const int *outerIndexPtr() const { return outer_.data(); }
+    const int *innerIndexPtr() const { return inner_.data(); }
+    const T *valuePtr() const { return values_.data(); }
+    T *valuePtr() { return values_.data(); }
+    // adopt raw CSR arrays (used by the device round trips)
+    void assign_csr(long rows, long cols, std::vector<int> outer, std::vector<int> inner, std::vector<T> values)
+    {
+        rows_ = rows, cols_ = cols;
+        outer_ = std::move(outer), inner_ = std::move(inner), values_ = std::move(values);
+    }
+    class InnerIterator {
+    public:
+        InnerIterator(const SparseMatrix &m, long outer) : m_(m), row_(outer), k_(m.outer_[outer]), end_(m.outer_[outer + 1]) {}
+        explicit operator bool() const { return k_ < end_; }
+        InnerIterator &operator++()
+        {
+            ++k_;
+            return *this;
+        }
+        long row() const { return row_; }
+        long col() const { return m_.inner_[k_]; }
+        T value() const { return m_.values_[k_]; }
+        long index() const { return k_; }
+
+    private:
+        const SparseMatrix &m_;
+        long row_;
+        int k_, end_;
+    };
+
+private:
+    long rows_ = 0, cols_ = 0;
+    std::vector<int> outer_{0};
+    std::vector<int> inner_;
+    std::vector<T> values_;
+};
+
+}  // namespace Eigen
+
+namespace ceres {
+enum LinearSolverType { DENSE_QR, SPARSE_NORMAL_CHOLESKY };
+struct Solver {
+    struct Options {
+        LinearSolverType linear_solver_type = DENSE_QR;  // accepted, unused: the solve is closed form
+        bool use_nonmonotonic_steps = false;              // accepted, unused
+        bool minimizer_progress_to_stdout = false;
+        int max_num_iterations = 50;
+        double function_tolerance = 1e-6;
+        int num_threads = 1;                              // accepted, unused: the work runs on the GPU
+    };
+    struct Summary {
+        double initial_cost = 0, final_cost = 0;
+        int num_successful_steps = 0;
+        std::string FullReport() const;
+    };
+};
+}  // namespace ceres
+
+#include "compat_impl.hpp"
+
+#endif  // PPCR_NO_COMPAT_TYPES

@@ -1,0 +1,63 @@
+// ErrorTerm — the per-correspondence residual functor of the reference API (error_term.hpp:10-51):
+// r = y - (R(q) x + t), q = (w,x,y,z) normalised before use, templated on the scalar so user code that
+// evaluates residuals (or differentiates them with its own Jet type) keeps working.  In this
+// implementation the registration itself never instantiates ErrorTerms: the same residual is evaluated
+// for every stored pair inside the HIP kernels (sq_residual in ppcr_kernels.hip.h).
+#pragma once
+#include <cmath>
+
+#include "prob_point_cloud_registration/compat.hpp"
+
+namespace prob_point_cloud_registration {
+
+// stand-in for ceres::LossFunctionWrapper(ScaledLoss(NULL, w)): rho(s) = w * s
+class ScaledLossHandle {
+public:
+    explicit ScaledLossHandle(double w = 1.0) : w_(w) {}
+    void Reset(double w) { w_ = w; }
+    double scale() const { return w_; }
+    void Evaluate(double s, double rho[3]) const
+    {
+        rho[0] = w_ * s;
+        rho[1] = w_;
+        rho[2] = 0.0;
+    }
+
+private:
+    double w_;
+};
+
+class ErrorTerm {
+public:
+    static const int kResiduals = 3;
+    ErrorTerm(const pcl::PointXYZ source_point, const pcl::PointXYZ target_point)
+        : source_{source_point.x, source_point.y, source_point.z}, target_{target_point.x, target_point.y, target_point.z}
+    {
+    }
+
+    template <typename T>
+    bool operator()(const T *const rotation, const T *const translation, T *residuals) const
+    {
+        using std::sqrt;
+        const T n = sqrt(rotation[0] * rotation[0] + rotation[1] * rotation[1] + rotation[2] * rotation[2] +
+                         rotation[3] * rotation[3]);
+        const T w = rotation[0] / n, x = rotation[1] / n, y = rotation[2] / n, z = rotation[3] / n;
+        const T p[3] = {T(source_[0]), T(source_[1]), T(source_[2])};
+        // v' = v + 2 w (u x v) + 2 u x (u x v), u = (x,y,z)
+        const T c0 = y * p[2] - z * p[1], c1 = z * p[0] - x * p[2], c2 = x * p[1] - y * p[0];
+        const T d0 = y * c2 - z * c1, d1 = z * c0 - x * c2, d2 = x * c1 - y * c0;
+        const T rot[3] = {p[0] + T(2) * (w * c0 + d0), p[1] + T(2) * (w * c1 + d1), p[2] + T(2) * (w * c2 + d2)};
+        for (int i = 0; i < kResiduals; i++) residuals[i] = T(target_[i]) - (rot[i] + translation[i]);
+        return true;
+    }
+
+    void updateWeight(double new_weight) { weight_.Reset(new_weight); }
+    ScaledLossHandle *weight() { return &weight_; }
+
+private:
+    double source_[3];
+    double target_[3];
+    ScaledLossHandle weight_;
+};
+
+}  // namespace prob_point_cloud_registration

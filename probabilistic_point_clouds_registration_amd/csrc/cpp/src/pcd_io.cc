@@ -1,0 +1,152 @@
+#include "prob_point_cloud_registration/pcd_io.hpp"
+
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+#include <vector>
+
+namespace prob_point_cloud_registration {
+namespace io {
+
+namespace {
+struct Field {
+    std::string name;
+    int size = 4;
+    char type = 'F';
+    int count = 1;
+    int offset = 0;
+};
+
+std::vector<std::string> split(const std::string &line)
+{
+    std::istringstream is(line);
+    std::vector<std::string> out;
+    std::string tok;
+    while (is >> tok) out.push_back(tok);
+    return out;
+}
+}  // namespace
+
+int loadPCDFile(const std::string &file_name, pcl::PointCloud<pcl::PointXYZ> &cloud)
+{
+    std::ifstream in(file_name, std::ios::binary);
+    if (!in) {
+        std::cerr << "[pcd] cannot open " << file_name << std::endl;
+        return -1;
+    }
+    std::vector<Field> fields;
+    long long width = 0, height = 1, points = -1;
+    std::string data_mode, line;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty() || line[0] == '#') continue;
+        const std::vector<std::string> tok = split(line);
+        if (tok.empty()) continue;
+        const std::string &key = tok[0];
+        if (key == "FIELDS" || key == "COLUMNS") {
+            fields.resize(tok.size() - 1);
+            for (std::size_t i = 1; i < tok.size(); i++) fields[i - 1].name = tok[i];
+        } else if (key == "SIZE") {
+            for (std::size_t i = 1; i < tok.size() && i - 1 < fields.size(); i++) fields[i - 1].size = std::stoi(tok[i]);
+        } else if (key == "TYPE") {
+            for (std::size_t i = 1; i < tok.size() && i - 1 < fields.size(); i++) fields[i - 1].type = tok[i][0];
+        } else if (key == "COUNT") {
+            for (std::size_t i = 1; i < tok.size() && i - 1 < fields.size(); i++) fields[i - 1].count = std::stoi(tok[i]);
+        } else if (key == "WIDTH") {
+            width = std::stoll(tok.at(1));
+        } else if (key == "HEIGHT") {
+            height = std::stoll(tok.at(1));
+        } else if (key == "POINTS") {
+            points = std::stoll(tok.at(1));
+        } else if (key == "DATA") {
+            data_mode = tok.size() > 1 ? tok[1] : "";
+            break;
+        }
+    }
+    if (points < 0) points = width * height;
+    int ix = -1, iy = -1, iz = -1, col = 0, off = 0;
+    std::vector<int> first_col(fields.size(), 0);
+    for (std::size_t f = 0; f < fields.size(); f++) {
+        fields[f].offset = off;
+        first_col[f] = col;
+        off += fields[f].size * fields[f].count;
+        col += fields[f].count;
+        if (fields[f].name == "x") ix = static_cast<int>(f);
+        if (fields[f].name == "y") iy = static_cast<int>(f);
+        if (fields[f].name == "z") iz = static_cast<int>(f);
+    }
+    if (ix < 0 || iy < 0 || iz < 0 || points < 0) {
+        std::cerr << "[pcd] " << file_name << ": header lacks x/y/z fields or a point count" << std::endl;
+        return -1;
+    }
+    for (int f : {ix, iy, iz})
+        if (fields[f].type != 'F' || fields[f].size != 4) {
+            std::cerr << "[pcd] " << file_name << ": x/y/z must be float32" << std::endl;
+            return -1;
+        }
+    cloud.points.assign(static_cast<std::size_t>(points), pcl::PointXYZ());
+    if (data_mode == "ascii") {
+        const int ncols = col;
+        std::vector<double> row(static_cast<std::size_t>(ncols));
+        for (long long i = 0; i < points; i++) {
+            if (!std::getline(in, line)) {
+                std::cerr << "[pcd] " << file_name << ": truncated ascii data" << std::endl;
+                return -1;
+            }
+            std::istringstream is(line);
+            for (int k = 0; k < ncols; k++) {
+                std::string tok;
+                if (!(is >> tok)) {
+                    std::cerr << "[pcd] " << file_name << ": short ascii row " << i << std::endl;
+                    return -1;
+                }
+                row[static_cast<std::size_t>(k)] = (tok == "nan" || tok == "NaN") ? NAN : std::strtod(tok.c_str(), nullptr);
+            }
+            pcl::PointXYZ &p = cloud.points[static_cast<std::size_t>(i)];
+            p.x = static_cast<float>(row[static_cast<std::size_t>(first_col[ix])]);
+            p.y = static_cast<float>(row[static_cast<std::size_t>(first_col[iy])]);
+            p.z = static_cast<float>(row[static_cast<std::size_t>(first_col[iz])]);
+        }
+    } else if (data_mode == "binary") {
+        const int stride = off;
+        std::vector<char> buf(static_cast<std::size_t>(stride) * static_cast<std::size_t>(points));
+        in.read(buf.data(), static_cast<std::streamsize>(buf.size()));
+        if (static_cast<std::size_t>(in.gcount()) != buf.size()) {
+            std::cerr << "[pcd] " << file_name << ": truncated binary data" << std::endl;
+            return -1;
+        }
+        for (long long i = 0; i < points; i++) {
+            const char *rec = buf.data() + static_cast<std::size_t>(i) * stride;
+            pcl::PointXYZ &p = cloud.points[static_cast<std::size_t>(i)];
+            std::memcpy(&p.x, rec + fields[ix].offset, 4);
+            std::memcpy(&p.y, rec + fields[iy].offset, 4);
+            std::memcpy(&p.z, rec + fields[iz].offset, 4);
+        }
+    } else {
+        std::cerr << "[pcd] " << file_name << ": DATA " << data_mode << " is not supported (ascii and binary are)" << std::endl;
+        return -1;
+    }
+    return 0;
+}
+
+int savePCDFile(const std::string &file_name, const pcl::PointCloud<pcl::PointXYZ> &cloud, bool binary_mode)
+{
+    std::ofstream out(file_name, std::ios::binary);
+    if (!out) return -1;
+    out << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\n"
+        << "WIDTH " << cloud.size() << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << cloud.size() << "\nDATA "
+        << (binary_mode ? "binary" : "ascii") << "\n";
+    if (binary_mode) {
+        for (const auto &p : cloud.points) out.write(reinterpret_cast<const char *>(&p.x), 12);
+    } else {
+        out << std::setprecision(9);
+        for (const auto &p : cloud.points) out << p.x << " " << p.y << " " << p.z << "\n";
+    }
+    return out ? 0 : -1;
+}
+
+}  // namespace io
+}  // namespace prob_point_cloud_registration

@@ -1144,6 +1144,47 @@ double ppcr_cost_from_moments(const double sums[PPCR_NSUMS], const double origin
     return cost_from_moments(sums, origin, Rm, Vec3{{t[0], t[1], t[2]}});
 }
 
+int ppcr_update_weights(int device_id, const int32_t *row_ptr, int64_t n_rows, const double *sq_errors, double dof,
+                        int dim, double *w_out)
+{
+    if (!row_ptr || n_rows < 0) return fail(nullptr, PPCR_ERR_INVALID, "bad row_ptr / n_rows");
+    if (!(dof > 0) || dim <= 0) return fail(nullptr, PPCR_ERR_INVALID, "dof and dim must be > 0 (probabilistic_weights.hpp:33-34)");
+    const int64_t nnz = row_ptr[n_rows];
+    if (nnz == 0) return PPCR_OK;
+    if (!sq_errors || !w_out) return fail(nullptr, PPCR_ERR_INVALID, "null errors / output");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, PPCR_ERR_NODEVICE, "no HIP device visible: this library has no CPU fallback");
+    }
+    if (device_id < 0 || device_id >= n) return fail(nullptr, PPCR_ERR_INVALID, "device_id out of range");
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    int *d_rp = nullptr;
+    double *d_s = nullptr, *d_w = nullptr;
+    auto cleanup = [&]() {
+        if (d_rp) (void)hipFree(d_rp);
+        if (d_s) (void)hipFree(d_s);
+        if (d_w) (void)hipFree(d_w);
+    };
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_rp), sizeof(int) * (size_t)(n_rows + 1));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_s), sizeof(double) * (size_t)nnz);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_w), sizeof(double) * (size_t)nnz);
+    if (e == hipSuccess) e = hipMemcpy(d_rp, row_ptr, sizeof(int) * (size_t)(n_rows + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_s, sq_errors, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        ppcr_ctx tmp;  // only used to derive the model constants
+        tmp.dof = dof;
+        tmp.dim = dim;
+        const Model md = make_model(&tmp);
+        weights_from_errors_kernel<<<nblocks(n_rows), kBlock>>>(d_rp, n_rows, d_s, md, d_w);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(w_out, d_w, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(nullptr, PPCR_ERR_HIP, std::string("ppcr_update_weights: ") + hipGetErrorString(e));
+    return PPCR_OK;
+}
+
 int ppcr_solve(ppcr_ctx *c, const double q0[4], const double t0[3], int max_steps, double f_tol, double T_out[12],
                double cost_out[2], int *steps_out)
 {

@@ -1199,6 +1199,30 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const double *__r
     }
 }
 
+// ProbabilisticWeights::updateWeights on caller-supplied squared errors (probabilistic_weights.hpp:48-105):
+// one lane per CSR row, the reference's exact formula (lp, row max, mll, exp(lp - mll) [* (v+d)/(v+s)]).
+__global__ void weights_from_errors_kernel(const int *__restrict__ row_ptr, int64_t n_rows,
+                                           const double *__restrict__ s, Model md, double *__restrict__ w)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const int b = row_ptr[i], e = row_ptr[i + 1];
+    if (b >= e) return;
+    double max_lp = -INFINITY;
+    for (int k = b; k < e; k++) {
+        const double lp = log_prob(md, s[k]);
+        max_lp = lp > max_lp ? lp : max_lp;
+    }
+    double z = 0;
+    for (int k = b; k < e; k++) z += exp(log_prob(md, s[k]) - max_lp);
+    const double mll = log(z) + max_lp;
+    for (int k = b; k < e; k++) {
+        double wk = exp(log_prob(md, s[k]) - mll);
+        if (!md.is_normal) wk *= md.vpd / (md.v + s[k]);
+        w[k] = wk;
+    }
+}
+
 // K4: x <- float(R x + t), f64 arithmetic summed left to right, f32 store, in place
 // (pcl::transformPointCloud semantics, src/prob_point_cloud_registration.cc:110-112).
 // The w lane (original index) is preserved.

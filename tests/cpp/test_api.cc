@@ -1,0 +1,202 @@
+// C++ API tests: the reference's own gtest cases (test/ProbabilisticWeightsTest.cc:35-66,
+// test/PointCloudRegistrationTest.cc:30-116) restated against the drop-in classes, plus checks of the outer
+// driver.  No gtest here: a tiny assert harness; exit code = number of failed checks.
+#include <cmath>
+#include <cstdio>
+#include <limits>
+#include <vector>
+
+#include "prob_point_cloud_registration/prob_point_cloud_registration.h"
+#include "prob_point_cloud_registration/utilities.hpp"
+
+using namespace prob_point_cloud_registration;
+
+static int g_failed = 0, g_checks = 0;
+#define EXPECT_NEAR(a, b, tol)                                                                            \
+    do {                                                                                                  \
+        ++g_checks;                                                                                       \
+        const double a_ = (a), b_ = (b);                                                                  \
+        if (!(std::fabs(a_ - b_) <= (tol))) {                                                             \
+            ++g_failed;                                                                                   \
+            std::printf("FAIL %s:%d: %s = %.12g, expected %.12g +- %g\n", __FILE__, __LINE__, #a, a_, b_, \
+                        (double)(tol));                                                                   \
+        }                                                                                                 \
+    } while (0)
+#define EXPECT_TRUE(c)                                                   \
+    do {                                                                 \
+        ++g_checks;                                                      \
+        if (!(c)) {                                                      \
+            ++g_failed;                                                  \
+            std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c);     \
+        }                                                                \
+    } while (0)
+
+static Eigen::SparseMatrix<double, Eigen::RowMajor> dataAssociation()
+{
+    Eigen::SparseMatrix<double, Eigen::RowMajor> m(2, 4);
+    std::vector<Eigen::Triplet<double>> t = {{0, 0, 1}, {0, 2, 1}, {0, 3, 1}, {1, 0, 1}, {1, 1, 1}, {1, 2, 1}, {1, 3, 1}};
+    m.setFromTriplets(t.begin(), t.end());
+    m.makeCompressed();
+    return m;
+}
+
+static void weightsTests()
+{
+    const std::vector<double> sq = {1, 1, 1, 1, 4, 9, 16};
+    const double expected_t[2][4] = {{1.0 / 3, 0, 1.0 / 3, 1.0 / 3}, {0.7151351, 0.1412613, 0.0241258, 0.0047656}};
+    const double expected_g[2][4] = {{1.0 / 3, 0, 1.0 / 3, 1.0 / 3},
+                                     {0.805153702921689, 0.179654074677018, 0.0147469044726408, 0.000445317928652638}};
+    {
+        ProbabilisticWeights w(5, 1, 4);
+        auto out = w.updateWeights(dataAssociation(), sq);
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 4; j++) EXPECT_NEAR(expected_t[i][j], out.coeff(i, j), 1e-6);
+    }
+    {
+        ProbabilisticWeights w(std::numeric_limits<double>::infinity(), 1, 4);
+        auto out = w.updateWeights(dataAssociation(), sq);
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 4; j++) EXPECT_NEAR(expected_g[i][j], out.coeff(i, j), 1e-6);
+    }
+}
+
+static pcl::PointCloud<pcl::PointXYZ> generateCloud()
+{
+    pcl::PointCloud<pcl::PointXYZ> cloud;
+    double x = 0;
+    for (int i = 0; i < 30; ++i) {
+        double y = 0;
+        for (int j = 0; j < 50; ++j) {
+            cloud.push_back(pcl::PointXYZ((float)x, (float)y, (float)(std::sin(x) + std::cos(y))));
+            y += 0.5;
+        }
+        x += 0.5;
+    }
+    return cloud;
+}
+
+static Eigen::Affine3d testTransform()
+{
+    // translation (2.5, 0, 0) then prerotate Rz(0.34): y = Rz (p + (2.5,0,0))
+    Eigen::Affine3d T;
+    const double a = 0.34;
+    T.R.m[0][0] = std::cos(a), T.R.m[0][1] = -std::sin(a), T.R.m[1][0] = std::sin(a), T.R.m[1][1] = std::cos(a);
+    T.t = Eigen::Vector3d(2.5 * std::cos(a), 2.5 * std::sin(a), 0);
+    return T;
+}
+
+static void exactAssociationTest(double dof)
+{
+    auto source = generateCloud();
+    pcl::PointCloud<pcl::PointXYZ> target;
+    pcl::transformPointCloud(source, target, testTransform());
+    Eigen::SparseMatrix<double, Eigen::RowMajor> assoc(source.size(), target.size());
+    std::vector<Eigen::Triplet<double>> tl;
+    for (std::size_t i = 0; i < source.size(); ++i) tl.push_back(Eigen::Triplet<double>((int)i, (int)i, 1));
+    assoc.setFromTriplets(tl.begin(), tl.end());
+    assoc.makeCompressed();
+    ProbPointCloudRegistrationParams params;
+    params.dof = dof;
+    params.max_neighbours = 3;
+    ProbPointCloudRegistrationIteration registration(source, target, assoc, params);
+    ceres::Solver::Options options;
+    options.linear_solver_type = ceres::SPARSE_NORMAL_CHOLESKY;
+    options.use_nonmonotonic_steps = true;
+    options.max_num_iterations = std::numeric_limits<int>::max();
+    options.function_tolerance = 10e-5;
+    options.num_threads = 8;
+    ceres::Solver::Summary summary;
+    registration.solve(options, &summary);
+    auto estimated = registration.transformation();
+    pcl::PointCloud<pcl::PointXYZ> aligned;
+    pcl::transformPointCloud(source, aligned, estimated);
+    double mean_error = 0;
+    for (std::size_t i = 0; i < target.size(); ++i)
+        mean_error += std::sqrt(std::pow(target.at(i).x - aligned[i].x, 2) + std::pow(target.at(i).y - aligned[i].y, 2) +
+                                std::pow(target.at(i).z - aligned[i].z, 2));
+    mean_error /= target.size();
+    EXPECT_NEAR(mean_error, 0, 1e-6);
+    EXPECT_TRUE(summary.final_cost <= summary.initial_cost);
+    EXPECT_TRUE(summary.num_successful_steps >= 1);
+}
+
+static void alignTest()
+{
+    // a jittered copy of the test surface, moved by a small known motion; full align() with kd-tree-free NN
+    auto target = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>(generateCloud());
+    Eigen::Affine3d T;
+    const double a = 0.02;
+    T.R.m[0][0] = std::cos(a), T.R.m[0][1] = -std::sin(a), T.R.m[1][0] = std::sin(a), T.R.m[1][1] = std::cos(a);
+    T.t = Eigen::Vector3d(0.05, -0.03, 0.02);
+    auto source = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+    // source = T^-1 target
+    Eigen::Affine3d Ti;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) Ti.R.m[r][c] = T.R.m[c][r];
+    for (int r = 0; r < 3; r++) Ti.t.v[r] = -(Ti.R.m[r][0] * T.t.v[0] + Ti.R.m[r][1] * T.t.v[1] + Ti.R.m[r][2] * T.t.v[2]);
+    pcl::transformPointCloud(*target, *source, Ti);
+    ProbPointCloudRegistrationParams params;
+    params.radius = 0.4;
+    params.max_neighbours = 5;
+    params.n_iter = 30;
+    params.summary = true;
+    auto gt = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>(*target);
+    const std::size_t n_before = target->size();
+    ProbPointCloudRegistration reg(source, target, params, gt);
+    reg.align();
+    EXPECT_TRUE(target->size() == n_before);  // no target filter: caller's cloud untouched
+    const auto hist = reg.transformation_history();
+    EXPECT_TRUE(hist.size() >= 6 && hist.size() <= 30);  // earliest stop of hasConverged is after 6 iterations
+    const auto est = reg.transformation();
+    EXPECT_NEAR(est.translation().x(), 0.05, 2e-3);
+    EXPECT_NEAR(est.translation().y(), -0.03, 2e-3);
+    EXPECT_NEAR(est.translation().z(), 0.02, 2e-3);
+    EXPECT_NEAR(est.rotation()(1, 0), std::sin(a), 1e-3);
+    const std::string rep = reg.report();
+    EXPECT_TRUE(rep.find("iter, n_success_steps, initial_cost, final_cost, tx, ty, tz, roll, pitch, yaw, mse_prev_iter, mse_gtruth") == 0);
+    std::size_t lines = 0;
+    for (char ch : rep) lines += ch == '\n';
+    EXPECT_TRUE(lines == hist.size() + 1);
+    // n_iter caps the loop; cost_drop_thresh = 0 runs exactly n_iter
+    params.n_iter = 4;
+    params.cost_drop_thresh = 0;
+    params.summary = false;
+    ProbPointCloudRegistration reg2(source, target, params);
+    reg2.align();
+    EXPECT_TRUE(reg2.transformation_history().size() == 4);
+    // filters: the caller's target IS filtered in place, the source copy is not the caller's
+    auto target2 = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>(*target);
+    params.target_filter_size = 1.0;
+    params.source_filter_size = 1.0;
+    const std::size_t src_n = source->size();
+    ProbPointCloudRegistration reg3(source, target2, params);
+    EXPECT_TRUE(target2->size() < n_before && target2->size() > 0);
+    EXPECT_TRUE(source->size() == src_n);
+    reg3.align();
+    EXPECT_TRUE(reg3.transformation_history().size() == 4);
+}
+
+static void errorTermTest()
+{
+    ErrorTerm e(pcl::PointXYZ(1, 0, 0), pcl::PointXYZ(0.5f, 1, 0));
+    const double q[4] = {3.7 * std::cos(M_PI / 4), 0, 0, 3.7 * std::sin(M_PI / 4)};  // un-normalised Rz(90 deg)
+    const double t[3] = {0.5, 0, 0};
+    double r[3];
+    e(q, t, r);  // R x = (0,1,0); + t = (0.5,1,0); y - that = 0
+    EXPECT_NEAR(r[0], 0, 1e-12);
+    EXPECT_NEAR(r[1], 0, 1e-12);
+    EXPECT_NEAR(r[2], 0, 1e-12);
+    e.updateWeight(0.25);
+    EXPECT_NEAR(e.weight()->scale(), 0.25, 0);
+}
+
+int main()
+{
+    weightsTests();
+    exactAssociationTest(std::numeric_limits<double>::infinity());
+    exactAssociationTest(5);
+    errorTermTest();
+    alignTest();
+    std::printf("%d checks, %d failed\n", g_checks, g_failed);
+    return g_failed;
+}

@@ -1,0 +1,111 @@
+"""The C++ host layer above the C ABI: the drop-in classes (tests/cpp/test_api.cc restates the reference's
+gtest cases) and the `probabilistic_point_cloud_registration` CLI with the reference's flags and outputs."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import binding as po
+from probabilistic_point_clouds_registration_amd import build, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def programs():
+    return build.build_host_programs()
+
+
+def write_pcd(path, pts, binary=False):
+    pts = np.asarray(pts, np.float32)[:, :3]
+    hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\n"
+           f"WIDTH {len(pts)}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {len(pts)}\nDATA {'binary' if binary else 'ascii'}\n")
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        if binary:
+            f.write(np.ascontiguousarray(pts).tobytes())
+        else:
+            for p in pts:
+                f.write(("%.9g %.9g %.9g\n" % tuple(p)).encode())
+
+
+def read_pcd_ascii(path):
+    lines = open(path).read().splitlines()
+    k = next(i for i, l in enumerate(lines) if l.startswith("DATA"))
+    return np.array([[float(v) for v in l.split()] for l in lines[k + 1:] if l.strip()], np.float32)
+
+
+def test_cli_argument_errors_exit_like_the_reference(programs):
+    cli = programs[0]
+    for args in ([], ["only_source.pcd"], ["-m", "notanint", "a.pcd", "b.pcd"], ["--bogus", "a.pcd", "b.pcd"], ["-r"]):
+        r = subprocess.run([cli] + args, capture_output=True, text=True)
+        assert r.returncode == 1 and "error:" in r.stderr and "for arg" in r.stderr
+    r = subprocess.run([cli, "/nonexistent/a.pcd", "/nonexistent/b.pcd"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Could not load source cloud, closing" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_api_restated_reference_tests(programs):
+    r = subprocess.run([programs[1]], capture_output=True, text=True, timeout=600)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 failed" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gauss", [False, True])
+def test_cli_end_to_end_matches_oracle(programs, tmp_path, gauss):
+    cli = programs[0]
+    src, tgt, Rgt, tgt_t = synth.make_pair(3000, cfg=1, stride=3)
+    write_pcd(tmp_path / "scan_a.pcd", src, binary=False)
+    write_pcd(tmp_path / "scan_b.pcd", tgt, binary=True)
+    gt = (src.astype(np.float64) @ Rgt.T + tgt_t).astype(np.float32)
+    write_pcd(tmp_path / "gt.pcd", gt)
+    args = [cli, "-r", "1.0", "-m", "5", "-i", "7", "-c", "0", "-v", "--dump", "-g", str(tmp_path / "gt.pcd")]
+    if gauss:
+        args.append("-u")
+    args += [str(tmp_path / "scan_a.pcd"), str(tmp_path / "scan_b.pcd")]
+    r = subprocess.run(args, capture_output=True, text=True, cwd=tmp_path, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    assert ("Using gaussian model" in out) == gauss
+    assert "Radius of the neighborhood search: 1" in out and "Max number of neighbours: 5" in out
+    assert "Transformation history:" in out and "Saving aligned source cloud to: aligned_scan_a.pcd" in out
+    assert "Saving registration report to: scan_a_scan_b_summary.txt" in out
+    assert re.search(r"MSE w\.r\.t\. ground truth: ", out)
+    hist = re.findall(r"^T: (.*) \|\|\| R: (.*)$", out, flags=re.M)
+    assert len(hist) == 7                                      # -c 0 -i 7 -> exactly 7 outer iterations
+    t_cli = np.array([float(v) for v in hist[-1][0].split(",")])
+    q_cli = np.array([float(v) for v in hist[-1][1].split(",")])   # x, y, z, w
+    dof = float("inf") if gauss else 5.0
+    ora = po.align(src, tgt, 1.0, 5, dof, 7, cost_drop_thresh=0.0, inner_max_steps=100, f_tol=10e-6)
+    R_cli = po.quat_to_R([q_cli[3], q_cli[0], q_cli[1], q_cli[2]])
+    # stdout carries 6 significant digits
+    assert np.linalg.norm(t_cli - ora["history"][-1][:, 3]) < 5e-6
+    assert synth.rotation_angle(R_cli, ora["history"][-1][:, :3]) < 5e-6
+    # aligned cloud (written only because of -v) = original source moved by the final transform
+    aligned = read_pcd_ascii(tmp_path / "aligned_scan_a.pcd")
+    exp = src.copy()
+    po.transform_cloud(exp, np.vstack([ora["history"][-1], [0, 0, 0, 1]]))
+    np.testing.assert_allclose(aligned, exp, atol=5e-6)
+    # summary file: 3 header lines + column header + one row per iteration
+    rep = open(tmp_path / "scan_a_scan_b_summary.txt").read().splitlines()
+    assert rep[0].startswith("Source: ") and rep[1].startswith("Target:") and rep[2].startswith("dof: ")
+    assert rep[3].startswith("iter, n_success_steps, initial_cost, final_cost, tx, ty, tz, roll, pitch, yaw")
+    assert len(rep) == 4 + 7
+    row = [float(v) for v in rep[-1].split(",")]
+    assert row[0] == 6 and abs(row[4] - t_cli[0]) < 1e-5
+    np.testing.assert_allclose([row[2], row[3]], ora["costs"][-1], rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_cli_without_verbose_writes_nothing(programs, tmp_path):
+    src, tgt, _, _ = synth.make_pair(1500, cfg=1, stride=3)
+    write_pcd(tmp_path / "a.pcd", src)
+    write_pcd(tmp_path / "b.pcd", tgt)
+    r = subprocess.run([programs[0], "-r", "1", "-m", "5", "-i", "3", str(tmp_path / "a.pcd"), str(tmp_path / "b.pcd")],
+                       capture_output=True, text=True, cwd=tmp_path, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert sorted(os.listdir(tmp_path)) == ["a.pcd", "b.pcd"]     # aligned_* only with -v, summary only with --dump
