@@ -25,7 +25,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from probabilistic_point_clouds_registration_amd import _lib, synth  # noqa: E402
+from probabilistic_point_clouds_registration_amd import _lib, batch, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 
@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel pass")
+    ap.add_argument("--pairs-per-gpu", type=int, default=1,
+                    help="independent pairs each rank registers back to back (BASELINE configs[4]: --config 5 --pairs-per-gpu 8)")
     return ap.parse_args()
 
 
@@ -81,31 +83,41 @@ def main():
 
     cfg = dict(synth.CONFIGS[a.config])
     n = a.n or cfg["n"]
-    # weak scaling: rank r registers its own pair (pair index r of the pinned generator)
-    src, tgt, Rgt, tgt_t = synth.make_pair(n, cfg=a.config, pair=rank)
-
-    ctx = _lib.Context(local_rank)
-    ctx.set_params(cfg["radius"], cfg["max_neighbours"], cfg["dof"], 3)
-    ctx.set_target(tgt)
-    ctx.set_source(src)
+    # weak scaling: rank r registers its own pair(s): pair p lives on rank p % world (batch.shard_pairs)
+    n_pairs = world * a.pairs_per_gpu
+    my_pairs = batch.shard_pairs(n_pairs, world, rank)
+    ctxs = []
+    for p in my_pairs:
+        src, tgt, Rgt, tgt_t = synth.make_pair(n, cfg=a.config, pair=p)
+        c = _lib.Context(local_rank)
+        c.set_params(cfg["radius"], cfg["max_neighbours"], cfg["dof"], 3)
+        c.set_target(tgt)
+        c.set_source(src)
+        ctxs.append(c)
+    ctx = ctxs[0]
+    src, tgt, Rgt, tgt_t = synth.make_pair(n, cfg=a.config, pair=my_pairs[0])   # rank 0's first pair (cpu baseline/parity)
 
     def barrier():
-        ctx.synchronize()
+        for c in ctxs:
+            c.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
     # warm-up (also builds the grid and sorts the source once)
     if a.warmup > 0:
-        ctx.align(a.warmup, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
+        for c in ctxs:
+            c.align(a.warmup, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
     barrier()
     gathered = None
     t0 = time.perf_counter()
-    res = ctx.align(a.steps, cost_drop_thresh=0.0, inner_steps=a.inner_steps)
+    local = {}
+    for p, c in zip(my_pairs, ctxs):
+        res = c.align(a.steps, cost_drop_thresh=0.0, inner_steps=a.inner_steps)
+        local[p] = res["history"][-1]
     if dist is not None:
-        mine = torch.from_numpy(res["history"][-1].reshape(12).copy()).cuda()
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)  # RCCL: the only collective — final gather of the transforms
+        # RCCL: the only collective of the job — final gather of the transforms (batch.gather_transforms)
+        gathered = batch.gather_transforms(local, n_pairs, dist=dist, device=torch.device("cuda", local_rank))
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -135,12 +147,12 @@ def main():
     ns, nt = src.shape[0], tgt.shape[0]
     out = {
         "metric": "registration iterations/sec (1M<->1M pts, r=1.0, m=10)",
-        "value": world * a.steps / dt,
+        "value": n_pairs * a.steps / dt,
         "unit": "iterations/s",
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
-        "ms_per_step": 1e3 * dt / a.steps,
+        "ms_per_step": 1e3 * dt / (a.steps * a.pairs_per_gpu),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -150,7 +162,8 @@ def main():
                                f"max_neighbours={cfg['max_neighbours']}, "
                                f"{'Gaussian' if np.isinf(cfg['dof']) else 't dof=%g' % cfg['dof']}, "
                                f"{a.inner_steps} inner IRLS step(s)/iteration, cost_drop_thresh=0",
-                   "pairs": world, "parallelism": f"{world} independent pair(s), one per GPU; final RCCL all_gather of transforms"},
+                   "pairs": n_pairs, "parallelism": f"{n_pairs} independent pair(s), {a.pairs_per_gpu} per GPU on {world} GPU(s); "
+                                                     "no data-path collective; final RCCL all_gather of the transforms"},
         "nnz": int(nnz),
     }
     # roofline of the dominant kernel (K1, nn_topm_kernel): algorithmic bytes B_nn = 16*Ns + 12*Nt + 4*nnz
@@ -169,8 +182,8 @@ def main():
         out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                            "traffic": None}
     out["iteration_roofline"] = {"algorithmic_bytes_per_iteration": b_iter,
-                                 "achieved_GBs": b_iter * a.steps / dt / 1e9,
-                                 "frac_of_hbm_peak": b_iter * a.steps / dt / 1e9 / HBM_PEAK_GBS}
+                                 "achieved_GBs_per_gpu": b_iter * a.steps * a.pairs_per_gpu / dt / 1e9,
+                                 "frac_of_hbm_peak": b_iter * a.steps * a.pairs_per_gpu / dt / 1e9 / HBM_PEAK_GBS}
     out["kernels_ms_per_launch"] = {k: v["total_ms"] / max(1, v["launches"]) for k, v in prof.items()
                                     if isinstance(v, dict)}
     if "_profiled_pass_ms_per_step" in prof:
@@ -192,10 +205,11 @@ def main():
                          "trans_err_m": float(np.linalg.norm(g["history"][-1][:, 3] - ora["history"][-1][:, 3])),
                          "vs": "oracle (CPU restatement); the reference itself cannot be built (PCL/Ceres absent)"}
     elif world > 1:
-        out["gathered_transforms"] = len(gathered) if gathered else 0
+        out["gathered_transforms"] = int(np.isfinite(gathered).all(axis=(1, 2)).sum()) if gathered is not None else 0
     print(json.dumps(out))
     sys.stdout.flush()
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -392,3 +392,30 @@ def test_profile_reports_kernels(ctx):
     ctx.profile_enable(False)
     assert st["nn_topm_kernel"]["launches"] == 3 and st["accumulate_kernel"]["launches"] == 3, st
     assert st["transform_kernel"]["launches"] == 3 and st["nn_topm_kernel"]["total_ms"] > 0
+
+
+# ----------------------------------------------------------------------------- python mirror + batch
+def test_python_mirror_and_batch_single_rank(ctx):
+    from probabilistic_point_clouds_registration_amd import batch, registration
+    g = load("align_trace_2k.npz")
+    prm = registration.ProbPointCloudRegistrationParams(max_neighbours=10, dof=5.0, radius=1.0, n_iter=6,
+                                                        cost_drop_thresh=0.0, inner_max_steps=1)
+    reg = registration.ProbPointCloudRegistration(g["src"], g["tgt"], prm)
+    assert reg.align() == 6
+    ref = g["hist_t5_inner1"][-1]
+    assert synth.rotation_angle(reg.transformation()[:3, :3], ref[:, :3]) < ROT_TOL
+    assert np.linalg.norm(reg.transformation()[:3, 3] - ref[:, 3]) < TRANS_TOL
+    # ProbabilisticWeights mirror = the reference's golden values
+    w = registration.ProbabilisticWeights(5, 1, 4).update_weights([0, 3, 7], [1, 1, 1, 1, 4, 9, 16])
+    np.testing.assert_allclose(w[3:], [0.7151351, 0.1412613, 0.0241258, 0.0047656], atol=1e-6)
+    # batched driver on one rank: three independent pairs, gathered array equals per-pair runs vs the oracle
+    def make_pair(p):
+        s, t, _, _ = synth.make_pair(1500, cfg=5, pair=p, stride=3)
+        return s, t, dict(radius=1.0, max_neighbours=10, dof=5.0)
+    local = batch.register_local_pairs(make_pair, 3, 1, 0, n_iter=4, inner_steps=1)
+    all_T = batch.gather_transforms(local, 3)
+    for p in range(3):
+        s, t, prm2 = make_pair(p)
+        ora = po.align(s, t, 1.0, 10, 5.0, 4, inner_max_steps=1)
+        assert synth.rotation_angle(all_T[p][:, :3], ora["history"][-1][:, :3]) < ROT_TOL
+        assert np.linalg.norm(all_T[p][:, 3] - ora["history"][-1][:, 3]) < TRANS_TOL
