@@ -569,17 +569,18 @@ __device__ __forceinline__ void last_block_reduce(const double *__restrict__ par
 constexpr int kTileRows = 128;   // halo rows per staging
 
 template <int BLOCK>
-struct LdsCands {  // candidate source = staged halo; list entries are LDS indices
-    const float4 *cand;
+struct LdsCands {  // candidate source = staged halo (SoA in LDS); list entries are LDS indices
+    const float *sx, *sy, *sz;
+    const int *spos;       // sorted-target position of every staged candidate
     unsigned short *list;  // [slot * BLOCK + tid]
     int tid;
-    __device__ __forceinline__ float4 get(int e) const { return cand[e]; }
+    __device__ __forceinline__ float4 get(int e) const { return make_float4(sx[e], sy[e], sz[e], 0.f); }
     __device__ __forceinline__ int load(int t) const { return list[t * BLOCK + tid]; }
     __device__ __forceinline__ void store(int t, int e) const { list[t * BLOCK + tid] = (unsigned short)e; }
-    __device__ __forceinline__ int pos_of(int e) const { return __float_as_int(cand[e].w); }
+    __device__ __forceinline__ int pos_of(int e) const { return spos[e]; }
     __device__ __forceinline__ unsigned orig_of(int e, const float4 *__restrict__ tgt) const
     {
-        return (unsigned)__float_as_int(tgt[__float_as_int(cand[e].w)].w);
+        return (unsigned)__float_as_int(tgt[spos[e]].w);
     }
 };
 struct GlobalCands {  // candidate source = global memory; list entries are sorted-target positions
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(const float4 *__restrict
                                                          unsigned long long *__restrict__ stamps, FusedMoments fm)
 {
     static_assert(C > M, "a compaction must leave room in the list");
-    static_assert(CAP <= 65536 && C * 64 * 4 <= CAP * 16, "the global fallback aliases the candidate buffer");
+    static_assert(CAP % 4 == 0 && CAP <= 65536 && C * 64 <= 4 * CAP, "the global fallback aliases the candidate buffer");
     static_assert(kTileRows == 128, "row table: two rows per lane of one wave");
     constexpr int kWaves = BLOCK / 64;
     constexpr int kStageUnroll = 8;  // halo rows in flight per wave
@@ -670,7 +671,11 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(const float4 *__restrict
         if (stamps && (threadIdx.x & 63) == 0)
             for (int k = 0; k < 8; k++) stamps[((size_t)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8 + k] = t_acc[k];
     };
-    __shared__ float4 s_cand[CAP];
+    // staged halo, structure-of-arrays: two candidates per ds_read_b64 and per packed-f32 instruction
+    __shared__ __attribute__((aligned(16))) float s_halo[4 * CAP];
+    float *const s_x = s_halo, *const s_y = s_halo + CAP, *const s_z = s_halo + 2 * CAP;
+    int *const s_pos = reinterpret_cast<int *>(s_halo + 3 * CAP);
+    int *const s_glist = reinterpret_cast<int *>(s_halo);  // global-fallback list aliases the halo buffer
     __shared__ unsigned short s_list[C * BLOCK];
     __shared__ int s_row_gb[kTileRows];
     __shared__ int s_row_off[kTileRows + 1];
@@ -800,29 +805,37 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(const float4 *__restrict
 #pragma unroll
                 for (int u = 0; u < kStageUnroll; u++) {
                     if (lane < sl[u]) {
-                        c[u].w = __int_as_float(sg[u] + lane);  // sorted-target position travels in the w lane
-                        s_cand[so[u] + lane] = c[u];
+                        const int d = so[u] + lane;
+                        s_x[d] = c[u].x;
+                        s_y[d] = c[u].y;
+                        s_z[d] = c[u].z;
+                        s_pos[d] = sg[u] + lane;
                     }
                     for (int k = lane + 64; k < sl[u]; k += 64) {  // rows longer than a wave (dense data)
-                        float4 t = tgt[sg[u] + k];
-                        t.w = __int_as_float(sg[u] + k);
-                        s_cand[so[u] + k] = t;
+                        const float4 t = tgt[sg[u] + k];
+                        const int d = so[u] + k;
+                        s_x[d] = t.x;
+                        s_y[d] = t.y;
+                        s_z[d] = t.z;
+                        s_pos[d] = sg[u] + k;
                     }
                 }
             }
             __syncthreads();
             stamp(2);
             if (!done && wave >= w0 && wave < w1) {
-                const LdsCands<BLOCK> L{s_cand, s_list, tid};
+                const LdsCands<BLOCK> L{s_x, s_y, s_z, s_pos, s_list, tid};
                 unsigned thr = 0xFFFFFFFFu;
-                auto test = [&](int f) {
-                    const float d2 = dist2_flann(q, s_cand[f]);
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                const v2f qx2 = {q.x, q.x}, qy2 = {q.y, q.y}, qz2 = {q.z, q.z};
+                auto accept = [&](int f, float d2) {
                     if (d2 < r2 && __float_as_uint(d2) <= thr) {
                         L.store(n, f);
                         n++;
                         if (n == C) n = select_top_m<M>(L, tgt, q, n, m, thr);
                     }
                 };
+                auto test1 = [&](int f) { accept(f, dist2_flann(q, make_float4(s_x[f], s_y[f], s_z[f], 0.f))); };
 #pragma unroll 1
                 for (int k = 0; k < 9; k++) {
                     // take the next prefetched run; rotate the register file instead of indexing it
@@ -836,21 +849,24 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(const float4 *__restrict
                     const int r = (qc.cz + (k / 3 - 1) - hz0) * ny_h + (qc.cy + (k % 3 - 1) - hy0);
                     const int fb = s_row_off[r] + (b - s_row_gb[r]), fe = fb + (e - b);
                     int f = fb;
-                    for (; f + 1 < fe; f += 2) {  // two candidates per trip: both LDS reads in flight
-                        const float4 c0 = s_cand[f], c1 = s_cand[f + 1];
-                        const float d0 = dist2_flann(q, c0), d1 = dist2_flann(q, c1);
-                        if (d0 < r2 && __float_as_uint(d0) <= thr) {
-                            L.store(n, f);
-                            n++;
-                            if (n == C) n = select_top_m<M>(L, tgt, q, n, m, thr);
-                        }
-                        if (d1 < r2 && __float_as_uint(d1) <= thr) {
-                            L.store(n, f + 1);
-                            n++;
-                            if (n == C) n = select_top_m<M>(L, tgt, q, n, m, thr);
-                        }
+                    if (f & 1) {  // align to a pair boundary (8-byte LDS reads)
+                        test1(f);
+                        f++;
                     }
-                    if (f < fe) test(f);
+                    for (; f + 1 < fe; f += 2) {
+                        // two candidates per trip: ds_read_b64 x3, packed f32 sub/mul/add (no FMA: the same
+                        // IEEE operations per element as dist2_flann, so d2 is bit-identical)
+                        const v2f cx = *reinterpret_cast<const v2f *>(&s_x[f]);
+                        const v2f cy = *reinterpret_cast<const v2f *>(&s_y[f]);
+                        const v2f cz = *reinterpret_cast<const v2f *>(&s_z[f]);
+                        const v2f dx = qx2 - cx, dy = qy2 - cy, dz = qz2 - cz;
+                        v2f d = dx * dx;
+                        d = d + dy * dy;
+                        d = d + dz * dz;
+                        accept(f, d.x);
+                        accept(f + 1, d.y);
+                    }
+                    if (f < fe) test1(f);
                 }
                 stamp(3);
                 if (n > m) n = select_top_m<M>(L, tgt, q, n, m, thr);
@@ -868,7 +884,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(const float4 *__restrict
         } else if (last_level) {
             // last resort for this wave: scan global memory (list of positions aliases the halo buffer)
             if (!done && wave == w0) {
-                const GlobalCands G{tgt, reinterpret_cast<int *>(s_cand), lane};
+                const GlobalCands G{tgt, s_glist, lane};
                 unsigned thr = 0xFFFFFFFFu;
                 for_each_candidate(q, g, cell_start, tgt, [&](int p, float4 t) {
                     const float d2 = dist2_flann(q, t);
