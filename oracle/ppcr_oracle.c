@@ -667,7 +667,7 @@ void po_transform_cloud(float *xyz, int64_t n, int stride, const double T[12], i
  *   weights primed at the initial state (:49)  -> initial_cost;
  *   step: theta_new = kabsch(moments(w(theta_old)));
  *         final_cost = 0.5 sum w(theta_old) s(theta_new)   (weights lag one update)
- *   stop after max_steps, or when (cost_old - final_cost) <= f_tol * cost_old
+ *   stop after max_steps, or when (cost_old - final_cost) <= max(f_tol * cost_old, 1e-14 * (Sxx+Syy)/2)
  *   (Ceres function_tolerance, src/prob_point_cloud_registration.cc:97).
  * Outputs: R,t of transformation() (:59-67), initial/final cost, steps taken. */
 int po_solve(const float *src, int ss, const float *tgt, int ts, const int *row_ptr, const int *col,
@@ -694,7 +694,8 @@ int po_solve(const float *src, int ss, const float *tgt, int ts, const int *row_
         memcpy(t, tn, sizeof(t));
         cost_out[1] = fc;
         if (degenerate || steps >= max_steps) break;
-        if ((cost_old - fc) <= f_tol * cost_old) break;
+        /* a decrease below the rounding floor of the moment-based cost (eps * (Sxx + Syy)) is no decrease */
+        if ((cost_old - fc) <= fmax(f_tol * cost_old, 1e-14 * 0.5 * (sums[17] + sums[18]))) break;
         po_R_to_quat(R, q);
         po_accumulate(src, ss, tgt, ts, row_ptr, col, ns, q, t, v, dim, c, threads, sums);
         cost_old = 0.5 * sums[16];

@@ -135,6 +135,8 @@ struct ppcr_ctx {
     DevBuf<double> partials, d_sums;
     DevBuf<unsigned> d_ticket;
     bool fused_sums_pending = false;  // K1 ran with the fused moments epilogue; d_sums holds them
+    bool move_pending = false;        // a source move that the next tiled K1 will apply in its prologue
+    double pending_T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     double *h_sums = nullptr;          // pinned
     unsigned long long *h_total = nullptr;  // pinned
 
@@ -403,13 +405,13 @@ int ensure_source_sorted(ppcr_ctx *c)
 // nn_variant: 0/3 = LDS-tiled halo + med3 selection (default), 2 = per-lane global scan + LDS list,
 // 1 = sorted register list inside the scan loop (first version, kept for A/B measurements)
 template <int M>
-void launch_topm(ppcr_ctx *c, float r2, int m, const FusedMoments &fm)
+void launch_topm(ppcr_ctx *c, float r2, int m, const FusedMoments &fm, const PendingMove &pm)
 {
     unsigned long long *st = c->opt_stamps ? c->d_stamps.p : nullptr;
 #define PPCR_TILE_F(Cc, B, CAPc, F)                                                                                 \
     nn_tile_kernel<M, Cc, B, CAPc, F><<<nblocks(c->ns, B), B, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p, \
                                                                               c->cell_start.p, c->grid, r2, m,      \
-                                                                              c->nbr.p, c->cnt.p, st, fm)
+                                                                              c->nbr.p, c->cnt.p, st, fm, pm)
 #define PPCR_TILE(Cc, B, CAPc) PPCR_TILE_F(Cc, B, CAPc, false)
     if (c->opt_nn_variant == 0 || c->opt_nn_variant == 3) {
         // LDS budget per 256-query block: halo CAP*16 B + list C*512 B (+1.1 KB tables), three blocks per CU.
@@ -444,27 +446,47 @@ void launch_topm(ppcr_ctx *c, float r2, int m, const FusedMoments &fm)
     }
 }
 
+constexpr int kAccumRows = 2;     // rows per lane of accumulate_ell_kernel
+constexpr int kAccumBlock = 256;  // threads per block of accumulate_ell_kernel (fewer partial vectors to fold)
+
 template <int W>
 void launch_accumulate_ell(ppcr_ctx *c, int nb, const Pose &P, const Model &md)
 {
-    accumulate_ell_kernel<W><<<nb, kBlock, 0, c->stream>>>(c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md,
+    accumulate_ell_kernel<W, kAccumRows, kAccumBlock><<<nb, kAccumBlock, 0, c->stream>>>(c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md,
                                                            c->partials.p, c->opt_inkernel_reduce ? c->d_ticket.p : nullptr,
                                                            c->d_sums.p);
 }
 
 bool tile_variant(const ppcr_ctx *c) { return c->opt_nn_variant == 0 || c->opt_nn_variant == 3; }
+int flush_pending_move(ppcr_ctx *c);
 
 // fused_theta (nullable): {R, t} of the state the first IRLS half-step is evaluated at; when given and
 // the tiled kernel runs, K1 also produces the moments (c->fused_sums_pending) and K23 is skipped once
 int associate_impl(ppcr_ctx *c, const Mat3 *fused_R = nullptr, const double *fused_t = nullptr)
 {
     PPCR_TRY(ensure_grid(c));
+    if (!c->src_sorted) PPCR_TRY(flush_pending_move(c));  // the one-time spatial sort reads the source
     PPCR_TRY(ensure_source_sorted(c));
     invalidate_association(c);
     c->fused_sums_pending = false;
     const int ns = (int)c->ns;
     const float r2 = (float)(c->radius * c->radius);  // PCL: static_cast<float>(radius * radius)
     const bool unbounded = (c->max_nb <= 0 || (int64_t)c->max_nb >= c->nt);
+    const bool tiled = !unbounded && c->max_nb <= kEllMaxWidth && tile_variant(c) && ns > 0;
+    PendingMove pm;
+    std::memset(&pm, 0, sizeof(pm));
+    if (c->move_pending && tiled) {
+        // the deferred source move rides in this kernel's prologue
+        pm.enabled = 1;
+        for (int a = 0; a < 3; a++) {
+            for (int b = 0; b < 3; b++) pm.P.R[3 * a + b] = c->pending_T[4 * a + b];
+            pm.P.t[a] = c->pending_T[4 * a + 3];
+            pm.P.c[a] = 0;
+        }
+        c->move_pending = false;
+    } else {
+        PPCR_TRY(flush_pending_move(c));
+    }
     if (!unbounded && c->max_nb <= kEllMaxWidth) {
         const int m = c->max_nb;
         HIP_TRY(c, c->nbr.reserve((size_t)m * (size_t)std::max(ns, 1)));
@@ -488,13 +510,13 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fused_R = nullptr, const double *fus
         }
         if (ns > 0) {
             ProfScope ps(c, K_NN_TOPM);
-            if (m <= 4) launch_topm<4>(c, r2, m, fm);
-            else if (m <= 5) launch_topm<5>(c, r2, m, fm);
-            else if (m <= 8) launch_topm<8>(c, r2, m, fm);
-            else if (m <= 10) launch_topm<10>(c, r2, m, fm);
-            else if (m <= 16) launch_topm<16>(c, r2, m, fm);
-            else if (m <= 20) launch_topm<20>(c, r2, m, fm);
-            else launch_topm<32>(c, r2, m, fm);
+            if (m <= 4) launch_topm<4>(c, r2, m, fm, pm);
+            else if (m <= 5) launch_topm<5>(c, r2, m, fm, pm);
+            else if (m <= 8) launch_topm<8>(c, r2, m, fm, pm);
+            else if (m <= 10) launch_topm<10>(c, r2, m, fm, pm);
+            else if (m <= 16) launch_topm<16>(c, r2, m, fm, pm);
+            else if (m <= 20) launch_topm<20>(c, r2, m, fm, pm);
+            else launch_topm<32>(c, r2, m, fm, pm);
         }
         PPCR_TRY(check_launch(c, "nn_topm_kernel"));
         c->fused_sums_pending = fm.enabled != 0;
@@ -668,6 +690,7 @@ int build_csr_cache(ppcr_ctx *c)
 int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PPCR_NSUMS])
 {
     if (c->assoc == ppcr_ctx::ASSOC_NONE) return fail(c, PPCR_ERR_STATE, "no association (call ppcr_associate or ppcr_set_association)");
+    PPCR_TRY(flush_pending_move(c));
     if (!c->origin_valid) {
         // set_association path without a grid: origin = 0 is fine for the exact-association API,
         // but prefer the target bounding-box centre when a grid has been built
@@ -676,7 +699,9 @@ int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PP
     const int ns = (int)c->ns;
     const Pose P = make_pose(c, R, t);
     const Model md = make_model(c);
-    const int nb = std::max(1, std::min(kAccumMaxBlocks, nblocks(ns)));
+    const bool ell_rows = c->assoc == ppcr_ctx::ASSOC_ELL && c->nt > 0;
+    // the ELL kernel covers every row exactly once (kAccumRows rows per lane); the generic one grid-strides
+    const int nb = ell_rows ? std::max(1, nblocks(ns, kAccumBlock * kAccumRows)) : std::max(1, std::min(kAccumMaxBlocks, nblocks(ns)));
     HIP_TRY(c, c->partials.reserve((size_t)nb * kNSums));
     HIP_TRY(c, c->d_sums.reserve(kNSums));
     if (!c->d_ticket.p) {
@@ -714,9 +739,31 @@ int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PP
     return PPCR_OK;
 }
 
-int apply_transform_impl(ppcr_ctx *c, const double T[12])
+int apply_transform_now(ppcr_ctx *c, const double T[12]);
+
+// make the device copy of the source current (a move deferred to the next tiled K1 is applied now)
+int flush_pending_move(ppcr_ctx *c)
+{
+    if (!c->move_pending) return PPCR_OK;
+    c->move_pending = false;
+    return apply_transform_now(c, c->pending_T);
+}
+
+// move the source; when `defer` the move rides along with the next tiled association instead of its own launch
+int apply_transform_impl(ppcr_ctx *c, const double T[12], bool defer = false)
 {
     if (!c->have_src) return fail(c, PPCR_ERR_STATE, "source cloud not set");
+    PPCR_TRY(flush_pending_move(c));
+    if (defer) {
+        std::memcpy(c->pending_T, T, sizeof(c->pending_T));
+        c->move_pending = true;
+        return PPCR_OK;
+    }
+    return apply_transform_now(c, T);
+}
+
+int apply_transform_now(ppcr_ctx *c, const double T[12])
+{
     Pose P;
     for (int a = 0; a < 3; a++) {
         for (int b = 0; b < 3; b++) P.R[3 * a + b] = T[4 * a + b];
@@ -760,7 +807,8 @@ int solve_impl(ppcr_ctx *c, const double q0[4], const double t0[3], int max_step
         t = rs.t;
         cost_out[1] = fc;
         if (rs.degenerate || steps >= max_steps) break;
-        if ((cost_old - fc) <= f_tol * cost_old) break;
+        // a decrease below the rounding floor of the moment-based cost (eps * (Sxx + Syy)) is no decrease
+        if ((cost_old - fc) <= std::max(f_tol * cost_old, 1e-14 * 0.5 * (sums[17] + sums[18]))) break;
         PPCR_TRY(run_accumulate(c, R, t.v, sums));
         cost_old = 0.5 * sums[16];
     }
@@ -927,6 +975,7 @@ static int set_target_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, in
 
 static int set_source_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, int64_t stride)
 {
+    c->move_pending = false;  // a deferred move of the previous source dies with it
     PPCR_TRY(upload_cloud(c, p, dev, n, stride, c->src));
     c->ns = n;
     c->have_src = true;
@@ -975,6 +1024,7 @@ int ppcr_association_size(ppcr_ctx *c, int64_t *n_rows, int64_t *nnz)
 int ppcr_get_association(ppcr_ctx *c, int32_t *row_ptr, int32_t *col, float *d2)
 {
     CTX_ENTER(c);
+    PPCR_TRY(flush_pending_move(c));
     PPCR_TRY(build_csr_cache(c));
     const size_t ns = (size_t)c->ns, nnz = c->h_csr_col.size();
     if (row_ptr) std::memcpy(row_ptr, c->h_csr_row_ptr.data(), sizeof(int) * (ns + 1));
@@ -1078,6 +1128,7 @@ int ppcr_weights(ppcr_ctx *c, const double q[4], const double t[3], double *w_ou
 {
     CTX_ENTER(c);
     if (!q || !t) return fail(c, PPCR_ERR_INVALID, "null pose");
+    PPCR_TRY(flush_pending_move(c));
     PPCR_TRY(build_csr_cache(c));
     const int ns = (int)c->ns;
     const size_t nnz = c->h_csr_col.size();
@@ -1213,7 +1264,7 @@ int ppcr_iterate(ppcr_ctx *c, const double q0[4], const double t0[3], int inner_
     const Mat3 R0 = quat_to_rot(q0);
     PPCR_TRY(associate_impl(c, &R0, t0));
     PPCR_TRY(solve_impl(c, q0, t0, inner_steps, f_tol, T_out, cost_out, steps_out));
-    return apply_transform_impl(c, T_out);
+    return apply_transform_impl(c, T_out, /*defer=*/true);
 }
 
 int ppcr_align(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_drop_it, const double q0[4],
@@ -1235,7 +1286,7 @@ int ppcr_align(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_d
         int st = 0;
         PPCR_TRY(associate_impl(c, &R0, t0));
         PPCR_TRY(solve_impl(c, q0, t0, inner_steps, f_tol, Tk, cost, &st));
-        PPCR_TRY(apply_transform_impl(c, Tk));
+        PPCR_TRY(apply_transform_impl(c, Tk, /*defer=*/true));  // rides in the next iteration's K1 prologue
         compose(Tk, Tcum, Tcum);  // T_cum <- T_k * T_cum (cc:101-107)
         const int it = rule.current_iteration;
         if (history) std::memcpy(history + (size_t)it * 12, Tcum, sizeof(Tcum));
@@ -1247,6 +1298,7 @@ int ppcr_align(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_d
         rule.cost_drop = (cost[0] - cost[1]) / cost[0];  // cc:119
         rule.current_iteration++;                        // cc:130
     }
+    PPCR_TRY(flush_pending_move(c));  // leave the device copy of the source current
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (n_done) *n_done = rule.current_iteration;
     return PPCR_OK;
@@ -1257,6 +1309,7 @@ int ppcr_get_source(ppcr_ctx *c, float *xyz, int64_t stride_bytes)
     CTX_ENTER(c);
     if (!c->have_src) return fail(c, PPCR_ERR_STATE, "source cloud not set");
     if (stride_bytes < 12 || stride_bytes % 4) return fail(c, PPCR_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
+    PPCR_TRY(flush_pending_move(c));
     if (c->ns == 0) return PPCR_OK;
     if (!xyz) return fail(c, PPCR_ERR_INVALID, "null output");
     std::vector<float4> h((size_t)c->ns);

@@ -642,13 +642,33 @@ __device__ __forceinline__ int select_top_m(const S &src, const float4 *__restri
     return w;
 }
 
+// rigid move of one point: f64 arithmetic summed left to right, f32 store (pcl::transformPointCloud
+// semantics, src/prob_point_cloud_registration.cc:110-112); the w lane (original index) is preserved
+__device__ __forceinline__ float4 move_point(float4 p, const Pose &P)
+{
+    const double x = p.x, y = p.y, z = p.z;
+    p.x = (float)(((P.R[0] * x + P.R[1] * y) + P.R[2] * z) + P.t[0]);
+    p.y = (float)(((P.R[3] * x + P.R[4] * y) + P.R[5] * z) + P.t[1]);
+    p.z = (float)(((P.R[6] * x + P.R[7] * y) + P.R[8] * z) + P.t[2]);
+    return p;
+}
+
+// Pending in-place move of the source (K4) folded into K1's prologue: the previous iteration's rigid
+// transform is applied while the query is loaded and the moved point is written back, which saves one
+// kernel launch and one 32 MB read+write pass per iteration.
+struct PendingMove {
+    int enabled;
+    Pose P;
+};
+
 template <int M, int C, int BLOCK, int CAP, bool FUSED>
-__global__ __launch_bounds__(BLOCK) void nn_tile_kernel(const float4 *__restrict__ src, int ns,
+__global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt,
                                                          const int *__restrict__ cell_start, GridDesc g,
                                                          float r2, int m, int *__restrict__ nbr,
                                                          int *__restrict__ cnt,
-                                                         unsigned long long *__restrict__ stamps, FusedMoments fm)
+                                                         unsigned long long *__restrict__ stamps, FusedMoments fm,
+                                                         PendingMove pm)
 {
     static_assert(C > M, "a compaction must leave room in the list");
     static_assert(CAP % 4 == 0 && CAP <= 65536 && C * 64 <= 4 * CAP, "the global fallback aliases the candidate buffer");
@@ -685,7 +705,11 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(const float4 *__restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = blockIdx.x * BLOCK + tid;
     const bool valid = i < ns;
-    const float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pm.enabled && valid) {
+        q = move_point(q, pm.P);
+        src[i] = q;
+    }
     const QueryCells qc = query_cells(q, g);
 
     // this lane's 9 stencil runs [rb, re) in sorted-target positions: issued now, consumed after the
@@ -1081,13 +1105,36 @@ __device__ __forceinline__ void block_reduce_finish(const RowAcc &acc, double *_
     }
     __syncthreads();
     if (!s_last) return;
+    // last block: every thread folds partial blocks b = t, t + BLOCK, ...; its 19 agent-scope loads per
+    // block are independent and issued back to back (about one round trip per pair of blocks)
     const int nb = gridDim.x;
-    for (int j = wave; j < kNSums; j += BLOCK / 64) {
-        double v = 0;
-        for (int b = lane; b < nb; b += 64)
-            v += __hip_atomic_load(&partials[(size_t)j * nb + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) sums[j] = v;
+    double v[kNSums];
+#pragma unroll
+    for (int j = 0; j < kNSums; j++) v[j] = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 2 * BLOCK) {
+        double t0[kNSums], t1[kNSums];
+        const int b1 = b + BLOCK;
+#pragma unroll
+        for (int j = 0; j < kNSums; j++)
+            t0[j] = __hip_atomic_load(&partials[(size_t)j * nb + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < kNSums; j++)
+            t1[j] = (b1 < nb) ? __hip_atomic_load(&partials[(size_t)j * nb + b1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+        for (int j = 0; j < kNSums; j++) v[j] += t0[j] + t1[j];
+    }
+    __syncthreads();  // sh is reused
+#pragma unroll
+    for (int j = 0; j < kNSums; j++) {
+        double x = v[j];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        if (lane == 0) sh[wave][j] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNSums) {
+        double x = sh[0][threadIdx.x];
+        for (int w = 1; w < BLOCK / 64; w++) x += sh[w][threadIdx.x];
+        sums[threadIdx.x] = x;
     }
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1136,11 +1183,13 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(A a, const float4 *_
     block_reduce_store(acc, partials);
 }
 
-// K23 (hot path), ELL rows of width <= W: all W neighbour indices are loaded first (coalesced,
-// k-major), then all W target points are gathered with the loads in flight together, and the row
-// is finished from registers in a single sweep — the row is never re-read.
-template <int W>
-__global__ __launch_bounds__(kBlock) void accumulate_ell_kernel(const int *__restrict__ nbr,
+// K23 (hot path), ELL rows of width <= W.  Latency, not arithmetic, bounds this kernel (three dependent
+// memory round trips per row: row header -> neighbour indices -> target points), so each lane owns ROWS
+// rows and issues ALL their loads before any arithmetic: 2 + ROWS*W index loads in flight, then ROWS*W
+// gathers in flight; the rows are then finished from registers in a single sweep (never re-read).  The
+// grid covers every row exactly once (no grid-stride loop).
+template <int W, int ROWS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__restrict__ nbr,
                                                                 const int *__restrict__ cnt,
                                                                 const float4 *__restrict__ src,
                                                                 const float4 *__restrict__ tgt, int ns, Pose P,
@@ -1151,41 +1200,54 @@ __global__ __launch_bounds__(kBlock) void accumulate_ell_kernel(const int *__res
     RowAcc acc;
 #pragma unroll
     for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < ns; i += gridDim.x * kBlock) {
-        const int n = cnt[i];
-        if (n == 0) continue;
-        const float4 xf = src[i];
-        int idx[W];
+    const int base = blockIdx.x * (BLOCK * ROWS) + threadIdx.x;
+    int n[ROWS];
+    float4 xf[ROWS];
+    float yx[ROWS][W], yy[ROWS][W], yz[ROWS][W];
+    {
+        int idx[ROWS][W];
 #pragma unroll
-        for (int k = 0; k < W; k++) idx[k] = (k < n) ? nbr[(size_t)k * ns + i] : 0;
-        float yx[W], yy[W], yz[W];
+        for (int r = 0; r < ROWS; r++) {
+            const int i = base + r * BLOCK;
+            const bool ok = i < ns;
+            n[r] = ok ? cnt[i] : 0;
+            xf[r] = src[ok ? i : 0];
 #pragma unroll
-        for (int k = 0; k < W; k++) {
-            const float4 y = tgt[idx[k]];  // slot 0 of the target for k >= n: harmless, masked below
-            yx[k] = y.x;
-            yy[k] = y.y;
-            yz[k] = y.z;
+            for (int k = 0; k < W; k++) idx[r][k] = ok ? nbr[(size_t)k * ns + i] : 0;  // slots >= cnt hold stale data
         }
+#pragma unroll
+        for (int r = 0; r < ROWS; r++)
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                const float4 y = tgt[(k < n[r]) ? idx[r][k] : 0];  // slot 0 of the target for unused slots: masked below
+                yx[r][k] = y.x;
+                yy[r][k] = y.y;
+                yz[r][k] = y.z;
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        if (n[r] == 0) continue;
         double xr[3];
-        rotate_point(P, xf, xr);
+        rotate_point(P, xf[r], xr);
         double s[W];
         double smin = INFINITY;
 #pragma unroll
         for (int k = 0; k < W; k++) {
-            const double r0 = (double)yx[k] - xr[0], r1 = (double)yy[k] - xr[1], r2 = (double)yz[k] - xr[2];
+            const double r0 = (double)yx[r][k] - xr[0], r1 = (double)yy[r][k] - xr[1], r2 = (double)yz[r][k] - xr[2];
             s[k] = r0 * r0 + r1 * r1 + r2 * r2;
-            smin = (k < n && s[k] < smin) ? s[k] : smin;
+            smin = (k < n[r] && s[k] < smin) ? s[k] : smin;
         }
         const double lp_max = (md.is_normal || md.vpd_int) ? 0.0 : log_prob(md, smin);
         double Z = 0, G = 0, Gs = 0, Gyy = 0, Gy[3] = {0, 0, 0};
 #pragma unroll
         for (int k = 0; k < W; k++) {
-            if (k < n) {
+            if (k < n[r]) {
                 const double inv_vs = md.is_normal ? 0.0 : fast_rcp(md.v + s[k]);
-            const double e = rel_likelihood(md, s[k], smin, lp_max, inv_vs);
+                const double e = rel_likelihood(md, s[k], smin, lp_max, inv_vs);
                 Z += e;
                 const double gk = md.is_normal ? e : e * (md.vpd * inv_vs);
-                const double yc0 = (double)yx[k] - P.c[0], yc1 = (double)yy[k] - P.c[1], yc2 = (double)yz[k] - P.c[2];
+                const double yc0 = (double)yx[r][k] - P.c[0], yc1 = (double)yy[r][k] - P.c[1], yc2 = (double)yz[r][k] - P.c[2];
                 G += gk;
                 Gs = fma(gk, s[k], Gs);
                 Gy[0] = fma(gk, yc0, Gy[0]);
@@ -1194,24 +1256,45 @@ __global__ __launch_bounds__(kBlock) void accumulate_ell_kernel(const int *__res
                 Gyy = fma(gk, yc0 * yc0 + yc1 * yc1 + yc2 * yc2, Gyy);
             }
         }
-        row_finish(acc, P, xf, Z, G, Gs, Gyy, Gy);
+        row_finish(acc, P, xf[r], Z, G, Gs, Gyy, Gy);
     }
-    if (ticket) block_reduce_finish<kBlock>(acc, partials, ticket, sums);  // experiment (uniform branch)
-    else block_reduce_store<kBlock>(acc, partials);
+    // (an in-kernel last-block fold — block_reduce_finish — was measured: its register footprint costs this
+    //  kernel more than the separate 17 us fold kernel does: 101.6 us vs 67.6 + 17.2 us)
+    (void)ticket;
+    (void)sums;
+    block_reduce_store<BLOCK>(acc, partials);
 }
 
-// fold partials[19][nblocks] -> sums[19]: one 1024-thread block, wave w owns sum j = w (and
-// j = w + 16); every lane adds a fixed strided subset, then a shuffle tree: fixed summation
-// order, no atomics, no block-level barrier.
+// fold partials[19][nblocks] -> sums[19].  One 1024-thread block; thread t owns partial block(s)
+// b = t, t + 1024, ... and issues its 19 loads (one per sum, coalesced across threads) back to back, so the
+// whole fold costs about one memory round trip; then a wave shuffle tree and a fixed-order LDS combine:
+// deterministic summation order, no atomics.
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const double *__restrict__ partials, int nblocks,
                                                                double *__restrict__ sums)
 {
+    __shared__ double sh[16][kNSums];
+    double v[kNSums];
+#pragma unroll
+    for (int j = 0; j < kNSums; j++) v[j] = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 1024) {
+        double t[kNSums];
+#pragma unroll
+        for (int j = 0; j < kNSums; j++) t[j] = partials[(size_t)j * nblocks + b];
+#pragma unroll
+        for (int j = 0; j < kNSums; j++) v[j] += t[j];
+    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int j = wave; j < kNSums; j += 16) {
-        double v = 0;
-        for (int b = lane; b < nblocks; b += 64) v += partials[(size_t)j * nblocks + b];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) sums[j] = v;
+#pragma unroll
+    for (int j = 0; j < kNSums; j++) {
+        double x = v[j];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        if (lane == 0) sh[wave][j] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNSums) {
+        double x = sh[0][threadIdx.x];
+        for (int w = 1; w < 16; w++) x += sh[w][threadIdx.x];
+        sums[threadIdx.x] = x;
     }
 }
 

@@ -94,6 +94,14 @@ def irls_step(src, tgt, row_ptr, col, R, t, v, dim):
     return Rn, tn, c_old, c_new, w, s
 
 
+def cost_floor(src, tgt, row_ptr, col, w):
+    """rounding floor of a moment-based cost: 1e-14 * (Sxx + Syy) / 2 about the target bounding-box centre"""
+    c = 0.5 * (tgt[:, :3].min(0).astype(np.float64) + tgt[:, :3].max(0).astype(np.float64))
+    x = np.repeat(src[:, :3].astype(np.float64), np.diff(row_ptr), axis=0) - c
+    y = tgt[col, :3].astype(np.float64) - c
+    return 1e-14 * 0.5 * ((w * (x ** 2).sum(1)).sum() + (w * (y ** 2).sum(1)).sum())
+
+
 def transform_inplace(cloud, R, t):
     p = cloud[:, :3].astype(np.float64)
     out = np.empty_like(p)
@@ -112,12 +120,12 @@ def align(src, tgt, radius, max_nn, v, n_iter, inner_steps, f_tol=1e-5, dim=3):
         steps = 0
         c0 = None
         while True:
-            Rn, tn, c_old, c_new, _, _ = irls_step(src, tgt, row_ptr, col, R, t, v, dim)
+            Rn, tn, c_old, c_new, w_, _ = irls_step(src, tgt, row_ptr, col, R, t, v, dim)
             if c0 is None:
                 c0 = c_old
             steps += 1
             R, t = Rn, tn
-            if steps >= inner_steps or (c_old - c_new) <= f_tol * c_old:
+            if steps >= inner_steps or (c_old - c_new) <= max(f_tol * c_old, cost_floor(src, tgt, row_ptr, col, w_)):
                 break
         Tk = np.eye(4)
         Tk[:3, :3], Tk[:3, 3] = R, t

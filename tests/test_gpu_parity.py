@@ -391,7 +391,8 @@ def test_profile_reports_kernels(ctx):
     st = ctx.profile_get()
     ctx.profile_enable(False)
     assert st["nn_topm_kernel"]["launches"] == 3 and st["accumulate_kernel"]["launches"] == 3, st
-    assert st["transform_kernel"]["launches"] == 3 and st["nn_topm_kernel"]["total_ms"] > 0
+    # the source move rides in the next K1 prologue; only the last one needs its own launch
+    assert st["transform_kernel"]["launches"] == 1 and st["nn_topm_kernel"]["total_ms"] > 0
 
 
 # ----------------------------------------------------------------------------- python mirror + batch
