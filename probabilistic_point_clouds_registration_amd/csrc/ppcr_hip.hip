@@ -126,6 +126,9 @@ struct ppcr_ctx {
     enum { ASSOC_NONE, ASSOC_ELL, ASSOC_CSR } assoc = ASSOC_NONE;
     int ell_width = 0;
     DevBuf<int> nbr, cnt, row_ptr;
+    DevBuf<unsigned> dm2;    // per (sorted) source row: float d2 bits of its m-th neighbour in the last tiled K1
+    bool dm2_valid = false;  // dm2 matches the current source order / target / radius / max_neighbours
+    int opt_temporal = 1;
     DevBuf<int> gen_counts, gen_row_ptr, gen_pos;
     DevBuf<unsigned long long> gen_keys;
     DevBuf<unsigned long long> d_total;
@@ -399,6 +402,7 @@ int ensure_source_sorted(ppcr_ctx *c)
     PPCR_TRY(sort_by_cell(c, c->src.p, (int)c->ns, c->src_alt.p, false, c->opt_sort_source == 1));
     std::swap(c->src, c->src_alt);
     c->src_sorted = true;
+    c->dm2_valid = false;  // row order changed
     return PPCR_OK;
 }
 
@@ -408,10 +412,12 @@ template <int M>
 void launch_topm(ppcr_ctx *c, float r2, int m, const FusedMoments &fm, const PendingMove &pm)
 {
     unsigned long long *st = c->opt_stamps ? c->d_stamps.p : nullptr;
+    const int dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
 #define PPCR_TILE_F(Cc, B, CAPc, F)                                                                                 \
     nn_tile_kernel<M, Cc, B, CAPc, F><<<nblocks(c->ns, B), B, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p, \
                                                                               c->cell_start.p, c->grid, r2, m,      \
-                                                                              c->nbr.p, c->cnt.p, st, fm, pm)
+                                                                              c->nbr.p, c->cnt.p, st, fm, pm,      \
+                                                                              c->dm2.p, dm2_in)
 #define PPCR_TILE(Cc, B, CAPc) PPCR_TILE_F(Cc, B, CAPc, false)
     if (c->opt_nn_variant == 0 || c->opt_nn_variant == 3) {
         // LDS budget per 256-query block: halo CAP*16 B + list C*512 B (+1.1 KB tables), three blocks per CU.
@@ -491,6 +497,10 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fused_R = nullptr, const double *fus
         const int m = c->max_nb;
         HIP_TRY(c, c->nbr.reserve((size_t)m * (size_t)std::max(ns, 1)));
         HIP_TRY(c, c->cnt.reserve((size_t)std::max(ns, 1)));
+        HIP_TRY(c, c->dm2.reserve((size_t)std::max(ns, 1)));
+        // dm2 is only trusted when the source moved by nothing but the deferred rigid move applied in this
+        // very kernel since the association that wrote it
+        if (!tiled) c->dm2_valid = false;
         FusedMoments fm;
         std::memset(&fm, 0, sizeof(fm));
         if (fused_R && c->opt_fused && m > 8 && m <= 10 && ns > 0 && c->nt > 0 && tile_variant(c)) {  // experiment: M = 10 only
@@ -520,6 +530,7 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fused_R = nullptr, const double *fus
         }
         PPCR_TRY(check_launch(c, "nn_topm_kernel"));
         c->fused_sums_pending = fm.enabled != 0;
+        c->dm2_valid = tiled;
         c->assoc = ppcr_ctx::ASSOC_ELL;
         c->ell_width = m;
         return PPCR_OK;
@@ -764,6 +775,7 @@ int apply_transform_impl(ppcr_ctx *c, const double T[12], bool defer = false)
 
 int apply_transform_now(ppcr_ctx *c, const double T[12])
 {
+    c->dm2_valid = false;  // the source moved outside a tiled K1: the temporal cut-off starts over
     Pose P;
     for (int a = 0; a < 3; a++) {
         for (int b = 0; b < 3; b++) P.R[3 * a + b] = T[4 * a + b];
@@ -892,6 +904,7 @@ int ppcr_destroy(ppcr_ctx *c)
     c->cub_tmp.release();
     c->bbox_part.release();
     c->nbr.release();
+    c->dm2.release();
     c->cnt.release();
     c->row_ptr.release();
     c->gen_counts.release();
@@ -922,7 +935,10 @@ int ppcr_set_params(ppcr_ctx *c, double radius, int max_neighbours, double dof, 
     if (!(radius > 0) || !std::isfinite(radius)) return fail(c, PPCR_ERR_INVALID, "radius must be positive and finite");
     if (!(dof > 0)) return fail(c, PPCR_ERR_INVALID, "dof must be > 0 (probabilistic_weights.hpp:34 asserts v > 0)");
     if (dim <= 0) return fail(c, PPCR_ERR_INVALID, "dim must be > 0 (probabilistic_weights.hpp:33)");
-    if (radius != c->radius || max_neighbours != c->max_nb) invalidate_association(c);
+    if (radius != c->radius || max_neighbours != c->max_nb) {
+        invalidate_association(c);
+        c->dm2_valid = false;
+    }
     c->radius = radius;
     c->max_nb = max_neighbours;
     c->dof = dof;
@@ -942,6 +958,10 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
     }
     if (std::strcmp(key, "nn_variant") == 0) {
         c->opt_nn_variant = value;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "temporal") == 0) {  // 1: start each query's cut-off from its previous m-th distance (default)
+        c->opt_temporal = value ? 1 : 0;
         return PPCR_OK;
     }
     if (std::strcmp(key, "inkernel_reduce") == 0) {
@@ -969,6 +989,7 @@ static int set_target_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, in
     c->have_tgt = true;
     c->grid_valid = false;
     c->origin_valid = false;
+    c->dm2_valid = false;
     invalidate_association(c);
     return PPCR_OK;
 }
@@ -976,6 +997,7 @@ static int set_target_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, in
 static int set_source_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, int64_t stride)
 {
     c->move_pending = false;  // a deferred move of the previous source dies with it
+    c->dm2_valid = false;
     PPCR_TRY(upload_cloud(c, p, dev, n, stride, c->src));
     c->ns = n;
     c->have_src = true;

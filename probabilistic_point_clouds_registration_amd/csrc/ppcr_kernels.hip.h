@@ -668,7 +668,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                                                          float r2, int m, int *__restrict__ nbr,
                                                          int *__restrict__ cnt,
                                                          unsigned long long *__restrict__ stamps, FusedMoments fm,
-                                                         PendingMove pm)
+                                                         PendingMove pm, unsigned *__restrict__ dm2, int dm2_valid)
 {
     static_assert(C > M, "a compaction must leave room in the list");
     static_assert(CAP % 4 == 0 && CAP <= 65536 && C * 64 <= 4 * CAP, "the global fallback aliases the candidate buffer");
@@ -706,9 +706,27 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
     const int i = blockIdx.x * BLOCK + tid;
     const bool valid = i < ns;
     float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float moved = 0.f;  // how far this query travelled since the association that produced dm2
     if (pm.enabled && valid) {
+        const float4 q0 = q;
         q = move_point(q, pm.P);
         src[i] = q;
+        const float ex = q.x - q0.x, ey = q.y - q0.y, ez = q.z - q0.z;
+        moved = sqrtf(ex * ex + ey * ey + ez * ez);
+    }
+    // Temporal cut-off.  dm2[i] holds the float d2 of this query's m-th neighbour in the previous
+    // association (all-ones when it had fewer than m).  Those m targets are now at most dm + |move| away, so
+    // the new m-th distance is <= dm + |move|: a candidate farther than that cannot be among the m closest
+    // and is never appended.  The bound is inflated by 1e-5 (float rounding of d2 is ~4e-7 relative), and the
+    // final selection below is exact as before — only the amount of list traffic changes.
+    unsigned thr0 = 0xFFFFFFFFu;
+    if (dm2_valid && valid) {
+        const unsigned prev = dm2[i];
+        if (prev != 0xFFFFFFFFu) {
+            const float bound = sqrtf(__uint_as_float(prev)) + moved;
+            const float t2 = bound * bound * 1.00001f + 1e-30f;
+            thr0 = (t2 < r2) ? __float_as_uint(t2) : 0xFFFFFFFFu;
+        }
     }
     const QueryCells qc = query_cells(q, g);
 
@@ -849,7 +867,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
             stamp(2);
             if (!done && wave >= w0 && wave < w1) {
                 const LdsCands<BLOCK> L{s_x, s_y, s_z, s_pos, s_list, tid};
-                unsigned thr = 0xFFFFFFFFu;
+                unsigned thr = thr0;
                 typedef float v2f __attribute__((ext_vector_type(2)));
                 const v2f qx2 = {q.x, q.x}, qy2 = {q.y, q.y}, qz2 = {q.z, q.z};
                 auto accept = [&](int f, float d2) {
@@ -893,10 +911,18 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                     if (f < fe) test1(f);
                 }
                 stamp(3);
-                if (n > m) n = select_top_m<M>(L, tgt, q, n, m, thr);
+                unsigned tm = 0xFFFFFFFFu;  // d2 bits of the m-th neighbour (all-ones: fewer than m found)
+                if (n > m) {
+                    n = select_top_m<M>(L, tgt, q, n, m, thr);
+                    tm = thr;
+                } else if (n == m) {
+                    tm = 0;
+                    for (int j = 0; j < n; j++) tm = max(tm, __float_as_uint(dist2_flann(q, L.get(L.load(j)))));
+                }
                 stamp(4);
                 for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = L.pos_of(L.load(j));
                 cnt[i] = n;
+                if (dm2) dm2[i] = tm;
                 done = true;
                 if constexpr (FUSED) row_moments(L, n, q, fm.P, fm.md, acc);  // winners are still in LDS
                 stamp(5);
@@ -909,7 +935,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
             // last resort for this wave: scan global memory (list of positions aliases the halo buffer)
             if (!done && wave == w0) {
                 const GlobalCands G{tgt, s_glist, lane};
-                unsigned thr = 0xFFFFFFFFu;
+                unsigned thr = thr0;
                 for_each_candidate(q, g, cell_start, tgt, [&](int p, float4 t) {
                     const float d2 = dist2_flann(q, t);
                     if (d2 < r2 && __float_as_uint(d2) <= thr) {
@@ -918,9 +944,17 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                         if (n == C) n = select_top_m<M>(G, tgt, q, n, m, thr);
                     }
                 });
-                if (n > m) n = select_top_m<M>(G, tgt, q, n, m, thr);
+                unsigned tm = 0xFFFFFFFFu;
+                if (n > m) {
+                    n = select_top_m<M>(G, tgt, q, n, m, thr);
+                    tm = thr;
+                } else if (n == m) {
+                    tm = 0;
+                    for (int j = 0; j < n; j++) tm = max(tm, __float_as_uint(dist2_flann(q, G.get(G.load(j)))));
+                }
                 for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = G.load(j);
                 cnt[i] = n;
+                if (dm2) dm2[i] = tm;
                 done = true;
                 if constexpr (FUSED) row_moments(G, n, q, fm.P, fm.md, acc);
             }

@@ -420,3 +420,46 @@ def test_python_mirror_and_batch_single_rank(ctx):
         ora = po.align(s, t, 1.0, 10, 5.0, 4, inner_max_steps=1)
         assert synth.rotation_angle(all_T[p][:, :3], ora["history"][-1][:, :3]) < ROT_TOL
         assert np.linalg.norm(all_T[p][:, 3] - ora["history"][-1][:, 3]) < TRANS_TOL
+
+
+def test_temporal_cutoff_and_deferred_move_change_nothing(ctx):
+    """The steady-state shortcuts (cut-off started from the previous m-th distance + own displacement; source move
+    folded into the next K1 prologue) must not change a single neighbour: compare against a context with the
+    cut-off disabled and against the oracle, association by association, while the source moves."""
+    src, tgt, _, _ = synth.make_pair(30000, cfg=2, stride=3)
+    a, b = _lib.Context(0), _lib.Context(0)
+    try:
+        b.set_option("temporal", 0)
+        for c in (a, b):
+            c.set_params(1.0, 10, 5.0, 3)
+            c.set_target(tgt)
+            c.set_source(src)
+        cur = src.copy()
+        for it in range(6):
+            Ta, ca, _ = a.iterate(inner_steps=1)
+            Tb, cb, _ = b.iterate(inner_steps=1)
+            np.testing.assert_array_equal(Ta, Tb)
+            ra, rb_ = a.get_association(), b.get_association()     # (flushes the deferred move: exercises both paths)
+            for x, y in zip(ra, rb_):
+                np.testing.assert_array_equal(x, y)
+            orp, ocol, _ = po.radius_search(cur, tgt, 1.0, 10, method=1)
+            np.testing.assert_array_equal(ra[0], orp)
+            np.testing.assert_array_equal(ra[1], ocol)
+            po.transform_cloud(cur, np.vstack([Ta, [0, 0, 0, 1]]))
+            np.testing.assert_array_equal(a.get_source(), cur)
+        # a big jump (cut-off bound = previous distance + displacement must still hold)
+        jump = np.eye(4)
+        jump[:3, :3] = synth.rodrigues([0.2, 1.0, -0.3], 0.4)
+        jump[:3, 3] = [0.7, -0.4, 0.3]
+        for c in (a, b):
+            c.apply_transform(jump)
+            c.associate()
+        po.transform_cloud(cur, jump)
+        orp, ocol, _ = po.radius_search(cur, tgt, 1.0, 10, method=1)
+        for c in (a, b):
+            rp, col, _ = c.get_association()
+            np.testing.assert_array_equal(rp, orp)
+            np.testing.assert_array_equal(col, ocol)
+    finally:
+        a.close()
+        b.close()
