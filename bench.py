@@ -156,7 +156,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 distances / f64 weights+moments",
+        "dtype": "f32 (distances) + f64 (weights, moments, solve)",
         "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{a.config - 1}]: {ns}<->{nt} synthetic clouds, radius={cfg['radius']}, "
                                f"max_neighbours={cfg['max_neighbours']}, "
@@ -174,8 +174,12 @@ def main():
         k = prof["nn_topm_kernel"]
         avg_ms = k["total_ms"] / max(1, k["launches"])
         ach = b_nn / (avg_ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "nn_topm_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+        traffic = None  # HBM bytes per launch from PMC counters: a separate rocprofv3 --pmc run (profiles/k1_traffic.json)
+        tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
+        if os.path.exists(tpath) and a.config in (3, 4) and a.n is None:
+            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
+        out["roofline"] = {"bound": "hbm", "kernel": "nn_tile_kernel (K1)", "achieved": ach, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "avg_kernel_ms": avg_ms, "algorithmic_bytes_per_launch": b_nn,
                            "candidate_tests_per_s": 27 * 3.8147 * ns / (avg_ms * 1e-3)}
     else:
