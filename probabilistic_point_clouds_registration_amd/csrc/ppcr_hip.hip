@@ -741,7 +741,7 @@ int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PP
     PPCR_TRY(check_launch(c, "accumulate_kernel"));
     if (!ell_fast) {
         ProfScope ps(c, K_REDUCE);
-        reduce_partials_kernel<<<1, 1024, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p);
+        reduce_partials_kernel<<<kNSums, kBlock, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p);
     }
     PPCR_TRY(check_launch(c, "reduce_partials_kernel"));
     HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->d_sums.p, sizeof(double) * kNSums, hipMemcpyDeviceToHost, c->stream));

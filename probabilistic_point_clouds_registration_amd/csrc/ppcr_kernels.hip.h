@@ -1299,36 +1299,32 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
     block_reduce_store<BLOCK>(acc, partials);
 }
 
-// fold partials[19][nblocks] -> sums[19].  One 1024-thread block; thread t owns partial block(s)
-// b = t, t + 1024, ... and issues its 19 loads (one per sum, coalesced across threads) back to back, so the
-// whole fold costs about one memory round trip; then a wave shuffle tree and a fixed-order LDS combine:
-// deterministic summation order, no atomics.
-__global__ __launch_bounds__(1024) void reduce_partials_kernel(const double *__restrict__ partials, int nblocks,
-                                                               double *__restrict__ sums)
+// fold partials[19][nblocks] -> sums[19].  One 256-thread block PER SUM (grid = 19): every thread issues its
+// (up to 8 per trip) loads of a contiguous row back to back, so the fold costs about one memory round trip;
+// then a wave shuffle tree and a fixed-order LDS combine: deterministic summation order, no atomics.
+__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double *__restrict__ partials, int nblocks,
+                                                                 double *__restrict__ sums)
 {
-    __shared__ double sh[16][kNSums];
-    double v[kNSums];
+    __shared__ double sh[kBlock / 64];
+    const double *row = partials + (size_t)blockIdx.x * nblocks;
+    double v = 0.0;
+    for (int b0 = 0; b0 < nblocks; b0 += 8 * kBlock) {
+        double t[8];
 #pragma unroll
-    for (int j = 0; j < kNSums; j++) v[j] = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 1024) {
-        double t[kNSums];
+        for (int u = 0; u < 8; u++) {
+            const int b = b0 + u * kBlock + threadIdx.x;
+            t[u] = (b < nblocks) ? row[b] : 0.0;
+        }
 #pragma unroll
-        for (int j = 0; j < kNSums; j++) t[j] = partials[(size_t)j * nblocks + b];
-#pragma unroll
-        for (int j = 0; j < kNSums; j++) v[j] += t[j];
+        for (int u = 0; u < 8; u++) v += t[u];
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-    for (int j = 0; j < kNSums; j++) {
-        double x = v[j];
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-        if (lane == 0) sh[wave][j] = x;
-    }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x < kNSums) {
-        double x = sh[0][threadIdx.x];
-        for (int w = 1; w < 16; w++) x += sh[w][threadIdx.x];
-        sums[threadIdx.x] = x;
+    if (threadIdx.x == 0) {
+        double x = sh[0];
+        for (int w = 1; w < kBlock / 64; w++) x += sh[w];
+        sums[blockIdx.x] = x;
     }
 }
 
