@@ -452,7 +452,7 @@ void launch_topm(ppcr_ctx *c, float r2, int m, const FusedMoments &fm, const Pen
     }
 }
 
-constexpr int kAccumRows = 2;     // rows per lane of accumulate_ell_kernel
+constexpr int kAccumRows = 1;     // rows per lane of accumulate_ell_kernel
 constexpr int kAccumBlock = 256;  // threads per block of accumulate_ell_kernel (fewer partial vectors to fold)
 
 template <int W>
