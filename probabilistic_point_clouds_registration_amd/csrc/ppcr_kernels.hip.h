@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
+#include <type_traits>
 
 namespace ppcr {
 namespace dev {
@@ -870,45 +871,67 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                 unsigned thr = thr0;
                 typedef float v2f __attribute__((ext_vector_type(2)));
                 const v2f qx2 = {q.x, q.x}, qy2 = {q.y, q.y}, qz2 = {q.z, q.z};
-                auto accept = [&](int f, float d2) {
-                    if (d2 < r2 && __float_as_uint(d2) <= thr) {
-                        L.store(n, f);
-                        n++;
-                        if (n == C) n = select_top_m<M>(L, tgt, q, n, m, thr);
+                // The 9-run scan.  Fast flavour (COMPACT = false): an accepted candidate is stored at slot
+                // min(n, C-1) and counted, nothing else — the list-full test stays out of the per-candidate path.
+                // A lane that ends with n >= C overflowed its list (dense neighbourhood and no usable cut-off);
+                // only those lanes re-run the scan in the compacting flavour, which reduces a full list to its
+                // top-m on the spot and tightens the lane's threshold.
+                auto scan_runs = [&](auto compact_tag) {
+                    constexpr bool COMPACT = decltype(compact_tag)::value;
+                    auto accept = [&](int f, float d2) {
+                        if (d2 < r2 && __float_as_uint(d2) <= thr) {
+                            if constexpr (COMPACT) {
+                                L.store(n, f);
+                                n++;
+                                if (n == C) n = select_top_m<M>(L, tgt, q, n, m, thr);
+                            } else {
+                                L.store(min(n, C - 1), f);
+                                n++;
+                            }
+                        }
+                    };
+                    auto test1 = [&](int f) { accept(f, dist2_flann(q, make_float4(s_x[f], s_y[f], s_z[f], 0.f))); };
+#pragma unroll 1
+                    for (int k = 0; k < 9; k++) {
+                        // take the next prefetched run; rotate the register file instead of indexing it (after nine
+                        // rotations the runs are back in place for a possible second pass)
+                        const int b = rb[0], e = re[0];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            rb[u] = rb[u + 1];
+                            re[u] = re[u + 1];
+                        }
+                        rb[8] = b;
+                        re[8] = e;
+                        if (b >= e) continue;
+                        const int r = (qc.cz + (k / 3 - 1) - hz0) * ny_h + (qc.cy + (k % 3 - 1) - hy0);
+                        const int fb = s_row_off[r] + (b - s_row_gb[r]), fe = fb + (e - b);
+                        int f = fb;
+                        if (f & 1) {  // align to a pair boundary (8-byte LDS reads)
+                            test1(f);
+                            f++;
+                        }
+                        for (; f + 1 < fe; f += 2) {
+                            // two candidates per trip: ds_read_b64 x3, packed f32 sub/mul/add (no FMA: the same
+                            // IEEE operations per element as dist2_flann, so d2 is bit-identical)
+                            const v2f cx = *reinterpret_cast<const v2f *>(&s_x[f]);
+                            const v2f cy = *reinterpret_cast<const v2f *>(&s_y[f]);
+                            const v2f cz = *reinterpret_cast<const v2f *>(&s_z[f]);
+                            const v2f dx = qx2 - cx, dy = qy2 - cy, dz = qz2 - cz;
+                            v2f d = dx * dx;
+                            d = d + dy * dy;
+                            d = d + dz * dz;
+                            accept(f, d.x);
+                            accept(f + 1, d.y);
+                        }
+                        if (f < fe) test1(f);
                     }
                 };
-                auto test1 = [&](int f) { accept(f, dist2_flann(q, make_float4(s_x[f], s_y[f], s_z[f], 0.f))); };
-#pragma unroll 1
-                for (int k = 0; k < 9; k++) {
-                    // take the next prefetched run; rotate the register file instead of indexing it
-                    const int b = rb[0], e = re[0];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        rb[u] = rb[u + 1];
-                        re[u] = re[u + 1];
-                    }
-                    if (b >= e) continue;
-                    const int r = (qc.cz + (k / 3 - 1) - hz0) * ny_h + (qc.cy + (k % 3 - 1) - hy0);
-                    const int fb = s_row_off[r] + (b - s_row_gb[r]), fe = fb + (e - b);
-                    int f = fb;
-                    if (f & 1) {  // align to a pair boundary (8-byte LDS reads)
-                        test1(f);
-                        f++;
-                    }
-                    for (; f + 1 < fe; f += 2) {
-                        // two candidates per trip: ds_read_b64 x3, packed f32 sub/mul/add (no FMA: the same
-                        // IEEE operations per element as dist2_flann, so d2 is bit-identical)
-                        const v2f cx = *reinterpret_cast<const v2f *>(&s_x[f]);
-                        const v2f cy = *reinterpret_cast<const v2f *>(&s_y[f]);
-                        const v2f cz = *reinterpret_cast<const v2f *>(&s_z[f]);
-                        const v2f dx = qx2 - cx, dy = qy2 - cy, dz = qz2 - cz;
-                        v2f d = dx * dx;
-                        d = d + dy * dy;
-                        d = d + dz * dz;
-                        accept(f, d.x);
-                        accept(f + 1, d.y);
-                    }
-                    if (f < fe) test1(f);
+                scan_runs(std::false_type{});
+                if (n >= C) {  // list overflow: redo this lane with in-loop compaction
+                    n = 0;
+                    thr = thr0;
+                    scan_runs(std::true_type{});
                 }
                 stamp(3);
                 unsigned tm = 0xFFFFFFFFu;  // d2 bits of the m-th neighbour (all-ones: fewer than m found)
