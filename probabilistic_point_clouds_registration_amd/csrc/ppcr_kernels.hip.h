@@ -868,7 +868,10 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
             stamp(2);
             if (!done && wave >= w0 && wave < w1) {
                 const LdsCands<BLOCK> L{s_x, s_y, s_z, s_pos, s_list, tid};
-                unsigned thr = thr0;
+                // d2 >= +0 and r2 > 0, so "d2 < r2" is "bits(d2) <= bits(r2) - 1" (a NaN d2 has larger bits and
+                // fails): the radius test and the running cut-off become ONE unsigned compare per candidate
+                const unsigned lim0 = min(thr0, __float_as_uint(r2) - 1u);
+                unsigned thr = lim0;
                 typedef float v2f __attribute__((ext_vector_type(2)));
                 const v2f qx2 = {q.x, q.x}, qy2 = {q.y, q.y}, qz2 = {q.z, q.z};
                 // The 9-run scan.  Fast flavour (COMPACT = false): an accepted candidate is stored at slot
@@ -879,7 +882,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                 auto scan_runs = [&](auto compact_tag) {
                     constexpr bool COMPACT = decltype(compact_tag)::value;
                     auto accept = [&](int f, float d2) {
-                        if (d2 < r2 && __float_as_uint(d2) <= thr) {
+                        if (__float_as_uint(d2) <= thr) {
                             if constexpr (COMPACT) {
                                 L.store(n, f);
                                 n++;
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                 scan_runs(std::false_type{});
                 if (n >= C) {  // list overflow: redo this lane with in-loop compaction
                     n = 0;
-                    thr = thr0;
+                    thr = lim0;
                     scan_runs(std::true_type{});
                 }
                 stamp(3);
