@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel pass")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even with one rank, to exercise the collective path")
     ap.add_argument("--pairs-per-gpu", type=int, default=1,
                     help="independent pairs each rank registers back to back (BASELINE configs[4]: --config 5 --pairs-per-gpu 8)")
     return ap.parse_args()
@@ -76,10 +78,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     cfg = dict(synth.CONFIGS[a.config])
     n = a.n or cfg["n"]
