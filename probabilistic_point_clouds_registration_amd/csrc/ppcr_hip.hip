@@ -141,6 +141,10 @@ struct ppcr_ctx {
     bool move_pending = false;        // a source move that the next tiled K1 will apply in its prologue
     double pending_T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     double *h_sums = nullptr;          // pinned
+    HostMailbox *h_mbox = nullptr;     // pinned + device-mapped: moments and sequence flag written by the GPU
+    HostMailbox *d_mbox = nullptr;     // device-side alias of h_mbox
+    unsigned mbox_seq = 0;
+    int opt_mailbox = 1;               // 1: deliver the moments through the mailbox and spin (default)
     unsigned long long *h_total = nullptr;  // pinned
 
     // weights export scratch
@@ -739,6 +743,34 @@ int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PP
         }
     }
     PPCR_TRY(check_launch(c, "accumulate_kernel"));
+    if (c->opt_mailbox && !ell_fast) {
+        // the fold delivers the moments to the host mailbox; the host spins on its sequence number
+        const unsigned seq = ++c->mbox_seq;
+        {
+            ProfScope ps(c, K_REDUCE);
+            reduce_partials_mailbox_kernel<<<kNSums, kBlock, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p, c->d_mbox,
+                                                                              c->d_ticket.p, seq);
+        }
+        PPCR_TRY(check_launch(c, "reduce_partials_mailbox_kernel"));
+        volatile unsigned *flag = &c->h_mbox->seq;
+        bool arrived = false;
+        for (long spin = 0; spin < 200000000L; spin++) {  // ~ seconds; a fault on the device ends up below
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) {
+                arrived = true;
+                break;
+            }
+            if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(c->stream) != hipErrorNotReady) {
+                arrived = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq;
+                break;
+            }
+        }
+        if (!arrived) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return fail(c, PPCR_ERR_HIP, "moment mailbox never arrived");
+        }
+        for (int j = 0; j < kNSums; j++) sums[j] = c->h_mbox->sums[j];
+        return PPCR_OK;
+    }
     if (!ell_fast) {
         ProfScope ps(c, K_REDUCE);
         reduce_partials_kernel<<<kNSums, kBlock, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p);
@@ -872,6 +904,11 @@ int ppcr_create(int device_id, ppcr_ctx **out)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_sums), sizeof(double) * kNSums, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_total), sizeof(unsigned long long), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_mbox), sizeof(HostMailbox), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) {
+        std::memset(c->h_mbox, 0, sizeof(HostMailbox));
+        e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_mbox), c->h_mbox, 0);
+    }
     if (e != hipSuccess) {
         std::string msg = std::string("context setup: ") + hipGetErrorString(e);
         ppcr_destroy(c);
@@ -920,6 +957,7 @@ int ppcr_destroy(ppcr_ctx *c)
     c->d_s.release();
     if (c->h_sums) (void)hipHostFree(c->h_sums);
     if (c->h_total) (void)hipHostFree(c->h_total);
+    if (c->h_mbox) (void)hipHostFree(c->h_mbox);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PPCR_OK;
@@ -958,6 +996,10 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
     }
     if (std::strcmp(key, "nn_variant") == 0) {
         c->opt_nn_variant = value;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "mailbox") == 0) {
+        c->opt_mailbox = value ? 1 : 0;
         return PPCR_OK;
     }
     if (std::strcmp(key, "temporal") == 0) {  // 1: start each query's cut-off from its previous m-th distance (default)

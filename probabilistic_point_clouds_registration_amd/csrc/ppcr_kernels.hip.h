@@ -1355,6 +1355,50 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double *_
     }
 }
 
+// Host mailbox in pinned, device-mapped memory: the final fold writes the moments there and then the
+// sequence number (system-scope release), and the host spins on `seq` — no copy kernel, no stream
+// synchronisation on the iteration's critical path.
+struct HostMailbox {
+    double sums[kNSums];
+    unsigned seq;
+};
+
+// Same fold as reduce_partials_kernel (one block per sum, fixed order) with the result delivered to the host
+// mailbox; the block that draws the last ticket publishes the sequence number.
+__global__ __launch_bounds__(kBlock) void reduce_partials_mailbox_kernel(const double *__restrict__ partials, int nblocks,
+                                                                         double *__restrict__ sums, HostMailbox *mbox,
+                                                                         unsigned *__restrict__ ticket, unsigned seq)
+{
+    __shared__ double sh[kBlock / 64];
+    const double *row = partials + (size_t)blockIdx.x * nblocks;
+    double v = 0.0;
+    for (int b0 = 0; b0 < nblocks; b0 += 8 * kBlock) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int b = b0 + u * kBlock + threadIdx.x;
+            t[u] = (b < nblocks) ? row[b] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) v += t[u];
+    }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double x = sh[0];
+        for (int w = 1; w < kBlock / 64; w++) x += sh[w];
+        sums[blockIdx.x] = x;
+        __hip_atomic_store(&mbox->sums[blockIdx.x], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __atomic_thread_fence(__ATOMIC_RELEASE);  // system scope: the sum is visible to the host before the ticket
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (t == gridDim.x - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&mbox->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // ProbabilisticWeights::updateWeights on caller-supplied squared errors (probabilistic_weights.hpp:48-105):
 // one lane per CSR row, the reference's exact formula (lp, row max, mll, exp(lp - mll) [* (v+d)/(v+s)]).
 __global__ void weights_from_errors_kernel(const int *__restrict__ row_ptr, int64_t n_rows,
