@@ -439,10 +439,12 @@ void launch_topm(ppcr_ctx *c, float r2, int m, const FusedMoments &fm, const Pen
         }
     } else if (c->opt_nn_variant >= 4 && c->opt_nn_variant <= 7) {  // block-shape experiments (M = 10 only)
         if constexpr (M == 10) {
+            // measured (fresh source, cut-off active, default = 153 us): CAP 1536 -> 231 us (halos stop fitting);
+            // list capacity 16 -> 819-919 us (lists overflow and lanes re-run); capacity 12 + CAP 1280 -> 2.2 ms
             if (c->opt_nn_variant == 4) PPCR_TILE(32, 256, 2048);
-            if (c->opt_nn_variant == 5) PPCR_TILE(32, 256, 2112);
-            if (c->opt_nn_variant == 6) PPCR_TILE(32, 256, 2176);
-            if (c->opt_nn_variant == 7) PPCR_TILE(32, 256, 2240);
+            if (c->opt_nn_variant == 5) PPCR_TILE(32, 256, 1536);
+            if (c->opt_nn_variant == 6) PPCR_TILE(16, 256, 2240);
+            if (c->opt_nn_variant == 7) PPCR_TILE(32, 256, 3072);
         }
     } else if (c->opt_nn_variant == 1) {
         nn_topm_kernel<M><<<nblocks(c->ns), kBlock, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p,

@@ -876,7 +876,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                 const v2f qx2 = {q.x, q.x}, qy2 = {q.y, q.y}, qz2 = {q.z, q.z};
                 // The 9-run scan.  Fast flavour (COMPACT = false): an accepted candidate is stored at slot
                 // min(n, C-1) and counted, nothing else — the list-full test stays out of the per-candidate path.
-                // A lane that ends with n >= C overflowed its list (dense neighbourhood and no usable cut-off);
+                // A lane that ends with n > C overflowed its list (dense neighbourhood and no usable cut-off);
                 // only those lanes re-run the scan in the compacting flavour, which reduces a full list to its
                 // top-m on the spot and tightens the lane's threshold.
                 auto scan_runs = [&](auto compact_tag) {
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                     }
                 };
                 scan_runs(std::false_type{});
-                if (n >= C) {  // list overflow: redo this lane with in-loop compaction
+                if (n > C) {  // list overflow (slot C-1 was overwritten): redo this lane with in-loop compaction
                     n = 0;
                     thr = lim0;
                     scan_runs(std::true_type{});

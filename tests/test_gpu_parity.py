@@ -463,3 +463,38 @@ def test_temporal_cutoff_and_deferred_move_change_nothing(ctx):
     finally:
         a.close()
         b.close()
+
+
+def test_nn_dense_and_clustered_stress(ctx):
+    """Neighbourhoods far denser than the benchmark (hundreds of in-radius candidates, halos that do not fit LDS:
+    per-wave passes and the global-memory fallback, list compactions) and a strongly non-uniform cloud."""
+    rng = np.random.default_rng(21)
+    # dense: ~420 candidates in radius, CLI-like m = 20
+    tgt = rng.uniform(0, 10, size=(30000, 3)).astype(np.float32)
+    src = (tgt[rng.permutation(30000)[:8000]] + rng.normal(0, 0.05, size=(8000, 3))).astype(np.float32)
+    for (r, m) in ((1.5, 20), (1.5, 3), (0.8, 32)):
+        rp, col, d2 = _assoc(ctx, src, tgt, r, m)
+        orp, ocol, od2 = po.radius_search(src, tgt, r, m, method=1)
+        np.testing.assert_array_equal(rp, orp)
+        np.testing.assert_array_equal(col, ocol)
+        np.testing.assert_array_equal(d2, od2)
+    # a second association on the same (unmoved) source goes through the temporal cut-off with tight bounds
+    ctx.associate()
+    rp2, col2, _ = ctx.get_association()
+    np.testing.assert_array_equal(col2, ocol)
+    # clustered: mixture of blobs of very different densities + sparse background, far from the origin
+    centres = rng.uniform(-40, 40, size=(30, 3)) + np.array([800.0, -300.0, 50.0])
+    parts = [c + rng.normal(0, s, size=(n, 3)) for c, s, n in zip(centres, rng.uniform(0.2, 4.0, 30), rng.integers(500, 6000, 30))]
+    parts.append(rng.uniform(-60, 60, size=(5000, 3)) + np.array([800.0, -300.0, 50.0]))
+    tgt = np.concatenate(parts).astype(np.float32)
+    src = (tgt[rng.permutation(len(tgt))[:40000]] + rng.normal(0, 0.02, size=(40000, 3))).astype(np.float32)
+    rp, col, d2 = _assoc(ctx, src, tgt, 1.0, 10)
+    orp, ocol, od2 = po.radius_search(src, tgt, 1.0, 10, method=1)
+    np.testing.assert_array_equal(rp, orp)
+    np.testing.assert_array_equal(col, ocol)
+    np.testing.assert_array_equal(d2, od2)
+    # and the loop on it agrees with the oracle
+    res = ctx.align(4, cost_drop_thresh=0.0, inner_steps=1)
+    ora = po.align(src, tgt, 1.0, 10, 5.0, 4, inner_max_steps=1)
+    assert synth.rotation_angle(res["history"][-1][:, :3], ora["history"][-1][:, :3]) < ROT_TOL
+    assert np.linalg.norm(res["history"][-1][:, 3] - ora["history"][-1][:, 3]) < TRANS_TOL
