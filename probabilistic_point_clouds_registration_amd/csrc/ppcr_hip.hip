@@ -100,7 +100,6 @@ struct ppcr_ctx {
     int opt_nn_variant = 0;
     int opt_stamps = 0;
     int opt_fused = 0;
-    int opt_inkernel_reduce = 0;  // measured slower (serialised agent-scope loads): 102 us vs 80 + 14 us
     DevBuf<unsigned long long> d_stamps;
 
     // clouds
@@ -465,8 +464,7 @@ template <int W>
 void launch_accumulate_ell(ppcr_ctx *c, int nb, const Pose &P, const Model &md)
 {
     accumulate_ell_kernel<W, kAccumRows, kAccumBlock><<<nb, kAccumBlock, 0, c->stream>>>(c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md,
-                                                           c->partials.p, c->opt_inkernel_reduce ? c->d_ticket.p : nullptr,
-                                                           c->d_sums.p);
+                                                           c->partials.p);
 }
 
 bool tile_variant(const ppcr_ctx *c) { return c->opt_nn_variant == 0 || c->opt_nn_variant == 3; }
@@ -725,7 +723,6 @@ int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PP
         HIP_TRY(c, c->d_ticket.reserve(1));
         HIP_TRY(c, hipMemsetAsync(c->d_ticket.p, 0, sizeof(unsigned), c->stream));
     }
-    const bool ell_fast = c->opt_inkernel_reduce && c->assoc == ppcr_ctx::ASSOC_ELL && c->nt > 0;  // reduce inside the kernel
     {
         ProfScope ps(c, K_ACCUMULATE);
         if (c->assoc == ppcr_ctx::ASSOC_ELL && c->nt > 0) {
@@ -745,7 +742,7 @@ int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PP
         }
     }
     PPCR_TRY(check_launch(c, "accumulate_kernel"));
-    if (c->opt_mailbox && !ell_fast) {
+    if (c->opt_mailbox) {
         // the fold delivers the moments to the host mailbox; the host spins on its sequence number
         const unsigned seq = ++c->mbox_seq;
         {
@@ -773,7 +770,7 @@ int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PP
         for (int j = 0; j < kNSums; j++) sums[j] = c->h_mbox->sums[j];
         return PPCR_OK;
     }
-    if (!ell_fast) {
+    {
         ProfScope ps(c, K_REDUCE);
         reduce_partials_kernel<<<kNSums, kBlock, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p);
     }
@@ -1006,10 +1003,6 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
     }
     if (std::strcmp(key, "temporal") == 0) {  // 1: start each query's cut-off from its previous m-th distance (default)
         c->opt_temporal = value ? 1 : 0;
-        return PPCR_OK;
-    }
-    if (std::strcmp(key, "inkernel_reduce") == 0) {
-        c->opt_inkernel_reduce = value ? 1 : 0;
         return PPCR_OK;
     }
     if (std::strcmp(key, "fused") == 0) {  // 1: K1 also evaluates the first weights+moments step (default)
