@@ -142,9 +142,14 @@ typedef struct ppcr_kernel_stat {
 int ppcr_profile_enable(ppcr_ctx *ctx, int enable); /* also clears accumulated stats */
 int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_out);
 
-/* Tuning / debugging knobs (do not change results): key is one of
- * "sort_source" (1: spatially sort the source once for coherent waves, default 1),
- * "nn_variant" (0: auto). */
+/* Tuning / debugging knobs (never change results): key is one of
+ *   "sort_source"  0 keep caller order, 1 brick/snake order (default), 2 x-fastest cell order;
+ *   "nn_variant"   0/3 LDS-tiled kernel (default), 2 per-lane global scan + LDS list, 1 sorted register list,
+ *                  4..7 tile-shape experiments (max_neighbours 9..10 only);
+ *   "temporal"     1 start each query's cut-off from its previous m-th distance (default), 0 off;
+ *   "mailbox"      1 deliver the moments through pinned host memory and spin (default), 0 copy + synchronise;
+ *   "fused"        1 K1 epilogue writes per-row partials (experiment, measured slower), 0 off (default);
+ *   "stamps"       1 collect per-phase cycle counts of the tiled kernel (diagnostic). */
 int ppcr_set_option(ppcr_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus

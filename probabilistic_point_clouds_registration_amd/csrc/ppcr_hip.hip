@@ -99,7 +99,7 @@ struct ppcr_ctx {
     int opt_sort_source = 1;
     int opt_nn_variant = 0;
     int opt_stamps = 0;
-    int opt_fused = 0;
+    int opt_fused = 0;  // split K23 (K1 epilogue writes per-row partials): measured slower, see FusedRows
     DevBuf<unsigned long long> d_stamps;
 
     // clouds
@@ -136,7 +136,8 @@ struct ppcr_ctx {
     // reductions
     DevBuf<double> partials, d_sums;
     DevBuf<unsigned> d_ticket;
-    bool fused_sums_pending = false;  // K1 ran with the fused moments epilogue; d_sums holds them
+    bool fused_sums_pending = false;  // K1 wrote per-row partials for theta0: the first solve step only streams them
+    DevBuf<double> rowpart;           // [6][ns]
     bool move_pending = false;        // a source move that the next tiled K1 will apply in its prologue
     double pending_T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     double *h_sums = nullptr;          // pinned
@@ -412,7 +413,7 @@ int ensure_source_sorted(ppcr_ctx *c)
 // nn_variant: 0/3 = LDS-tiled halo + med3 selection (default), 2 = per-lane global scan + LDS list,
 // 1 = sorted register list inside the scan loop (first version, kept for A/B measurements)
 template <int M>
-void launch_topm(ppcr_ctx *c, float r2, int m, const FusedMoments &fm, const PendingMove &pm)
+void launch_topm(ppcr_ctx *c, float r2, int m, const FusedRows &fm, const PendingMove &pm)
 {
     unsigned long long *st = c->opt_stamps ? c->d_stamps.p : nullptr;
     const int dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
@@ -432,7 +433,7 @@ void launch_topm(ppcr_ctx *c, float r2, int m, const FusedMoments &fm, const Pen
         constexpr int C = (M <= 24) ? 32 : 48;
         constexpr int CAP = (M <= 24) ? 2240 : 2048;
         if (fm.enabled) {
-            if constexpr (M == 10) PPCR_TILE_F(C, 256, CAP, true);
+            if constexpr (M == 10) PPCR_TILE_F(C, 256, CAP, true);  // experiment: only instantiated for M = 10
         } else {
             PPCR_TILE(C, 256, CAP);
         }
@@ -505,22 +506,14 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fused_R = nullptr, const double *fus
         // dm2 is only trusted when the source moved by nothing but the deferred rigid move applied in this
         // very kernel since the association that wrote it
         if (!tiled) c->dm2_valid = false;
-        FusedMoments fm;
+        FusedRows fm;
         std::memset(&fm, 0, sizeof(fm));
-        if (fused_R && c->opt_fused && m > 8 && m <= 10 && ns > 0 && c->nt > 0 && tile_variant(c)) {  // experiment: M = 10 only
-            const int nb = nblocks(ns);
-            HIP_TRY(c, c->partials.reserve((size_t)nb * kNSums));
-            HIP_TRY(c, c->d_sums.reserve(kNSums));
-            if (!c->d_ticket.p) {
-                HIP_TRY(c, c->d_ticket.reserve(1));
-                HIP_TRY(c, hipMemsetAsync(c->d_ticket.p, 0, sizeof(unsigned), c->stream));
-            }
+        if (fused_R && c->opt_fused && m > 8 && m <= 10 && ns > 0 && c->nt > 0 && tile_variant(c)) {
+            HIP_TRY(c, c->rowpart.reserve((size_t)6 * (size_t)ns));
             fm.enabled = 1;
             fm.P = make_pose(c, *fused_R, fused_t);
             fm.md = make_model(c);
-            fm.partials = c->partials.p;
-            fm.ticket = c->d_ticket.p;
-            fm.sums = c->d_sums.p;
+            fm.rowpart = c->rowpart.p;
         }
         if (ns > 0) {
             ProfScope ps(c, K_NN_TOPM);
@@ -702,6 +695,48 @@ int build_csr_cache(ppcr_ctx *c)
     return PPCR_OK;
 }
 
+// fold partials[19][nb] and deliver the 19 moments to the host (mailbox + spin, or copy + synchronise)
+int fold_and_deliver(ppcr_ctx *c, int nb, double sums[PPCR_NSUMS])
+{
+    if (c->opt_mailbox) {
+        // the fold delivers the moments to the host mailbox; the host spins on its sequence number
+        const unsigned seq = ++c->mbox_seq;
+        {
+            ProfScope ps(c, K_REDUCE);
+            reduce_partials_mailbox_kernel<<<kNSums, kBlock, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p, c->d_mbox,
+                                                                              c->d_ticket.p, seq);
+        }
+        PPCR_TRY(check_launch(c, "reduce_partials_mailbox_kernel"));
+        volatile unsigned *flag = &c->h_mbox->seq;
+        bool arrived = false;
+        for (long spin = 0; spin < 200000000L; spin++) {  // ~ seconds; a fault on the device ends up below
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) {
+                arrived = true;
+                break;
+            }
+            if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(c->stream) != hipErrorNotReady) {
+                arrived = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq;
+                break;
+            }
+        }
+        if (!arrived) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return fail(c, PPCR_ERR_HIP, "moment mailbox never arrived");
+        }
+        for (int j = 0; j < kNSums; j++) sums[j] = c->h_mbox->sums[j];
+        return PPCR_OK;
+    }
+    {
+        ProfScope ps(c, K_REDUCE);
+        reduce_partials_kernel<<<kNSums, kBlock, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p);
+    }
+    PPCR_TRY(check_launch(c, "reduce_partials_kernel"));
+    HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->d_sums.p, sizeof(double) * kNSums, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::memcpy(sums, c->h_sums, sizeof(double) * kNSums);
+    return PPCR_OK;
+}
+
 int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PPCR_NSUMS])
 {
     if (c->assoc == ppcr_ctx::ASSOC_NONE) return fail(c, PPCR_ERR_STATE, "no association (call ppcr_associate or ppcr_set_association)");
@@ -742,43 +777,29 @@ int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PP
         }
     }
     PPCR_TRY(check_launch(c, "accumulate_kernel"));
-    if (c->opt_mailbox) {
-        // the fold delivers the moments to the host mailbox; the host spins on its sequence number
-        const unsigned seq = ++c->mbox_seq;
-        {
-            ProfScope ps(c, K_REDUCE);
-            reduce_partials_mailbox_kernel<<<kNSums, kBlock, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p, c->d_mbox,
-                                                                              c->d_ticket.p, seq);
-        }
-        PPCR_TRY(check_launch(c, "reduce_partials_mailbox_kernel"));
-        volatile unsigned *flag = &c->h_mbox->seq;
-        bool arrived = false;
-        for (long spin = 0; spin < 200000000L; spin++) {  // ~ seconds; a fault on the device ends up below
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) {
-                arrived = true;
-                break;
-            }
-            if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(c->stream) != hipErrorNotReady) {
-                arrived = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq;
-                break;
-            }
-        }
-        if (!arrived) {
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return fail(c, PPCR_ERR_HIP, "moment mailbox never arrived");
-        }
-        for (int j = 0; j < kNSums; j++) sums[j] = c->h_mbox->sums[j];
-        return PPCR_OK;
+    return fold_and_deliver(c, nb, sums);
+}
+
+// first IRLS half-step after a fused association: the per-row partials K1 left behind are streamed into moments
+int run_moments_from_rows(ppcr_ctx *c, double sums[PPCR_NSUMS])
+{
+    const int ns = (int)c->ns;
+    const int nb = std::max(1, std::min(kAccumMaxBlocks, nblocks(ns)));
+    HIP_TRY(c, c->partials.reserve((size_t)nb * kNSums));
+    HIP_TRY(c, c->d_sums.reserve(kNSums));
+    if (!c->d_ticket.p) {
+        HIP_TRY(c, c->d_ticket.reserve(1));
+        HIP_TRY(c, hipMemsetAsync(c->d_ticket.p, 0, sizeof(unsigned), c->stream));
     }
+    Pose P;
+    std::memset(&P, 0, sizeof(P));
+    for (int a = 0; a < 3; a++) P.c[a] = c->origin[a];
     {
-        ProfScope ps(c, K_REDUCE);
-        reduce_partials_kernel<<<kNSums, kBlock, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p);
+        ProfScope ps(c, K_ACCUMULATE);
+        moments_from_rows_kernel<<<nb, kBlock, 0, c->stream>>>(c->src.p, c->rowpart.p, ns, P, c->partials.p);
     }
-    PPCR_TRY(check_launch(c, "reduce_partials_kernel"));
-    HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->d_sums.p, sizeof(double) * kNSums, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    std::memcpy(sums, c->h_sums, sizeof(double) * kNSums);
-    return PPCR_OK;
+    PPCR_TRY(check_launch(c, "moments_from_rows_kernel"));
+    return fold_and_deliver(c, nb, sums);
 }
 
 int apply_transform_now(ppcr_ctx *c, const double T[12]);
@@ -830,11 +851,9 @@ int solve_impl(ppcr_ctx *c, const double q0[4], const double t0[3], int max_step
     Vec3 t{{t0[0], t0[1], t0[2]}};
     double sums[PPCR_NSUMS];
     if (c->fused_sums_pending) {
-        // K1's epilogue already evaluated the weights and moments at (q0, t0)
+        // K1's epilogue already evaluated the weights at (q0, t0) and left six per-row partials: stream them
         c->fused_sums_pending = false;
-        HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->d_sums.p, sizeof(double) * kNSums, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        std::memcpy(sums, c->h_sums, sizeof(sums));
+        PPCR_TRY(run_moments_from_rows(c, sums));
     } else {
         PPCR_TRY(run_accumulate(c, R, t.v, sums));
     }
@@ -950,6 +969,7 @@ int ppcr_destroy(ppcr_ctx *c)
     c->d_total.release();
     c->d_stamps.release();
     c->partials.release();
+    c->rowpart.release();
     c->d_sums.release();
     c->d_ticket.release();
     c->d_w.release();
@@ -1005,7 +1025,7 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
         c->opt_temporal = value ? 1 : 0;
         return PPCR_OK;
     }
-    if (std::strcmp(key, "fused") == 0) {  // 1: K1 also evaluates the first weights+moments step (default)
+    if (std::strcmp(key, "fused") == 0) {  // 1: K1 epilogue + stream kernel replace K23 for the first step (experiment, M = 10)
         c->opt_fused = value ? 1 : 0;
         return PPCR_OK;
     }

@@ -470,85 +470,93 @@ __device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__
 }
 
 
-// Arguments of the fused first IRLS half-step (weights at theta0 + moments) that nn_tile_kernel<FUSED>
-// can run as an epilogue while the winners are still in LDS.  MEASURED NEGATIVE on MI355X (1M<->1M):
-// the 19 f64 accumulators + division code push the kernel to 226 VGPRs (2 waves/SIMD) and the per-block
-// 19-value reduction + agent release cost more than the separate K23 launch saves (797 us fused vs
-// 260 + 80 + 14 us separate).  Kept (option "fused", off by default) so the experiment is repeatable.
-struct FusedMoments {
+// Split K23.  When the state theta0 of the first IRLS half-step is known at association time (it always is
+// inside align()/iterate()), nn_tile_kernel<FUSED> finishes each row while its winners are still in LDS and
+// writes SIX per-row quantities (no gathers, only short-lived temporaries):
+//     rowpart[0][i] = W_i = sum_k w_ik          rowpart[1..3][i] = sum_k w_ik (y_k - c)
+//     rowpart[4][i] = sum_k w_ik s_ik           rowpart[5][i]    = sum_k w_ik |y_k - c|^2
+// and moments_from_rows_kernel (a plain stream over src + rowpart, 23 us) forms the 19 moments.
+// MEASURED NEGATIVE on MI355X (1M<->1M, m = 10), kept behind option "fused" (off by default):
+//   v1, all 19 moments accumulated inside K1: 226 VGPRs, 2 waves/SIMD: 797 us vs 260 + 80 + 14 us separate;
+//   v2, this row-partial form: 197 VGPRs (2 waves/SIMD) 288 + 23 us, or forced to 168 VGPRs with 104 B of
+//       scratch 248 + 23 us, against 179 + 58 us for K1 + the standalone accumulate_ell_kernel.
+// The f64 per-row arithmetic (~450 instructions per lane) is simply cheaper in its own kernel at 4 waves/SIMD
+// than inside K1, whose register budget is already spent on the scan.
+struct FusedRows {
     int enabled;
     Pose P;
     Model md;
-    double *partials;        // [kNSums][gridDim.x]
-    unsigned *ticket;        // arrival counter (zero before the launch; reset by the last block)
-    double *sums;            // [kNSums] final moments, written by the last block to arrive
+    double *rowpart;  // [6][ns]
 };
 
-// moments of one source row from its (<= m) winners; src.get(e) yields the target point of entry e
 template <class S>
-__device__ __forceinline__ void row_moments(const S &src, int n, float4 xf, const Pose &P, const Model &md, RowAcc &acc)
+__device__ __forceinline__ void row_partials(const S &src, int n, float4 xf, const Pose &P, const Model &md,
+                                             double *__restrict__ rowpart, int ns, int i)
 {
-    if (n == 0) return;
-    double xr[3];
-    rotate_point(P, xf, xr);
-    double smin = INFINITY;
-    for (int j = 0; j < n; j++) {
-        const double sj = sq_residual(src.get(src.load(j)), xr);
-        smin = sj < smin ? sj : smin;
-    }
-    const double lp_max = (md.is_normal || md.vpd_int) ? 0.0 : log_prob(md, smin);
-    double Z = 0, G = 0, Gs = 0, Gyy = 0, Gy[3] = {0, 0, 0};
-    for (int j = 0; j < n; j++) {
-        const float4 y = src.get(src.load(j));
-        const double sj = sq_residual(y, xr);
-        const double inv_vs = md.is_normal ? 0.0 : fast_rcp(md.v + sj);
+    double Wi = 0, wy0 = 0, wy1 = 0, wy2 = 0, gs = 0, gyy = 0;
+    if (n > 0) {
+        double xr[3];
+        rotate_point(P, xf, xr);
+        double smin = INFINITY;
+        for (int j = 0; j < n; j++) {
+            const double sj = sq_residual(src.get(src.load(j)), xr);
+            smin = sj < smin ? sj : smin;
+        }
+        const double lp_max = (md.is_normal || md.vpd_int) ? 0.0 : log_prob(md, smin);
+        double Z = 0, G = 0, Gs = 0, Gyy = 0, Gy0 = 0, Gy1 = 0, Gy2 = 0;
+        for (int j = 0; j < n; j++) {
+            const float4 y = src.get(src.load(j));
+            const double sj = sq_residual(y, xr);
+            const double inv_vs = md.is_normal ? 0.0 : fast_rcp(md.v + sj);
             const double e = rel_likelihood(md, sj, smin, lp_max, inv_vs);
-        Z += e;
-        const double gk = md.is_normal ? e : e * (md.vpd * inv_vs);
-        const double yc0 = (double)y.x - P.c[0], yc1 = (double)y.y - P.c[1], yc2 = (double)y.z - P.c[2];
-        G += gk;
-        Gs = fma(gk, sj, Gs);
-        Gy[0] = fma(gk, yc0, Gy[0]);
-        Gy[1] = fma(gk, yc1, Gy[1]);
-        Gy[2] = fma(gk, yc2, Gy[2]);
-        Gyy = fma(gk, yc0 * yc0 + yc1 * yc1 + yc2 * yc2, Gyy);
+            Z += e;
+            const double gk = md.is_normal ? e : e * (md.vpd * inv_vs);
+            const double yc0 = (double)y.x - P.c[0], yc1 = (double)y.y - P.c[1], yc2 = (double)y.z - P.c[2];
+            G += gk;
+            Gs = fma(gk, sj, Gs);
+            Gy0 = fma(gk, yc0, Gy0);
+            Gy1 = fma(gk, yc1, Gy1);
+            Gy2 = fma(gk, yc2, Gy2);
+            Gyy = fma(gk, yc0 * yc0 + yc1 * yc1 + yc2 * yc2, Gyy);
+        }
+        const double iz = fast_rcp(Z);
+        Wi = G * iz, wy0 = Gy0 * iz, wy1 = Gy1 * iz, wy2 = Gy2 * iz, gs = Gs * iz, gyy = Gyy * iz;
     }
-    row_finish(acc, P, xf, Z, G, Gs, Gyy, Gy);
+    rowpart[(size_t)0 * ns + i] = Wi;
+    rowpart[(size_t)1 * ns + i] = wy0;
+    rowpart[(size_t)2 * ns + i] = wy1;
+    rowpart[(size_t)3 * ns + i] = wy2;
+    rowpart[(size_t)4 * ns + i] = gs;
+    rowpart[(size_t)5 * ns + i] = gyy;
 }
 
-// Last-block final reduction.  Every block has stored its partial vector; the block that draws the
-// last ticket folds partials[j][0..nblocks) in a fixed order (deterministic, no float atomics).
-// Inter-workgroup visibility per the CDNA4 rules: every storing wave drains its stores, barrier,
-// one lane releases at agent scope, explicit vmcnt(0), then the relaxed ticket; the last block
-// acquires at agent scope before it reads.
-template <int BLOCK>
-__device__ __forceinline__ void last_block_reduce(const double *__restrict__ partials, unsigned *ticket,
-                                                  double *__restrict__ sums)
+// second half of the split K23: stream src + rowpart, form the 19 moments, block-reduce
+__global__ __launch_bounds__(kBlock) void moments_from_rows_kernel(const float4 *__restrict__ src,
+                                                                   const double *__restrict__ rowpart, int ns, Pose P,
+                                                                   double *__restrict__ partials)
 {
-    __shared__ unsigned s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gridDim.x - 1) ? 1u : 0u;
-        if (s_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RowAcc acc;
+#pragma unroll
+    for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < ns; i += gridDim.x * kBlock) {
+        const float4 xf = src[i];
+        const double Wi = rowpart[i];
+        const double wy[3] = {rowpart[(size_t)ns + i], rowpart[(size_t)2 * ns + i], rowpart[(size_t)3 * ns + i]};
+        const double gs = rowpart[(size_t)4 * ns + i], gyy = rowpart[(size_t)5 * ns + i];
+        const double xc[3] = {(double)xf.x - P.c[0], (double)xf.y - P.c[1], (double)xf.z - P.c[2]};
+        acc.a[0] += Wi;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            acc.a[1 + d] = fma(Wi, xc[d], acc.a[1 + d]);
+            acc.a[4 + d] += wy[d];
+#pragma unroll
+            for (int b = 0; b < 3; b++) acc.a[7 + 3 * d + b] = fma(xc[d], wy[b], acc.a[7 + 3 * d + b]);
         }
+        acc.a[16] += gs;
+        acc.a[17] = fma(Wi, xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2], acc.a[17]);
+        acc.a[18] += gyy;
     }
-    __syncthreads();
-    if (!s_last) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int nb = gridDim.x;
-    for (int j = wave; j < kNSums; j += BLOCK / 64) {
-        double v = 0;
-        for (int b = lane; b < nb; b += 64) v += partials[(size_t)j * nb + b];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) sums[j] = v;
-    }
-    if (threadIdx.x == 0) *ticket = 0;  // ready for the next launch on this stream
+    block_reduce_store<kBlock>(acc, partials);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -668,7 +676,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                                                          const int *__restrict__ cell_start, GridDesc g,
                                                          float r2, int m, int *__restrict__ nbr,
                                                          int *__restrict__ cnt,
-                                                         unsigned long long *__restrict__ stamps, FusedMoments fm,
+                                                         unsigned long long *__restrict__ stamps, FusedRows fm,
                                                          PendingMove pm, unsigned *__restrict__ dm2, int dm2_valid)
 {
     static_assert(C > M, "a compaction must leave room in the list");
@@ -765,11 +773,6 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
 
     int n = 0;
     bool done = !valid;
-    RowAcc acc;  // only live in the FUSED instantiation
-    if constexpr (FUSED) {
-#pragma unroll
-        for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
-    }
     // Halo passes, coarse to fine: all waves together; if that halo does not fit, halves, then single
     // waves (binary subdivision of the wave range).  done_mask (uniform over the block) has a bit per
     // finished wave; a pass whose waves are all finished is skipped.
@@ -978,7 +981,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                 cnt[i] = n;
                 if (dm2) dm2[i] = tm;
                 done = true;
-                if constexpr (FUSED) row_moments(L, n, q, fm.P, fm.md, acc);  // winners are still in LDS
+                if constexpr (FUSED) row_partials(L, n, q, fm.P, fm.md, fm.rowpart, ns, i);  // winners still in LDS
                 stamp(5);
             }
             done_mask |= pass_mask;
@@ -1010,18 +1013,13 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                 cnt[i] = n;
                 if (dm2) dm2[i] = tm;
                 done = true;
-                if constexpr (FUSED) row_moments(G, n, q, fm.P, fm.md, acc);
+                if constexpr (FUSED) row_partials(G, n, q, fm.P, fm.md, fm.rowpart, ns, i);
             }
             done_mask |= pass_mask;
             __syncthreads();
             stamp(7);
         }
       }
-    if constexpr (FUSED) {
-        block_reduce_store<BLOCK>(acc, fm.partials);
-        last_block_reduce<BLOCK>(fm.partials, fm.ticket, fm.sums);
-        stamp(6);
-    }
     flush_stamps();
 }
 
