@@ -149,6 +149,10 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *   "temporal"     1 start each query's cut-off from its previous m-th distance (default), 0 off;
  *   "mailbox"      1 deliver the moments through pinned host memory and spin (default), 0 copy + synchronise;
  *   "fused"        1 K1 epilogue writes per-row partials (experiment, measured slower), 0 off (default);
+ *   "verlet"       1 keep per-query skin lists (all targets within radius*(1+skin)) and answer later associations
+ *                  from them while the accumulated motion stays inside the skin (experiment, measured slower than
+ *                  the direct scan: per-lane gathers), 0 off (default);
+ *   "verlet_skin_permille"  skin as a fraction of the radius in 1/1000 (default 200);
  *   "stamps"       1 collect per-phase cycle counts of the tiled kernel (diagnostic). */
 int ppcr_set_option(ppcr_ctx *ctx, const char *key, int value);
 

@@ -35,6 +35,7 @@ enum KernelId {
     K_GATHER,
     K_CELL_START,
     K_NN_TOPM,
+    K_VERLET_BUILD,
     K_NN_COUNT,
     K_NN_SCAN,
     K_NN_FILL,
@@ -49,7 +50,7 @@ enum KernelId {
 };
 const char *const kKernelNames[K_NUM] = {
     "repack_kernel",   "bbox_kernel",    "cell_key_kernel",   "radix_sort",       "gather_points_kernel",
-    "cell_start_kernel", "nn_topm_kernel", "nn_count_kernel",  "nn_scan",          "nn_fill_kernel",
+    "cell_start_kernel", "nn_topm_kernel", "verlet_build_kernel", "nn_count_kernel",  "nn_scan",          "nn_fill_kernel",
     "nn_select_kernel", "csr_compact_kernel", "ell_count_sum_kernel", "weights_kernel", "accumulate_kernel",
     "reduce_partials_kernel", "transform_kernel"};
 
@@ -162,7 +163,29 @@ struct ppcr_ctx {
     double prof_ms[K_NUM] = {0};
     int64_t prof_n[K_NUM] = {0};
 
-    const float4 *tgt_cur() const { return grid_valid ? tgt_sorted.p : tgt_raw.p; }
+    // Verlet (skin) lists: second grid with cells >= r + skin, its own sorted copy of the target, the lists, and
+    // the rigid motion accumulated since they were built
+    int opt_verlet = 0;      // measured slower than the direct tiled scan on gfx950, kept as an option
+    double skin_frac = 0.2;  // skin = skin_frac * radius
+    float tgt_lo[3] = {0, 0, 0}, tgt_hi[3] = {0, 0, 0};
+    bool grid2_valid = false;
+    double grid2_cell_radius = -1;
+    GridDesc grid2{};
+    DevBuf<int> cell_start2;
+    DevBuf<float4> tgt_sorted2;
+    DevBuf<int> vl_nbr, vl_cnt;
+    bool vl_valid = false;
+    double vl_skin = 0;
+    double T_since[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    float vl_src_lo[3] = {0, 0, 0}, vl_src_hi[3] = {0, 0, 0};
+    int vl_moves_since = 0;
+    double last_move_T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};  // most recent rigid move of the source
+    bool moved_since_assoc = false;                                  // ... applied after the last association
+    int64_t stat_verlet_builds = 0, stat_verlet_uses = 0, stat_direct = 0;
+    // which copy of the target the association's positions index: 0 caller order, 1 grid-sorted, 2 grid2-sorted
+    int assoc_space = 0;
+    const float4 *tgt_space(int sp) const { return sp == 2 ? tgt_sorted2.p : (sp == 1 ? tgt_sorted.p : tgt_raw.p); }
+    const float4 *tgt_cur() const { return tgt_space(assoc_space); }
 };
 
 namespace {
@@ -284,8 +307,10 @@ int upload_cloud(ppcr_ctx *c, const void *ptr, bool on_device, int64_t n, int64_
 }
 
 // sort `n` points of `in` by grid cell into `out` (stable: ties keep ascending original index)
-int sort_by_cell(ppcr_ctx *c, const float4 *in, int n, float4 *out, bool want_cell_start, bool brick_order = false)
+int sort_by_cell(ppcr_ctx *c, const GridDesc &g, const float4 *in, int n, float4 *out, DevBuf<int> *cell_start_out,
+                 bool brick_order = false)
 {
+    const bool want_cell_start = cell_start_out != nullptr;
     HIP_TRY(c, c->keys_a.reserve((size_t)n + 1));
     HIP_TRY(c, c->keys_b.reserve((size_t)n + 1));
     HIP_TRY(c, c->vals_a.reserve((size_t)n + 1));
@@ -294,14 +319,13 @@ int sort_by_cell(ppcr_ctx *c, const float4 *in, int n, float4 *out, bool want_ce
         {
             ProfScope ps(c, K_CELL_KEY);
             if (brick_order)
-                brick_key_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(in, n, c->grid, c->keys_a.p, c->vals_a.p);
+                brick_key_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(in, n, g, c->keys_a.p, c->vals_a.p);
             else
-                cell_key_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(in, n, c->grid, c->keys_a.p, c->vals_a.p);
+                cell_key_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(in, n, g, c->keys_a.p, c->vals_a.p);
         }
         PPCR_TRY(check_launch(c, "cell_key_kernel"));
-        long long nkeys = c->grid.ncells;
-        if (brick_order)
-            nkeys = 64ll * ((c->grid.n[0] + 3) / 4) * ((c->grid.n[1] + 3) / 4) * ((c->grid.n[2] + 3) / 4);
+        long long nkeys = g.ncells;
+        if (brick_order) nkeys = 64ll * ((g.n[0] + 3) / 4) * ((g.n[1] + 3) / 4) * ((g.n[2] + 3) / 4);
         int end_bit = 1;
         while (end_bit < 32 && (1ll << end_bit) < nkeys) end_bit++;
         size_t tmp_bytes = 0;
@@ -320,57 +344,53 @@ int sort_by_cell(ppcr_ctx *c, const float4 *in, int n, float4 *out, bool want_ce
         PPCR_TRY(check_launch(c, "gather_points_kernel"));
     }
     if (want_cell_start) {
-        HIP_TRY(c, c->cell_start.reserve((size_t)c->grid.ncells + 1));
+        HIP_TRY(c, cell_start_out->reserve((size_t)g.ncells + 1));
         {
             ProfScope ps(c, K_CELL_START);
-            cell_start_kernel<<<nblocks((int64_t)n + 1), kBlock, 0, c->stream>>>(c->keys_b.p, n, c->grid.ncells,
-                                                                                 c->cell_start.p);
+            cell_start_kernel<<<nblocks((int64_t)n + 1), kBlock, 0, c->stream>>>(c->keys_b.p, n, g.ncells, cell_start_out->p);
         }
         PPCR_TRY(check_launch(c, "cell_start_kernel"));
     }
     return PPCR_OK;
 }
 
-// K0: bounding box -> cell edge -> cell-sorted target + cell_start
-int ensure_grid(ppcr_ctx *c)
+// bounding box of the finite points of a float4 cloud (device) -> host
+int cloud_bbox(ppcr_ctx *c, const float4 *pts, int n, float lo[3], float hi[3])
 {
-    if (!c->have_tgt) return fail(c, PPCR_ERR_STATE, "target cloud not set");
-    if (c->grid_valid && c->grid_radius == c->radius) return PPCR_OK;
-    if (!(c->radius > 0) || !std::isfinite(c->radius)) return fail(c, PPCR_ERR_INVALID, "radius must be positive and finite");
-    invalidate_association(c);
-    const int n = (int)c->nt;
-    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-    if (n > 0) {
-        const int nb = std::min(1024, nblocks(n));
-        HIP_TRY(c, c->bbox_part.reserve((size_t)nb * 6));
-        {
-            ProfScope ps(c, K_BBOX);
-            bbox_kernel<<<nb, kBlock, 0, c->stream>>>(c->tgt_raw.p, n, c->bbox_part.p);
-        }
-        PPCR_TRY(check_launch(c, "bbox_kernel"));
-        std::vector<float> part((size_t)nb * 6);
-        HIP_TRY(c, hipMemcpyAsync(part.data(), c->bbox_part.p, part.size() * sizeof(float), hipMemcpyDeviceToHost,
-                                  c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        for (int a = 0; a < 3; a++) {
-            lo[a] = INFINITY;
-            hi[a] = -INFINITY;
-        }
-        for (int b = 0; b < nb; b++)
-            for (int a = 0; a < 3; a++) {
-                lo[a] = std::min(lo[a], part[(size_t)b * 6 + a]);
-                hi[a] = std::max(hi[a], part[(size_t)b * 6 + 3 + a]);
-            }
-        for (int a = 0; a < 3; a++)
-            if (!(lo[a] <= hi[a])) lo[a] = hi[a] = 0;  // no finite coordinate at all
+    for (int a = 0; a < 3; a++) lo[a] = hi[a] = 0;
+    if (n <= 0) return PPCR_OK;
+    const int nb = std::min(1024, nblocks(n));
+    HIP_TRY(c, c->bbox_part.reserve((size_t)nb * 6));
+    {
+        ProfScope ps(c, K_BBOX);
+        bbox_kernel<<<nb, kBlock, 0, c->stream>>>(pts, n, c->bbox_part.p);
     }
-    for (int a = 0; a < 3; a++) c->origin[a] = 0.5 * ((double)lo[a] + (double)hi[a]);
-    c->origin_valid = true;
+    PPCR_TRY(check_launch(c, "bbox_kernel"));
+    std::vector<float> part((size_t)nb * 6);
+    HIP_TRY(c, hipMemcpyAsync(part.data(), c->bbox_part.p, part.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int a = 0; a < 3; a++) {
+        lo[a] = INFINITY;
+        hi[a] = -INFINITY;
+    }
+    for (int b = 0; b < nb; b++)
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::min(lo[a], part[(size_t)b * 6 + a]);
+            hi[a] = std::max(hi[a], part[(size_t)b * 6 + 3 + a]);
+        }
+    for (int a = 0; a < 3; a++)
+        if (!(lo[a] <= hi[a])) lo[a] = hi[a] = 0;  // no finite coordinate at all
+    return PPCR_OK;
+}
+
+// uniform grid over [lo, hi] whose 27-cell stencil covers a search of `cell_radius`
+void make_grid_desc(int n, const float lo[3], const float hi[3], double cell_radius, GridDesc &g)
+{
     float amax = 0;
     for (int a = 0; a < 3; a++) amax = std::max(amax, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
-    // cell edge slightly above r: float rounding of the cell index can then never push an
+    // cell edge slightly above the radius: float rounding of the cell index can then never push an
     // in-radius target outside the query's 27-cell stencil
-    float h = (float)c->radius * 1.001f + 16.0f * FLT_EPSILON * amax;
+    float h = (float)cell_radius * 1.001f + 16.0f * FLT_EPSILON * amax;
     // table bound: ~4 cells per target point, and small enough that brick-order keys fit 32 bits
     const double max_cells = std::min(4.0 * (double)n + 4096.0, 67108864.0);
     double ext[3];
@@ -383,17 +403,47 @@ int ensure_grid(ppcr_ctx *c)
     }
     int64_t ncells = 1;
     for (int a = 0; a < 3; a++) {
-        c->grid.org[a] = lo[a];
-        c->grid.n[a] = (int)std::floor(ext[a] / h) + 1;
-        ncells *= c->grid.n[a];
+        g.org[a] = lo[a];
+        g.n[a] = (int)std::floor(ext[a] / h) + 1;
+        ncells *= g.n[a];
     }
-    c->grid.inv_h = 1.0f / h;
-    c->grid.ncells = (int)ncells;
+    g.inv_h = 1.0f / h;
+    g.ncells = (int)ncells;
+}
+
+// K0: bounding box -> cell edge -> cell-sorted target + cell_start
+int ensure_grid(ppcr_ctx *c)
+{
+    if (!c->have_tgt) return fail(c, PPCR_ERR_STATE, "target cloud not set");
+    if (c->grid_valid && c->grid_radius == c->radius) return PPCR_OK;
+    if (!(c->radius > 0) || !std::isfinite(c->radius)) return fail(c, PPCR_ERR_INVALID, "radius must be positive and finite");
+    invalidate_association(c);
+    c->vl_valid = false;
+    c->grid2_valid = false;
+    const int n = (int)c->nt;
+    PPCR_TRY(cloud_bbox(c, c->tgt_raw.p, n, c->tgt_lo, c->tgt_hi));
+    for (int a = 0; a < 3; a++) c->origin[a] = 0.5 * ((double)c->tgt_lo[a] + (double)c->tgt_hi[a]);
+    c->origin_valid = true;
+    make_grid_desc(n, c->tgt_lo, c->tgt_hi, c->radius, c->grid);
     HIP_TRY(c, c->tgt_sorted.reserve((size_t)std::max(n, 1)));
-    PPCR_TRY(sort_by_cell(c, c->tgt_raw.p, n, c->tgt_sorted.p, true));
+    PPCR_TRY(sort_by_cell(c, c->grid, c->tgt_raw.p, n, c->tgt_sorted.p, &c->cell_start));
     c->grid_valid = true;
     c->grid_radius = c->radius;
     c->src_sorted = false;  // re-sort against the new grid at the next associate()
+    return PPCR_OK;
+}
+
+// second grid for the Verlet builds: cells cover r + skin
+int ensure_grid2(ppcr_ctx *c, double cell_radius)
+{
+    if (c->grid2_valid && c->grid2_cell_radius == cell_radius) return PPCR_OK;
+    const int n = (int)c->nt;
+    c->vl_valid = false;
+    make_grid_desc(n, c->tgt_lo, c->tgt_hi, cell_radius, c->grid2);
+    HIP_TRY(c, c->tgt_sorted2.reserve((size_t)std::max(n, 1)));
+    PPCR_TRY(sort_by_cell(c, c->grid2, c->tgt_raw.p, n, c->tgt_sorted2.p, &c->cell_start2));
+    c->grid2_valid = true;
+    c->grid2_cell_radius = cell_radius;
     return PPCR_OK;
 }
 
@@ -403,10 +453,11 @@ int ensure_source_sorted(ppcr_ctx *c)
     if (c->src_sorted || !c->opt_sort_source || c->ns == 0) return PPCR_OK;
     invalidate_association(c);
     HIP_TRY(c, c->src_alt.reserve((size_t)c->ns));
-    PPCR_TRY(sort_by_cell(c, c->src.p, (int)c->ns, c->src_alt.p, false, c->opt_sort_source == 1));
+    PPCR_TRY(sort_by_cell(c, c->grid, c->src.p, (int)c->ns, c->src_alt.p, nullptr, c->opt_sort_source == 1));
     std::swap(c->src, c->src_alt);
     c->src_sorted = true;
     c->dm2_valid = false;  // row order changed
+    c->vl_valid = false;
     return PPCR_OK;
 }
 
@@ -417,11 +468,12 @@ void launch_topm(ppcr_ctx *c, float r2, int m, const FusedRows &fm, const Pendin
 {
     unsigned long long *st = c->opt_stamps ? c->d_stamps.p : nullptr;
     const int dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
+    const VerletBuild vb_none{0, nullptr, nullptr};
 #define PPCR_TILE_F(Cc, B, CAPc, F)                                                                                 \
     nn_tile_kernel<M, Cc, B, CAPc, F><<<nblocks(c->ns, B), B, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p, \
                                                                               c->cell_start.p, c->grid, r2, m,      \
                                                                               c->nbr.p, c->cnt.p, st, fm, pm,      \
-                                                                              c->dm2.p, dm2_in)
+                                                                              c->dm2.p, dm2_in, vb_none)
 #define PPCR_TILE(Cc, B, CAPc) PPCR_TILE_F(Cc, B, CAPc, false)
     if (c->opt_nn_variant == 0 || c->opt_nn_variant == 3) {
         // LDS budget per 256-query block: halo CAP*16 B + list C*512 B (+1.1 KB tables), three blocks per CU.
@@ -471,6 +523,72 @@ void launch_accumulate_ell(ppcr_ctx *c, int nb, const Pose &P, const Model &md)
 bool tile_variant(const ppcr_ctx *c) { return c->opt_nn_variant == 0 || c->opt_nn_variant == 3; }
 int flush_pending_move(ppcr_ctx *c);
 
+constexpr int kVerletCap = 48;  // entries per Verlet list (rows with more fall back to scanning the grid)
+
+// largest distance any point of the box [lo, hi] travels under the rigid transform T (|T x - x| is convex in x,
+// so the maximum over a box is attained at a corner)
+double max_displacement(const double T[12], const float lo[3], const float hi[3])
+{
+    double worst = 0;
+    for (int k = 0; k < 8; k++) {
+        const double x[3] = {(k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2]};
+        double d2 = 0;
+        for (int a = 0; a < 3; a++) {
+            const double y = T[4 * a] * x[0] + T[4 * a + 1] * x[1] + T[4 * a + 2] * x[2] + T[4 * a + 3];
+            d2 += (y - x[a]) * (y - x[a]);
+        }
+        worst = std::max(worst, std::sqrt(d2));
+    }
+    return worst;
+}
+
+PendingMove no_move()
+{
+    PendingMove pm;
+    std::memset(&pm, 0, sizeof(pm));
+    return pm;
+}
+
+// BUILD: all targets within radius + skin of every query (tile kernel on the second grid, list capacity
+// kVerletCap); also records the source bounding box the displacement bound is evaluated on
+int verlet_build(ppcr_ctx *c, double skin, const PendingMove &pm)
+{
+    const int ns = (int)c->ns;
+    PPCR_TRY(ensure_grid2(c, c->radius + skin));
+    HIP_TRY(c, c->vl_nbr.reserve((size_t)kVerletCap * (size_t)ns));
+    HIP_TRY(c, c->vl_cnt.reserve((size_t)ns));
+    const double rs = c->radius + skin;
+    const float rs2 = (float)(rs * rs);
+    FusedRows fm;
+    std::memset(&fm, 0, sizeof(fm));
+    const VerletBuild vb{1, c->vl_nbr.p, c->vl_cnt.p};
+    {
+        ProfScope ps(c, K_VERLET_BUILD);
+        nn_tile_kernel<32, kVerletCap, 256, 3072, false><<<nblocks(ns), 256, 0, c->stream>>>(
+            c->src.p, ns, c->tgt_sorted2.p, c->cell_start2.p, c->grid2, rs2, kVerletCap, c->nbr.p, c->cnt.p, nullptr, fm, pm,
+            nullptr, 0, vb);
+    }
+    PPCR_TRY(check_launch(c, "nn_tile_kernel (verlet build)"));
+    PPCR_TRY(cloud_bbox(c, c->src.p, ns, c->vl_src_lo, c->vl_src_hi));
+    const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    std::memcpy(c->T_since, I, sizeof(I));
+    c->vl_moves_since = 0;
+    c->vl_skin = skin;
+    c->vl_valid = true;
+    c->stat_verlet_builds++;
+    return PPCR_OK;
+}
+
+template <int M>
+void launch_verlet_use(ppcr_ctx *c, float r2, int m, const PendingMove &pm)
+{
+    const VerletUse vu{c->vl_nbr.p, c->vl_cnt.p};
+    const int dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
+    nn_verlet_kernel<M><<<nblocks(c->ns), kBlock, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted2.p, c->cell_start2.p,
+                                                                       c->grid2, r2, m, c->nbr.p, c->cnt.p, vu, pm, c->dm2.p,
+                                                                       dm2_in);
+}
+
 // fused_theta (nullable): {R, t} of the state the first IRLS half-step is evaluated at; when given and
 // the tiled kernel runs, K1 also produces the moments (c->fused_sums_pending) and K23 is skipped once
 int associate_impl(ppcr_ctx *c, const Mat3 *fused_R = nullptr, const double *fused_t = nullptr)
@@ -486,8 +604,10 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fused_R = nullptr, const double *fus
     const bool tiled = !unbounded && c->max_nb <= kEllMaxWidth && tile_variant(c) && ns > 0;
     PendingMove pm;
     std::memset(&pm, 0, sizeof(pm));
+    double pending_copy[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     if (c->move_pending && tiled) {
         // the deferred source move rides in this kernel's prologue
+        std::memcpy(pending_copy, c->pending_T, sizeof(pending_copy));
         pm.enabled = 1;
         for (int a = 0; a < 3; a++) {
             for (int b = 0; b < 3; b++) pm.P.R[3 * a + b] = c->pending_T[4 * a + b];
@@ -515,7 +635,52 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fused_R = nullptr, const double *fus
             fm.md = make_model(c);
             fm.rowpart = c->rowpart.p;
         }
-        if (ns > 0) {
+        // ---- Verlet (skin) lists: reuse / rebuild / plain scan --------------------------------------------
+        bool use_lists = false, build_lists = false;
+        const double skin = c->skin_frac * c->radius;
+        if (tiled && c->opt_verlet && !fm.enabled && m <= 20 && c->nt > 0) {
+            double Ttot[12];
+            if (pm.enabled) compose(pending_copy, c->T_since, Ttot);
+            else std::memcpy(Ttot, c->T_since, sizeof(Ttot));
+            if (c->vl_valid && c->vl_skin == skin) {
+                double corner = 0;
+                for (int a = 0; a < 3; a++) corner = std::max(corner, (double)std::max(std::fabs(c->vl_src_lo[a]), std::fabs(c->vl_src_hi[a])));
+                // float re-rounding of the moved source, one ulp-ish per applied move
+                const double slack = (c->vl_moves_since + 1) * 2.4e-7 * corner * 1.8 + 1e-5 * c->radius;
+                use_lists = max_displacement(Ttot, c->vl_src_lo, c->vl_src_hi) * 1.00001 + slack <= skin;
+            }
+            if (!use_lists && c->moved_since_assoc) {
+                // worth a rebuild only if the motion per iteration is small against the skin
+                float lo[3], hi[3];
+                for (int a = 0; a < 3; a++) {
+                    lo[a] = c->vl_valid ? c->vl_src_lo[a] : c->tgt_lo[a] - (float)c->radius;
+                    hi[a] = c->vl_valid ? c->vl_src_hi[a] : c->tgt_hi[a] + (float)c->radius;
+                }
+                build_lists = max_displacement(c->last_move_T, lo, hi) * 3.0 <= skin;
+            }
+            if (use_lists) {
+                std::memcpy(c->T_since, Ttot, sizeof(Ttot));
+                if (pm.enabled) c->vl_moves_since++;
+            }
+        }
+        c->moved_since_assoc = false;
+        if (build_lists) {
+            PPCR_TRY(verlet_build(c, skin, pm));  // applies the pending move in its prologue
+            if (pm.enabled) c->dm2_valid = false;  // the source moved in a kernel that does not maintain dm2
+            pm = no_move();
+            use_lists = true;
+        }
+        if (ns > 0 && use_lists) {
+            ProfScope ps(c, K_NN_TOPM);
+            if (m <= 4) launch_verlet_use<4>(c, r2, m, pm);
+            else if (m <= 5) launch_verlet_use<5>(c, r2, m, pm);
+            else if (m <= 8) launch_verlet_use<8>(c, r2, m, pm);
+            else if (m <= 10) launch_verlet_use<10>(c, r2, m, pm);
+            else if (m <= 16) launch_verlet_use<16>(c, r2, m, pm);
+            else launch_verlet_use<20>(c, r2, m, pm);
+            c->stat_verlet_uses++;
+            c->assoc_space = 2;
+        } else if (ns > 0) {
             ProfScope ps(c, K_NN_TOPM);
             if (m <= 4) launch_topm<4>(c, r2, m, fm, pm);
             else if (m <= 5) launch_topm<5>(c, r2, m, fm, pm);
@@ -524,6 +689,14 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fused_R = nullptr, const double *fus
             else if (m <= 16) launch_topm<16>(c, r2, m, fm, pm);
             else if (m <= 20) launch_topm<20>(c, r2, m, fm, pm);
             else launch_topm<32>(c, r2, m, fm, pm);
+            c->stat_direct++;
+            c->assoc_space = 1;
+            if (pm.enabled) {  // the lists (if any) stay in step with the motion applied to the source
+                compose(pending_copy, c->T_since, c->T_since);
+                c->vl_moves_since++;
+            }
+        } else {
+            c->assoc_space = 1;
         }
         PPCR_TRY(check_launch(c, "nn_topm_kernel"));
         c->fused_sums_pending = fm.enabled != 0;
@@ -533,6 +706,7 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fused_R = nullptr, const double *fus
         return PPCR_OK;
     }
     // generic path: count -> scan -> fill [-> select + compact]
+    c->assoc_space = 1;
     HIP_TRY(c, c->gen_counts.reserve((size_t)ns + 1));
     HIP_TRY(c, c->gen_row_ptr.reserve((size_t)ns + 1));
     HIP_TRY(c, hipMemsetAsync(c->gen_counts.p, 0, sizeof(int) * ((size_t)ns + 1), c->stream));
@@ -817,6 +991,8 @@ int apply_transform_impl(ppcr_ctx *c, const double T[12], bool defer = false)
 {
     if (!c->have_src) return fail(c, PPCR_ERR_STATE, "source cloud not set");
     PPCR_TRY(flush_pending_move(c));
+    std::memcpy(c->last_move_T, T, sizeof(c->last_move_T));
+    c->moved_since_assoc = true;
     if (defer) {
         std::memcpy(c->pending_T, T, sizeof(c->pending_T));
         c->move_pending = true;
@@ -828,6 +1004,8 @@ int apply_transform_impl(ppcr_ctx *c, const double T[12], bool defer = false)
 int apply_transform_now(ppcr_ctx *c, const double T[12])
 {
     c->dm2_valid = false;  // the source moved outside a tiled K1: the temporal cut-off starts over
+    compose(T, c->T_since, c->T_since);  // Verlet lists stay in step with every motion applied to the source
+    c->vl_moves_since++;
     Pose P;
     for (int a = 0; a < 3; a++) {
         for (int b = 0; b < 3; b++) P.R[3 * a + b] = T[4 * a + b];
@@ -952,6 +1130,10 @@ int ppcr_destroy(ppcr_ctx *c)
     c->src.release();
     c->src_alt.release();
     c->cell_start.release();
+    c->cell_start2.release();
+    c->tgt_sorted2.release();
+    c->vl_nbr.release();
+    c->vl_cnt.release();
     c->keys_a.release();
     c->keys_b.release();
     c->vals_a.release();
@@ -1017,6 +1199,17 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
         c->opt_nn_variant = value;
         return PPCR_OK;
     }
+    if (std::strcmp(key, "verlet") == 0) {  // 1: Verlet (skin) neighbour lists while the source moves little (default)
+        c->opt_verlet = value ? 1 : 0;
+        c->vl_valid = false;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "verlet_skin_permille") == 0) {  // skin as a fraction of the radius, in 1/1000 (default 200)
+        if (value < 1 || value > 1000) return fail(c, PPCR_ERR_INVALID, "verlet_skin_permille must be in [1, 1000]");
+        c->skin_frac = value / 1000.0;
+        c->vl_valid = false;
+        return PPCR_OK;
+    }
     if (std::strcmp(key, "mailbox") == 0) {
         c->opt_mailbox = value ? 1 : 0;
         return PPCR_OK;
@@ -1045,8 +1238,11 @@ static int set_target_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, in
     c->nt = n;
     c->have_tgt = true;
     c->grid_valid = false;
+    c->grid2_valid = false;
+    c->vl_valid = false;
     c->origin_valid = false;
     c->dm2_valid = false;
+    c->assoc_space = 0;
     invalidate_association(c);
     return PPCR_OK;
 }
@@ -1055,6 +1251,7 @@ static int set_source_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, in
 {
     c->move_pending = false;  // a deferred move of the previous source dies with it
     c->dm2_valid = false;
+    c->vl_valid = false;
     PPCR_TRY(upload_cloud(c, p, dev, n, stride, c->src));
     c->ns = n;
     c->have_src = true;
@@ -1151,6 +1348,7 @@ int ppcr_set_association(ppcr_ctx *c, const int32_t *row_ptr, const int32_t *col
     for (int64_t k = 0; k < nnz; k++)
         if (col[k] < 0 || col[k] >= c->nt) return fail(c, PPCR_ERR_INVALID, "column index out of range");
     invalidate_association(c);
+    c->assoc_space = c->grid_valid ? 1 : 0;
     std::vector<int> src_order, tgt_order;
     PPCR_TRY(download_order(c, c->src.p, ns, src_order));
     PPCR_TRY(download_order(c, c->tgt_cur(), c->nt, tgt_order));
@@ -1417,6 +1615,16 @@ int ppcr_debug_get_stamps(ppcr_ctx *c, unsigned long long out[8])
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int k = 0; k < 8; k++) out[k] = 0;
     for (size_t i = 0; i < nst; i++) out[i % 8] += h[i];
+    return PPCR_OK;
+}
+
+// diagnostic: {verlet builds, verlet uses, plain scans} since the handle was created
+int ppcr_debug_get_counters(ppcr_ctx *c, long long out[3])
+{
+    CTX_ENTER(c);
+    out[0] = c->stat_verlet_builds;
+    out[1] = c->stat_verlet_uses;
+    out[2] = c->stat_direct;
     return PPCR_OK;
 }
 

@@ -592,13 +592,14 @@ struct LdsCands {  // candidate source = staged halo (SoA in LDS); list entries 
         return (unsigned)__float_as_int(tgt[spos[e]].w);
     }
 };
+template <int STRIDE = 64>
 struct GlobalCands {  // candidate source = global memory; list entries are sorted-target positions
     const float4 *tgt;
-    int *list;  // [slot * 64 + lane]
+    int *list;  // [slot * STRIDE + lane]
     int lane;
     __device__ __forceinline__ float4 get(int e) const { return tgt[e]; }
-    __device__ __forceinline__ int load(int t) const { return list[t * 64 + lane]; }
-    __device__ __forceinline__ void store(int t, int e) const { list[t * 64 + lane] = e; }
+    __device__ __forceinline__ int load(int t) const { return list[t * STRIDE + lane]; }
+    __device__ __forceinline__ void store(int t, int e) const { list[t * STRIDE + lane] = e; }
     __device__ __forceinline__ int pos_of(int e) const { return e; }
     __device__ __forceinline__ unsigned orig_of(int e, const float4 *__restrict__) const
     {
@@ -670,6 +671,18 @@ struct PendingMove {
     Pose P;
 };
 
+// Verlet (skin) neighbour lists.  BUILD (rare): nn_tile_kernel run with the skin radius r + delta collects, for
+// every query, ALL targets within r + delta (no cut-off, no top-m) into vl_nbr[k][i] / vl_cnt[i] (-1: more than the
+// list holds).  USE (every iteration while no query has moved farther than delta since the build — the host checks
+// that from the accumulated rigid transform): nn_verlet_kernel re-tests only those stored candidates.  Any target
+// within r of a query's current position was within r + delta of its build position, so the exact in-radius set,
+// and with it the exact top-m, is contained in the list: results are bit-identical to a full scan.
+struct VerletBuild {
+    int enabled;
+    int *vl_nbr;  // [C][ns]
+    int *vl_cnt;  // [ns]
+};
+
 template <int M, int C, int BLOCK, int CAP, bool FUSED>
 __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt,
@@ -677,7 +690,8 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                                                          float r2, int m, int *__restrict__ nbr,
                                                          int *__restrict__ cnt,
                                                          unsigned long long *__restrict__ stamps, FusedRows fm,
-                                                         PendingMove pm, unsigned *__restrict__ dm2, int dm2_valid)
+                                                         PendingMove pm, unsigned *__restrict__ dm2, int dm2_valid,
+                                                         VerletBuild vb)
 {
     static_assert(C > M, "a compaction must leave room in the list");
     static_assert(CAP % 4 == 0 && CAP <= 65536 && C * 64 <= 4 * CAP, "the global fallback aliases the candidate buffer");
@@ -962,6 +976,13 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                     }
                 };
                 scan_runs(std::false_type{});
+                if (vb.enabled) {
+                    // Verlet build: the list IS the result (r2 here is the skin radius squared)
+                    const int nv = (n > C) ? 0 : n;
+                    for (int j = 0; j < nv; j++) vb.vl_nbr[(size_t)j * ns + i] = L.pos_of(L.load(j));
+                    vb.vl_cnt[i] = (n > C) ? -1 : n;
+                    done = true;
+                } else {
                 if (n > C) {  // list overflow (slot C-1 was overwritten): redo this lane with in-loop compaction
                     n = 0;
                     thr = lim0;
@@ -982,6 +1003,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                 if (dm2) dm2[i] = tm;
                 done = true;
                 if constexpr (FUSED) row_partials(L, n, q, fm.P, fm.md, fm.rowpart, ns, i);  // winners still in LDS
+                }
                 stamp(5);
             }
             done_mask |= pass_mask;
@@ -991,8 +1013,20 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
         } else if (last_level) {
             // last resort for this wave: scan global memory (list of positions aliases the halo buffer)
             if (!done && wave == w0) {
-                const GlobalCands G{tgt, s_glist, lane};
+                const GlobalCands<64> G{tgt, s_glist, lane};
                 unsigned thr = thr0;
+                if (vb.enabled) {
+                    for_each_candidate(q, g, cell_start, tgt, [&](int p, float4 t) {
+                        if (dist2_flann(q, t) < r2) {
+                            G.store(min(n, C - 1), p);
+                            n++;
+                        }
+                    });
+                    const int nv = (n > C) ? 0 : n;
+                    for (int j = 0; j < nv; j++) vb.vl_nbr[(size_t)j * ns + i] = G.load(j);
+                    vb.vl_cnt[i] = (n > C) ? -1 : n;
+                    done = true;
+                } else {
                 for_each_candidate(q, g, cell_start, tgt, [&](int p, float4 t) {
                     const float d2 = dist2_flann(q, t);
                     if (d2 < r2 && __float_as_uint(d2) <= thr) {
@@ -1014,6 +1048,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                 if (dm2) dm2[i] = tm;
                 done = true;
                 if constexpr (FUSED) row_partials(G, n, q, fm.P, fm.md, fm.rowpart, ns, i);
+                }
             }
             done_mask |= pass_mask;
             __syncthreads();
@@ -1021,6 +1056,169 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
         }
       }
     flush_stamps();
+}
+
+// Verlet USE: one lane per query, no grid, no halo, no LDS, no barrier.  (A first version kept an LDS list and
+// re-gathered its entries in the selection passes: a dependent load chain, 148 us — no faster than the scan.)
+// Rows whose list overflowed at build time (vl_cnt < 0) walk the grid instead.
+struct VerletUse {
+    const int *vl_nbr;  // [cap][ns]
+    const int *vl_cnt;  // [ns]
+};
+
+template <int M>
+__global__ __launch_bounds__(kBlock) void nn_verlet_kernel(float4 *__restrict__ src, int ns,
+                                                           const float4 *__restrict__ tgt,
+                                                           const int *__restrict__ cell_start, GridDesc g, float r2,
+                                                           int m, int *__restrict__ nbr, int *__restrict__ cnt,
+                                                           VerletUse vu, PendingMove pm, unsigned *__restrict__ dm2,
+                                                           int dm2_valid)
+{
+    constexpr int CL = 32;  // in-radius entries cached per lane (more: the lane takes the two-pass route)
+    __shared__ unsigned s_b[CL * kBlock];      // d2 bits of the in-radius candidates, [slot][lane]
+    __shared__ unsigned char s_k[CL * kBlock];  // their index in the stored list
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kBlock + tid;
+    if (i >= ns) return;  // lane-private LDS slots only: no barrier
+    float4 q = src[i];
+    float moved = 0.f;
+    if (pm.enabled) {
+        const float4 q0 = q;
+        q = move_point(q, pm.P);
+        src[i] = q;
+        const float ex = q.x - q0.x, ey = q.y - q0.y, ez = q.z - q0.z;
+        moved = sqrtf(ex * ex + ey * ey + ez * ez);
+    }
+    unsigned thr0 = 0xFFFFFFFFu;  // temporal cut-off, as in nn_tile_kernel
+    if (dm2_valid) {
+        const unsigned prev = dm2[i];
+        if (prev != 0xFFFFFFFFu) {
+            const float bound = sqrtf(__uint_as_float(prev)) + moved;
+            const float t2 = bound * bound * 1.00001f + 1e-30f;
+            thr0 = (t2 < r2) ? __float_as_uint(t2) : 0xFFFFFFFFu;
+        }
+    }
+    const unsigned lim0 = min(thr0, __float_as_uint(r2) - 1u);
+    const int nv = vu.vl_cnt[i];
+
+    // generic exact answer by walking the candidates twice (plus twice more for exact ties); used for rows
+    // whose stored list overflowed (they walk the grid) and for lanes with more than CL in-radius entries
+    auto answer = [&](auto &&for_all) {
+        unsigned K[M];
+#pragma unroll
+        for (int j = 0; j < M; j++) K[j] = 0xFFFFFFFFu;
+        int inside = 0;
+        for_all([&](int, float4 t) {
+            const unsigned b = __float_as_uint(dist2_flann(q, t));
+            if (b <= lim0) {
+                sorted_insert<M>(K, b);
+                inside++;
+            }
+        });
+        const bool full = inside >= m;
+        const unsigned T = full ? pick<M>(K, m - 1) : lim0;
+        int j = 0;
+        for_all([&](int p, float4 t) {
+            if (__float_as_uint(dist2_flann(q, t)) <= T) {
+                if (j < m) nbr[(size_t)j * ns + i] = p;
+                j++;
+            }
+        });
+        if (j > m) {  // more ties at the cut-off than room: the lowest original target indices win
+            int c_less = 0;
+#pragma unroll
+            for (int a = 0; a < M; a++) K[a] = 0xFFFFFFFFu;
+            for_all([&](int, float4 t) {
+                const unsigned b = __float_as_uint(dist2_flann(q, t));
+                if (b < T) c_less++;
+                else if (b == T) sorted_insert<M>(K, (unsigned)__float_as_int(t.w));
+            });
+            const unsigned T2 = pick<M>(K, m - c_less - 1);
+            j = 0;
+            for_all([&](int p, float4 t) {
+                const unsigned b = __float_as_uint(dist2_flann(q, t));
+                if (b < T || (b == T && (unsigned)__float_as_int(t.w) <= T2)) {
+                    if (j < m) nbr[(size_t)j * ns + i] = p;
+                    j++;
+                }
+            });
+        }
+        cnt[i] = min(j, m);
+        if (dm2) dm2[i] = full ? T : 0xFFFFFFFFu;
+    };
+    auto walk_list = [&](auto &&f) {  // stored candidates: eight index loads, then eight gathers, in flight
+        int k = 0;
+        for (; k < nv; k += 8) {
+            int p[8];
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) p[u] = (k + u < nv) ? vu.vl_nbr[(size_t)(k + u) * ns + i] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = tgt[p[u]];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (k + u < nv) f(k + u, p[u], t[u]);
+        }
+    };
+
+    if (nv < 0) {
+        answer([&](auto &&f) { for_each_candidate(q, g, cell_start, tgt, f); });  // list overflowed at build time
+        return;
+    }
+    // Fast route: ONE pass of gathers.  d2 bits and list index of every in-radius candidate are parked in LDS while
+    // the bits also go through the sorted register list; afterwards the winners (bits <= T) re-read only their
+    // position from the stored list.
+    unsigned K[M];
+#pragma unroll
+    for (int j = 0; j < M; j++) K[j] = 0xFFFFFFFFu;
+    int n = 0;
+    walk_list([&](int k, int, float4 t) {
+        const unsigned b = __float_as_uint(dist2_flann(q, t));
+        if (b <= lim0) {
+            const int slot = min(n, CL - 1);
+            s_b[slot * kBlock + tid] = b;
+            s_k[slot * kBlock + tid] = (unsigned char)k;
+            sorted_insert<M>(K, b);
+            n++;
+        }
+    });
+    if (n > CL) {  // more in-radius entries than the LDS cache holds: exact two-pass route over the stored list
+        answer([&](auto &&f) { walk_list([&](int, int p, float4 t) { f(p, t); }); });
+        return;
+    }
+    const bool full = n >= m;
+    const unsigned T = full ? pick<M>(K, m - 1) : lim0;
+    int j = 0, c_less = 0;
+    for (int e = 0; e < n; e++) {
+        const unsigned b = s_b[e * kBlock + tid];
+        if (b <= T) {
+            if (j < m) nbr[(size_t)j * ns + i] = vu.vl_nbr[(size_t)s_k[e * kBlock + tid] * ns + i];
+            j++;
+            c_less += (b < T) ? 1 : 0;
+        }
+    }
+    if (j > m) {  // exact ties at the cut-off (rare): lowest original target indices win
+#pragma unroll
+        for (int a = 0; a < M; a++) K[a] = 0xFFFFFFFFu;
+        for (int e = 0; e < n; e++)
+            if (s_b[e * kBlock + tid] == T) {
+                const int p = vu.vl_nbr[(size_t)s_k[e * kBlock + tid] * ns + i];
+                sorted_insert<M>(K, (unsigned)__float_as_int(tgt[p].w));
+            }
+        const unsigned T2 = pick<M>(K, m - c_less - 1);
+        j = 0;
+        for (int e = 0; e < n; e++) {
+            const unsigned b = s_b[e * kBlock + tid];
+            if (b > T) continue;
+            const int p = vu.vl_nbr[(size_t)s_k[e * kBlock + tid] * ns + i];
+            if (b < T || (unsigned)__float_as_int(tgt[p].w) <= T2) {
+                if (j < m) nbr[(size_t)j * ns + i] = p;
+                j++;
+            }
+        }
+    }
+    cnt[i] = min(j, m);
+    if (dm2) dm2[i] = full ? T : 0xFFFFFFFFu;
 }
 
 // Generic path (unbounded, or max_neighbours above the register-list variants):

@@ -429,7 +429,9 @@ def test_temporal_cutoff_and_deferred_move_change_nothing(ctx):
     src, tgt, _, _ = synth.make_pair(30000, cfg=2, stride=3)
     a, b = _lib.Context(0), _lib.Context(0)
     try:
+        a.set_option("verlet", 1)        # skin lists on top (off by default: measured slower, must still be exact)
         b.set_option("temporal", 0)
+        b.set_option("verlet", 0)
         for c in (a, b):
             c.set_params(1.0, 10, 5.0, 3)
             c.set_target(tgt)
@@ -438,7 +440,7 @@ def test_temporal_cutoff_and_deferred_move_change_nothing(ctx):
         for it in range(6):
             Ta, ca, _ = a.iterate(inner_steps=1)
             Tb, cb, _ = b.iterate(inner_steps=1)
-            np.testing.assert_array_equal(Ta, Tb)
+            np.testing.assert_allclose(Ta, Tb, rtol=0, atol=1e-12)   # same neighbours, different summation order
             ra, rb_ = a.get_association(), b.get_association()     # (flushes the deferred move: exercises both paths)
             for x, y in zip(ra, rb_):
                 np.testing.assert_array_equal(x, y)
@@ -447,6 +449,9 @@ def test_temporal_cutoff_and_deferred_move_change_nothing(ctx):
             np.testing.assert_array_equal(ra[1], ocol)
             po.transform_cloud(cur, np.vstack([Ta, [0, 0, 0, 1]]))
             np.testing.assert_array_equal(a.get_source(), cur)
+        builds, uses, direct = a.counters()
+        assert builds >= 1 and uses >= 3, (builds, uses, direct)      # the Verlet path really ran in context a
+        assert b.counters()[:2] == (0, 0)
         # a big jump (cut-off bound = previous distance + displacement must still hold)
         jump = np.eye(4)
         jump[:3, :3] = synth.rodrigues([0.2, 1.0, -0.3], 0.4)
