@@ -39,29 +39,53 @@ def parse():
     ap.add_argument("--n", type=int, default=None, help="override the cloud size (debugging)")
     ap.add_argument("--inner-steps", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-iters", type=int, default=0,
+                    help="outer iterations of the CPU baseline sample (0 = auto: about 6 s of wall time, 3..30)")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel pass")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank, to exercise the collective path")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="pairs in flight per GPU when --pairs-per-gpu > 1 (ppcr_align_many host worker threads)")
     ap.add_argument("--pairs-per-gpu", type=int, default=1,
                     help="independent pairs each rank registers back to back (BASELINE configs[4]: --config 5 --pairs-per-gpu 8)")
     return ap.parse_args()
+
+
+def effective_cores():
+    """Host cores this process can really use: the affinity mask capped by the container's CFS quota
+    (the GPU boxes expose all hardware threads but cap CPU time, /sys/fs/cgroup/cpu.max)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(period) + 0.5))
+    except (OSError, ValueError):
+        pass
+    return (min(n, quota) if quota else n), n, quota
 
 
 def cpu_baseline(src, tgt, cfg, iters, inner_steps):
     """The oracle (kind 'port': OpenMP-generous variant — grid built per call, all loops parallel) timed on
     this box's host cores on a bounded sample: `iters` outer iterations of the SAME workload."""
     from oracle import binding as po  # checker-side import, only on this leg
-    threads = po.num_threads()
+    cores, visible, quota = effective_cores()
+    threads = max(1, min(po.num_threads(), cores))
+    tw = time.perf_counter()
     po.align(src, tgt, cfg["radius"], cfg["max_neighbours"], cfg["dof"], 1, inner_max_steps=inner_steps,
              threads=threads)  # warm-up (page-in, thread pool)
+    tw = time.perf_counter() - tw
+    if iters <= 0:
+        iters = int(min(30, max(3, round(6.0 / max(tw, 1e-3)))))
     t0 = time.perf_counter()
     res = po.align(src, tgt, cfg["radius"], cfg["max_neighbours"], cfg["dof"], iters,
                    inner_max_steps=inner_steps, threads=threads)
     dt = time.perf_counter() - t0
+    iters = len(res["history"])   # iterations really performed (hasConverged may stop a converged run early)
     return dict(value=iters / dt, unit="iterations/s", cores=threads, kind="port",
                 sample=f"{iters} outer iterations of the same {src.shape[0]}<->{tgt.shape[0]} workload "
-                       f"(oracle/ppcr_oracle.c, OpenMP x{threads}, grid NN)",
+                       f"(oracle/ppcr_oracle.c, OpenMP x{threads}, grid NN; host shows {visible} hardware threads, "
+                       f"container CPU quota {quota if quota else 'none'})",
                 seconds=dt), res
 
 
@@ -109,15 +133,28 @@ def main():
 
     # warm-up (also builds the grid and sorts the source once)
     if a.warmup > 0:
-        for c in ctxs:
-            c.align(a.warmup, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
+        if len(ctxs) > 1 and a.lanes > 1:
+            # same concurrency as the timed region: the runtime creates its extra hardware queues on first
+            # concurrent use (a one-off ~50 ms stall measured when this ran sequentially)
+            _lib.align_many(ctxs, a.warmup, lanes=a.lanes, cost_drop_thresh=0.0, inner_steps=a.inner_steps)
+        else:
+            for c in ctxs:
+                c.align(a.warmup, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
     barrier()
     gathered = None
     t0 = time.perf_counter()
     local = {}
-    for p, c in zip(my_pairs, ctxs):
-        res = c.align(a.steps, cost_drop_thresh=0.0, inner_steps=a.inner_steps)
-        local[p] = res["history"][-1]
+    if len(ctxs) > 1 and a.lanes > 1:
+        # several resident pairs per GPU: a.lanes of them in flight, each on its own handle/stream
+        T_fin, done = _lib.align_many(ctxs, a.steps, lanes=a.lanes, cost_drop_thresh=0.0, inner_steps=a.inner_steps)
+        assert all(int(d) == a.steps for d in done), f"early stop inside the timed region: {list(done)}"
+        for k, p in enumerate(my_pairs):
+            local[p] = T_fin[k]
+    else:
+        for p, c in zip(my_pairs, ctxs):
+            res = c.align(a.steps, cost_drop_thresh=0.0, inner_steps=a.inner_steps)
+            assert res["n_iter"] == a.steps, f"early stop inside the timed region: {res['n_iter']}"
+            local[p] = res["history"][-1]
     if dist is not None:
         # RCCL: the only collective of the job — final gather of the transforms (batch.gather_transforms)
         gathered = batch.gather_transforms(local, n_pairs, dist=dist, device=torch.device("cuda", local_rank))
@@ -149,7 +186,9 @@ def main():
 
     ns, nt = src.shape[0], tgt.shape[0]
     out = {
-        "metric": "registration iterations/sec (1M<->1M pts, r=1.0, m=10)",
+        # BASELINE.json's metric; the label follows the cloud size actually run (configs other than the headline)
+        "metric": "registration iterations/sec (%s<->%s pts, r=%.1f, m=%d)" % (
+            (("1M", "1M") if ns == nt == 1000000 else (ns, nt)) + (cfg["radius"], cfg["max_neighbours"])),
         "value": n_pairs * a.steps / dt,
         "unit": "iterations/s",
         "n_gpus": world,
@@ -165,7 +204,8 @@ def main():
                                f"max_neighbours={cfg['max_neighbours']}, "
                                f"{'Gaussian' if np.isinf(cfg['dof']) else 't dof=%g' % cfg['dof']}, "
                                f"{a.inner_steps} inner IRLS step(s)/iteration, cost_drop_thresh=0",
-                   "pairs": n_pairs, "parallelism": f"{n_pairs} independent pair(s), {a.pairs_per_gpu} per GPU on {world} GPU(s); "
+                   "pairs": n_pairs, "lanes_per_gpu": (a.lanes if a.pairs_per_gpu > 1 else 1),
+                   "parallelism": f"{n_pairs} independent pair(s), {a.pairs_per_gpu} per GPU on {world} GPU(s); "
                                                      "no data-path collective; final RCCL all_gather of the transforms"},
         "nnz": int(nnz),
     }
@@ -205,9 +245,11 @@ def main():
         chk.set_params(cfg["radius"], cfg["max_neighbours"], cfg["dof"], 3)
         chk.set_target(tgt)
         chk.set_source(src)
-        g = chk.align(a.cpu_iters, cost_drop_thresh=0.0, inner_steps=a.inner_steps)
+        n_par = int(ora["n_iter"]) if "n_iter" in ora else len(ora["history"])
+        g = chk.align(n_par, cost_drop_thresh=0.0, inner_steps=a.inner_steps)
         chk.close()
-        out["parity"] = {"iterations": a.cpu_iters,
+        assert g["n_iter"] == len(ora["history"]), (g["n_iter"], len(ora["history"]))
+        out["parity"] = {"iterations": n_par,
                          "rot_err_rad": synth.rotation_angle(g["history"][-1][:, :3], ora["history"][-1][:, :3]),
                          "trans_err_m": float(np.linalg.norm(g["history"][-1][:, 3] - ora["history"][-1][:, 3])),
                          "vs": "oracle (CPU restatement); the reference itself cannot be built (PCL/Ceres absent)"}

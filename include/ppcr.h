@@ -128,6 +128,49 @@ int ppcr_align(ppcr_ctx *ctx, int n_iter, double cost_drop_thresh, double n_cost
                const double q0[4], const double t0[3], int inner_steps, double f_tol, double *history,
                double *costs, int32_t *steps, int *n_done);
 
+/* ---- multi-pair batches (BASELINE configs[4]; the reference registers one pair per process run) ----
+ * Independent pairs never exchange data, so a batch is a work list: pair p is registered on
+ * device_ids[p % n_devices] by one of `lanes_per_device` host worker threads of that device (each with its
+ * own handle and HIP stream, so one pair's upload / 3x3 host solve overlaps another pair's kernels).
+ * In the one-process-per-GPU deployment (torch.distributed / RCCL) each rank passes its own pairs and
+ * n_devices = 1; the final gather of the transforms is the caller's (the only collective of the job). */
+typedef struct ppcr_pair {
+    const float *source;          /* host, float32 xyz */
+    int64_t n_source;
+    int64_t source_stride_bytes;
+    const float *target;
+    int64_t n_target;
+    int64_t target_stride_bytes;
+} ppcr_pair;
+
+/* the knobs of ProbPointCloudRegistrationParams (..._params.hpp:5-18) that reach the loop */
+typedef struct ppcr_batch_options {
+    double radius;
+    double dof;              /* +inf => Gaussian (-u) */
+    double cost_drop_thresh;
+    double n_cost_drop_it;
+    double f_tol;            /* Ceres function_tolerance, cc:97 */
+    double q0[4];            /* initial_rotation (w,x,y,z) */
+    double t0[3];            /* initial_translation */
+    int32_t max_neighbours;
+    int32_t dim;
+    int32_t n_iter;
+    int32_t inner_steps;
+} ppcr_batch_options;
+
+/* T_all: n_pairs*12 doubles (final cumulative [R|t] of each pair, identity when no iteration ran);
+ * n_iter_done: n_pairs ints or NULL.  On failure the first error text is copied to err (may be NULL). */
+int ppcr_batch_run(const ppcr_pair *pairs, int64_t n_pairs, const ppcr_batch_options *opt,
+                   const int *device_ids, int n_devices, int lanes_per_device, double *T_all,
+                   int32_t *n_iter_done, char *err, int64_t err_capacity);
+
+/* The same loop over handles whose clouds are already resident (set_source/set_target done by the caller):
+ * ppcr_align on each of the n handles, `lanes` of them in flight at a time on their own streams.
+ * T_final: n*12 doubles; n_done: n ints or NULL.  Handles may live on different devices. */
+int ppcr_align_many(ppcr_ctx *const *ctxs, int n, int lanes, int n_iter, double cost_drop_thresh,
+                    double n_cost_drop_it, const double q0[4], const double t0[3], int inner_steps,
+                    double f_tol, double *T_final, int32_t *n_done);
+
 /* current (moved) source in the caller's original point order */
 int ppcr_get_source(ppcr_ctx *ctx, float *xyz, int64_t stride_bytes);
 

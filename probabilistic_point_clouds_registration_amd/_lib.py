@@ -20,12 +20,23 @@ SYMBOLS = [
     "ppcr_set_association", "ppcr_weights", "ppcr_update_weights", "ppcr_accumulate", "ppcr_get_origin",
     "ppcr_solve_moments", "ppcr_cost_from_moments", "ppcr_solve", "ppcr_apply_transform",
     "ppcr_iterate", "ppcr_align", "ppcr_get_source", "ppcr_synchronize", "ppcr_profile_enable",
-    "ppcr_profile_get", "ppcr_set_option",
+    "ppcr_profile_get", "ppcr_set_option", "ppcr_batch_run", "ppcr_align_many",
 ]
 
 
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
+
+
+class Pair(C.Structure):
+    _fields_ = [("source", C.c_void_p), ("n_source", C.c_int64), ("source_stride_bytes", C.c_int64),
+                ("target", C.c_void_p), ("n_target", C.c_int64), ("target_stride_bytes", C.c_int64)]
+
+
+class BatchOptions(C.Structure):
+    _fields_ = [("radius", C.c_double), ("dof", C.c_double), ("cost_drop_thresh", C.c_double),
+                ("n_cost_drop_it", C.c_double), ("f_tol", C.c_double), ("q0", C.c_double * 4), ("t0", C.c_double * 3),
+                ("max_neighbours", C.c_int32), ("dim", C.c_int32), ("n_iter", C.c_int32), ("inner_steps", C.c_int32)]
 
 
 class PpcrError(RuntimeError):
@@ -77,6 +88,9 @@ def load():
     L.ppcr_profile_enable.argtypes = [vp, i32]
     L.ppcr_profile_get.argtypes = [vp, C.POINTER(KernelStat), i32, C.POINTER(i32)]
     L.ppcr_set_option.argtypes = [vp, C.c_char_p, i32]
+    L.ppcr_batch_run.argtypes = [C.POINTER(Pair), i64, C.POINTER(BatchOptions), C.POINTER(i32), i32, i32, vp, vp,
+                                 C.c_char_p, i64]
+    L.ppcr_align_many.argtypes = [C.POINTER(vp), i32, i32, i32, dbl, dbl, vp, vp, i32, dbl, vp, vp]
     for name in SYMBOLS:
         f = getattr(L, name)
         if name not in ("ppcr_last_error", "ppcr_cost_from_moments"):
@@ -294,3 +308,51 @@ def solve_moments(sums, origin):
 def cost_from_moments(sums, origin, R, t):
     s, o, R, t = _f64(sums, NSUMS), _f64(origin, 3), _f64(R, 9), _f64(t, 3)
     return load().ppcr_cost_from_moments(s.ctypes.data, o.ctypes.data, R.ctypes.data, t.ctypes.data)
+
+
+def _cloud(a):
+    a = np.asarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] not in (3, 4):
+        raise ValueError("clouds are float32 [n,3] or [n,4]")
+    return np.ascontiguousarray(a)
+
+
+def batch_run(pairs, radius, max_neighbours, dof=5.0, n_iter=20, cost_drop_thresh=0.0, n_cost_drop_it=5,
+              inner_steps=1, f_tol=1e-5, q0=(1, 0, 0, 0), t0=(0, 0, 0), device_ids=(0,), lanes_per_device=2, dim=3):
+    """ppcr_batch_run: pairs = [(src, tgt), ...] host arrays -> ([n,3,4] final transforms, [n] iterations done)."""
+    L = load()
+    n = len(pairs)
+    keep = [(_cloud(s), _cloud(t)) for s, t in pairs]
+    arr = (Pair * max(n, 1))()
+    for k, (s, t) in enumerate(keep):
+        arr[k] = Pair(s.ctypes.data, s.shape[0], s.shape[1] * 4, t.ctypes.data, t.shape[0], t.shape[1] * 4)
+    opt = BatchOptions(float(radius), float(dof), float(cost_drop_thresh), float(n_cost_drop_it), float(f_tol),
+                       (C.c_double * 4)(*[float(v) for v in q0]), (C.c_double * 3)(*[float(v) for v in t0]),
+                       int(max_neighbours), int(dim), int(n_iter), int(inner_steps))
+    devs = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+    T = np.zeros((n, 3, 4))
+    done = np.zeros(n, dtype=np.int32)
+    err = C.create_string_buffer(512)
+    rc = L.ppcr_batch_run(arr, n, C.byref(opt), devs, len(device_ids), int(lanes_per_device), T.ctypes.data,
+                          done.ctypes.data, err, 512)
+    if rc != 0:
+        raise PpcrError(rc, err.value.decode())
+    return T, done
+
+
+def align_many(ctxs, n_iter, lanes=2, cost_drop_thresh=0.0, n_cost_drop_it=5, q0=(1, 0, 0, 0), t0=(0, 0, 0),
+               inner_steps=1, f_tol=1e-5):
+    """ppcr_align_many over resident handles -> ([n,3,4] final transforms, [n] iterations done)."""
+    L = load()
+    n = len(ctxs)
+    hs = (C.c_void_p * max(n, 1))(*[c._h for c in ctxs])
+    T = np.zeros((n, 3, 4))
+    done = np.zeros(n, dtype=np.int32)
+    q0, t0 = _f64(q0, 4), _f64(t0, 3)
+    rc = L.ppcr_align_many(hs, n, int(lanes), int(n_iter), float(cost_drop_thresh), float(n_cost_drop_it),
+                           q0.ctypes.data, t0.ctypes.data, int(inner_steps), float(f_tol), T.ctypes.data,
+                           done.ctypes.data)
+    if rc != 0:
+        msgs = [L.ppcr_last_error(c._h).decode() for c in ctxs]
+        raise PpcrError(rc, next((m for m in msgs if m), "ppcr_align_many failed"))
+    return T, done

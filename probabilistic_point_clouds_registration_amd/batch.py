@@ -26,6 +26,27 @@ def register_pair_hip(src, tgt, params, device_id=0, n_iter=20, inner_steps=1, c
     return res["history"][-1] if res["n_iter"] > 0 else np.eye(4)[:3]
 
 
+def register_local_pairs_hip(make_pair, n_pairs, world_size, rank, device_id=0, lanes=2, n_iter=20, inner_steps=1,
+                             cost_drop_thresh=0.0, n_cost_drop_it=5):
+    """This rank's share through ppcr_batch_run: `lanes` pairs in flight on the rank's GPU (their uploads and
+    3x3 host solves overlap each other's kernels). All pairs must share one parameter set. -> {pair: 3x4}"""
+    from . import _lib
+    mine = shard_pairs(n_pairs, world_size, rank)
+    if not mine:
+        return {}
+    clouds, params = [], None
+    for p in mine:
+        src, tgt, prm = make_pair(p)
+        if params is not None and prm != params:
+            raise ValueError("ppcr_batch_run takes one parameter set per batch")
+        params = prm
+        clouds.append((src, tgt))
+    T, _ = _lib.batch_run(clouds, params["radius"], params["max_neighbours"], params["dof"], n_iter=n_iter,
+                          cost_drop_thresh=cost_drop_thresh, n_cost_drop_it=n_cost_drop_it, inner_steps=inner_steps,
+                          device_ids=(device_id,), lanes_per_device=lanes)
+    return {p: T[k] for k, p in enumerate(mine)}
+
+
 def register_local_pairs(make_pair, n_pairs, world_size, rank, register=register_pair_hip, **kw):
     """Run this rank's share. make_pair(p) -> (src, tgt, params). Returns {pair index: 3x4 transform}."""
     out = {}

@@ -15,6 +15,10 @@
 #include <limits>
 #include <numeric>
 #include <string>
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "ppcr_host_math.hpp"
@@ -165,6 +169,7 @@ struct ppcr_ctx {
 
     // Verlet (skin) lists: second grid with cells >= r + skin, its own sorted copy of the target, the lists, and
     // the rigid motion accumulated since they were built
+    double dbg_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics of the last ppcr_align (ppcr_debug_get_host_times)
     int opt_verlet = 0;      // measured slower than the direct tiled scan on gfx950, kept as an option
     double skin_frac = 0.2;  // skin = skin_frac * radius
     float tgt_lo[3] = {0, 0, 0}, tgt_hi[3] = {0, 0, 0};
@@ -875,6 +880,7 @@ int fold_and_deliver(ppcr_ctx *c, int nb, double sums[PPCR_NSUMS])
     if (c->opt_mailbox) {
         // the fold delivers the moments to the host mailbox; the host spins on its sequence number
         const unsigned seq = ++c->mbox_seq;
+        const auto tl0 = std::chrono::steady_clock::now();
         {
             ProfScope ps(c, K_REDUCE);
             reduce_partials_mailbox_kernel<<<kNSums, kBlock, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p, c->d_mbox,
@@ -883,6 +889,8 @@ int fold_and_deliver(ppcr_ctx *c, int nb, double sums[PPCR_NSUMS])
         PPCR_TRY(check_launch(c, "reduce_partials_mailbox_kernel"));
         volatile unsigned *flag = &c->h_mbox->seq;
         bool arrived = false;
+        const auto tw0 = std::chrono::steady_clock::now();
+        c->dbg_host[6] = std::max(c->dbg_host[6], std::chrono::duration<double>(tw0 - tl0).count());
         for (long spin = 0; spin < 200000000L; spin++) {  // ~ seconds; a fault on the device ends up below
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) {
                 arrived = true;
@@ -898,6 +906,12 @@ int fold_and_deliver(ppcr_ctx *c, int nb, double sums[PPCR_NSUMS])
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return fail(c, PPCR_ERR_HIP, "moment mailbox never arrived");
         }
         for (int j = 0; j < kNSums; j++) sums[j] = c->h_mbox->sums[j];
+        {
+            const double w = std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+            c->dbg_host[0] += 1;
+            c->dbg_host[1] += w;
+            c->dbg_host[2] = std::max(c->dbg_host[2], w);
+        }
         return PPCR_OK;
     }
     {
@@ -1558,11 +1572,20 @@ int ppcr_align(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_d
     const Mat3 R0 = quat_to_rot(q0);
     ConvergenceRule rule;
     double Tcum[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    for (double &v : c->dbg_host) v = 0;
+    const auto ta0 = std::chrono::steady_clock::now();
     while (!rule.has_converged(n_iter, cost_drop_thresh, n_cost_drop_it)) {
         double Tk[12], cost[2];
         int st = 0;
+        const auto ti0 = std::chrono::steady_clock::now();
+        const double w_before = c->dbg_host[1];
         PPCR_TRY(associate_impl(c, &R0, t0));
+        const auto ti1 = std::chrono::steady_clock::now();
+        c->dbg_host[5] = std::max(c->dbg_host[5], std::chrono::duration<double>(ti1 - ti0).count());
+        const double fold0 = c->dbg_host[6];
         PPCR_TRY(solve_impl(c, q0, t0, inner_steps, f_tol, Tk, cost, &st));
+        c->dbg_host[7] = std::max(c->dbg_host[7], std::chrono::duration<double>(std::chrono::steady_clock::now() - ti1).count() -
+                                                      (c->dbg_host[1] - w_before) - std::max(0.0, c->dbg_host[6] - fold0));
         PPCR_TRY(apply_transform_impl(c, Tk, /*defer=*/true));  // rides in the next iteration's K1 prologue
         compose(Tk, Tcum, Tcum);  // T_cum <- T_k * T_cum (cc:101-107)
         const int it = rule.current_iteration;
@@ -1574,7 +1597,14 @@ int ppcr_align(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_d
         if (steps) steps[it] = st;
         rule.cost_drop = (cost[0] - cost[1]) / cost[0];  // cc:119
         rule.current_iteration++;                        // cc:130
+        {
+            const double it_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - ti0).count();
+            const double busy = it_s - (c->dbg_host[1] - w_before);  // launches + host solve, waits excluded
+            c->dbg_host[3] += busy;
+            c->dbg_host[4] = std::max(c->dbg_host[4], busy);
+        }
     }
+    (void)ta0;
     PPCR_TRY(flush_pending_move(c));  // leave the device copy of the source current
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (n_done) *n_done = rule.current_iteration;
@@ -1619,6 +1649,15 @@ int ppcr_debug_get_stamps(ppcr_ctx *c, unsigned long long out[8])
 }
 
 // diagnostic: {verlet builds, verlet uses, plain scans} since the handle was created
+// diagnostic: host-side time of the last ppcr_align: {iterations, total wait (s), max wait, total launch+solve, max,
+// max associate call, max reduce launch call, max (accumulate launch + host solve)}
+int ppcr_debug_get_host_times(ppcr_ctx *c, double out[8])
+{
+    CTX_ENTER(c);
+    for (int k = 0; k < 8; k++) out[k] = c->dbg_host[k];
+    return PPCR_OK;
+}
+
 int ppcr_debug_get_counters(ppcr_ctx *c, long long out[3])
 {
     CTX_ENTER(c);
@@ -1678,6 +1717,149 @@ int ppcr_profile_get(ppcr_ctx *c, ppcr_kernel_stat *out, int capacity, int *n_ou
         n++;
     }
     if (n_out) *n_out = n;
+    return PPCR_OK;
+}
+
+}  // extern "C"
+
+// ---- batches of independent pairs -------------------------------------------------------------------------------
+namespace {
+
+void identity12(double *T)
+{
+    static const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    std::memcpy(T, I, sizeof(I));
+}
+
+// align() on one handle, keeping only the last cumulative transform
+int align_final(ppcr_ctx *c, int n_iter, double thresh, double n_cost_drop_it, const double q0[4], const double t0[3],
+                int inner_steps, double f_tol, double *T_final, int32_t *n_done)
+{
+    std::vector<double> hist((size_t)std::max(n_iter, 0) * 12);
+    int done = 0;
+    const int rc = ppcr_align(c, n_iter, thresh, n_cost_drop_it, q0, t0, inner_steps, f_tol,
+                              hist.empty() ? nullptr : hist.data(), nullptr, nullptr, &done);
+    if (rc != PPCR_OK) return rc;
+    if (done > 0) std::memcpy(T_final, hist.data() + (size_t)(done - 1) * 12, 12 * sizeof(double));
+    else identity12(T_final);
+    if (n_done) *n_done = done;
+    return PPCR_OK;
+}
+
+struct FirstError {
+    std::mutex mu;
+    int rc = PPCR_OK;
+    std::string text;
+    void set(int code, const std::string &msg)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc == PPCR_OK) {
+            rc = code;
+            text = msg;
+        }
+    }
+    bool failed()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        return rc != PPCR_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int ppcr_align_many(ppcr_ctx *const *ctxs, int n, int lanes, int n_iter, double cost_drop_thresh,
+                    double n_cost_drop_it, const double q0[4], const double t0[3], int inner_steps, double f_tol,
+                    double *T_final, int32_t *n_done)
+{
+    if (n < 0 || (n > 0 && (!ctxs || !T_final)) || !q0 || !t0) return PPCR_ERR_INVALID;
+    for (int k = 0; k < n; k++) {
+        if (!ctxs[k]) return PPCR_ERR_INVALID;
+        for (int j = 0; j < k; j++)
+            if (ctxs[j] == ctxs[k]) return fail(ctxs[k], PPCR_ERR_INVALID, "ppcr_align_many: the same handle appears twice");
+    }
+    lanes = std::max(1, std::min(lanes, n));
+    std::atomic<int> next{0};
+    FirstError first;
+    auto worker = [&]() {
+        for (;;) {
+            const int k = next.fetch_add(1);
+            if (k >= n || first.failed()) return;
+            const int rc = align_final(ctxs[k], n_iter, cost_drop_thresh, n_cost_drop_it, q0, t0, inner_steps, f_tol,
+                                       T_final + (size_t)k * 12, n_done ? n_done + k : nullptr);
+            if (rc != PPCR_OK) first.set(rc, ppcr_last_error(ctxs[k]));
+        }
+    };
+    if (lanes == 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (int l = 0; l < lanes; l++) pool.emplace_back(worker);
+        for (auto &th : pool) th.join();
+    }
+    return first.rc;
+}
+
+int ppcr_batch_run(const ppcr_pair *pairs, int64_t n_pairs, const ppcr_batch_options *opt, const int *device_ids,
+                   int n_devices, int lanes_per_device, double *T_all, int32_t *n_iter_done, char *err,
+                   int64_t err_capacity)
+{
+    auto report = [&](int code, const std::string &msg) {
+        if (err && err_capacity > 0) std::snprintf(err, (size_t)err_capacity, "%s", msg.c_str());
+        return fail(nullptr, code, msg);
+    };
+    if (err && err_capacity > 0) err[0] = 0;
+    if (n_pairs < 0 || !opt || n_devices <= 0 || !device_ids || lanes_per_device <= 0)
+        return report(PPCR_ERR_INVALID, "ppcr_batch_run: bad argument");
+    if (n_pairs == 0) return PPCR_OK;
+    if (!pairs || !T_all) return report(PPCR_ERR_INVALID, "ppcr_batch_run: null pairs/T_all");
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
+        (void)hipGetLastError();
+        return report(PPCR_ERR_NODEVICE, "no HIP device visible: this library has no CPU fallback");
+    }
+    for (int d = 0; d < n_devices; d++)
+        if (device_ids[d] < 0 || device_ids[d] >= visible) return report(PPCR_ERR_INVALID, "ppcr_batch_run: device id out of range");
+
+    // one work list per device (pair p -> device p % n_devices), drained by that device's lanes
+    std::vector<std::atomic<int64_t>> next(n_devices);
+    for (auto &a : next) a.store(0);
+    FirstError first;
+    auto worker = [&](int d) {
+        ppcr_ctx *c = nullptr;
+        int rc = ppcr_create(device_ids[d], &c);
+        if (rc != PPCR_OK) {
+            first.set(rc, ppcr_last_error(nullptr));
+            return;
+        }
+        for (;;) {
+            const int64_t k = next[d].fetch_add(1);
+            const int64_t p = (int64_t)d + k * n_devices;
+            if (p >= n_pairs || first.failed()) break;
+            const ppcr_pair &pr = pairs[p];
+            rc = ppcr_set_params(c, opt->radius, opt->max_neighbours, opt->dof, opt->dim);
+            if (rc == PPCR_OK) rc = ppcr_set_target(c, pr.target, pr.n_target, pr.target_stride_bytes);
+            if (rc == PPCR_OK) rc = ppcr_set_source(c, pr.source, pr.n_source, pr.source_stride_bytes);
+            if (rc == PPCR_OK)
+                rc = align_final(c, opt->n_iter, opt->cost_drop_thresh, opt->n_cost_drop_it, opt->q0, opt->t0,
+                                 opt->inner_steps, opt->f_tol, T_all + (size_t)p * 12,
+                                 n_iter_done ? n_iter_done + p : nullptr);
+            if (rc != PPCR_OK) {
+                first.set(rc, "pair " + std::to_string(p) + ": " + ppcr_last_error(c));
+                break;
+            }
+        }
+        ppcr_destroy(c);
+    };
+    std::vector<std::thread> pool;
+    for (int d = 0; d < n_devices; d++) {
+        const int64_t mine = (n_pairs - d + n_devices - 1) / n_devices;
+        const int lanes = (int)std::max<int64_t>(1, std::min<int64_t>(lanes_per_device, mine));
+        for (int l = 0; l < lanes; l++) pool.emplace_back(worker, d);
+    }
+    for (auto &th : pool) th.join();
+    if (first.rc != PPCR_OK) return report(first.rc, first.text);
     return PPCR_OK;
 }
 

@@ -422,6 +422,58 @@ def test_python_mirror_and_batch_single_rank(ctx):
         assert np.linalg.norm(all_T[p][:, 3] - ora["history"][-1][:, 3]) < TRANS_TOL
 
 
+def test_batch_run_and_align_many(ctx):
+    """ppcr_batch_run (host buffers in, worker lanes inside) and ppcr_align_many (resident handles): every pair's
+    final transform equals the same pair registered alone, and the oracle's, whatever the lane count."""
+    prm = dict(radius=1.0, max_neighbours=10, dof=5.0)
+    pairs = [synth.make_pair(3000 + 500 * p, cfg=5, pair=p, stride=3 + (p % 2))[:2] for p in range(5)]
+    solo = []
+    for s, t in pairs:
+        with _lib.Context(0) as c:
+            c.set_params(1.0, 10, 5.0, 3)
+            c.set_target(t)
+            c.set_source(s)
+            solo.append(c.align(5, cost_drop_thresh=0.0, inner_steps=1)["history"][-1])
+    for lanes in (1, 3):
+        T, done = _lib.batch_run(pairs, n_iter=5, device_ids=(0,), lanes_per_device=lanes, **prm)
+        assert list(done) == [5] * 5
+        for p in range(5):
+            np.testing.assert_array_equal(T[p], solo[p])          # same kernels, same order: bit-identical
+    ora = po.align(pairs[2][0][:, :3], pairs[2][1][:, :3], 1.0, 10, 5.0, 5, inner_max_steps=1)
+    assert synth.rotation_angle(T[2][:, :3], ora["history"][-1][:, :3]) < ROT_TOL
+    assert np.linalg.norm(T[2][:, 3] - ora["history"][-1][:, 3]) < TRANS_TOL
+    # resident handles
+    ctxs = []
+    try:
+        for s, t in pairs:
+            c = _lib.Context(0)
+            c.set_params(1.0, 10, 5.0, 3)
+            c.set_target(t)
+            c.set_source(s)
+            ctxs.append(c)
+        T2, done2 = _lib.align_many(ctxs, 5, lanes=2)
+        assert list(done2) == [5] * 5
+        for p in range(5):
+            np.testing.assert_array_equal(T2[p], solo[p])
+        with pytest.raises(_lib.PpcrError):
+            _lib.align_many([ctxs[0], ctxs[0]], 2)                 # a handle is single-threaded
+    finally:
+        for c in ctxs:
+            c.close()
+    # empty batch, zero iterations (identity), early stop rule, errors
+    T0, d0 = _lib.batch_run([], n_iter=3, **prm)
+    assert T0.shape == (0, 3, 4)
+    T1, d1 = _lib.batch_run(pairs[:1], n_iter=0, **prm)
+    np.testing.assert_array_equal(T1[0], np.eye(4)[:3])
+    assert d1[0] == 0
+    T3, d3 = _lib.batch_run(pairs[:2], n_iter=50, cost_drop_thresh=0.5, n_cost_drop_it=2, **prm)
+    assert all(0 < d < 50 for d in d3)
+    with pytest.raises(_lib.PpcrError, match="device id"):
+        _lib.batch_run(pairs[:1], n_iter=1, device_ids=(99,), **prm)
+    with pytest.raises(_lib.PpcrError, match="pair [01]: radius"):
+        _lib.batch_run(pairs[:2], n_iter=1, radius=-1.0, max_neighbours=10)
+
+
 def test_temporal_cutoff_and_deferred_move_change_nothing(ctx):
     """The steady-state shortcuts (cut-off started from the previous m-th distance + own displacement; source move
     folded into the next K1 prologue) must not change a single neighbour: compare against a context with the
