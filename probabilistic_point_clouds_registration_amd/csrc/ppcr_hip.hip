@@ -170,6 +170,10 @@ struct ppcr_ctx {
     // Verlet (skin) lists: second grid with cells >= r + skin, its own sorted copy of the target, the lists, and
     // the rigid motion accumulated since they were built
     double dbg_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics of the last ppcr_align (ppcr_debug_get_host_times)
+    int opt_xcd_remap = 0;
+    int opt_emit_xyz = 0;        // K1 also leaves the neighbours' coordinates (k-major SoA) for K23 to stream: measured neutral
+    DevBuf<float> nbr_xyz;
+    bool nbr_xyz_valid = false;  // nbr_xyz matches the current ELL association
     int opt_verlet = 0;      // measured slower than the direct tiled scan on gfx950, kept as an option
     double skin_frac = 0.2;  // skin = skin_frac * radius
     float tgt_lo[3] = {0, 0, 0}, tgt_hi[3] = {0, 0, 0};
@@ -258,6 +262,7 @@ void invalidate_association(ppcr_ctx *c)
 {
     c->fused_sums_pending = false;
     c->assoc = ppcr_ctx::ASSOC_NONE;
+    c->nbr_xyz_valid = false;
     c->nnz = -1;
     c->csr_cache_valid = false;
 }
@@ -474,11 +479,13 @@ void launch_topm(ppcr_ctx *c, float r2, int m, const FusedRows &fm, const Pendin
     unsigned long long *st = c->opt_stamps ? c->d_stamps.p : nullptr;
     const int dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
     const VerletBuild vb_none{0, nullptr, nullptr};
+    float *nxyz = (c->opt_emit_xyz && !fm.enabled && (c->opt_nn_variant == 0 || c->opt_nn_variant == 3) && c->nbr_xyz.p) ? c->nbr_xyz.p : nullptr;
+    c->nbr_xyz_valid = nxyz != nullptr;
 #define PPCR_TILE_F(Cc, B, CAPc, F)                                                                                 \
     nn_tile_kernel<M, Cc, B, CAPc, F><<<nblocks(c->ns, B), B, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p, \
                                                                               c->cell_start.p, c->grid, r2, m,      \
                                                                               c->nbr.p, c->cnt.p, st, fm, pm,      \
-                                                                              c->dm2.p, dm2_in, vb_none)
+                                                                              c->dm2.p, dm2_in, vb_none, nxyz)
 #define PPCR_TILE(Cc, B, CAPc) PPCR_TILE_F(Cc, B, CAPc, false)
     if (c->opt_nn_variant == 0 || c->opt_nn_variant == 3) {
         // LDS budget per 256-query block: halo CAP*16 B + list C*512 B (+1.1 KB tables), three blocks per CU.
@@ -491,6 +498,10 @@ void launch_topm(ppcr_ctx *c, float r2, int m, const FusedRows &fm, const Pendin
         constexpr int CAP = (M <= 24) ? 2240 : 2048;
         if (fm.enabled) {
             if constexpr (M == 10) PPCR_TILE_F(C, 256, CAP, true);  // experiment: only instantiated for M = 10
+        } else if (c->opt_xcd_remap) {
+            nn_tile_kernel<M, C, 256, CAP, false, true><<<nblocks(c->ns, 256), 256, 0, c->stream>>>(
+                c->src.p, (int)c->ns, c->tgt_sorted.p, c->cell_start.p, c->grid, r2, m, c->nbr.p, c->cnt.p, st, fm, pm,
+                c->dm2.p, dm2_in, vb_none, nxyz);
         } else {
             PPCR_TILE(C, 256, CAP);
         }
@@ -521,6 +532,11 @@ constexpr int kAccumBlock = 256;  // threads per block of accumulate_ell_kernel 
 template <int W>
 void launch_accumulate_ell(ppcr_ctx *c, int nb, const Pose &P, const Model &md)
 {
+    if (c->nbr_xyz_valid) {
+        accumulate_ell_kernel<W, kAccumRows, kAccumBlock, true><<<nb, kAccumBlock, 0, c->stream>>>(
+            c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md, c->partials.p, c->nbr_xyz.p);
+        return;
+    }
     accumulate_ell_kernel<W, kAccumRows, kAccumBlock><<<nb, kAccumBlock, 0, c->stream>>>(c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md,
                                                            c->partials.p);
 }
@@ -628,6 +644,8 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fused_R = nullptr, const double *fus
         HIP_TRY(c, c->nbr.reserve((size_t)m * (size_t)std::max(ns, 1)));
         HIP_TRY(c, c->cnt.reserve((size_t)std::max(ns, 1)));
         HIP_TRY(c, c->dm2.reserve((size_t)std::max(ns, 1)));
+        c->nbr_xyz_valid = false;
+        if (c->opt_emit_xyz && tiled) HIP_TRY(c, c->nbr_xyz.reserve((size_t)3 * (size_t)m * (size_t)std::max(ns, 1)));
         // dm2 is only trusted when the source moved by nothing but the deferred rigid move applied in this
         // very kernel since the association that wrote it
         if (!tiled) c->dm2_valid = false;
@@ -1147,6 +1165,7 @@ int ppcr_destroy(ppcr_ctx *c)
     c->cell_start2.release();
     c->tgt_sorted2.release();
     c->vl_nbr.release();
+    c->nbr_xyz.release();
     c->vl_cnt.release();
     c->keys_a.release();
     c->keys_b.release();
@@ -1216,6 +1235,15 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
     if (std::strcmp(key, "verlet") == 0) {  // 1: Verlet (skin) neighbour lists while the source moves little (default)
         c->opt_verlet = value ? 1 : 0;
         c->vl_valid = false;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "emit_xyz") == 0) {
+        c->opt_emit_xyz = value ? 1 : 0;
+        c->nbr_xyz_valid = false;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "xcd_remap") == 0) {
+        c->opt_xcd_remap = value ? 1 : 0;
         return PPCR_OK;
     }
     if (std::strcmp(key, "verlet_skin_permille") == 0) {  // skin as a fraction of the radius, in 1/1000 (default 200)
@@ -1390,6 +1418,7 @@ int ppcr_set_association(ppcr_ctx *c, const int32_t *row_ptr, const int32_t *col
         HIP_TRY(c, hipMemcpyAsync(c->cnt.p, h_cnt.data(), h_cnt.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->assoc = ppcr_ctx::ASSOC_ELL;
+        c->nbr_xyz_valid = false;
         c->ell_width = w;
     } else {
         std::vector<int> h_rp((size_t)ns + 1, 0), h_nbr((size_t)std::max<int64_t>(nnz, 1));
@@ -1409,6 +1438,7 @@ int ppcr_set_association(ppcr_ctx *c, const int32_t *row_ptr, const int32_t *col
         HIP_TRY(c, hipMemcpyAsync(c->nbr.p, h_nbr.data(), h_nbr.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->assoc = ppcr_ctx::ASSOC_CSR;
+        c->nbr_xyz_valid = false;
     }
     c->nnz = nnz;
     c->csr_cache_valid = true;

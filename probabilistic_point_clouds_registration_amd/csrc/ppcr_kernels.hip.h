@@ -449,23 +449,42 @@ __device__ __forceinline__ void row_finish(RowAcc &acc, const Pose &P, float4 xf
     acc.a[18] += Gyy * iz;
 }
 
-// wave shuffle reduction -> LDS across the block's waves -> partials[j * nblocks + block]
+// Block fold of the 19 per-lane accumulators -> partials[j * nblocks + block], through an LDS transpose.
+// (A shuffle tree costs 19 sums x 6 steps x 2 ds_bpermute + add per WAVE — a third of all instructions of the
+// one-row-per-lane K23 kernel.)  Every lane parks its 19 doubles in sh[j][tid]; thread (j = t % 32 < 19,
+// part = t / 32) then adds 32 consecutive entries of row j, and 19 threads add the 8 parts: ~90 instructions per
+// wave, fixed summation order, no atomics.  Row stride 257 doubles: lanes j = 0..18 of a half-wave hit
+// consecutive 8-byte bank pairs.
 template <int BLOCK = kBlock>
 __device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__restrict__ partials)
 {
-    __shared__ double sh[BLOCK / 64][kNSums];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    static_assert(BLOCK == 256, "fold layout assumes 256 lanes (8 parts of 32)");
+    constexpr int STRIDE = BLOCK + 1;
+    __shared__ double sh[kNSums * STRIDE];
+    __shared__ double part[kNSums][8];
+    const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < kNSums; j++) {
-        double v = acc.a[j];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) sh[wave][j] = v;
+    for (int j = 0; j < kNSums; j++) sh[j * STRIDE + tid] = acc.a[j];
+    __syncthreads();
+    const int j = tid & 31, p = tid >> 5;
+    if (j < kNSums) {
+        const double *row = sh + j * STRIDE + p * 32;
+        double v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
+#pragma unroll
+        for (int k = 4; k < 32; k += 4) {
+            v0 += row[k];
+            v1 += row[k + 1];
+            v2 += row[k + 2];
+            v3 += row[k + 3];
+        }
+        part[j][p] = (v0 + v1) + (v2 + v3);
     }
     __syncthreads();
-    if (threadIdx.x < kNSums) {
-        double v = sh[0][threadIdx.x];
-        for (int w = 1; w < BLOCK / 64; w++) v += sh[w][threadIdx.x];
-        partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
+    if (tid < kNSums) {
+        double v = part[tid][0];
+#pragma unroll
+        for (int q = 1; q < 8; q++) v += part[tid][q];
+        partials[(size_t)tid * gridDim.x + blockIdx.x] = v;
     }
 }
 
@@ -683,7 +702,7 @@ struct VerletBuild {
     int *vl_cnt;  // [ns]
 };
 
-template <int M, int C, int BLOCK, int CAP, bool FUSED>
+template <int M, int C, int BLOCK, int CAP, bool FUSED, bool XCD_REMAP = false>
 __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt,
                                                          const int *__restrict__ cell_start, GridDesc g,
@@ -691,7 +710,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                                                          int *__restrict__ cnt,
                                                          unsigned long long *__restrict__ stamps, FusedRows fm,
                                                          PendingMove pm, unsigned *__restrict__ dm2, int dm2_valid,
-                                                         VerletBuild vb)
+                                                         VerletBuild vb, float *__restrict__ nxyz = nullptr)
 {
     static_assert(C > M, "a compaction must leave room in the list");
     static_assert(CAP % 4 == 0 && CAP <= 65536 && C * 64 <= 4 * CAP, "the global fallback aliases the candidate buffer");
@@ -726,7 +745,15 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = blockIdx.x * BLOCK + tid;
+    // Workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with its own L2.  The
+    // source is in brick order, so neighbouring blocks share most of their target halo: give every XCD one
+    // contiguous eighth of the bricks instead of every eighth brick.
+    int bid = blockIdx.x;
+    if (XCD_REMAP) {
+        const int nb = gridDim.x, x = bid & 7, j = bid >> 3;
+        bid = x * (nb >> 3) + min(x, nb & 7) + j;
+    }
+    const int i = bid * BLOCK + tid;
     const bool valid = i < ns;
     float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     float moved = 0.f;  // how far this query travelled since the association that produced dm2
@@ -998,7 +1025,20 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                     for (int j = 0; j < n; j++) tm = max(tm, __float_as_uint(dist2_flann(q, L.get(L.load(j)))));
                 }
                 stamp(4);
-                for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = L.pos_of(L.load(j));
+                if (nxyz) {
+                    // the winners' coordinates are in LDS right now: leave them next to the indices
+                    // (k-major SoA) so that K23 streams them instead of gathering 16 B out of 128-B lines
+                    for (int j = 0; j < n; j++) {
+                        const int e = L.load(j);
+                        const float4 y = L.get(e);
+                        nbr[(size_t)j * ns + i] = L.pos_of(e);
+                        nxyz[(size_t)(3 * j + 0) * ns + i] = y.x;
+                        nxyz[(size_t)(3 * j + 1) * ns + i] = y.y;
+                        nxyz[(size_t)(3 * j + 2) * ns + i] = y.z;
+                    }
+                } else {
+                    for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = L.pos_of(L.load(j));
+                }
                 cnt[i] = n;
                 if (dm2) dm2[i] = tm;
                 done = true;
@@ -1043,7 +1083,16 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                     tm = 0;
                     for (int j = 0; j < n; j++) tm = max(tm, __float_as_uint(dist2_flann(q, G.get(G.load(j)))));
                 }
-                for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = G.load(j);
+                for (int j = 0; j < n; j++) {
+                    const int e = G.load(j);
+                    nbr[(size_t)j * ns + i] = e;
+                    if (nxyz) {
+                        const float4 y = G.get(e);
+                        nxyz[(size_t)(3 * j + 0) * ns + i] = y.x;
+                        nxyz[(size_t)(3 * j + 1) * ns + i] = y.y;
+                        nxyz[(size_t)(3 * j + 2) * ns + i] = y.z;
+                    }
+                }
                 cnt[i] = n;
                 if (dm2) dm2[i] = tm;
                 done = true;
@@ -1407,12 +1456,15 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(A a, const float4 *_
 // gathers in flight; the rows are then finished from registers in a single sweep (never re-read).  The
 // grid covers every row exactly once (no grid-stride loop).  Measured at 1M rows, W = 10: ROWS = 1
 // (124 VGPRs, 4 waves/SIMD) 58.6 us; ROWS = 2 (168 VGPRs, 3 waves/SIMD) 67 us; forcing 96 VGPRs spills: 74 us.
-template <int W, int ROWS, int BLOCK>
+// XYZ = true: the neighbours' coordinates were left by K1 in nxyz (k-major SoA, [3k + c][ns]) and are streamed
+// with coalesced loads; nbr and tgt are not touched.
+template <int W, int ROWS, int BLOCK, bool XYZ = false>
 __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__restrict__ nbr,
                                                                 const int *__restrict__ cnt,
                                                                 const float4 *__restrict__ src,
                                                                 const float4 *__restrict__ tgt, int ns, Pose P,
-                                                                Model md, double *__restrict__ partials)
+                                                                Model md, double *__restrict__ partials,
+                                                                const float *__restrict__ nxyz = nullptr)
 {
     RowAcc acc;
 #pragma unroll
@@ -1421,7 +1473,22 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
     int n[ROWS];
     float4 xf[ROWS];
     float yx[ROWS][W], yy[ROWS][W], yz[ROWS][W];
-    {
+    if constexpr (XYZ) {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const int i = base + r * BLOCK;
+            const bool ok = i < ns;
+            const int ic = ok ? i : 0;
+            n[r] = ok ? cnt[ic] : 0;
+            xf[r] = src[ic];
+#pragma unroll
+            for (int k = 0; k < W; k++) {  // slots >= cnt hold stale data: masked below
+                yx[r][k] = nxyz[(size_t)(3 * k + 0) * ns + ic];
+                yy[r][k] = nxyz[(size_t)(3 * k + 1) * ns + ic];
+                yz[r][k] = nxyz[(size_t)(3 * k + 2) * ns + ic];
+            }
+        }
+    } else {
         int idx[ROWS][W];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {

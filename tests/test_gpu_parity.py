@@ -482,6 +482,8 @@ def test_temporal_cutoff_and_deferred_move_change_nothing(ctx):
     a, b = _lib.Context(0), _lib.Context(0)
     try:
         a.set_option("verlet", 1)        # skin lists on top (off by default: measured slower, must still be exact)
+        b.set_option("emit_xyz", 1)      # K23 streams coordinates left by K1 (off by default: measured neutral)
+        b.set_option("xcd_remap", 1)
         b.set_option("temporal", 0)
         b.set_option("verlet", 0)
         for c in (a, b):
