@@ -537,8 +537,15 @@ void launch_accumulate_ell(ppcr_ctx *c, int nb, const Pose &P, const Model &md)
             c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md, c->partials.p, c->nbr_xyz.p);
         return;
     }
-    accumulate_ell_kernel<W, kAccumRows, kAccumBlock><<<nb, kAccumBlock, 0, c->stream>>>(c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md,
-                                                           c->partials.p);
+    // the two models the reference's CLI reaches by default are compiled in (Gaussian -u; t with dof 5, dim 3:
+    // v + dim = 8); any other dof takes the run-time form of the same arithmetic
+#define PPCR_K23(TMc)                                                                                              \
+    accumulate_ell_kernel<W, kAccumRows, kAccumBlock, false, TMc><<<nb, kAccumBlock, 0, c->stream>>>(              \
+        c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md, c->partials.p)
+    if (md.is_normal) PPCR_K23(0);
+    else if (md.vpd_int == 8) PPCR_K23(8);
+    else PPCR_K23(-1);
+#undef PPCR_K23
 }
 
 bool tile_variant(const ppcr_ctx *c) { return c->opt_nn_variant == 0 || c->opt_nn_variant == 3; }

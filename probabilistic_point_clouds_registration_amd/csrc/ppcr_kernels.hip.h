@@ -409,12 +409,32 @@ __device__ __forceinline__ double fast_rcp(double x)
 // v + d is an integer (every practical dof) this is an integer power times at most one sqrt — no
 // log1p/exp at all; otherwise the reference's exp(texp * log1p(s/v)) form.  Gaussian: exp(-(s-smin)/2).
 // inv_vs = 1/(v + s) (shared with the expected-weight factor; unused by the Gaussian model)
+// TM (compile-time model): -1 = read md at run time; 0 = Gaussian; k > 0 = t model with v + dim == k.
+// (The run-time form keeps the odd-power sqrt behind an opaque branch: as a plain ?: the compiler if-converts
+//  it and every pair pays the 20-instruction f64 sqrt expansion — measured: 220 of 970 VALU instructions per row.)
+template <int TM = -1>
 __device__ __forceinline__ double rel_likelihood(const Model &md, double s, double smin, double lp_max, double inv_vs)
 {
+    if constexpr (TM == 0) return exp(-0.5 * (s - smin));
+    if constexpr (TM > 0) {
+        const double rho = (md.v + smin) * inv_vs;
+        double r = 1.0, base = rho;  // same multiplication sequence as the run-time loop below (1.0 * x is exact)
+        if constexpr (TM & 1) r = sqrt(rho);
+#pragma unroll
+        for (int k = TM >> 1; k; k >>= 1) {
+            if (k & 1) r *= base;
+            base *= base;
+        }
+        return r;
+    }
     if (md.is_normal) return exp(-0.5 * (s - smin));
     if (md.vpd_int) {
         const double rho = (md.v + smin) * inv_vs;  // = u_min / u  in (0, 1]
-        double r = (md.vpd_int & 1) ? sqrt(rho) : 1.0;
+        double r = 1.0;
+        if (md.vpd_int & 1) {
+            r = sqrt(rho);
+            asm volatile("" : "+v"(r));  // not speculatable: keeps the sqrt out of the even-power path
+        }
         double base = rho;
         for (int k = md.vpd_int >> 1; k; k >>= 1) {     // wave-uniform trip count
             if (k & 1) r *= base;
@@ -1458,7 +1478,7 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(A a, const float4 *_
 // (124 VGPRs, 4 waves/SIMD) 58.6 us; ROWS = 2 (168 VGPRs, 3 waves/SIMD) 67 us; forcing 96 VGPRs spills: 74 us.
 // XYZ = true: the neighbours' coordinates were left by K1 in nxyz (k-major SoA, [3k + c][ns]) and are streamed
 // with coalesced loads; nbr and tgt are not touched.
-template <int W, int ROWS, int BLOCK, bool XYZ = false>
+template <int W, int ROWS, int BLOCK, bool XYZ = false, int TM = -1>
 __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__restrict__ nbr,
                                                                 const int *__restrict__ cnt,
                                                                 const float4 *__restrict__ src,
@@ -1522,15 +1542,17 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
             s[k] = r0 * r0 + r1 * r1 + r2 * r2;
             smin = (k < n[r] && s[k] < smin) ? s[k] : smin;
         }
-        const double lp_max = (md.is_normal || md.vpd_int) ? 0.0 : log_prob(md, smin);
+        // model known at compile time (TM >= 0): no run-time model tests inside the pair loop
+        const bool normal = (TM >= 0) ? (TM == 0) : (md.is_normal != 0);
+        const double lp_max = (TM >= 0 || md.is_normal || md.vpd_int) ? 0.0 : log_prob(md, smin);
         double Z = 0, G = 0, Gs = 0, Gyy = 0, Gy[3] = {0, 0, 0};
 #pragma unroll
         for (int k = 0; k < W; k++) {
             if (k < n[r]) {
-                const double inv_vs = md.is_normal ? 0.0 : fast_rcp(md.v + s[k]);
-                const double e = rel_likelihood(md, s[k], smin, lp_max, inv_vs);
+                const double inv_vs = normal ? 0.0 : fast_rcp(md.v + s[k]);
+                const double e = rel_likelihood<TM>(md, s[k], smin, lp_max, inv_vs);
                 Z += e;
-                const double gk = md.is_normal ? e : e * (md.vpd * inv_vs);
+                const double gk = normal ? e : e * (md.vpd * inv_vs);
                 const double yc0 = (double)yx[r][k] - P.c[0], yc1 = (double)yy[r][k] - P.c[1], yc2 = (double)yz[r][k] - P.c[2];
                 G += gk;
                 Gs = fma(gk, s[k], Gs);
