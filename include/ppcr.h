@@ -192,6 +192,8 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *   "temporal"     1 start each query's cut-off from its previous m-th distance (default), 0 off;
  *   "mailbox"      1 deliver the moments through pinned host memory and spin (default), 0 copy + synchronise;
  *   "fused"        1 K1 epilogue writes per-row partials (experiment, measured slower), 0 off (default);
+ *   "grid_xf"      x slices per grid cell, 1/2/4/8 (default 4; set before the target): every stencil row is clipped
+ *                  to the x window the search sphere needs in that row;
  *   "emit_xyz"     1 K1 also writes the neighbours' coordinates so that K23 streams instead of gathering
  *                  (experiment, measured neutral: K23 is instruction-bound, not gather-bound), 0 off (default);
  *   "xcd_remap"    1 give each XCD a contiguous eighth of the source bricks (experiment, measured neutral), 0 off;

@@ -171,6 +171,7 @@ struct ppcr_ctx {
     // the rigid motion accumulated since they were built
     double dbg_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics of the last ppcr_align (ppcr_debug_get_host_times)
     int opt_xcd_remap = 0;
+    int opt_grid_xf = 4;         // x slices per grid cell (GridDesc::xr)
     int opt_emit_xyz = 0;        // K1 also leaves the neighbours' coordinates (k-major SoA) for K23 to stream: measured neutral
     DevBuf<float> nbr_xyz;
     bool nbr_xyz_valid = false;  // nbr_xyz matches the current ELL association
@@ -335,7 +336,7 @@ int sort_by_cell(ppcr_ctx *c, const GridDesc &g, const float4 *in, int n, float4
         }
         PPCR_TRY(check_launch(c, "cell_key_kernel"));
         long long nkeys = g.ncells;
-        if (brick_order) nkeys = 64ll * ((g.n[0] + 3) / 4) * ((g.n[1] + 3) / 4) * ((g.n[2] + 3) / 4);
+        if (brick_order) nkeys = 64ll * (((g.n[0] >> g.xr_shift) + 3) / 4) * ((g.n[1] + 3) / 4) * ((g.n[2] + 3) / 4);
         int end_bit = 1;
         while (end_bit < 32 && (1ll << end_bit) < nkeys) end_bit++;
         size_t tmp_bytes = 0;
@@ -394,7 +395,7 @@ int cloud_bbox(ppcr_ctx *c, const float4 *pts, int n, float lo[3], float hi[3])
 }
 
 // uniform grid over [lo, hi] whose 27-cell stencil covers a search of `cell_radius`
-void make_grid_desc(int n, const float lo[3], const float hi[3], double cell_radius, GridDesc &g)
+void make_grid_desc(int n, const float lo[3], const float hi[3], double cell_radius, int xf, GridDesc &g)
 {
     float amax = 0;
     for (int a = 0; a < 3; a++) amax = std::max(amax, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
@@ -406,18 +407,27 @@ void make_grid_desc(int n, const float lo[3], const float hi[3], double cell_rad
     double ext[3];
     for (int a = 0; a < 3; a++) ext[a] = (double)hi[a] - (double)lo[a];
     for (;;) {
-        double nc = 1;
+        double nc = xf;
         for (int a = 0; a < 3; a++) nc *= std::floor(ext[a] / h) + 1;
         if (nc <= max_cells) break;
-        h *= 1.26f;
+        if (xf > 1) xf >>= 1;  // a table that large: give up the x refinement before growing the cells
+        else h *= 1.26f;
     }
     int64_t ncells = 1;
     for (int a = 0; a < 3; a++) {
         g.org[a] = lo[a];
-        g.n[a] = (int)std::floor(ext[a] / h) + 1;
+        g.n[a] = ((int)std::floor(ext[a] / h) + 1) * (a == 0 ? xf : 1);
         ncells *= g.n[a];
     }
     g.inv_h = 1.0f / h;
+    g.inv_hx = (float)xf * g.inv_h;  // exact (power of two)
+    g.h = h;
+    double emax = 0;
+    for (int a = 0; a < 3; a++) emax = std::max(emax, ext[a]);
+    g.eps = 32.0f * FLT_EPSILON * (float)(amax + emax + h);
+    g.xr = xf;
+    g.xr_shift = 0;
+    while ((1 << g.xr_shift) < xf) g.xr_shift++;
     g.ncells = (int)ncells;
 }
 
@@ -434,7 +444,7 @@ int ensure_grid(ppcr_ctx *c)
     PPCR_TRY(cloud_bbox(c, c->tgt_raw.p, n, c->tgt_lo, c->tgt_hi));
     for (int a = 0; a < 3; a++) c->origin[a] = 0.5 * ((double)c->tgt_lo[a] + (double)c->tgt_hi[a]);
     c->origin_valid = true;
-    make_grid_desc(n, c->tgt_lo, c->tgt_hi, c->radius, c->grid);
+    make_grid_desc(n, c->tgt_lo, c->tgt_hi, c->radius, c->opt_grid_xf, c->grid);
     HIP_TRY(c, c->tgt_sorted.reserve((size_t)std::max(n, 1)));
     PPCR_TRY(sort_by_cell(c, c->grid, c->tgt_raw.p, n, c->tgt_sorted.p, &c->cell_start));
     c->grid_valid = true;
@@ -449,7 +459,7 @@ int ensure_grid2(ppcr_ctx *c, double cell_radius)
     if (c->grid2_valid && c->grid2_cell_radius == cell_radius) return PPCR_OK;
     const int n = (int)c->nt;
     c->vl_valid = false;
-    make_grid_desc(n, c->tgt_lo, c->tgt_hi, cell_radius, c->grid2);
+    make_grid_desc(n, c->tgt_lo, c->tgt_hi, cell_radius, c->opt_grid_xf, c->grid2);
     HIP_TRY(c, c->tgt_sorted2.reserve((size_t)std::max(n, 1)));
     PPCR_TRY(sort_by_cell(c, c->grid2, c->tgt_raw.p, n, c->tgt_sorted2.p, &c->cell_start2));
     c->grid2_valid = true;
@@ -1242,6 +1252,12 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
     if (std::strcmp(key, "verlet") == 0) {  // 1: Verlet (skin) neighbour lists while the source moves little (default)
         c->opt_verlet = value ? 1 : 0;
         c->vl_valid = false;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "grid_xf") == 0) {
+        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, PPCR_ERR_INVALID, "grid_xf must be 1, 2, 4 or 8");
+        if (c->have_tgt) return fail(c, PPCR_ERR_STATE, "grid_xf must be set before the target cloud");
+        c->opt_grid_xf = value;
         return PPCR_OK;
     }
     if (std::strcmp(key, "emit_xyz") == 0) {

@@ -21,11 +21,21 @@ namespace dev {
 constexpr int kNSums = 19;
 constexpr int kBlock = 256;
 
+// Uniform grid over the target's bounding box.  Cells are cubes of edge h >= radius in y and z; in x every cell is
+// split into xr slices (edge h / xr, inv_hx = xr * inv_h): a (dy, dz) row of the stencil is one contiguous run
+// of the cell-sorted target whatever xr is, and a finer x lets every query clip each of its nine runs to the
+// x window the sphere really needs in that row (nn_tile_kernel) instead of three full cells.
+// n[0] counts x SLICES; the stencil reaches xr slices either side of the query's slice.
 struct GridDesc {
     float org[3];
     float inv_h;
     int n[3];
     int ncells;
+    float inv_hx;  // xr * inv_h
+    float h;       // cell edge in y and z
+    float eps;     // absolute slack that covers the float rounding of cell coordinates and gaps
+    int xr;        // x slices per cell edge (1, 2, 4, 8) = stencil reach in x slices
+    int xr_shift;  // log2(xr)
 };
 
 struct Pose {  // y ~ R x + t ; c = fixed origin of the moments
@@ -108,7 +118,7 @@ __global__ void cell_key_kernel(const float4 *__restrict__ pts, int n, GridDesc 
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float4 p = pts[i];
-    int cx = clampi(cell_coord(p.x, g.org[0], g.inv_h, g.n[0]), 0, g.n[0] - 1);
+    int cx = clampi(cell_coord(p.x, g.org[0], g.inv_hx, g.n[0]), 0, g.n[0] - 1);
     int cy = clampi(cell_coord(p.y, g.org[1], g.inv_h, g.n[1]), 0, g.n[1] - 1);
     int cz = clampi(cell_coord(p.z, g.org[2], g.inv_h, g.n[2]), 0, g.n[2] - 1);
     keys[i] = (unsigned)((cz * g.n[1] + cy) * g.n[0] + cx);
@@ -125,10 +135,11 @@ __global__ void brick_key_kernel(const float4 *__restrict__ pts, int n, GridDesc
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float4 p = pts[i];
-    const int cx = clampi(cell_coord(p.x, g.org[0], g.inv_h, g.n[0]), 0, g.n[0] - 1);
+    // bricks are measured in whole cells: x slices are folded back to cells first
+    const int cx = clampi(cell_coord(p.x, g.org[0], g.inv_hx, g.n[0]), 0, g.n[0] - 1) >> g.xr_shift;
     const int cy = clampi(cell_coord(p.y, g.org[1], g.inv_h, g.n[1]), 0, g.n[1] - 1);
     const int cz = clampi(cell_coord(p.z, g.org[2], g.inv_h, g.n[2]), 0, g.n[2] - 1);
-    const int nbx = (g.n[0] + 3) >> 2, nby = (g.n[1] + 3) >> 2;
+    const int nbx = ((g.n[0] >> g.xr_shift) + 3) >> 2, nby = (g.n[1] + 3) >> 2;
     const int bx = cx >> 2, by = cy >> 2, bz = cz >> 2;
     const int byy = (bz & 1) ? nby - 1 - by : by;
     const int row = bz * nby + byy;
@@ -184,7 +195,7 @@ struct QueryCells {
 __device__ __forceinline__ QueryCells query_cells(float4 q, const GridDesc &g)
 {
     QueryCells c;
-    c.cx = cell_coord(q.x, g.org[0], g.inv_h, g.n[0]);
+    c.cx = cell_coord(q.x, g.org[0], g.inv_hx, g.n[0]);
     c.cy = cell_coord(q.y, g.org[1], g.inv_h, g.n[1]);
     c.cz = cell_coord(q.z, g.org[2], g.inv_h, g.n[2]);
     return c;
@@ -197,7 +208,7 @@ __device__ __forceinline__ void for_each_candidate(float4 q, const GridDesc &g,
                                                    const float4 *__restrict__ tgt, F &&f)
 {
     const QueryCells c = query_cells(q, g);
-    const int x0 = max(c.cx - 1, 0), x1 = min(c.cx + 1, g.n[0] - 1);
+    const int x0 = max(c.cx - g.xr, 0), x1 = min(c.cx + g.xr, g.n[0] - 1);
     if (x0 > x1) return;
 #pragma unroll 1
     for (int dz = -1; dz <= 1; dz++) {
@@ -801,16 +812,33 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
     const QueryCells qc = query_cells(q, g);
 
     // this lane's 9 stencil runs [rb, re) in sorted-target positions: issued now, consumed after the
-    // halo has been staged, so their latency hides behind the staging phase
-    const int x0 = max(qc.cx - 1, 0), x1 = min(qc.cx + 1, g.n[0] - 1);
+    // halo has been staged, so their latency hides behind the staging phase.
+    // Each run is clipped in x: a target of row (dy, dz) is at least (gy, gz) away in y and z (the gap between the
+    // query and that row's slab, under-estimated by g.eps), so it can only be within the cut-off radius R if
+    // |dx| <= sqrt(R^2 - gy^2 - gz^2); R^2 is the radius or the temporal cut-off, inflated by 4e-6 for the float
+    // rounding of d2.  The x slices that window touches are the run; a row with no window is skipped.
+    const int x0 = max(qc.cx - g.xr, 0), x1 = min(qc.cx + g.xr, g.n[0] - 1);
     int rb[9], re[9];
+    {
+        const float R2 = __uint_as_float(min(thr0, __float_as_uint(r2))) * 1.000004f;
+        const float fy = q.y - g.org[1], fz = q.z - g.org[2];
+        const float gy[3] = {fmaxf(fy - (float)qc.cy * g.h - g.eps, 0.f), 0.f,
+                             fmaxf((float)(qc.cy + 1) * g.h - fy - g.eps, 0.f)};
+        const float gz[3] = {fmaxf(fz - (float)qc.cz * g.h - g.eps, 0.f), 0.f,
+                             fmaxf((float)(qc.cz + 1) * g.h - fz - g.eps, 0.f)};
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-        const int cz = qc.cz + (k / 3 - 1), cy = qc.cy + (k % 3 - 1);
-        const bool in = valid && x0 <= x1 && (unsigned)cz < (unsigned)g.n[2] && (unsigned)cy < (unsigned)g.n[1];
-        const int base = in ? (cz * g.n[1] + cy) * g.n[0] : 0;
-        rb[k] = in ? cell_start[base + x0] : 0;
-        re[k] = in ? cell_start[base + x1 + 1] : 0;
+        for (int k = 0; k < 9; k++) {
+            const int cz = qc.cz + (k / 3 - 1), cy = qc.cy + (k % 3 - 1);
+            const float w2 = R2 - (gy[k % 3] * gy[k % 3] + gz[k / 3] * gz[k / 3]);
+            const float w = sqrtf(fmaxf(w2, 0.f)) * 1.000001f + g.eps;
+            const int fa = max(cell_coord(q.x - w, g.org[0], g.inv_hx, g.n[0]), x0);
+            const int fb = min(cell_coord(q.x + w, g.org[0], g.inv_hx, g.n[0]), x1);
+            const bool in = valid && w2 >= 0.f && fa <= fb && (unsigned)cz < (unsigned)g.n[2] &&
+                            (unsigned)cy < (unsigned)g.n[1];
+            const int base = in ? (cz * g.n[1] + cy) * g.n[0] : 0;
+            rb[k] = in ? cell_start[base + fa] : 0;
+            re[k] = in ? cell_start[base + fb + 1] : 0;
+        }
     }
 
     // per-wave bounding box of the query cells
@@ -851,7 +879,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                 hi[a] = max(hi[a], s_whi[w][a]);
             }
         const bool any = lo[0] <= hi[0];  // at least one valid query among these waves
-        const int hx0 = max(lo[0] - 1, 0), hx1 = min(hi[0] + 1, g.n[0] - 1);
+        const int hx0 = max(lo[0] - g.xr, 0), hx1 = min(hi[0] + g.xr, g.n[0] - 1);
         const int hy0 = max(lo[1] - 1, 0), hy1 = min(hi[1] + 1, g.n[1] - 1);
         const int hz0 = max(lo[2] - 1, 0), hz1 = min(hi[2] + 1, g.n[2] - 1);
         const int ny_h = hy1 - hy0 + 1, nz_h = hz1 - hz0 + 1;
@@ -986,40 +1014,45 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                             }
                         }
                     };
-                    auto test1 = [&](int f) { accept(f, dist2_flann(q, make_float4(s_x[f], s_y[f], s_z[f], 0.f))); };
-#pragma unroll 1
-                    for (int k = 0; k < 9; k++) {
-                        // take the next run; rotate the register file instead of indexing it (after nine rotations
-                        // the runs are back in place for a possible second pass)
-                        const int fb = rf[0], len = rl[0];
-#pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            rf[u] = rf[u + 1];
-                            rl[u] = rl[u + 1];
-                        }
-                        rf[8] = fb;
-                        rl[8] = len;
-                        if (len <= 0) continue;
+                    // One run: ALIGNED pairs from (fb & ~1) while p < fe.  The element below fb (first trip of an
+                    // odd start) and the element at fe (last trip of an odd end) belong to other runs: they are
+                    // kept out by the two index tests, which replace the odd head / tail singles of the previous
+                    // version (two compares per trip instead of ~34 instructions per run, and one code path).
+                    // Two candidates per trip: ds_read_b64 x3, packed f32 sub/mul/add (no FMA: the same IEEE
+                    // operations per element as dist2_flann, so d2 is bit-identical).
+                    auto scan_run = [&](int fb, int len) {
+                        if (len <= 0) return;
                         const int fe = fb + len;
-                        int f = fb;
-                        if (f & 1) {  // align to a pair boundary (8-byte LDS reads)
-                            test1(f);
-                            f++;
-                        }
-                        for (; f + 1 < fe; f += 2) {
-                            // two candidates per trip: ds_read_b64 x3, packed f32 sub/mul/add (no FMA: the same
-                            // IEEE operations per element as dist2_flann, so d2 is bit-identical)
-                            const v2f cx = *reinterpret_cast<const v2f *>(&s_x[f]);
-                            const v2f cy = *reinterpret_cast<const v2f *>(&s_y[f]);
-                            const v2f cz = *reinterpret_cast<const v2f *>(&s_z[f]);
+                        for (int p = fb & ~1; p < fe; p += 2) {
+                            const v2f cx = *reinterpret_cast<const v2f *>(&s_x[p]);
+                            const v2f cy = *reinterpret_cast<const v2f *>(&s_y[p]);
+                            const v2f cz = *reinterpret_cast<const v2f *>(&s_z[p]);
                             const v2f dx = qx2 - cx, dy = qy2 - cy, dz = qz2 - cz;
                             v2f d = dx * dx;
                             d = d + dy * dy;
                             d = d + dz * dz;
-                            accept(f, d.x);
-                            accept(f + 1, d.y);
+                            if (p >= fb) accept(p, d.x);
+                            if (p + 1 < fe) accept(p + 1, d.y);
                         }
-                        if (f < fe) test1(f);
+                    };
+                    if constexpr (COMPACT) {
+                        // rare flavour: keep the code small — one loop body, the runs rotated through rf[0] / rl[0]
+                        // (after nine rotations they are back in place)
+#pragma unroll 1
+                        for (int k = 0; k < 9; k++) {
+                            const int fb = rf[0], len = rl[0];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) {
+                                rf[u] = rf[u + 1];
+                                rl[u] = rl[u + 1];
+                            }
+                            rf[8] = fb;
+                            rl[8] = len;
+                            scan_run(fb, len);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 9; k++) scan_run(rf[k], rl[k]);
                     }
                 };
                 scan_runs(std::false_type{});

@@ -11,16 +11,18 @@ c = _lib.Context(0)
 c.set_params(1.0, m, 5.0, 3); c.set_target(tgt); c.set_source(src)
 fused = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 c.set_option("fused", fused)
-c.iterate(); c.synchronize()
+c.associate(); c.synchronize()
 c.set_option("stamps", 1)
-c.iterate(); c.synchronize()
-out = (C.c_ulonglong * 8)()
 L = _lib.load(); L.ppcr_debug_get_stamps.argtypes = [C.c_void_p, C.c_void_p]
-assert L.ppcr_debug_get_stamps(c._h, out) == 0
-v = np.array(list(out), dtype=np.float64)
 names = ["bbox", "rowtable", "stage", "scan", "select", "emit+moments", "reduce/tail", "fallback"]
-tot = v[:8].sum()
-for k in range(8):
-    print(f"{names[k]:10s} {v[k]:14.0f} ticks  {100*v[k]/tot:5.1f}%")
 nw = (n + 255)//256*4
-print(f"cycles per wave: {tot/nw:.0f}")
+def show(tag):
+    out = (C.c_ulonglong * 8)()
+    assert L.ppcr_debug_get_stamps(c._h, out) == 0
+    v = np.array(list(out), dtype=np.float64)
+    tot = v[:8].sum()
+    print(tag, " ".join(f"{names[k]}={v[k]/nw:.0f}" for k in range(8)), f"| ticks per wave: {tot/nw:.0f}")
+c.associate(); c.synchronize(); show("fresh    ")
+for k in range(8):
+    c.iterate(); c.synchronize()
+    if k in (0, 3, 7): show(f"iterate {k}")
