@@ -174,6 +174,27 @@ int ppcr_align_many(ppcr_ctx *const *ctxs, int n, int lanes, int n_iter, double 
 /* current (moved) source in the caller's original point order */
 int ppcr_get_source(ppcr_ctx *ctx, float *xyz, int64_t stride_bytes);
 
+/* ---- the steps either side of the loop (reporting and down-sampling) ------------------------------------------
+ * The reference moves TWO copies of the source every iteration (the full cloud and the voxel-filtered one the
+ * association runs on, cc:110-112) and reports mean point distances on the full one (cc:114-122).
+ * ppcr_set_companion gives the handle that full-resolution copy: it is moved on the device by every transform
+ * applied to the source (same f64 -> f32 arithmetic) and is what the two reports below look at; without a
+ * companion they look at the source itself.  All clouds are in the caller's index order. */
+int ppcr_set_companion(ppcr_ctx *ctx, const float *xyz, int64_t n, int64_t stride_bytes);
+int ppcr_get_companion(ppcr_ctx *ctx, float *xyz, int64_t stride_bytes);
+int ppcr_set_ground_truth(ppcr_ctx *ctx, const float *xyz, int64_t n, int64_t stride_bytes);
+/* calculateMSE(source, ground_truth) (utilities.hpp:16-26: the mean Euclidean distance of index-paired points);
+ * PPCR_ERR_INVALID when the sizes differ (the reference asserts). */
+int ppcr_mse_ground_truth(ppcr_ctx *ctx, double *mse);
+/* calculateMSE(source, source at the previous call), then remembers the current cloud (cc:121-122).
+ * The first call reports 0 and only takes the snapshot; mse may be NULL. */
+int ppcr_mse_previous(ppcr_ctx *ctx, double *mse);
+
+/* pcl::VoxelGrid<PointXYZ> centroid down-sampling with leaf (l,l,l) (cc:24-41): one output point per occupied
+ * voxel, voxels in ascending index; out_xyz must hold n points.  Stateless (temporary handle on device_id). */
+int ppcr_voxel_filter(int device_id, const float *xyz, int64_t n, int64_t stride_bytes, float leaf, float *out_xyz,
+                      int64_t out_stride_bytes, int64_t *n_out);
+
 int ppcr_synchronize(ppcr_ctx *ctx);
 
 /* Per-kernel device timing with HIP events recorded on the handle's own stream. */

@@ -207,5 +207,18 @@ def calculate_mse(a, b):
     return lib().po_calculate_mse(a, sa, b, sb, a.shape[0])
 
 
+def voxel_filter(cloud, leaf):
+    """pcl::VoxelGrid centroid down-sampling (restated) -> float32 [k, 3]"""
+    a, sa = _cloud(cloud)
+    out = np.zeros((max(a.shape[0], 1), 3), dtype=np.float32)
+    L = lib()
+    L.po_voxel_filter.restype = C.c_int64
+    L.po_voxel_filter.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_int]
+    k = L.po_voxel_filter(a.ctypes.data, sa, a.shape[0], float(leaf), out.ctypes.data, 3)
+    if k < 0:
+        raise ValueError("bad arguments")
+    return out[:k].copy()
+
+
 def num_threads():
     return lib().po_num_threads()

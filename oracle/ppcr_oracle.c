@@ -821,6 +821,86 @@ double po_calculate_mse(const float *a, int sa, const float *b, int sb, int64_t 
     return mse / (double)n;
 }
 
+/* pcl::VoxelGrid<PointXYZ> centroid down-sampling as the reference uses it (src/prob_point_cloud_registration.cc:24-41:
+ * setLeafSize(l,l,l), default min_points_per_voxel = 0, no field filter).  Third-party (PCL, unpinned), restated from
+ * its published algorithm:
+ *   min/max over the finite points; inv = 1/leaf (float); if the voxel count (dx*dy*dz, 64-bit) exceeds INT32_MAX the
+ *   input is returned unchanged (PCL warns "Leaf size is too small"); min_b = floor(min*inv), div_b = max_b - min_b + 1;
+ *   voxel index = ijk . (1, div_x, div_x*div_y) with ijk = floor(p*inv) - min_b; points grouped by index; output =
+ *   float centroid of every occupied voxel, voxels in ascending index.
+ * PCL orders the points of one voxel with std::sort (unstable), so its float centroid is only defined up to the order
+ * of the additions; here (and in the HIP path, bit for bit) they are added in ascending original index.
+ * parity unpinned: the reference has no test for it.
+ * Returns the number of output points (out holds up to n); -1 on bad arguments. */
+typedef struct { int32_t idx; int32_t pt; } po_vox_pair;
+static int po_vox_cmp(const void *a, const void *b)
+{
+    const po_vox_pair *x = (const po_vox_pair *)a, *y = (const po_vox_pair *)b;
+    if (x->idx != y->idx) return x->idx < y->idx ? -1 : 1;
+    return x->pt < y->pt ? -1 : (x->pt > y->pt ? 1 : 0);
+}
+
+int64_t po_voxel_filter(const float *in, int sin, int64_t n, float leaf, float *out, int sout)
+{
+    if (n < 0 || !(leaf > 0) || sin < 3 || sout < 3) return -1;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    int64_t nfin = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const float *p = in + i * sin;
+        if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+        for (int a = 0; a < 3; a++) {
+            if (p[a] < lo[a]) lo[a] = p[a];
+            if (p[a] > hi[a]) hi[a] = p[a];
+        }
+        nfin++;
+    }
+    if (nfin == 0) return 0;
+    const float inv = 1.0f / leaf;
+    int64_t d[3];
+    for (int a = 0; a < 3; a++) d[a] = (int64_t)((hi[a] - lo[a]) * inv) + 1;
+    if (d[0] * d[1] * d[2] > (int64_t)INT32_MAX) {  /* PCL: "Leaf size is too small for the input dataset" */
+        for (int64_t i = 0; i < n; i++)
+            for (int a = 0; a < 3; a++) out[i * sout + a] = in[i * sin + a];
+        return n;
+    }
+    int32_t min_b[3], div_b[3];
+    for (int a = 0; a < 3; a++) {
+        min_b[a] = (int32_t)floorf(lo[a] * inv);
+        div_b[a] = (int32_t)floorf(hi[a] * inv) - min_b[a] + 1;
+    }
+    const int32_t mul[3] = {1, div_b[0], div_b[0] * div_b[1]};
+    po_vox_pair *pr = (po_vox_pair *)malloc(sizeof(po_vox_pair) * (size_t)(nfin > 0 ? nfin : 1));
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const float *p = in + i * sin;
+        if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+        int32_t idx = 0;
+        for (int a = 0; a < 3; a++) idx += (int32_t)(floorf(p[a] * inv) - (float)min_b[a]) * mul[a];
+        pr[k].idx = idx;
+        pr[k].pt = (int32_t)i;
+        k++;
+    }
+    qsort(pr, (size_t)nfin, sizeof(po_vox_pair), po_vox_cmp);
+    int64_t nout = 0;
+    for (int64_t b = 0; b < nfin;) {
+        int64_t e = b;
+        float c[3] = {0.f, 0.f, 0.f};
+        while (e < nfin && pr[e].idx == pr[b].idx) {
+            const float *p = in + (int64_t)pr[e].pt * sin;
+            c[0] += p[0];
+            c[1] += p[1];
+            c[2] += p[2];
+            e++;
+        }
+        const float cnt = (float)(e - b);
+        for (int a = 0; a < 3; a++) out[nout * sout + a] = c[a] / cnt;
+        nout++;
+        b = e;
+    }
+    free(pr);
+    return nout;
+}
+
 int po_num_threads(void)
 {
 #ifdef _OPENMP

@@ -20,7 +20,8 @@ SYMBOLS = [
     "ppcr_set_association", "ppcr_weights", "ppcr_update_weights", "ppcr_accumulate", "ppcr_get_origin",
     "ppcr_solve_moments", "ppcr_cost_from_moments", "ppcr_solve", "ppcr_apply_transform",
     "ppcr_iterate", "ppcr_align", "ppcr_get_source", "ppcr_synchronize", "ppcr_profile_enable",
-    "ppcr_profile_get", "ppcr_set_option", "ppcr_batch_run", "ppcr_align_many",
+    "ppcr_profile_get", "ppcr_set_option", "ppcr_batch_run", "ppcr_align_many", "ppcr_set_companion",
+    "ppcr_get_companion", "ppcr_set_ground_truth", "ppcr_mse_ground_truth", "ppcr_mse_previous", "ppcr_voxel_filter",
 ]
 
 
@@ -88,6 +89,12 @@ def load():
     L.ppcr_profile_enable.argtypes = [vp, i32]
     L.ppcr_profile_get.argtypes = [vp, C.POINTER(KernelStat), i32, C.POINTER(i32)]
     L.ppcr_set_option.argtypes = [vp, C.c_char_p, i32]
+    for f in (L.ppcr_set_companion, L.ppcr_set_ground_truth):
+        f.argtypes = [vp, vp, i64, i64]
+    L.ppcr_get_companion.argtypes = [vp, vp, i64]
+    L.ppcr_mse_ground_truth.argtypes = [vp, C.POINTER(dbl)]
+    L.ppcr_mse_previous.argtypes = [vp, C.POINTER(dbl)]
+    L.ppcr_voxel_filter.argtypes = [i32, vp, i64, i64, C.c_float, vp, i64, C.POINTER(i64)]
     L.ppcr_batch_run.argtypes = [C.POINTER(Pair), i64, C.POINTER(BatchOptions), C.POINTER(i32), i32, i32, vp, vp,
                                  C.c_char_p, i64]
     L.ppcr_align_many.argtypes = [C.POINTER(vp), i32, i32, i32, dbl, dbl, vp, vp, i32, dbl, vp, vp]
@@ -263,6 +270,32 @@ class Context:
         self._ck(self._L.ppcr_get_source(self._h, out.ctypes.data, stride * 4))
         return out
 
+    # -- reporting clouds (full-resolution companion, ground truth, previous-iteration snapshot)
+    def set_companion(self, cloud):
+        a = _cloud(cloud)
+        self._keep_companion = a
+        self._ck(self._L.ppcr_set_companion(self._h, a.ctypes.data if a.size else None, a.shape[0], a.shape[1] * 4))
+        self.n_companion = a.shape[0]
+
+    def get_companion(self, stride=3):
+        out = np.zeros((self.n_companion, stride), dtype=np.float32)
+        self._ck(self._L.ppcr_get_companion(self._h, out.ctypes.data, stride * 4))
+        return out
+
+    def set_ground_truth(self, cloud):
+        a = _cloud(cloud)
+        self._ck(self._L.ppcr_set_ground_truth(self._h, a.ctypes.data if a.size else None, a.shape[0], a.shape[1] * 4))
+
+    def mse_ground_truth(self):
+        v = C.c_double(0)
+        self._ck(self._L.ppcr_mse_ground_truth(self._h, C.byref(v)))
+        return v.value
+
+    def mse_previous(self):
+        v = C.c_double(0)
+        self._ck(self._L.ppcr_mse_previous(self._h, C.byref(v)))
+        return v.value
+
     def counters(self):
         """Diagnostic: (Verlet builds, Verlet uses, plain grid scans) performed by this handle."""
         out = (C.c_longlong * 3)()
@@ -356,3 +389,16 @@ def align_many(ctxs, n_iter, lanes=2, cost_drop_thresh=0.0, n_cost_drop_it=5, q0
         msgs = [L.ppcr_last_error(c._h).decode() for c in ctxs]
         raise PpcrError(rc, next((m for m in msgs if m), "ppcr_align_many failed"))
     return T, done
+
+
+def voxel_filter(cloud, leaf, device_id=0):
+    """ppcr_voxel_filter: pcl::VoxelGrid centroid down-sampling on the device -> float32 [k, 3]"""
+    a = _cloud(cloud)
+    out = np.zeros((max(a.shape[0], 1), 3), dtype=np.float32)
+    k = C.c_int64(0)
+    L = load()
+    rc = L.ppcr_voxel_filter(int(device_id), a.ctypes.data if a.size else None, a.shape[0], a.shape[1] * 4, float(leaf),
+                             out.ctypes.data, 12, C.byref(k))
+    if rc != 0:
+        raise PpcrError(rc, L.ppcr_last_error(None).decode())
+    return out[:k.value].copy()

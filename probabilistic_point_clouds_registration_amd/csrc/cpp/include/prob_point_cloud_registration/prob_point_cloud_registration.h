@@ -15,9 +15,10 @@
 
 namespace prob_point_cloud_registration {
 
-// centroid-per-voxel down-sampling (the pcl::VoxelGrid step of the reference's constructor); host code,
+// centroid-per-voxel down-sampling (the pcl::VoxelGrid step of the reference's constructor) on the device,
 // runs once before the loop
-void voxelGridFilter(const pcl::PointCloud<pcl::PointXYZ> &in, double leaf, pcl::PointCloud<pcl::PointXYZ> &out);
+void voxelGridFilter(const pcl::PointCloud<pcl::PointXYZ> &in, double leaf, pcl::PointCloud<pcl::PointXYZ> &out,
+                     int device_id = 0);
 
 class ProbPointCloudRegistration {
 public:
@@ -36,7 +37,7 @@ public:
     inline std::string report() { return report_.str(); }
 
 private:
-    void fetchSource();  // device -> source_cloud_ (only when something on the host needs it)
+    void fetchSource();  // device -> source_cloud_ (once, after the loop)
 
     ProbPointCloudRegistrationParams parameters_;
     pcl::PointCloud<pcl::PointXYZ>::Ptr target_cloud_;

@@ -13,10 +13,11 @@
 
 namespace prob_point_cloud_registration {
 
-// Centroid per occupied voxel, voxels visited in ascending (z, y, x) index order over the cloud's
-// bounding box — the layout pcl::VoxelGrid produces for its default settings.  (Parity with PCL is
-// unpinned: the reference has no test for it and PCL is not available here.)
-void voxelGridFilter(const pcl::PointCloud<pcl::PointXYZ> &in, double leaf, pcl::PointCloud<pcl::PointXYZ> &out)
+// pcl::VoxelGrid centroid down-sampling on the device (ppcr_voxel_filter): one point per occupied voxel, voxels in
+// ascending index.  (Parity with PCL itself is unpinned: the reference has no test for it and PCL is not
+// available here; the definition is pinned against the CPU restatement in the test tree.)
+void voxelGridFilter(const pcl::PointCloud<pcl::PointXYZ> &in, double leaf, pcl::PointCloud<pcl::PointXYZ> &out,
+                     int device_id)
 {
     pcl::PointCloud<pcl::PointXYZ> result;
     if (!(leaf > 0) || in.empty()) {
@@ -24,34 +25,12 @@ void voxelGridFilter(const pcl::PointCloud<pcl::PointXYZ> &in, double leaf, pcl:
         out = result;
         return;
     }
-    float lo[3] = {INFINITY, INFINITY, INFINITY};
-    for (const auto &p : in.points) {
-        if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
-        lo[0] = std::fmin(lo[0], p.x), lo[1] = std::fmin(lo[1], p.y), lo[2] = std::fmin(lo[2], p.z);
-    }
-    const double inv = 1.0 / leaf;
-    const std::int64_t b[3] = {static_cast<std::int64_t>(std::floor(lo[0] * inv)), static_cast<std::int64_t>(std::floor(lo[1] * inv)),
-                               static_cast<std::int64_t>(std::floor(lo[2] * inv))};
-    struct Acc {
-        double s[3] = {0, 0, 0};
-        std::int64_t n = 0;
-    };
-    std::map<std::tuple<std::int64_t, std::int64_t, std::int64_t>, Acc> cells;  // ordered (z, y, x)
-    for (const auto &p : in.points) {
-        if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
-        const std::int64_t ix = static_cast<std::int64_t>(std::floor(p.x * inv)) - b[0];
-        const std::int64_t iy = static_cast<std::int64_t>(std::floor(p.y * inv)) - b[1];
-        const std::int64_t iz = static_cast<std::int64_t>(std::floor(p.z * inv)) - b[2];
-        Acc &a = cells[std::make_tuple(iz, iy, ix)];
-        a.s[0] += p.x, a.s[1] += p.y, a.s[2] += p.z;
-        a.n++;
-    }
-    result.reserve(cells.size());
-    for (const auto &kv : cells) {
-        const Acc &a = kv.second;
-        result.push_back(pcl::PointXYZ(static_cast<float>(a.s[0] / a.n), static_cast<float>(a.s[1] / a.n),
-                                       static_cast<float>(a.s[2] / a.n)));
-    }
+    result.points.resize(in.size());
+    int64_t n_out = 0;
+    const int rc = ppcr_voxel_filter(device_id, &in[0].x, static_cast<int64_t>(in.size()), sizeof(pcl::PointXYZ),
+                                     static_cast<float>(leaf), &result.points[0].x, sizeof(pcl::PointXYZ), &n_out);
+    if (rc != PPCR_OK) throw DeviceError(rc, std::string("ppcr_voxel_filter: ") + ppcr_last_error(nullptr));
+    result.points.resize(static_cast<size_t>(n_out));
     out = result;
 }
 
@@ -74,17 +53,16 @@ ProbPointCloudRegistration::ProbPointCloudRegistration(pcl::PointCloud<pcl::Poin
     filtered_source_cloud_ = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
     if (parameters_.source_filter_size > 0) {
         output_stream_ << "Filtering source point cloud with leaf of size " << parameters_.source_filter_size << "\n";
-        voxelGridFilter(*source_cloud_, parameters_.source_filter_size, *filtered_source_cloud_);
+        voxelGridFilter(*source_cloud_, parameters_.source_filter_size, *filtered_source_cloud_, parameters_.device_id);
         filtered_ = true;
     } else {
         *filtered_source_cloud_ = *source_cloud_;
     }
     if (parameters_.target_filter_size > 0) {
         output_stream_ << "Filtering target point cloud with leaf of size " << parameters_.target_filter_size << "\n";
-        voxelGridFilter(*target_cloud_, parameters_.target_filter_size, *target_cloud_);
+        voxelGridFilter(*target_cloud_, parameters_.target_filter_size, *target_cloud_, parameters_.device_id);
     }
     if (parameters_.summary) {
-        prev_source_cloud_ = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>(*source_cloud);
         report_ << "iter, n_success_steps, initial_cost, final_cost, tx, ty, tz, roll, pitch, yaw, mse_prev_iter, mse_gtruth"
                 << std::endl;
     }
@@ -95,11 +73,16 @@ ProbPointCloudRegistration::ProbPointCloudRegistration(pcl::PointCloud<pcl::Poin
     device_->check(ppcr_set_target(c, target_cloud_->size() ? &(*target_cloud_)[0].x : nullptr,
                                    static_cast<int64_t>(target_cloud_->size()), sizeof(pcl::PointXYZ)),
                    "ppcr_set_target");
-    // the association runs on the (possibly filtered) copy; the full copy is moved on the host when it
-    // differs from it (it is only ever read back for reporting)
+    // the association runs on the (possibly filtered) copy; when the two differ the full copy rides along on the
+    // device as the handle's companion: moved by every iteration, looked at by the reports, read back once
     device_->check(ppcr_set_source(c, filtered_source_cloud_->size() ? &(*filtered_source_cloud_)[0].x : nullptr,
                                    static_cast<int64_t>(filtered_source_cloud_->size()), sizeof(pcl::PointXYZ)),
                    "ppcr_set_source");
+    if (filtered_)
+        device_->check(ppcr_set_companion(c, source_cloud_->size() ? &(*source_cloud_)[0].x : nullptr,
+                                          static_cast<int64_t>(source_cloud_->size()), sizeof(pcl::PointXYZ)),
+                       "ppcr_set_companion");
+    if (parameters_.summary) device_->check(ppcr_mse_previous(c, nullptr), "ppcr_mse_previous");  // prev = source (cc:51)
 }
 
 ProbPointCloudRegistration::ProbPointCloudRegistration(pcl::PointCloud<pcl::PointXYZ>::Ptr source_cloud,
@@ -110,17 +93,23 @@ ProbPointCloudRegistration::ProbPointCloudRegistration(pcl::PointCloud<pcl::Poin
 {
     ground_truth_cloud_ = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>(*ground_truth_cloud);
     ground_truth_ = true;
-    mse_ground_truth_ = calculateMSE(source_cloud_, ground_truth_cloud_);
+    device_->check(ppcr_set_ground_truth(device_->get(), ground_truth_cloud_->size() ? &(*ground_truth_cloud_)[0].x : nullptr,
+                                         static_cast<int64_t>(ground_truth_cloud_->size()), sizeof(pcl::PointXYZ)),
+                   "ppcr_set_ground_truth");
+    device_->check(ppcr_mse_ground_truth(device_->get(), &mse_ground_truth_), "ppcr_mse_ground_truth");
     output_stream_ << "Initial MSE w.r.t. ground truth: " << mse_ground_truth_ << "\n";
 }
 
 ProbPointCloudRegistration::~ProbPointCloudRegistration() = default;
 
+// the caller-visible full-resolution source, read back from the device (companion when the source was filtered)
 void ProbPointCloudRegistration::fetchSource()
 {
-    if (filtered_) return;  // the full-resolution copy is maintained on the host in that case
     if (source_cloud_->empty()) return;
-    device_->check(ppcr_get_source(device_->get(), &(*source_cloud_)[0].x, sizeof(pcl::PointXYZ)), "ppcr_get_source");
+    if (filtered_)
+        device_->check(ppcr_get_companion(device_->get(), &(*source_cloud_)[0].x, sizeof(pcl::PointXYZ)), "ppcr_get_companion");
+    else
+        device_->check(ppcr_get_source(device_->get(), &(*source_cloud_)[0].x, sizeof(pcl::PointXYZ)), "ppcr_get_source");
 }
 
 void ProbPointCloudRegistration::align()
@@ -138,20 +127,14 @@ void ProbPointCloudRegistration::align()
         transformation_history_.push_back(current_trans);
         output_stream_ << "iteration " << current_iteration_ << ": initial_cost " << cost[0] << " final_cost " << cost[1]
                        << " inner steps " << steps << "\n";
-        const bool need_host_source = ground_truth_ || parameters_.summary;
-        if (filtered_) {
-            transformPointCloud(*source_cloud_, *source_cloud_, incremental);  // full copy follows on the host
-        } else if (need_host_source) {
-            fetchSource();
-        }
+        // both copies of the source were moved on the device by ppcr_iterate; the reports are device reductions
         if (ground_truth_) {
-            mse_ground_truth_ = calculateMSE(source_cloud_, ground_truth_cloud_);
+            device_->check(ppcr_mse_ground_truth(device_->get(), &mse_ground_truth_), "ppcr_mse_ground_truth");
             output_stream_ << "MSE w.r.t. ground truth: " << mse_ground_truth_ << "\n";
         }
         cost_drop_ = (cost[0] - cost[1]) / cost[0];
         if (parameters_.summary) {
-            mse_prev_it_ = calculateMSE(source_cloud_, prev_source_cloud_);
-            *prev_source_cloud_ = *source_cloud_;
+            device_->check(ppcr_mse_previous(device_->get(), &mse_prev_it_), "ppcr_mse_previous");
             const Eigen::Vector3d rpy = current_trans.rotation().eulerAngles(0, 1, 2);
             report_ << current_iteration_ << ", " << steps << ", " << cost[0] << ", " << cost[1] << ", "
                     << current_trans.translation().x() << ", " << current_trans.translation().y() << ", "
@@ -160,9 +143,9 @@ void ProbPointCloudRegistration::align()
         }
         current_iteration_++;
     }
-    if (!filtered_) fetchSource();
+    fetchSource();
     if (ground_truth_) {
-        mse_ground_truth_ = calculateMSE(source_cloud_, ground_truth_cloud_);
+        device_->check(ppcr_mse_ground_truth(device_->get(), &mse_ground_truth_), "ppcr_mse_ground_truth");
         std::cout << "MSE w.r.t. ground truth: " << mse_ground_truth_ << std::endl;
     }
 }

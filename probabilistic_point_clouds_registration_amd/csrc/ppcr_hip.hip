@@ -170,6 +170,12 @@ struct ppcr_ctx {
     // Verlet (skin) lists: second grid with cells >= r + skin, its own sorted copy of the target, the lists, and
     // the rigid motion accumulated since they were built
     double dbg_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics of the last ppcr_align (ppcr_debug_get_host_times)
+    // reporting clouds (the step after each iteration: cc:110-129): a full-resolution companion that follows every
+    // move of the source, the ground truth and the previous-iteration snapshot, all in the caller's index order
+    DevBuf<float4> companion, ground_truth, previous;
+    int64_t n_companion = 0, n_ground_truth = 0, n_previous = 0;
+    bool have_companion = false, have_ground_truth = false, have_previous = false;
+    DevBuf<double> mse_part;
     int opt_xcd_remap = 0;
     int opt_grid_xf = 4;         // x slices per grid cell (GridDesc::xr)
     int opt_emit_xyz = 0;        // K1 also leaves the neighbours' coordinates (k-major SoA) for K23 to stream: measured neutral
@@ -1042,6 +1048,17 @@ int apply_transform_impl(ppcr_ctx *c, const double T[12], bool defer = false)
     PPCR_TRY(flush_pending_move(c));
     std::memcpy(c->last_move_T, T, sizeof(c->last_move_T));
     c->moved_since_assoc = true;
+    if (c->have_companion && c->n_companion > 0) {
+        // the full-resolution copy moves with the same f64 -> f32 arithmetic, at once (it is off the hot path)
+        Pose P;
+        for (int a = 0; a < 3; a++) {
+            for (int b = 0; b < 3; b++) P.R[3 * a + b] = T[4 * a + b];
+            P.t[a] = T[4 * a + 3];
+            P.c[a] = 0;
+        }
+        ProfScope ps(c, K_TRANSFORM);
+        transform_kernel<<<nblocks(c->n_companion), kBlock, 0, c->stream>>>(c->companion.p, (int)c->n_companion, P);
+    }
     if (defer) {
         std::memcpy(c->pending_T, T, sizeof(c->pending_T));
         c->move_pending = true;
@@ -1183,6 +1200,9 @@ int ppcr_destroy(ppcr_ctx *c)
     c->tgt_sorted2.release();
     c->vl_nbr.release();
     c->nbr_xyz.release();
+    c->companion.release();
+    c->ground_truth.release();
+    c->previous.release();
     c->vl_cnt.release();
     c->keys_a.release();
     c->keys_b.release();
@@ -1321,6 +1341,7 @@ static int set_source_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, in
     c->ns = n;
     c->have_src = true;
     c->src_sorted = false;
+    if (!c->have_companion) c->have_previous = false;  // the snapshot belonged to the previous source
     invalidate_association(c);
     return PPCR_OK;
 }
@@ -1771,6 +1792,229 @@ int ppcr_profile_get(ppcr_ctx *c, ppcr_kernel_stat *out, int capacity, int *n_ou
     }
     if (n_out) *n_out = n;
     return PPCR_OK;
+}
+
+}  // extern "C"
+
+// ---- reporting clouds, voxel filter ----------------------------------------------------
+namespace {
+
+// the cloud the reference reports on: the full-resolution companion when one is set, else the source itself
+struct Tracked {
+    const float4 *p;
+    int64_t n;
+    int sorted;  // 1: the handle's sorted source (w lane = caller's index)
+};
+int tracked_cloud(ppcr_ctx *c, Tracked &t)
+{
+    if (c->have_companion) {
+        t = Tracked{c->companion.p, c->n_companion, 0};
+        return PPCR_OK;
+    }
+    if (!c->have_src) return fail(c, PPCR_ERR_STATE, "source cloud not set");
+    PPCR_TRY(flush_pending_move(c));
+    t = Tracked{c->src.p, c->ns, 1};
+    return PPCR_OK;
+}
+
+int mean_distance(ppcr_ctx *c, const Tracked &t, const float4 *other, double *out)
+{
+    if (t.n == 0) {
+        *out = std::numeric_limits<double>::quiet_NaN();  // 0 / 0, as the reference's loop would produce
+        return PPCR_OK;
+    }
+    const int nb = std::min(1024, nblocks(t.n));
+    HIP_TRY(c, c->mse_part.reserve((size_t)nb));
+    mean_distance_kernel<<<nb, kBlock, 0, c->stream>>>(t.p, (int)t.n, other, t.sorted, c->mse_part.p);
+    PPCR_TRY(check_launch(c, "mean_distance_kernel"));
+    std::vector<double> h((size_t)nb);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->mse_part.p, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double sum = 0;
+    for (double v : h) sum += v;
+    *out = sum / (double)t.n;
+    return PPCR_OK;
+}
+
+int snapshot_tracked(ppcr_ctx *c, const Tracked &t)
+{
+    HIP_TRY(c, c->previous.reserve((size_t)std::max<int64_t>(t.n, 1)));
+    if (t.n > 0) snapshot_kernel<<<nblocks(t.n), kBlock, 0, c->stream>>>(t.p, (int)t.n, t.sorted, c->previous.p);
+    PPCR_TRY(check_launch(c, "snapshot_kernel"));
+    c->n_previous = t.n;
+    c->have_previous = true;
+    return PPCR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ppcr_set_companion(ppcr_ctx *c, const float *xyz, int64_t n, int64_t stride_bytes)
+{
+    CTX_ENTER(c);
+    PPCR_TRY(upload_cloud(c, xyz, false, n, stride_bytes, c->companion));
+    c->n_companion = n;
+    c->have_companion = true;
+    c->have_previous = false;
+    return PPCR_OK;
+}
+
+int ppcr_get_companion(ppcr_ctx *c, float *xyz, int64_t stride_bytes)
+{
+    CTX_ENTER(c);
+    if (!c->have_companion) return fail(c, PPCR_ERR_STATE, "companion cloud not set");
+    if (stride_bytes < 12 || stride_bytes % 4) return fail(c, PPCR_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
+    if (c->n_companion == 0) return PPCR_OK;
+    if (!xyz) return fail(c, PPCR_ERR_INVALID, "null output");
+    std::vector<float4> h((size_t)c->n_companion);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->companion.p, sizeof(float4) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned char *out = reinterpret_cast<unsigned char *>(xyz);
+    for (size_t r = 0; r < h.size(); r++) {
+        float *p = reinterpret_cast<float *>(out + r * (size_t)stride_bytes);
+        p[0] = h[r].x;
+        p[1] = h[r].y;
+        p[2] = h[r].z;
+    }
+    return PPCR_OK;
+}
+
+int ppcr_set_ground_truth(ppcr_ctx *c, const float *xyz, int64_t n, int64_t stride_bytes)
+{
+    CTX_ENTER(c);
+    PPCR_TRY(upload_cloud(c, xyz, false, n, stride_bytes, c->ground_truth));
+    c->n_ground_truth = n;
+    c->have_ground_truth = true;
+    return PPCR_OK;
+}
+
+int ppcr_mse_ground_truth(ppcr_ctx *c, double *mse)
+{
+    CTX_ENTER(c);
+    if (!mse) return fail(c, PPCR_ERR_INVALID, "null output");
+    if (!c->have_ground_truth) return fail(c, PPCR_ERR_STATE, "ground truth cloud not set");
+    Tracked t;
+    PPCR_TRY(tracked_cloud(c, t));
+    // utilities.hpp:19 asserts equal sizes
+    if (t.n != c->n_ground_truth) return fail(c, PPCR_ERR_INVALID, "ground truth and source clouds differ in size");
+    return mean_distance(c, t, c->ground_truth.p, mse);
+}
+
+int ppcr_mse_previous(ppcr_ctx *c, double *mse)
+{
+    CTX_ENTER(c);
+    Tracked t;
+    PPCR_TRY(tracked_cloud(c, t));
+    if (mse) {
+        if (c->have_previous && c->n_previous == t.n) PPCR_TRY(mean_distance(c, t, c->previous.p, mse));
+        else *mse = 0.0;  // first call: nothing to compare with yet
+    }
+    return snapshot_tracked(c, t);  // *prev_source_cloud_ = *source_cloud_ (cc:122)
+}
+
+int ppcr_voxel_filter(int device_id, const float *xyz, int64_t n, int64_t stride_bytes, float leaf, float *out_xyz,
+                      int64_t out_stride_bytes, int64_t *n_out)
+{
+    if (!n_out) return fail(nullptr, PPCR_ERR_INVALID, "null n_out");
+    *n_out = 0;
+    if (!(leaf > 0) || !std::isfinite(leaf)) return fail(nullptr, PPCR_ERR_INVALID, "leaf size must be positive and finite");
+    if (out_stride_bytes < 12 || out_stride_bytes % 4) return fail(nullptr, PPCR_ERR_INVALID, "out_stride_bytes must be a multiple of 4 and >= 12");
+    if (n > 0 && !out_xyz) return fail(nullptr, PPCR_ERR_INVALID, "null output");
+    ppcr_ctx *c = nullptr;
+    PPCR_TRY(ppcr_create(device_id, &c));
+    auto body = [&]() -> int {
+        DevBuf<float4> pts;
+        struct Release {
+            DevBuf<float4> &b;
+            ~Release() { b.release(); }
+        } rel{pts};
+        PPCR_TRY(upload_cloud(c, xyz, false, n, stride_bytes, pts));
+        if (n == 0) return PPCR_OK;
+        float lo[3], hi[3];
+        // bounding box of the finite points; an all-non-finite cloud leaves no voxel at all
+        {
+            const int nbb = std::min(1024, nblocks(n));
+            HIP_TRY(c, c->bbox_part.reserve((size_t)nbb * 6));
+            bbox_kernel<<<nbb, kBlock, 0, c->stream>>>(pts.p, (int)n, c->bbox_part.p);
+            PPCR_TRY(check_launch(c, "bbox_kernel"));
+            std::vector<float> part((size_t)nbb * 6);
+            HIP_TRY(c, hipMemcpyAsync(part.data(), c->bbox_part.p, part.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            for (int a = 0; a < 3; a++) lo[a] = INFINITY, hi[a] = -INFINITY;
+            for (int b = 0; b < nbb; b++)
+                for (int a = 0; a < 3; a++) {
+                    lo[a] = std::min(lo[a], part[(size_t)b * 6 + a]);
+                    hi[a] = std::max(hi[a], part[(size_t)b * 6 + 3 + a]);
+                }
+            if (!(lo[0] <= hi[0])) return PPCR_OK;  // no finite point
+        }
+        VoxelDesc v;
+        v.inv = 1.0f / leaf;
+        int64_t d[3];
+        for (int a = 0; a < 3; a++) d[a] = (int64_t)((hi[a] - lo[a]) * v.inv) + 1;
+        unsigned char *out = reinterpret_cast<unsigned char *>(out_xyz);
+        if (d[0] * d[1] * d[2] > (int64_t)INT32_MAX) {
+            // pcl::VoxelGrid: "Leaf size is too small for the input dataset" -> the input is passed through
+            const unsigned char *in = reinterpret_cast<const unsigned char *>(xyz);
+            for (int64_t i = 0; i < n; i++)
+                std::memcpy(out + (size_t)i * (size_t)out_stride_bytes, in + (size_t)i * (size_t)stride_bytes, 12);
+            *n_out = n;
+            return PPCR_OK;
+        }
+        int div_b[3];
+        for (int a = 0; a < 3; a++) {
+            v.min_b[a] = (int)std::floor(lo[a] * v.inv);
+            div_b[a] = (int)std::floor(hi[a] * v.inv) - v.min_b[a] + 1;
+        }
+        v.mul[0] = 1;
+        v.mul[1] = div_b[0];
+        v.mul[2] = div_b[0] * div_b[1];
+        const int ni = (int)n;
+        HIP_TRY(c, c->keys_a.reserve((size_t)n + 1));
+        HIP_TRY(c, c->keys_b.reserve((size_t)n + 1));
+        HIP_TRY(c, c->vals_a.reserve((size_t)n + 1));
+        HIP_TRY(c, c->vals_b.reserve((size_t)n + 1));
+        voxel_key_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(pts.p, ni, v, c->keys_a.p, c->vals_a.p);
+        PPCR_TRY(check_launch(c, "voxel_key_kernel"));
+        size_t tmp_bytes = 0;
+        HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, c->keys_a.p, c->keys_b.p, c->vals_a.p, c->vals_b.p,
+                                                     ni, 0, 32, c->stream));
+        HIP_TRY(c, c->cub_tmp.reserve(tmp_bytes + 16));
+        HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp_bytes, c->keys_a.p, c->keys_b.p, c->vals_a.p,
+                                                     c->vals_b.p, ni, 0, 32, c->stream));
+        // run heads -> output slots (exclusive scan); keys_a / vals_a are free again
+        int *head = reinterpret_cast<int *>(c->keys_a.p), *slot = c->vals_a.p;
+        voxel_head_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(c->keys_b.p, ni, head);
+        PPCR_TRY(check_launch(c, "voxel_head_kernel"));
+        size_t scan_bytes = 0;
+        HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, head, slot, ni, c->stream));
+        HIP_TRY(c, c->cub_tmp.reserve(scan_bytes + 16));
+        HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, scan_bytes, head, slot, ni, c->stream));
+        int last_head = 0, last_slot = 0;
+        HIP_TRY(c, hipMemcpyAsync(&last_head, head + (ni - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&last_slot, slot + (ni - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const int64_t nv = (int64_t)last_slot + last_head;
+        DevBuf<float> cent;
+        struct Release2 {
+            DevBuf<float> &b;
+            ~Release2() { b.release(); }
+        } rel2{cent};
+        HIP_TRY(c, cent.reserve((size_t)std::max<int64_t>(nv, 1) * 3));
+        voxel_centroid_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(pts.p, c->keys_b.p, c->vals_b.p, head, slot, ni, cent.p);
+        PPCR_TRY(check_launch(c, "voxel_centroid_kernel"));
+        std::vector<float> h((size_t)nv * 3);
+        if (nv > 0) HIP_TRY(c, hipMemcpyAsync(h.data(), cent.p, sizeof(float) * h.size(), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (int64_t k = 0; k < nv; k++) std::memcpy(out + (size_t)k * (size_t)out_stride_bytes, &h[(size_t)k * 3], 12);
+        *n_out = nv;
+        return PPCR_OK;
+    };
+    const int rc = body();
+    if (rc != PPCR_OK) g_create_error = c->err;  // the temporary handle goes away: keep its message
+    ppcr_destroy(c);
+    return rc;
 }
 
 }  // extern "C"

@@ -1714,5 +1714,104 @@ __global__ void transform_kernel(float4 *__restrict__ pts, int n, Pose P)
     pts[i] = p;
 }
 
+// ---------------------------------------------------------------------------------------------
+// pcl::VoxelGrid centroid down-sampling (the step before the path: src/prob_point_cloud_registration.cc:24-41).
+// One fixed definition (the CPU checker in the test tree restates it bit for bit): voxel index from float floor(p * inv),
+// points of one voxel added in ascending original index (the radix sort is stable), float sums, float division.
+// ---------------------------------------------------------------------------------------------
+struct VoxelDesc {
+    float inv;
+    int min_b[3];
+    int mul[3];
+};
+constexpr unsigned kVoxelInvalid = 0xFFFFFFFFu;  // non-finite points: sorted to the end and dropped
+
+__global__ void voxel_key_kernel(const float4 *__restrict__ pts, int n, VoxelDesc v, unsigned *__restrict__ keys,
+                                 int *__restrict__ vals)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    unsigned key = kVoxelInvalid;
+    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+        const int ix = (int)(floorf(__fmul_rn(p.x, v.inv)) - (float)v.min_b[0]);
+        const int iy = (int)(floorf(__fmul_rn(p.y, v.inv)) - (float)v.min_b[1]);
+        const int iz = (int)(floorf(__fmul_rn(p.z, v.inv)) - (float)v.min_b[2]);
+        key = (unsigned)(ix * v.mul[0] + iy * v.mul[1] + iz * v.mul[2]);
+    }
+    keys[i] = key;
+    vals[i] = i;
+}
+
+// head[i] = 1 where a voxel's run starts in the sorted keys
+__global__ void voxel_head_kernel(const unsigned *__restrict__ keys, int n, int *__restrict__ head)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned k = keys[i];
+    head[i] = (k != kVoxelInvalid && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
+}
+
+// one lane per voxel run: sequential float sum in sorted (= ascending original index) order
+__global__ void voxel_centroid_kernel(const float4 *__restrict__ pts, const unsigned *__restrict__ keys,
+                                      const int *__restrict__ order, const int *__restrict__ head,
+                                      const int *__restrict__ slot, int n, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !head[i]) return;
+    const unsigned k = keys[i];
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    int e = i;
+    while (e < n && keys[e] == k) {
+        const float4 p = pts[order[e]];
+        cx = __fadd_rn(cx, p.x);
+        cy = __fadd_rn(cy, p.y);
+        cz = __fadd_rn(cz, p.z);
+        e++;
+    }
+    const float cnt = (float)(e - i);
+    float *o = out + (size_t)slot[i] * 3;
+    o[0] = __fdiv_rn(cx, cnt);
+    o[1] = __fdiv_rn(cy, cnt);
+    o[2] = __fdiv_rn(cz, cnt);
+}
+
+// ---------------------------------------------------------------------------------------------
+// calculateMSE (utilities.hpp:16-26; despite the name: the MEAN EUCLIDEAN DISTANCE of index-paired points, float
+// distance as pcl::euclideanDistance, double sum).  a is either a plain cloud (pair i <-> b[i]) or the handle's
+// sorted source, whose w lane holds the caller's index (pair r <-> b[w(r)]).  partials[block] = block sum.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void mean_distance_kernel(const float4 *__restrict__ a, int n,
+                                                               const float4 *__restrict__ b, int a_is_sorted_source,
+                                                               double *__restrict__ partials)
+{
+    __shared__ double sh[kBlock / 64];
+    double acc = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float4 p = a[i];
+        const float4 q = b[a_is_sorted_source ? __float_as_int(p.w) : i];
+        const float dx = __fsub_rn(p.x, q.x), dy = __fsub_rn(p.y, q.y), dz = __fsub_rn(p.z, q.z);
+        // sqrtf, not __fsqrt_rn: the intrinsic maps to the 1-ulp hardware sqrt, sqrtf is correctly rounded
+        acc += (double)sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double v = sh[0];
+        for (int w = 1; w < kBlock / 64; w++) v += sh[w];
+        partials[blockIdx.x] = v;
+    }
+}
+
+// snapshot of the tracked cloud in the caller's index order: dst[w(r)] = a[r] (sorted source) or dst[i] = a[i]
+__global__ void snapshot_kernel(const float4 *__restrict__ a, int n, int a_is_sorted_source, float4 *__restrict__ dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = a[i];
+    dst[a_is_sorted_source ? __float_as_int(p.w) : i] = p;
+}
+
 }  // namespace dev
 }  // namespace ppcr

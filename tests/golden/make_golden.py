@@ -137,8 +137,39 @@ def align(src, tgt, radius, max_nn, v, n_iter, inner_steps, f_tol=1e-5, dim=3):
     return np.asarray(hist), np.asarray(costs), np.asarray(steps_l, np.int32), src
 
 
+def voxel_grid(cloud, leaf):
+    """pcl::VoxelGrid<PointXYZ> centroid down-sampling, numpy restatement (float32 throughout; the points of a voxel
+    are added in ascending original index)."""
+    a = np.asarray(cloud, np.float32)[:, :3]
+    fin = np.isfinite(a).all(1)
+    idx_pts = np.nonzero(fin)[0]
+    a = a[fin]
+    inv = np.float32(1.0) / np.float32(leaf)
+    lo, hi = a.min(0), a.max(0)
+    minb = np.floor(lo * inv).astype(np.int32)
+    divb = np.floor(hi * inv).astype(np.int32) - minb + 1
+    ijk = (np.floor(a * inv) - minb.astype(np.float32)).astype(np.int32)
+    idx = ijk[:, 0] + ijk[:, 1] * divb[0] + ijk[:, 2] * divb[0] * divb[1]
+    order = np.lexsort((idx_pts, idx))
+    _, start, cnt = np.unique(idx[order], return_index=True, return_counts=True)
+    out = np.zeros((len(start), 3), np.float32)
+    for k, (s0, c) in enumerate(zip(start, cnt)):
+        acc = np.zeros(3, np.float32)
+        for j in order[s0:s0 + c]:
+            acc = acc + a[j]
+        out[k] = acc / np.float32(c)
+    return out
+
+
 # --------------------------------------------------------------------------- fixtures
 def main():
+    # 0. voxel-grid down-sampling (the step before the path)
+    rng = np.random.default_rng(77)
+    cloud = (rng.random((4000, 3)) * np.array([12, 9, 5]) - np.array([6, 2, 1])).astype(np.float32)
+    cloud[::97, 2] = np.nan
+    np.savez_compressed(os.path.join(HERE, "voxel_4k.npz"), cloud=cloud, leaf_1=voxel_grid(cloud, 1.0),
+                        leaf_037=voxel_grid(cloud, 0.37))
+
     # 1. random 2k clouds at the benchmark density, m = 10 and m = 5, plus unbounded
     src, tgt, Rgt, tgt_t = synth.make_pair(2000, cfg=1, stride=3)
     out = dict(src=src, tgt=tgt, R_gt=Rgt, t_gt=tgt_t)

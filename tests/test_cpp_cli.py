@@ -109,3 +109,48 @@ def test_cli_without_verbose_writes_nothing(programs, tmp_path):
                        capture_output=True, text=True, cwd=tmp_path, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert sorted(os.listdir(tmp_path)) == ["a.pcd", "b.pcd"]     # aligned_* only with -v, summary only with --dump
+
+
+@pytest.mark.gpu
+def test_cli_with_voxel_filters_ground_truth_and_report(programs, tmp_path):
+    """-s / -t down-sample on the device, the association runs on the filtered source while the FULL source is
+    moved along (cc:110-112) and reported on (cc:114-122): emulate the whole pipeline with the oracle."""
+    cli = programs[0]
+    src, tgt, Rgt, tgt_t = synth.make_pair(12000, cfg=1, stride=3)
+    gt = (src.astype(np.float64) @ Rgt.T + tgt_t).astype(np.float32)
+    write_pcd(tmp_path / "a.pcd", src, binary=True)
+    write_pcd(tmp_path / "b.pcd", tgt, binary=True)
+    write_pcd(tmp_path / "gt.pcd", gt, binary=True)
+    n_it = 5
+    r = subprocess.run([cli, "-r", "1.5", "-m", "6", "-i", str(n_it), "-c", "0", "-s", "0.9", "-t", "0.8", "-v", "--dump",
+                        "-g", str(tmp_path / "gt.pcd"), str(tmp_path / "a.pcd"), str(tmp_path / "b.pcd")],
+                       capture_output=True, text=True, cwd=tmp_path, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # oracle emulation
+    fs, ft = po.voxel_filter(src, 0.9), po.voxel_filter(tgt, 0.8)
+    assert 0 < fs.shape[0] < src.shape[0] and 0 < ft.shape[0] < tgt.shape[0]
+    ora = po.align(fs, ft, 1.5, 6, 5.0, n_it, cost_drop_thresh=0.0, inner_max_steps=100, f_tol=10e-6)
+    full, prev = src.copy(), src.copy()
+    mse_prev, mse_gt = [], []
+    Tcum_prev = np.eye(4)
+    for k in range(n_it):
+        Tcum = np.vstack([ora["history"][k], [0, 0, 0, 1]])
+        Tk = Tcum @ np.linalg.inv(Tcum_prev)                 # incremental transform of iteration k
+        Tcum_prev = Tcum
+        po.transform_cloud(full, Tk)
+        mse_gt.append(po.calculate_mse(full, gt))
+        mse_prev.append(po.calculate_mse(full, prev))
+        prev = full.copy()
+    rep = open(tmp_path / "a_b_summary.txt").read().splitlines()
+    assert len(rep) == 4 + n_it
+    for k in range(n_it):
+        row = [float(v) for v in rep[4 + k].split(",")]
+        np.testing.assert_allclose([row[2], row[3]], ora["costs"][k], rtol=1e-5)
+        np.testing.assert_allclose(row[4:7], ora["history"][k][:, 3], atol=2e-6, rtol=1e-5)
+        assert abs(row[10] - mse_prev[k]) < 2e-6 * max(1.0, mse_prev[k]) + 1e-7      # six significant digits in the file
+        assert abs(row[11] - mse_gt[k]) < 2e-6 * max(1.0, mse_gt[k]) + 1e-7
+    m = re.findall(r"MSE w\.r\.t\. ground truth: ([0-9.eE+-]+)", r.stdout)
+    assert abs(float(m[-1]) - mse_gt[-1]) < 2e-6
+    aligned = read_pcd_ascii(tmp_path / "aligned_a.pcd")     # the FULL source, moved
+    assert aligned.shape[0] == src.shape[0]
+    np.testing.assert_allclose(aligned, full, atol=2e-5)

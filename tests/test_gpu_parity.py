@@ -422,6 +422,78 @@ def test_python_mirror_and_batch_single_rank(ctx):
         assert np.linalg.norm(all_T[p][:, 3] - ora["history"][-1][:, 3]) < TRANS_TOL
 
 
+def test_voxel_filter_matches_oracle_bit_for_bit(ctx):
+    """The VoxelGrid step before the path: voxel membership, output order and the float centroids equal the oracle's
+    (same voxel index arithmetic, points of a voxel added in ascending original index)."""
+    rng = np.random.default_rng(5)
+    for n, leaf, stride in ((5000, 1.0, 3), (40000, 0.37, 4), (1000, 25.0, 3), (3, 0.5, 3)):
+        a = np.zeros((n, stride), np.float32)
+        a[:, :3] = (rng.random((n, 3)) * 20 - 7).astype(np.float32)
+        g = _lib.voxel_filter(a, leaf)
+        o = po.voxel_filter(a, leaf)
+        assert g.shape == o.shape and g.shape[0] <= n
+        np.testing.assert_array_equal(g, o)
+    # non-finite points are skipped; an all-non-finite cloud yields nothing; empty cloud
+    a = (rng.random((300, 3)) * 4).astype(np.float32)
+    b = a.copy()
+    b[::7, 1] = np.nan
+    b[5, 0] = np.inf
+    np.testing.assert_array_equal(_lib.voxel_filter(b, 0.5), po.voxel_filter(b, 0.5))
+    assert _lib.voxel_filter(np.full((4, 3), np.nan, np.float32), 1.0).shape == (0, 3)
+    assert _lib.voxel_filter(np.zeros((0, 3), np.float32), 1.0).shape == (0, 3)
+    # leaf too small for the extent: PCL passes the input through
+    wide = np.array([[0, 0, 0], [3e5, 3e5, 3e5], [1, 2, 3]], np.float32)
+    np.testing.assert_array_equal(_lib.voxel_filter(wide, 0.01), wide)
+    np.testing.assert_array_equal(po.voxel_filter(wide, 0.01), wide)
+    # 1M points
+    big = (rng.random((1000000, 3)) * 64 - 32).astype(np.float32)
+    np.testing.assert_array_equal(_lib.voxel_filter(big, 0.8), po.voxel_filter(big, 0.8))
+    with pytest.raises(_lib.PpcrError):
+        _lib.voxel_filter(a, 0.0)
+
+
+def test_companion_and_reports_follow_the_source(ctx):
+    """The reporting step after each iteration (cc:110-129): the full-resolution companion is moved by every
+    transform applied to the source, bit for bit as the oracle's transform; the two mean-distance reports equal
+    calculateMSE on the host copies."""
+    src, tgt, _, _ = synth.make_pair(6000, cfg=1, stride=3)
+    full = np.concatenate([src, (src + np.float32(0.013))[::2]]).astype(np.float32)   # any cloud, another size
+    gt = full + np.float32(0.05)
+    with _lib.Context(0) as c:
+        c.set_params(1.0, 10, 5.0, 3)
+        c.set_target(tgt)
+        c.set_source(src)
+        c.set_companion(full)
+        c.set_ground_truth(gt)
+        assert abs(c.mse_ground_truth() - po.calculate_mse(full, gt)) < 1e-12
+        assert c.mse_previous() == 0.0                      # first call only takes the snapshot
+        cur, prev = full.copy(), full.copy()
+        for it in range(4):
+            T, _, _ = c.iterate(inner_steps=1)
+            po.transform_cloud(cur, np.vstack([T, [0, 0, 0, 1]]))
+            np.testing.assert_array_equal(c.get_companion(), cur)
+            assert abs(c.mse_ground_truth() - po.calculate_mse(cur, gt)) < 1e-12
+            assert abs(c.mse_previous() - po.calculate_mse(cur, prev)) < 1e-12
+            prev = cur.copy()
+        c.set_ground_truth(gt[:-1])
+        with pytest.raises(_lib.PpcrError, match="differ in size"):
+            c.mse_ground_truth()
+    # without a companion the reports look at the source itself (caller's order, whatever the device order is)
+    with _lib.Context(0) as c:
+        c.set_params(1.0, 10, 5.0, 3)
+        c.set_target(tgt)
+        c.set_source(src)
+        c.set_ground_truth(tgt[:src.shape[0]])
+        cur = src.copy()
+        c.mse_previous()
+        for it in range(3):
+            T, _, _ = c.iterate(inner_steps=1)
+            prev = cur.copy()
+            po.transform_cloud(cur, np.vstack([T, [0, 0, 0, 1]]))
+            assert abs(c.mse_ground_truth() - po.calculate_mse(cur, tgt[:src.shape[0]])) < 1e-12
+            assert abs(c.mse_previous() - po.calculate_mse(cur, prev)) < 1e-12
+
+
 def test_batch_run_and_align_many(ctx):
     """ppcr_batch_run (host buffers in, worker lanes inside) and ppcr_align_many (resident handles): every pair's
     final transform equals the same pair registered alone, and the oracle's, whatever the lane count."""

@@ -148,3 +148,12 @@ def test_transform_cloud_rounding():
     po.transform_cloud(p4, T)
     np.testing.assert_array_equal(p4[:, :3], got)
     assert (p4[:, 3] == 7.0).all()
+
+
+def test_voxel_filter_matches_numpy_restatement():
+    """po_voxel_filter against the independent numpy restatement of pcl::VoxelGrid (tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(GOLD, "voxel_4k.npz"))
+    for key, leaf in (("leaf_1", 1.0), ("leaf_037", 0.37)):
+        out = po.voxel_filter(g["cloud"], leaf)
+        np.testing.assert_array_equal(out, g[key])
+    assert po.voxel_filter(np.zeros((0, 3), np.float32), 1.0).shape == (0, 3)
