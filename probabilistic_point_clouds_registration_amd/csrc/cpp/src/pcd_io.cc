@@ -20,6 +20,38 @@ struct Field {
     int offset = 0;
 };
 
+// LZF decoder (the stream format of liblzf, which PCL bundles for DATA binary_compressed).  A control byte c:
+//   c < 32        -> copy the next c + 1 bytes literally;
+//   otherwise     -> back reference: length = c >> 5 (7 means "add the next byte"), then + 2;
+//                    distance = ((c & 31) << 8 | next byte) + 1 behind the write position (may overlap it).
+// Returns the number of bytes produced, 0 on a malformed or over-long stream.
+std::size_t lzfDecompress(const unsigned char *in, std::size_t in_len, unsigned char *out, std::size_t out_cap)
+{
+    std::size_t ip = 0, op = 0;
+    while (ip < in_len) {
+        const unsigned ctrl = in[ip++];
+        if (ctrl < 32) {
+            const std::size_t run = ctrl + 1;
+            if (ip + run > in_len || op + run > out_cap) return 0;
+            std::memcpy(out + op, in + ip, run);
+            ip += run;
+            op += run;
+        } else {
+            std::size_t len = ctrl >> 5;
+            if (len == 7) {
+                if (ip >= in_len) return 0;
+                len += in[ip++];
+            }
+            if (ip >= in_len) return 0;
+            const std::size_t dist = (static_cast<std::size_t>(ctrl & 31u) << 8 | in[ip++]) + 1;
+            len += 2;
+            if (dist > op || op + len > out_cap) return 0;
+            for (std::size_t k = 0; k < len; k++, op++) out[op] = out[op - dist];  // byte-wise: source may overlap
+        }
+    }
+    return op;
+}
+
 std::vector<std::string> split(const std::string &line)
 {
     std::istringstream is(line);
@@ -125,8 +157,45 @@ int loadPCDFile(const std::string &file_name, pcl::PointCloud<pcl::PointXYZ> &cl
             std::memcpy(&p.y, rec + fields[iy].offset, 4);
             std::memcpy(&p.z, rec + fields[iz].offset, 4);
         }
+    } else if (data_mode == "binary_compressed") {
+        // uint32 compressed size, uint32 uncompressed size, LZF stream; the payload is a struct of arrays: all
+        // values of field 0 for every point, then field 1, ... (each field block is size * count * points bytes)
+        std::uint32_t sizes[2] = {0, 0};
+        in.read(reinterpret_cast<char *>(sizes), 8);
+        if (in.gcount() != 8) {
+            std::cerr << "[pcd] " << file_name << ": truncated binary_compressed header" << std::endl;
+            return -1;
+        }
+        const std::size_t expect = static_cast<std::size_t>(off) * static_cast<std::size_t>(points);
+        if (sizes[1] != expect) {
+            std::cerr << "[pcd] " << file_name << ": uncompressed size " << sizes[1] << " does not match the header (" << expect
+                      << ")" << std::endl;
+            return -1;
+        }
+        std::vector<unsigned char> comp(sizes[0]), raw(expect);
+        in.read(reinterpret_cast<char *>(comp.data()), static_cast<std::streamsize>(comp.size()));
+        if (static_cast<std::size_t>(in.gcount()) != comp.size()) {
+            std::cerr << "[pcd] " << file_name << ": truncated binary_compressed data" << std::endl;
+            return -1;
+        }
+        if (expect > 0 && lzfDecompress(comp.data(), comp.size(), raw.data(), raw.size()) != expect) {
+            std::cerr << "[pcd] " << file_name << ": corrupt LZF stream" << std::endl;
+            return -1;
+        }
+        const std::size_t np = static_cast<std::size_t>(points);
+        auto block = [&](int f) { return raw.data() + static_cast<std::size_t>(fields[f].offset) * np; };
+        const std::size_t sx = static_cast<std::size_t>(fields[ix].size * fields[ix].count);
+        const std::size_t sy = static_cast<std::size_t>(fields[iy].size * fields[iy].count);
+        const std::size_t sz = static_cast<std::size_t>(fields[iz].size * fields[iz].count);
+        for (std::size_t i = 0; i < np; i++) {
+            pcl::PointXYZ &p = cloud.points[i];
+            std::memcpy(&p.x, block(ix) + i * sx, 4);
+            std::memcpy(&p.y, block(iy) + i * sy, 4);
+            std::memcpy(&p.z, block(iz) + i * sz, 4);
+        }
     } else {
-        std::cerr << "[pcd] " << file_name << ": DATA " << data_mode << " is not supported (ascii and binary are)" << std::endl;
+        std::cerr << "[pcd] " << file_name << ": DATA " << data_mode << " is not supported (ascii, binary and binary_compressed are)"
+                  << std::endl;
         return -1;
     }
     return 0;

@@ -31,6 +31,69 @@ def write_pcd(path, pts, binary=False):
                 f.write(("%.9g %.9g %.9g\n" % tuple(p)).encode())
 
 
+def lzf_compress(data):
+    """Small greedy LZF encoder for the tests (literal runs + back references with a 3-byte hash), producing the
+    stream format liblzf defines; the decoder under test is the C++ one."""
+    data = bytes(data)
+    out = bytearray()
+    lit = bytearray()
+    table = {}
+    i, n = 0, len(data)
+
+    def flush():
+        nonlocal lit
+        for k in range(0, len(lit), 32):
+            chunk = lit[k:k + 32]
+            out.append(len(chunk) - 1)
+            out.extend(chunk)
+        lit = bytearray()
+
+    while i < n:
+        ref = table.get(data[i:i + 3]) if i + 2 < n else None
+        if i + 2 < n:
+            table[data[i:i + 3]] = i
+        if ref is not None and 0 < i - ref <= 8192:
+            length = 3
+            while i + length < n and length < 264 and data[ref + length] == data[i + length]:
+                length += 1
+            flush()
+            dist, l2 = i - ref - 1, length - 2
+            if l2 < 7:
+                out.append((l2 << 5) | (dist >> 8))
+            else:
+                out.append((7 << 5) | (dist >> 8))
+                out.append(l2 - 7)
+            out.append(dist & 0xFF)
+            i += length
+        else:
+            lit.append(data[i])
+            i += 1
+    flush()
+    return bytes(out)
+
+
+def write_pcd_compressed(path, pts, extra_field=True):
+    """DATA binary_compressed: uint32 sizes + LZF of the struct-of-arrays payload (optionally with a 4th field)."""
+    import struct
+    pts = np.asarray(pts, np.float32)[:, :3]
+    n = len(pts)
+    cols = [pts[:, 0], pts[:, 1], pts[:, 2]]
+    fields, sizes, types = "x y z", "4 4 4", "F F F"
+    if extra_field:                                              # an intensity column between y and z
+        cols = [pts[:, 0], pts[:, 1], np.arange(n, dtype=np.float32), pts[:, 2]]
+        fields, sizes, types = "x y intensity z", "4 4 4 4", "F F F F"
+    raw = b"".join(np.ascontiguousarray(c).tobytes() for c in cols)
+    comp = lzf_compress(raw)
+    hdr = (f"# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS {fields}\nSIZE {sizes}\nTYPE {types}\n"
+           f"COUNT {' '.join('1' for _ in cols)}\nWIDTH {n}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {n}\n"
+           "DATA binary_compressed\n")
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        f.write(struct.pack("<II", len(comp), len(raw)))
+        f.write(comp)
+    return len(comp), len(raw)
+
+
 def read_pcd_ascii(path):
     lines = open(path).read().splitlines()
     k = next(i for i, l in enumerate(lines) if l.startswith("DATA"))
@@ -98,6 +161,35 @@ def test_cli_end_to_end_matches_oracle(programs, tmp_path, gauss):
     row = [float(v) for v in rep[-1].split(",")]
     assert row[0] == 6 and abs(row[4] - t_cli[0]) < 1e-5
     np.testing.assert_allclose([row[2], row[3]], ora["costs"][-1], rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_cli_reads_binary_compressed_pcd(programs, tmp_path):
+    """DATA binary_compressed (LZF, struct-of-arrays payload, extra field in the middle): same result as the same
+    clouds given as plain binary files."""
+    cli = programs[0]
+    src, tgt, _, _ = synth.make_pair(2500, cfg=1, stride=3)
+    src = np.round(src * 8) / 8                                  # repetitive bytes: the encoder emits back references
+    tgt = np.round(tgt * 8) / 8
+    nc, nr = write_pcd_compressed(tmp_path / "a.pcd", src, extra_field=True)
+    assert nc < nr                                               # really compressed
+    write_pcd_compressed(tmp_path / "b.pcd", tgt, extra_field=False)
+    write_pcd(tmp_path / "a_plain.pcd", src, binary=True)
+    write_pcd(tmp_path / "b_plain.pcd", tgt, binary=True)
+    outs = []
+    for a, b in (("a.pcd", "b.pcd"), ("a_plain.pcd", "b_plain.pcd")):
+        r = subprocess.run([cli, "-r", "1", "-m", "5", "-i", "3", "-c", "0", "-v", str(tmp_path / a), str(tmp_path / b)],
+                           capture_output=True, text=True, cwd=tmp_path, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(re.findall(r"^T: .*$", r.stdout, flags=re.M))
+    assert len(outs[0]) == 3 and outs[0] == outs[1]
+    np.testing.assert_array_equal(read_pcd_ascii(tmp_path / "aligned_a.pcd"), read_pcd_ascii(tmp_path / "aligned_a_plain.pcd"))
+    # a corrupt stream is refused like any unreadable cloud
+    blob = bytearray(open(tmp_path / "a.pcd", "rb").read())
+    blob[-40:] = b"\xff" * 40
+    open(tmp_path / "bad.pcd", "wb").write(blob)
+    r = subprocess.run([cli, str(tmp_path / "bad.pcd"), str(tmp_path / "b.pcd")], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 1 and "Could not load source cloud, closing" in r.stdout
 
 
 @pytest.mark.gpu
