@@ -657,8 +657,30 @@ struct GlobalCands {  // candidate source = global memory; list entries are sort
     }
 };
 
+// Visit the lane's list entries [0, n) as f(slot, entry, d2 bits), FOUR entries per trip: their index loads, then
+// their coordinate loads, are issued together, so a trip costs two LDS round trips instead of eight (selection
+// phase -10 % while the source moves; it is mostly instruction-bound: ~36 instructions per entry over two passes).
+// f may store to slots <= the one it is called with (in-place compaction): a trip reads before it writes.
+template <class S, class F>
+__device__ __forceinline__ void for_each_entry(const S &src, float4 q, int n, F &&f)
+{
+    for (int t = 0; t < n; t += 4) {
+        int e[4];
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = src.load(min(t + u, n - 1));
+#pragma unroll
+        for (int u = 0; u < 4; u++) p[u] = src.get(e[u]);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (t + u < n) f(t + u, e[u], __float_as_uint(dist2_flann(q, p[u])));
+    }
+}
+
 // reduce a lane's list (n > m entries) to its top-m by (d2, original index); returns the new n and
 // the threshold T (bit pattern of the m-th smallest d2)
+// (Keeping the first 16 entries' d2 bits in registers between the two passes was measured too: selection
+//  -20 %, but 176 VGPRs -> 2 waves/SIMD (190 us), or 168 with spills for a net 1 %: not kept.)
 template <int M, class S>
 __device__ __forceinline__ int select_top_m(const S &src, const float4 *__restrict__ tgt, float4 q, int n, int m,
                                             unsigned &thr)
@@ -666,18 +688,16 @@ __device__ __forceinline__ int select_top_m(const S &src, const float4 *__restri
     unsigned K[M];
 #pragma unroll
     for (int j = 0; j < M; j++) K[j] = 0xFFFFFFFFu;
-    for (int t = 0; t < n; t++) sorted_insert<M>(K, __float_as_uint(dist2_flann(q, src.get(src.load(t)))));
+    for_each_entry(src, q, n, [&](int, int, unsigned b) { sorted_insert<M>(K, b); });
     const unsigned T = pick<M>(K, m - 1);
     int w = 0, c_eq = 0;
-    for (int t = 0; t < n; t++) {
-        const int e = src.load(t);
-        const unsigned b = __float_as_uint(dist2_flann(q, src.get(e)));
+    for_each_entry(src, q, n, [&](int, int e, unsigned b) {
         if (b <= T) {
             src.store(w, e);
             w++;
             c_eq += (b == T) ? 1 : 0;
         }
-    }
+    });
     if (w > m) {  // more ties at the cut-off than room: lowest original target indices win
         const int need = m - (w - c_eq);
 #pragma unroll
@@ -1075,7 +1095,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                     tm = thr;
                 } else if (n == m) {
                     tm = 0;
-                    for (int j = 0; j < n; j++) tm = max(tm, __float_as_uint(dist2_flann(q, L.get(L.load(j)))));
+                    for_each_entry(L, q, n, [&](int, int, unsigned b) { tm = max(tm, b); });
                 }
                 stamp(4);
                 if (nxyz) {
@@ -1134,7 +1154,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                     tm = thr;
                 } else if (n == m) {
                     tm = 0;
-                    for (int j = 0; j < n; j++) tm = max(tm, __float_as_uint(dist2_flann(q, G.get(G.load(j)))));
+                    for_each_entry(G, q, n, [&](int, int, unsigned b) { tm = max(tm, b); });
                 }
                 for (int j = 0; j < n; j++) {
                     const int e = G.load(j);
