@@ -627,6 +627,16 @@ __global__ __launch_bounds__(kBlock) void moments_from_rows_kernel(const float4 
 // ---------------------------------------------------------------------------------------------
 constexpr int kTileRows = 128;   // halo rows per staging
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL load
+// (s_waitcnt vmcnt(0)): in nn_tile_kernel that serialises the run-bound loads issued in the prologue with the
+// row-table and staging loads behind the barrier; with the LDS-only fences they stay in flight across it.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <int BLOCK>
 struct LdsCands {  // candidate source = staged halo (SoA in LDS); list entries are LDS indices
     const float *sx, *sy, *sz;
@@ -877,7 +887,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                 s_whi[wave][a] = hi[a];
             }
     }
-    __syncthreads();
+    lds_barrier();
     stamp(0);
 
     int n = 0;
@@ -976,7 +986,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             stamp(2);
             if (!done && wave >= w0 && wave < w1) {
                 const LdsCands<BLOCK> L{s_x, s_y, s_z, s_pos, s_list, tid};
@@ -1121,7 +1131,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
             }
             done_mask |= pass_mask;
             if (done_mask == (1u << kWaves) - 1u) break;  // common case: nothing left, no trailing barrier
-            __syncthreads();                              // the halo buffer is reused by the next pass
+            lds_barrier();                              // the halo buffer is reused by the next pass
             stamp(6);
         } else if (last_level) {
             // last resort for this wave: scan global memory (list of positions aliases the halo buffer)
@@ -1173,7 +1183,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                 }
             }
             done_mask |= pass_mask;
-            __syncthreads();
+            lds_barrier();
             stamp(7);
         }
       }
