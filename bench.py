@@ -140,6 +140,10 @@ def main():
         else:
             for c in ctxs:
                 c.align(a.warmup, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
+    if dist is not None:
+        # the collective is warmed up too (communicator set-up and its buffers are not part of a step)
+        batch.gather_transforms({p: np.eye(4)[:3] for p in my_pairs}, n_pairs, dist=dist,
+                                device=torch.device("cuda", local_rank))
     barrier()
     gathered = None
     t0 = time.perf_counter()

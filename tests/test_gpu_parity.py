@@ -596,6 +596,51 @@ def test_temporal_cutoff_and_deferred_move_change_nothing(ctx):
         b.close()
 
 
+@pytest.mark.parametrize("xf", [1, 2, 4, 8])
+def test_nn_exact_for_every_grid_slicing(ctx, xf):
+    """The x-sliced grid and the per-row clipped runs must not change a single neighbour or d2 bit, whatever the
+    number of slices: moving source (temporal cut-off active), queries outside the target's bounding box, a radius
+    that does not divide the extent, a tiny cloud whose table cap drops the slices again."""
+    rng = np.random.default_rng(100 + xf)
+    src, tgt, _, _ = synth.make_pair(20000, cfg=2, stride=3)
+    src = src.copy()
+    src[:200] += rng.normal(0, 8.0, (200, 3)).astype(np.float32)        # far outside the grid
+    src[200:400, 0] += np.float32(0.999)                                 # just inside / outside neighbouring slices
+    for radius, m in ((1.0, 10), (0.73, 6), (1.9, 20)):
+        with _lib.Context(0) as c:
+            c.set_option("grid_xf", xf)
+            c.set_params(radius, m, 5.0, 3)
+            c.set_target(tgt)
+            c.set_source(src)
+            cur = src.copy()
+            for it in range(3):
+                c.associate()
+                rp, col, d2 = c.get_association()
+                orp, ocol, od2 = po.radius_search(cur, tgt, radius, m, method=1)
+                np.testing.assert_array_equal(rp, orp)
+                np.testing.assert_array_equal(col, ocol)
+                np.testing.assert_array_equal(d2, od2)
+                T = np.eye(4)
+                T[:3, :3] = synth.rodrigues([0.3, -1.0, 0.5], 0.004 * (it + 1))
+                T[:3, 3] = [0.011, -0.007, 0.004]
+                c.apply_transform(T)
+                po.transform_cloud(cur, T)
+    small_s, small_t, _, _ = synth.make_pair(300, cfg=1, stride=3)
+    with _lib.Context(0) as c:
+        c.set_option("grid_xf", xf)
+        c.set_params(1.0, 5, 5.0, 3)
+        c.set_target(small_t)
+        c.set_source(small_s)
+        c.associate()
+        rp, col, d2 = c.get_association()
+        orp, ocol, od2 = po.radius_search(small_s, small_t, 1.0, 5, method=1)
+        np.testing.assert_array_equal(rp, orp)
+        np.testing.assert_array_equal(col, ocol)
+    with pytest.raises(_lib.PpcrError):
+        with _lib.Context(0) as c:
+            c.set_option("grid_xf", 3)
+
+
 def test_nn_dense_and_clustered_stress(ctx):
     """Neighbourhoods far denser than the benchmark (hundreds of in-radius candidates, halos that do not fit LDS:
     per-wave passes and the global-memory fallback, list compactions) and a strongly non-uniform cloud."""
