@@ -176,6 +176,7 @@ struct ppcr_ctx {
     int64_t n_companion = 0, n_ground_truth = 0, n_previous = 0;
     bool have_companion = false, have_ground_truth = false, have_previous = false;
     DevBuf<double> mse_part;
+    int opt_short_lists = 1;
     int opt_xcd_remap = 0;
     int opt_grid_xf = 4;         // x slices per grid cell (GridDesc::xr)
     int opt_emit_xyz = 0;        // K1 also leaves the neighbours' coordinates (k-major SoA) for K23 to stream: measured neutral
@@ -518,6 +519,11 @@ void launch_topm(ppcr_ctx *c, float r2, int m, const FusedRows &fm, const Pendin
             nn_tile_kernel<M, C, 256, CAP, false, true><<<nblocks(c->ns, 256), 256, 0, c->stream>>>(
                 c->src.p, (int)c->ns, c->tgt_sorted.p, c->cell_start.p, c->grid, r2, m, c->nbr.p, c->cnt.p, st, fm, pm,
                 c->dm2.p, dm2_in, vb_none, nxyz);
+        } else if (dm2_in && c->opt_short_lists && M <= 12) {
+            // steady state: the temporal cut-off keeps every list near m entries, so half the list capacity does
+            // (an overflowing lane re-runs with in-loop compaction as always); with the one-byte row ids that
+            // brings the workgroup under 40 KB of LDS and 128 VGPRs: FOUR workgroups per CU instead of three
+            if constexpr (M <= 12) PPCR_TILE(16, 256, CAP);
         } else {
             PPCR_TILE(C, 256, CAP);
         }
@@ -1278,6 +1284,10 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
         if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, PPCR_ERR_INVALID, "grid_xf must be 1, 2, 4 or 8");
         if (c->have_tgt) return fail(c, PPCR_ERR_STATE, "grid_xf must be set before the target cloud");
         c->opt_grid_xf = value;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "short_lists") == 0) {
+        c->opt_short_lists = value ? 1 : 0;
         return PPCR_OK;
     }
     if (std::strcmp(key, "emit_xyz") == 0) {

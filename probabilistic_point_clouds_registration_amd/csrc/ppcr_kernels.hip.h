@@ -640,16 +640,21 @@ __device__ __forceinline__ void lds_barrier()
 template <int BLOCK>
 struct LdsCands {  // candidate source = staged halo (SoA in LDS); list entries are LDS indices
     const float *sx, *sy, *sz;
-    const int *spos;       // sorted-target position of every staged candidate
+    const unsigned char *srow;  // halo row of every staged candidate: its sorted-target position is
+    const int *row_gb, *row_off;  //   row_gb[row] + (LDS index - row_off[row])  (one byte instead of four per candidate)
     unsigned short *list;  // [slot * BLOCK + tid]
     int tid;
     __device__ __forceinline__ float4 get(int e) const { return make_float4(sx[e], sy[e], sz[e], 0.f); }
     __device__ __forceinline__ int load(int t) const { return list[t * BLOCK + tid]; }
     __device__ __forceinline__ void store(int t, int e) const { list[t * BLOCK + tid] = (unsigned short)e; }
-    __device__ __forceinline__ int pos_of(int e) const { return spos[e]; }
+    __device__ __forceinline__ int pos_of(int e) const
+    {
+        const int r = srow[e];
+        return row_gb[r] + (e - row_off[r]);
+    }
     __device__ __forceinline__ unsigned orig_of(int e, const float4 *__restrict__ tgt) const
     {
-        return (unsigned)__float_as_int(tgt[spos[e]].w);
+        return (unsigned)__float_as_int(tgt[pos_of(e)].w);
     }
 };
 template <int STRIDE = 64>
@@ -764,7 +769,7 @@ struct VerletBuild {
 };
 
 template <int M, int C, int BLOCK, int CAP, bool FUSED, bool XCD_REMAP = false>
-__global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src, int ns,
+__global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt,
                                                          const int *__restrict__ cell_start, GridDesc g,
                                                          float r2, int m, int *__restrict__ nbr,
@@ -774,7 +779,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                                                          VerletBuild vb, float *__restrict__ nxyz = nullptr)
 {
     static_assert(C > M, "a compaction must leave room in the list");
-    static_assert(CAP % 4 == 0 && CAP <= 65536 && C * 64 <= 4 * CAP, "the global fallback aliases the candidate buffer");
+    static_assert(CAP % 4 == 0 && CAP <= 65536 && C * 64 <= 3 * CAP && kTileRows <= 256, "the global fallback aliases the candidate buffer");
     static_assert(kTileRows == 128, "row table: two rows per lane of one wave");
     constexpr int kWaves = BLOCK / 64;
     constexpr int kStageUnroll = 8;  // halo rows in flight per wave
@@ -795,9 +800,9 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
             for (int k = 0; k < 8; k++) stamps[((size_t)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8 + k] = t_acc[k];
     };
     // staged halo, structure-of-arrays: two candidates per ds_read_b64 and per packed-f32 instruction
-    __shared__ __attribute__((aligned(16))) float s_halo[4 * CAP];
+    __shared__ __attribute__((aligned(16))) float s_halo[3 * CAP + CAP / 4];
     float *const s_x = s_halo, *const s_y = s_halo + CAP, *const s_z = s_halo + 2 * CAP;
-    int *const s_pos = reinterpret_cast<int *>(s_halo + 3 * CAP);
+    unsigned char *const s_rowid = reinterpret_cast<unsigned char *>(s_halo + 3 * CAP);
     int *const s_glist = reinterpret_cast<int *>(s_halo);  // global-fallback list aliases the halo buffer
     __shared__ unsigned short s_list[C * BLOCK];
     __shared__ int s_row_gb[kTileRows];
@@ -974,7 +979,7 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                         s_x[d] = c[u].x;
                         s_y[d] = c[u].y;
                         s_z[d] = c[u].z;
-                        s_pos[d] = sg[u] + lane;
+                        s_rowid[d] = (unsigned char)(wave + kWaves * (k0 + u));
                     }
                     for (int k = lane + 64; k < sl[u]; k += 64) {  // rows longer than a wave (dense data)
                         const float4 t = tgt[sg[u] + k];
@@ -982,14 +987,14 @@ __global__ __launch_bounds__(BLOCK) void nn_tile_kernel(float4 *__restrict__ src
                         s_x[d] = t.x;
                         s_y[d] = t.y;
                         s_z[d] = t.z;
-                        s_pos[d] = sg[u] + k;
+                        s_rowid[d] = (unsigned char)(wave + kWaves * (k0 + u));
                     }
                 }
             }
             lds_barrier();
             stamp(2);
             if (!done && wave >= w0 && wave < w1) {
-                const LdsCands<BLOCK> L{s_x, s_y, s_z, s_pos, s_list, tid};
+                const LdsCands<BLOCK> L{s_x, s_y, s_z, s_rowid, s_row_gb, s_row_off, s_list, tid};
                 // d2 >= +0 and r2 > 0, so "d2 < r2" is "bits(d2) <= bits(r2) - 1" (a NaN d2 has larger bits and
                 // fails): the radius test and the running cut-off become ONE unsigned compare per candidate
                 const unsigned lim0 = min(thr0, __float_as_uint(r2) - 1u);
