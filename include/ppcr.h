@@ -215,6 +215,8 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *   "fused"        1 K1 epilogue writes per-row partials (experiment, measured slower), 0 off (default);
  *   "grid_xf"      x slices per grid cell, 1/2/4/8 (default 4; set before the target): every stencil row is clipped
  *                  to the x window the search sphere needs in that row;
+ *   "short_lists"  1 once the temporal cut-off is valid K1 runs with 16-slot lists and four workgroups per CU
+ *                  (default), 0 always 32 slots / three workgroups;
  *   "emit_xyz"     1 K1 also writes the neighbours' coordinates so that K23 streams instead of gathering
  *                  (experiment, measured neutral: K23 is instruction-bound, not gather-bound), 0 off (default);
  *   "xcd_remap"    1 give each XCD a contiguous eighth of the source bricks (experiment, measured neutral), 0 off;
