@@ -658,6 +658,29 @@ def test_nn_dense_and_clustered_stress(ctx):
     ctx.associate()
     rp2, col2, _ = ctx.get_association()
     np.testing.assert_array_equal(col2, ocol)
+    # steady-state variant (16-slot lists, four workgroups per CU) in a dense cloud: after a move the cut-off admits
+    # far more than 16 candidates per lane (lists overflow -> in-loop compaction), and halos that do not fit
+    dense_t = rng.uniform(0, 6, size=(40000, 3)).astype(np.float32)              # ~185 per unit volume
+    dense_s = (dense_t[rng.permutation(40000)[:6000]] + rng.normal(0, 0.02, size=(6000, 3))).astype(np.float32)
+    for m in (10, 5, 12):
+        with _lib.Context(0) as c:
+            c.set_params(0.6, m, 5.0, 3)
+            c.set_target(dense_t)
+            c.set_source(dense_s)
+            cur = dense_s.copy()
+            c.associate()
+            for step in (0.002, 0.05, 0.3):
+                T = np.eye(4)
+                T[:3, :3] = synth.rodrigues([1.0, 0.2, -0.4], step)
+                T[:3, 3] = [step, -0.5 * step, 0.25 * step]
+                c.apply_transform(T)
+                po.transform_cloud(cur, T)
+                c.iterate(inner_steps=1)                       # deferred move + cut-off path
+                rpd, cold, _ = c.get_association()             # association made BEFORE iterate's own move
+                orp_d, ocol_d, _ = po.radius_search(cur, dense_t, 0.6, m, method=1)   # (exported d2 is post-move)
+                np.testing.assert_array_equal(rpd, orp_d)
+                np.testing.assert_array_equal(cold, ocol_d)
+                cur = c.get_source()
     # clustered: mixture of blobs of very different densities + sparse background, far from the origin
     centres = rng.uniform(-40, 40, size=(30, 3)) + np.array([800.0, -300.0, 50.0])
     parts = [c + rng.normal(0, s, size=(n, 3)) for c, s, n in zip(centres, rng.uniform(0.2, 4.0, 30), rng.integers(500, 6000, 30))]
