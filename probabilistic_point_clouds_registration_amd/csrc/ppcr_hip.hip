@@ -556,14 +556,14 @@ void launch_accumulate_ell(ppcr_ctx *c, int nb, const Pose &P, const Model &md)
 {
     if (c->nbr_xyz_valid) {
         accumulate_ell_kernel<W, kAccumRows, kAccumBlock, true><<<nb, kAccumBlock, 0, c->stream>>>(
-            c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md, c->partials.p, c->nbr_xyz.p);
+            c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md, c->partials.p, c->ell_width, c->nbr_xyz.p);
         return;
     }
     // the two models the reference's CLI reaches by default are compiled in (Gaussian -u; t with dof 5, dim 3:
     // v + dim = 8); any other dof takes the run-time form of the same arithmetic
 #define PPCR_K23(TMc)                                                                                              \
     accumulate_ell_kernel<W, kAccumRows, kAccumBlock, false, TMc><<<nb, kAccumBlock, 0, c->stream>>>(              \
-        c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md, c->partials.p)
+        c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md, c->partials.p, c->ell_width)
     if (md.is_normal) PPCR_K23(0);
     else if (md.vpd_int == 8) PPCR_K23(8);
     else PPCR_K23(-1);

@@ -1557,9 +1557,10 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
                                                                 const int *__restrict__ cnt,
                                                                 const float4 *__restrict__ src,
                                                                 const float4 *__restrict__ tgt, int ns, Pose P,
-                                                                Model md, double *__restrict__ partials,
+                                                                Model md, double *__restrict__ partials, int width,
                                                                 const float *__restrict__ nxyz = nullptr)
 {
+    // width = slots the association really has per row (<= W): slots beyond it do not exist in nbr / nxyz
     RowAcc acc;
 #pragma unroll
     for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
@@ -1577,9 +1578,10 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
             xf[r] = src[ic];
 #pragma unroll
             for (int k = 0; k < W; k++) {  // slots >= cnt hold stale data: masked below
-                yx[r][k] = nxyz[(size_t)(3 * k + 0) * ns + ic];
-                yy[r][k] = nxyz[(size_t)(3 * k + 1) * ns + ic];
-                yz[r][k] = nxyz[(size_t)(3 * k + 2) * ns + ic];
+                const int kc = k < width ? k : 0;
+                yx[r][k] = nxyz[(size_t)(3 * kc + 0) * ns + ic];
+                yy[r][k] = nxyz[(size_t)(3 * kc + 1) * ns + ic];
+                yz[r][k] = nxyz[(size_t)(3 * kc + 2) * ns + ic];
             }
         }
     } else {
@@ -1591,7 +1593,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
             n[r] = ok ? cnt[i] : 0;
             xf[r] = src[ok ? i : 0];
 #pragma unroll
-            for (int k = 0; k < W; k++) idx[r][k] = ok ? nbr[(size_t)k * ns + i] : 0;  // slots >= cnt hold stale data
+            for (int k = 0; k < W; k++) idx[r][k] = (ok && k < width) ? nbr[(size_t)k * ns + i] : 0;  // slots >= cnt: stale
         }
 #pragma unroll
         for (int r = 0; r < ROWS; r++)

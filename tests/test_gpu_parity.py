@@ -697,3 +697,47 @@ def test_nn_dense_and_clustered_stress(ctx):
     ora = po.align(src, tgt, 1.0, 10, 5.0, 4, inner_max_steps=1)
     assert synth.rotation_angle(res["history"][-1][:, :3], ora["history"][-1][:, :3]) < ROT_TOL
     assert np.linalg.norm(res["history"][-1][:, 3] - ora["history"][-1][:, 3]) < TRANS_TOL
+
+
+def test_randomised_association_soak(ctx):
+    """Seeded random sweep over cloud shapes, radii, max_neighbours, grid slicings and motions: every association of
+    every trial equals the oracle's neighbour sets (the clipped runs, the cut-off and both list capacities are all
+    exercised as the source moves), and the moments at a random pose agree."""
+    rng = np.random.default_rng(20260101)
+    for trial in range(24):
+        nt = int(rng.integers(200, 30000))
+        ns = int(rng.integers(1, 12000))
+        ext = rng.uniform(2.0, 40.0, size=3) * rng.choice([1.0, 0.05], size=3, p=[0.8, 0.2])   # sometimes nearly flat
+        off = rng.uniform(-500, 500, size=3) * rng.choice([0.0, 1.0])
+        tgt = (rng.uniform(0, 1, size=(nt, 3)) * ext + off).astype(np.float32)
+        if trial % 3 == 0:                                     # quantised coordinates: exact d2 ties
+            tgt = (np.round(tgt * 4) / 4).astype(np.float32)
+        pick = rng.integers(0, nt, size=ns)
+        src = (tgt[pick] + rng.normal(0, rng.choice([0.0, 0.02, 0.5]), size=(ns, 3))).astype(np.float32)
+        radius = float(rng.uniform(0.2, 3.0))
+        m = int(rng.choice([1, 2, 5, 10, 12, 16, 20, 32]))
+        xf = int(rng.choice([1, 2, 4, 8]))
+        with _lib.Context(0) as c:
+            c.set_option("grid_xf", xf)
+            c.set_params(radius, m, 5.0, 3)
+            c.set_target(tgt)
+            c.set_source(src)
+            cur = src.copy()
+            for step in range(4):
+                c.associate()
+                rp, col, d2 = c.get_association()
+                orp, ocol, od2 = po.radius_search(cur, tgt, radius, m, method=1)
+                np.testing.assert_array_equal(rp, orp, err_msg=f"trial {trial} step {step}")
+                np.testing.assert_array_equal(col, ocol, err_msg=f"trial {trial} step {step}")
+                np.testing.assert_array_equal(d2, od2, err_msg=f"trial {trial} step {step}")
+                if step == 1 and orp[-1] > 0:
+                    q = np.array([0.999, 0.01, -0.02, 0.015])
+                    t = np.array([0.01, 0.02, -0.015])
+                    sums = c.accumulate(q, t)
+                    osums = po.accumulate(cur, tgt, orp, ocol, q, t, 5.0, 3, origin=c.origin())
+                    np.testing.assert_allclose(sums, osums, rtol=1e-9, atol=1e-9 * max(1.0, float(np.abs(osums).max())))
+                T = np.eye(4)
+                T[:3, :3] = synth.rodrigues(rng.normal(size=3), float(rng.choice([0.0, 0.003, 0.05])))
+                T[:3, 3] = rng.normal(0, float(rng.choice([0.0, 0.01, 0.3])) * radius, size=3)
+                c.apply_transform(T)
+                po.transform_cloud(cur, T)
