@@ -741,3 +741,36 @@ def test_randomised_association_soak(ctx):
                 T[:3, 3] = rng.normal(0, float(rng.choice([0.0, 0.01, 0.3])) * radius, size=3)
                 c.apply_transform(T)
                 po.transform_cloud(cur, T)
+
+
+def test_randomised_align_soak(ctx):
+    """Seeded random sweep of whole registrations (weight models incl. odd and non-integer v + dim and Gaussian,
+    max_neighbours, inner step counts, the early-stop rule): per-iteration transforms, costs and step counts follow
+    the oracle."""
+    rng = np.random.default_rng(777)
+    for trial in range(16):
+        n = int(rng.integers(800, 9000))
+        L = 0.64 * n ** (1 / 3) * float(rng.uniform(0.8, 1.3))
+        tgt = rng.uniform(-L / 2, L / 2, size=(n, 3)).astype(np.float32)
+        Rg = synth.rodrigues(rng.normal(size=3), float(rng.uniform(0.0, 0.02)))
+        tg = rng.normal(0, 0.05, size=3)
+        keep = rng.permutation(n)[: int(n * rng.uniform(0.5, 1.0))]
+        src = ((tgt[keep].astype(np.float64) - tg) @ Rg + rng.normal(0, 0.01, size=(len(keep), 3))).astype(np.float32)
+        dof = float(rng.choice([1.0, 2.0, 3.5, 5.0, 10.0, np.inf]))
+        m = int(rng.choice([3, 5, 10, 16, 24]))
+        inner = int(rng.choice([1, 1, 30]))
+        thresh = float(rng.choice([0.0, 0.0, 0.3]))
+        n_iter = 5
+        with _lib.Context(0) as c:
+            c.set_params(1.0, m, dof, 3)
+            c.set_target(tgt)
+            c.set_source(src)
+            res = c.align(n_iter, cost_drop_thresh=thresh, n_cost_drop_it=1, inner_steps=inner)
+        ora = po.align(src, tgt, 1.0, m, dof, n_iter, cost_drop_thresh=thresh, n_cost_drop_it=1, inner_max_steps=inner)
+        tag = f"trial {trial}: n={n} dof={dof} m={m} inner={inner} thresh={thresh}"
+        assert res["n_iter"] == len(ora["history"]), tag
+        np.testing.assert_array_equal(res["inner_steps"], ora["inner_steps"], err_msg=tag)
+        for k in range(res["n_iter"]):
+            assert synth.rotation_angle(res["history"][k][:, :3], ora["history"][k][:, :3]) < 1e-8, tag
+            assert np.linalg.norm(res["history"][k][:, 3] - ora["history"][k][:, 3]) < 1e-8, tag
+        np.testing.assert_allclose(res["costs"], ora["costs"], rtol=1e-8, err_msg=tag)
