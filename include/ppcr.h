@@ -195,6 +195,12 @@ int ppcr_mse_previous(ppcr_ctx *ctx, double *mse);
 int ppcr_voxel_filter(int device_id, const float *xyz, int64_t n, int64_t stride_bytes, float leaf, float *out_xyz,
                       int64_t out_stride_bytes, int64_t *n_out);
 
+/* Squared distance from every query to its exact nearest target (pcl::KdTreeFLANN::nearestKSearch with k = 1, as the
+ * evaluation metrics of utilities.hpp:28-234 call it: averageClosestDistance, sumSquaredError, the robust and median
+ * variants).  d2_out: nq floats in query order.  Stateless (temporary handle on device_id); nt must be > 0. */
+int ppcr_nearest_sq_distances(int device_id, const float *queries, int64_t nq, int64_t q_stride_bytes,
+                              const float *targets, int64_t nt, int64_t t_stride_bytes, float *d2_out);
+
 int ppcr_synchronize(ppcr_ctx *ctx);
 
 /* Per-kernel device timing with HIP events recorded on the handle's own stream. */

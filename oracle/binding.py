@@ -220,5 +220,17 @@ def voxel_filter(cloud, leaf):
     return out[:k].copy()
 
 
+def nearest_sq_distances(q, t, threads=0):
+    """exact 1-NN squared distances (brute force) -> float32 [nq]"""
+    q, sq = _cloud(q)
+    t, st = _cloud(t)
+    out = np.zeros(q.shape[0], dtype=np.float32)
+    L = lib()
+    L.po_nearest_sq_distances.restype = None
+    L.po_nearest_sq_distances.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int]
+    L.po_nearest_sq_distances(q.ctypes.data, sq, q.shape[0], t.ctypes.data, st, t.shape[0], out.ctypes.data, int(threads))
+    return out
+
+
 def num_threads():
     return lib().po_num_threads()

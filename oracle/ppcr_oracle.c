@@ -901,6 +901,32 @@ int64_t po_voxel_filter(const float *in, int sin, int64_t n, float leaf, float *
     return nout;
 }
 
+/* nearestKSearch(k = 1) squared distances as the metrics of utilities.hpp:28-234 use them (third-party FLANN,
+ * restated: exact nearest neighbour, float d2 accumulated x, y, z like L2_Simple).  Brute force, O(nq * nt). */
+void po_nearest_sq_distances(const float *q, int sq, int64_t nq, const float *t, int st, int64_t nt, float *d2_out,
+                             int threads)
+{
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nq; i++) {
+        const float *a = q + i * sq;
+        float best = INFINITY;
+        for (int64_t j = 0; j < nt; j++) {
+            const float *b = t + j * st;
+            float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+            float d = dx * dx;
+            d = d + dy * dy;
+            d = d + dz * dz;
+            if (d < best) best = d;
+        }
+        d2_out[i] = best;
+    }
+}
+
 int po_num_threads(void)
 {
 #ifdef _OPENMP

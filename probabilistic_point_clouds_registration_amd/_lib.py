@@ -22,6 +22,7 @@ SYMBOLS = [
     "ppcr_iterate", "ppcr_align", "ppcr_get_source", "ppcr_synchronize", "ppcr_profile_enable",
     "ppcr_profile_get", "ppcr_set_option", "ppcr_batch_run", "ppcr_align_many", "ppcr_set_companion",
     "ppcr_get_companion", "ppcr_set_ground_truth", "ppcr_mse_ground_truth", "ppcr_mse_previous", "ppcr_voxel_filter",
+    "ppcr_nearest_sq_distances",
 ]
 
 
@@ -95,6 +96,7 @@ def load():
     L.ppcr_mse_ground_truth.argtypes = [vp, C.POINTER(dbl)]
     L.ppcr_mse_previous.argtypes = [vp, C.POINTER(dbl)]
     L.ppcr_voxel_filter.argtypes = [i32, vp, i64, i64, C.c_float, vp, i64, C.POINTER(i64)]
+    L.ppcr_nearest_sq_distances.argtypes = [i32, vp, i64, i64, vp, i64, i64, vp]
     L.ppcr_batch_run.argtypes = [C.POINTER(Pair), i64, C.POINTER(BatchOptions), C.POINTER(i32), i32, i32, vp, vp,
                                  C.c_char_p, i64]
     L.ppcr_align_many.argtypes = [C.POINTER(vp), i32, i32, i32, dbl, dbl, vp, vp, i32, dbl, vp, vp]
@@ -402,3 +404,15 @@ def voxel_filter(cloud, leaf, device_id=0):
     if rc != 0:
         raise PpcrError(rc, L.ppcr_last_error(None).decode())
     return out[:k.value].copy()
+
+
+def nearest_sq_distances(queries, targets, device_id=0):
+    """ppcr_nearest_sq_distances: exact 1-NN squared distances on the device -> float32 [nq]"""
+    q, t = _cloud(queries), _cloud(targets)
+    out = np.zeros(max(q.shape[0], 1), dtype=np.float32)
+    L = load()
+    rc = L.ppcr_nearest_sq_distances(int(device_id), q.ctypes.data if q.size else None, q.shape[0], q.shape[1] * 4,
+                                     t.ctypes.data if t.size else None, t.shape[0], t.shape[1] * 4, out.ctypes.data)
+    if rc != 0:
+        raise PpcrError(rc, L.ppcr_last_error(None).decode())
+    return out[:q.shape[0]].copy()

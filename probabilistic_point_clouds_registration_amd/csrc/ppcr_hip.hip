@@ -2029,6 +2029,54 @@ int ppcr_voxel_filter(int device_id, const float *xyz, int64_t n, int64_t stride
 
 }  // extern "C"
 
+extern "C" {
+
+int ppcr_nearest_sq_distances(int device_id, const float *queries, int64_t nq, int64_t q_stride_bytes, const float *targets,
+                              int64_t nt, int64_t t_stride_bytes, float *d2_out)
+{
+    if (nq < 0 || nt <= 0) return fail(nullptr, PPCR_ERR_INVALID, "ppcr_nearest_sq_distances: needs at least one target point");
+    if (nq > 0 && !d2_out) return fail(nullptr, PPCR_ERR_INVALID, "null output");
+    ppcr_ctx *c = nullptr;
+    PPCR_TRY(ppcr_create(device_id, &c));
+    auto body = [&]() -> int {
+        PPCR_TRY(set_target_common(c, targets, false, nt, t_stride_bytes));
+        PPCR_TRY(set_source_common(c, queries, false, nq, q_stride_bytes));
+        if (nq == 0) return PPCR_OK;
+        // a cubic grid with a few points per cell: the nearest neighbour is then usually in the first shell or two
+        float lo[3], hi[3];
+        PPCR_TRY(cloud_bbox(c, c->tgt_raw.p, (int)nt, lo, hi));
+        double vol = 1, emax = 0;
+        for (int a = 0; a < 3; a++) {
+            const double e = (double)hi[a] - (double)lo[a];
+            emax = std::max(emax, e);
+            vol *= std::max(e, 1e-30);
+        }
+        double h = std::cbrt(vol * 3.0 / (double)nt);
+        if (!(h > emax * 1e-4)) h = std::max(emax * 1e-4, 1e-30);  // degenerate (flat) clouds
+        if (!std::isfinite(h) || !(h > 0)) h = 1.0;
+        c->radius = h;
+        c->opt_grid_xf = 1;
+        PPCR_TRY(ensure_grid(c));
+        DevBuf<float> d2;
+        struct Release {
+            DevBuf<float> &b;
+            ~Release() { b.release(); }
+        } rel{d2};
+        HIP_TRY(c, d2.reserve((size_t)nq));
+        nn1_kernel<<<nblocks(nq), kBlock, 0, c->stream>>>(c->src.p, (int)nq, c->tgt_sorted.p, c->cell_start.p, c->grid, d2.p);
+        PPCR_TRY(check_launch(c, "nn1_kernel"));
+        HIP_TRY(c, hipMemcpyAsync(d2_out, d2.p, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return PPCR_OK;
+    };
+    const int rc = body();
+    if (rc != PPCR_OK) g_create_error = c->err;
+    ppcr_destroy(c);
+    return rc;
+}
+
+}  // extern "C"
+
 // ---- batches of independent pairs -------------------------------------------------------------------------------
 namespace {
 

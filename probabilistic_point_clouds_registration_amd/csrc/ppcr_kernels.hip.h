@@ -1856,5 +1856,65 @@ __global__ void snapshot_kernel(const float4 *__restrict__ a, int n, int a_is_so
     dst[a_is_sorted_source ? __float_as_int(p.w) : i] = p;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Exact nearest neighbour (k = 1, no radius) for the evaluation metrics of utilities.hpp:28-234
+// (averageClosestDistance, sumSquaredError, the robust / median variants: all built on nearestKSearch(…, 1, …)).
+// One lane per query: shells of cells of growing Chebyshev radius around the query's (clamped) cell are scanned
+// until the best d2 found is no larger than the distance to everything not yet scanned — the gap between the query
+// and the faces of the scanned block that are not grid faces (under-estimated by g.eps).  Same float d2 as the
+// association (dist2_flann).  Queries far outside the cloud degrade to a full scan, which is still exact.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void nn1_kernel(const float4 *__restrict__ queries, int nq,
+                                                     const float4 *__restrict__ tgt,
+                                                     const int *__restrict__ cell_start, GridDesc g,
+                                                     float *__restrict__ d2_out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nq) return;
+    const float4 q = queries[i];
+    const float qp[3] = {q.x, q.y, q.z};
+    const float inv[3] = {g.inv_hx, g.inv_h, g.inv_h};
+    int c0[3];
+    for (int a = 0; a < 3; a++) c0[a] = clampi(cell_coord(qp[a], g.org[a], inv[a], g.n[a]), 0, g.n[a] - 1);
+    const float hx = g.h / (float)g.xr;
+    const float edge[3] = {hx, g.h, g.h};
+    float best = INFINITY;
+    auto scan_cells = [&](int base, int xa, int xb) {
+        const int b = cell_start[base + xa], e = cell_start[base + xb + 1];
+        for (int p = b; p < e; p++) best = fminf(best, dist2_flann(q, tgt[p]));
+    };
+    for (int rho = 0;; rho++) {
+        int lo[3], hi[3];
+        bool whole = true;
+        for (int a = 0; a < 3; a++) {
+            lo[a] = max(c0[a] - rho, 0);
+            hi[a] = min(c0[a] + rho, g.n[a] - 1);
+            whole = whole && lo[a] == 0 && hi[a] == g.n[a] - 1;
+        }
+        for (int z = lo[2]; z <= hi[2]; z++)
+            for (int y = lo[1]; y <= hi[1]; y++) {
+                const int base = (z * g.n[1] + y) * g.n[0];
+                const bool shell_row = (z == c0[2] - rho) || (z == c0[2] + rho) || (y == c0[1] - rho) || (y == c0[1] + rho);
+                if (shell_row || rho == 0) {
+                    scan_cells(base, lo[0], hi[0]);
+                } else {
+                    if (c0[0] - rho >= 0) scan_cells(base, c0[0] - rho, c0[0] - rho);
+                    if (c0[0] + rho <= g.n[0] - 1) scan_cells(base, c0[0] + rho, c0[0] + rho);
+                }
+            }
+        if (whole) break;
+        // everything not scanned yet lies beyond a face of the block that is not a face of the grid
+        float gap = INFINITY;
+        for (int a = 0; a < 3; a++) {
+            const float f = qp[a] - g.org[a];
+            if (lo[a] > 0) gap = fminf(gap, f - (float)lo[a] * edge[a]);
+            if (hi[a] < g.n[a] - 1) gap = fminf(gap, (float)(hi[a] + 1) * edge[a] - f);
+        }
+        gap -= g.eps;
+        if (gap > 0.f && best <= gap * gap * 0.999999f) break;
+    }
+    d2_out[i] = best;
+}
+
 }  // namespace dev
 }  // namespace ppcr

@@ -1,9 +1,11 @@
 // C++ API tests: the reference's own gtest cases (test/ProbabilisticWeightsTest.cc:35-66,
 // test/PointCloudRegistrationTest.cc:30-116) restated against the drop-in classes, plus checks of the outer
 // driver.  No gtest here: a tiny assert harness; exit code = number of failed checks.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <limits>
+#include <memory>
 #include <vector>
 
 #include "prob_point_cloud_registration/prob_point_cloud_registration.h"
@@ -190,9 +192,60 @@ static void errorTermTest()
     EXPECT_NEAR(e.weight()->scale(), 0.25, 0);
 }
 
+// utilities.hpp:28-234: closest-point metrics against a brute-force nearest neighbour computed right here
+static void closestPointMetricsTest()
+{
+    auto a = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+    auto b = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+    unsigned s = 12345u;
+    auto rnd = [&]() {
+        s = s * 1664525u + 1013904223u;
+        return (float)((s >> 8) & 0xFFFF) / 65536.0f;
+    };
+    for (int i = 0; i < 901; i++) b->push_back(pcl::PointXYZ(10 * rnd(), 7 * rnd(), 3 * rnd()));
+    for (int i = 0; i < 401; i++) a->push_back(pcl::PointXYZ(12 * rnd() - 1, 9 * rnd() - 1, 5 * rnd() - 1));
+    a->push_back(pcl::PointXYZ(500.f, -300.f, 80.f));  // far outlier
+    std::vector<double> d;
+    for (const auto &p : a->points) {
+        float best = INFINITY;
+        for (const auto &q : b->points) {
+            const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+            float v = dx * dx;
+            v = v + dy * dy;
+            v = v + dz * dz;
+            best = std::fmin(best, v);
+        }
+        d.push_back(best);
+    }
+    double sum = 0;
+    for (double v : d) sum += v;
+    EXPECT_NEAR(sumSquaredError(a, b), sum, 1e-9 * sum);
+    EXPECT_NEAR(averageClosestDistance(a, b), sum / d.size(), 1e-9 * sum);
+    std::vector<double> sd = d;
+    std::sort(sd.begin(), sd.end());
+    const std::size_t n = sd.size();  // 402: even -> (sd[n/2] + sd[n/2+1]) / 2, the reference's convention
+    const double med = (sd[n / 2] + sd[n / 2 + 1]) / 2.0;
+    EXPECT_NEAR(medianClosestDistance(a, b), med, 1e-6 * med);
+    double rs = 0;
+    int nf = 0;
+    for (double v : sd)
+        if (v <= med * 3 && v >= med / 3) {
+            rs += v;
+            nf++;
+        }
+    EXPECT_TRUE(nf >= 10);
+    EXPECT_NEAR(robustSumSquaredError(a, b), rs, 1e-6 * rs);
+    EXPECT_NEAR(robustSumSquaredError(a, b, 3.0), rs, 1e-6 * rs);
+    EXPECT_NEAR(robustAveragedSumSquaredError(a, b), rs / nf, 1e-6 * rs / nf);
+    EXPECT_TRUE(robustSumSquaredError(a, b, 1.0000001) == std::numeric_limits<double>::max() ||
+                robustSumSquaredError(a, b, 1.0000001) < rs);
+    EXPECT_TRUE(robustMedianClosestDistance(a, b) > 0);
+}
+
 int main()
 {
     weightsTests();
+    closestPointMetricsTest();
     exactAssociationTest(std::numeric_limits<double>::infinity());
     exactAssociationTest(5);
     errorTermTest();

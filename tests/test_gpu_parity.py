@@ -774,3 +774,29 @@ def test_randomised_align_soak(ctx):
             assert synth.rotation_angle(res["history"][k][:, :3], ora["history"][k][:, :3]) < 1e-8, tag
             assert np.linalg.norm(res["history"][k][:, 3] - ora["history"][k][:, 3]) < 1e-8, tag
         np.testing.assert_allclose(res["costs"], ora["costs"], rtol=1e-8, err_msg=tag)
+
+
+def test_nearest_neighbour_distances_exact(ctx):
+    """k = 1 search without a radius (the closest-point metrics of utilities.hpp:28-234): d2 bit-identical to the
+    brute-force oracle — inside the cloud, far outside it, flat clouds, a single target, duplicated points."""
+    rng = np.random.default_rng(9)
+    cases = []
+    t = (rng.random((20000, 3)) * [30, 20, 10]).astype(np.float32)
+    q = (rng.random((7000, 3)) * [36, 26, 16] - 3).astype(np.float32)
+    q[:50] += np.float32(400.0)                                         # far outliers: the search degrades to a full scan
+    cases.append((q, t))
+    flat = t.copy()
+    flat[:, 2] = np.float32(1.25)                                       # exactly planar target
+    cases.append((q[:3000], flat))
+    cases.append((q[:500], t[:1]))                                      # one target point
+    dup = np.repeat(t[:300], 5, axis=0)                                 # duplicated targets, queries on top of them
+    cases.append((dup[::3].copy(), dup))
+    cases.append(((rng.normal(0, 1, (4000, 3)) * [0.01, 50, 50]).astype(np.float32),
+                  (rng.normal(0, 1, (9000, 3)) * [0.01, 50, 50]).astype(np.float32)))   # needle-thin in x
+    for q, t in cases:
+        g = _lib.nearest_sq_distances(q, t)
+        o = po.nearest_sq_distances(q, t)
+        np.testing.assert_array_equal(g, o)
+    assert _lib.nearest_sq_distances(np.zeros((0, 3), np.float32), t).shape == (0,)
+    with pytest.raises(_lib.PpcrError):
+        _lib.nearest_sq_distances(q, np.zeros((0, 3), np.float32))
