@@ -782,7 +782,7 @@ __global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float
     static_assert(CAP % 4 == 0 && CAP <= 65536 && C * 64 <= 3 * CAP && kTileRows <= 256, "the global fallback aliases the candidate buffer");
     static_assert(kTileRows == 128, "row table: two rows per lane of one wave");
     constexpr int kWaves = BLOCK / 64;
-    constexpr int kStageUnroll = 8;  // halo rows in flight per wave
+    constexpr int kStageUnroll = (C <= 16 ? 4 : 8);  // halo rows in flight per wave (fewer under the 128-VGPR budget of the 16-slot variant: 134 -> 127 us)
     // diagnostic only (stamps == nullptr in every timed run): per-wave, per-phase cycle counts kept in
     // registers and written once at exit to stamps[(block * waves + wave) * 8 + phase]
     unsigned long long t_prev = stamps ? clock64() : 0;
