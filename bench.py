@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel pass")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank, to exercise the collective path")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=4,
                     help="pairs in flight per GPU when --pairs-per-gpu > 1 (ppcr_align_many host worker threads)")
     ap.add_argument("--pairs-per-gpu", type=int, default=1,
                     help="independent pairs each rank registers back to back (BASELINE configs[4]: --config 5 --pairs-per-gpu 8)")
