@@ -24,7 +24,7 @@ class ProbPointCloudRegistrationParams:
     summary: bool = False
     initial_rotation: tuple = (1.0, 0.0, 0.0, 0.0)      # (w, x, y, z)
     initial_translation: tuple = (0.0, 0.0, 0.0)
-    source_filter_size: float = 0.0                      # voxel filters live in the C++ layer / CLI only
+    source_filter_size: float = 0.0                      # voxel-grid leaf sizes (0 = no filter), src/...cc:24-41
     target_filter_size: float = 0.0
     device_id: int = 0
     inner_max_steps: int = 100
@@ -66,16 +66,29 @@ class ProbPointCloudRegistrationIteration:
 
 class ProbPointCloudRegistration:
     def __init__(self, source_cloud, target_cloud, parameters, ground_truth_cloud=None):
-        if parameters.source_filter_size > 0 or parameters.target_filter_size > 0:
-            raise NotImplementedError("voxel filtering is provided by the C++ layer (CLI -s/-t)")
         self.parameters = parameters
+        source_cloud = np.ascontiguousarray(np.asarray(source_cloud, np.float32)[:, :3])
+        target_cloud = np.ascontiguousarray(np.asarray(target_cloud, np.float32)[:, :3])
         self.ctx = _lib.Context(parameters.device_id)
         self.ctx.set_params(parameters.radius, parameters.max_neighbours, parameters.dof, 3)
+        # the constructor's two pcl::VoxelGrid filters (src/...cc:24-41) run on the device; the association uses the
+        # filtered source while the full one rides along as the handle's companion (cc:110-112)
+        self.filtered = parameters.source_filter_size > 0
+        if parameters.target_filter_size > 0:
+            target_cloud = _lib.voxel_filter(target_cloud, parameters.target_filter_size, parameters.device_id)
+        self.target_cloud = target_cloud
         self.ctx.set_target(target_cloud)
-        self.ctx.set_source(source_cloud)
+        if self.filtered:
+            self.ctx.set_source(_lib.voxel_filter(source_cloud, parameters.source_filter_size, parameters.device_id))
+            self.ctx.set_companion(source_cloud)
+        else:
+            self.ctx.set_source(source_cloud)
         self._history = []
         self._costs = []
-        self.ground_truth = None if ground_truth_cloud is None else np.asarray(ground_truth_cloud, np.float32)[:, :3]
+        self.ground_truth = None
+        if ground_truth_cloud is not None:
+            self.ground_truth = np.ascontiguousarray(np.asarray(ground_truth_cloud, np.float32)[:, :3])
+            self.ctx.set_ground_truth(self.ground_truth)
 
     def align(self):
         p = self.parameters
@@ -95,5 +108,8 @@ class ProbPointCloudRegistration:
         """calculateMSE(source, ground truth): mean Euclidean distance of index-paired points (utilities.hpp:16-26)."""
         if self.ground_truth is None:
             return None
-        cur = self.ctx.get_source()
-        return float(np.mean(np.linalg.norm(cur.astype(np.float32) - self.ground_truth, axis=1)))
+        return self.ctx.mse_ground_truth()      # device reduction over the full-resolution source
+
+    def source_cloud(self):
+        """The (moved) full-resolution source, as the reference's source_cloud_ after align()."""
+        return self.ctx.get_companion() if self.filtered else self.ctx.get_source()

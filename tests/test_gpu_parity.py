@@ -800,3 +800,26 @@ def test_nearest_neighbour_distances_exact(ctx):
     assert _lib.nearest_sq_distances(np.zeros((0, 3), np.float32), t).shape == (0,)
     with pytest.raises(_lib.PpcrError):
         _lib.nearest_sq_distances(q, np.zeros((0, 3), np.float32))
+
+
+def test_python_mirror_with_voxel_filters_and_ground_truth(ctx):
+    """The Python mirror of ProbPointCloudRegistration with -s / -t style filters and a ground truth: same pipeline as
+    the oracle emulation (filter both clouds, register the filtered source, move the full one along)."""
+    from probabilistic_point_clouds_registration_amd import registration
+    src, tgt, Rgt, tgt_t = synth.make_pair(9000, cfg=1, stride=3)
+    gt = (src.astype(np.float64) @ Rgt.T + tgt_t).astype(np.float32)
+    prm = registration.ProbPointCloudRegistrationParams(max_neighbours=6, dof=5.0, radius=1.5, n_iter=4, cost_drop_thresh=0.0,
+                                                       source_filter_size=0.9, target_filter_size=0.8, inner_max_steps=100)
+    reg = registration.ProbPointCloudRegistration(src, tgt, prm, ground_truth_cloud=gt)
+    assert reg.align() == 4
+    fs, ft = po.voxel_filter(src, 0.9), po.voxel_filter(tgt, 0.8)
+    ora = po.align(fs, ft, 1.5, 6, 5.0, 4, cost_drop_thresh=0.0, inner_max_steps=100, f_tol=10e-6)
+    assert synth.rotation_angle(reg.transformation()[:3, :3], ora["history"][-1][:, :3]) < ROT_TOL
+    assert np.linalg.norm(reg.transformation()[:3, 3] - ora["history"][-1][:, 3]) < TRANS_TOL
+    full, prev = src.copy(), np.eye(4)
+    for k in range(4):
+        Tc = np.vstack([ora["history"][k], [0, 0, 0, 1]])
+        po.transform_cloud(full, Tc @ np.linalg.inv(prev))
+        prev = Tc
+    np.testing.assert_allclose(reg.source_cloud(), full, atol=2e-5)
+    assert abs(reg.mse_ground_truth() - po.calculate_mse(full, gt)) < 1e-5
