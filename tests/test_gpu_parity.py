@@ -823,3 +823,66 @@ def test_python_mirror_with_voxel_filters_and_ground_truth(ctx):
         prev = Tc
     np.testing.assert_allclose(reg.source_cloud(), full, atol=2e-5)
     assert abs(reg.mse_ground_truth() - po.calculate_mse(full, gt)) < 1e-5
+
+
+def test_device_pointer_inputs(ctx):
+    """ppcr_set_target_device / ppcr_set_source_device: clouds that already live in HBM (allocated here with the HIP
+    runtime the library itself uses; strides 12 and 16 bytes) give the same registration as the host-buffer entry
+    points, and the caller's buffers are left untouched."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    src, tgt, _, _ = synth.make_pair(5000, cfg=1, stride=3)
+    with _lib.Context(0) as ref:
+        ref.set_params(1.0, 5, 5.0, 3)
+        ref.set_target(tgt)
+        ref.set_source(src)
+        want = ref.align(4, cost_drop_thresh=0.0, inner_steps=1)["history"]
+    src4 = np.zeros((src.shape[0], 4), np.float32)
+    src4[:, :3] = src
+    d_tgt, d_src = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_tgt), tgt.nbytes) == 0 and hip.hipMalloc(C.byref(d_src), src4.nbytes) == 0
+    try:
+        assert hip.hipMemcpy(d_tgt, tgt.ctypes.data, tgt.nbytes, 1) == 0          # hipMemcpyHostToDevice
+        assert hip.hipMemcpy(d_src, src4.ctypes.data, src4.nbytes, 1) == 0
+        with _lib.Context(0) as c:
+            c.set_params(1.0, 5, 5.0, 3)
+            assert c._L.ppcr_set_target_device(c._h, d_tgt, tgt.shape[0], 12) == 0
+            assert c._L.ppcr_set_source_device(c._h, d_src, src.shape[0], 16) == 0
+            c.ns, c.nt = src.shape[0], tgt.shape[0]
+            got = c.align(4, cost_drop_thresh=0.0, inner_steps=1)["history"]
+            np.testing.assert_array_equal(got, want)
+        back = np.zeros_like(src4)
+        assert hip.hipMemcpy(back.ctypes.data, d_src, src4.nbytes, 2) == 0        # hipMemcpyDeviceToHost
+        np.testing.assert_array_equal(back, src4)
+    finally:
+        hip.hipFree(d_tgt)
+        hip.hipFree(d_src)
+
+
+@pytest.mark.parametrize("opts", [dict(nn_variant=1), dict(nn_variant=2), dict(short_lists=0), dict(mailbox=0),
+                                  dict(fused=1), dict(sort_source=0), dict(sort_source=2), dict(temporal=0, short_lists=0)])
+def test_every_tuning_option_keeps_the_result(ctx, opts):
+    """ppcr_set_option knobs never change results: the association of every iteration is identical and the transforms
+    agree to rounding with the default configuration."""
+    src, tgt, _, _ = synth.make_pair(12000, cfg=2, stride=3)
+    a, b = _lib.Context(0), _lib.Context(0)
+    try:
+        for k, v in opts.items():
+            b.set_option(k, v)
+        for c in (a, b):
+            c.set_params(1.0, 10, 5.0, 3)
+            c.set_target(tgt)
+            c.set_source(src)
+        for it in range(4):
+            Ta, ca, _ = a.iterate(inner_steps=1)
+            Tb, cb, _ = b.iterate(inner_steps=1)
+            np.testing.assert_allclose(Ta, Tb, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(ca, cb, rtol=1e-12)
+            for x, y in zip(a.get_association()[:2], b.get_association()[:2]):
+                np.testing.assert_array_equal(x, y)
+    finally:
+        a.close()
+        b.close()
