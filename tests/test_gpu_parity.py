@@ -703,8 +703,8 @@ def test_randomised_association_soak(ctx):
     """Seeded random sweep over cloud shapes, radii, max_neighbours, grid slicings and motions: every association of
     every trial equals the oracle's neighbour sets (the clipped runs, the cut-off and both list capacities are all
     exercised as the source moves), and the moments at a random pose agree."""
-    rng = np.random.default_rng(20260101)
-    for trial in range(24):
+    rng = np.random.default_rng(int(os.environ.get("PPCR_SOAK_SEED", "20260101")))
+    for trial in range(int(os.environ.get("PPCR_SOAK_TRIALS", "24"))):
         nt = int(rng.integers(200, 30000))
         ns = int(rng.integers(1, 12000))
         ext = rng.uniform(2.0, 40.0, size=3) * rng.choice([1.0, 0.05], size=3, p=[0.8, 0.2])   # sometimes nearly flat
@@ -747,8 +747,8 @@ def test_randomised_align_soak(ctx):
     """Seeded random sweep of whole registrations (weight models incl. odd and non-integer v + dim and Gaussian,
     max_neighbours, inner step counts, the early-stop rule): per-iteration transforms, costs and step counts follow
     the oracle."""
-    rng = np.random.default_rng(777)
-    for trial in range(16):
+    rng = np.random.default_rng(int(os.environ.get("PPCR_SOAK_SEED", "777")))
+    for trial in range(int(os.environ.get("PPCR_SOAK_TRIALS", "16"))):
         n = int(rng.integers(800, 9000))
         L = 0.64 * n ** (1 / 3) * float(rng.uniform(0.8, 1.3))
         tgt = rng.uniform(-L / 2, L / 2, size=(n, 3)).astype(np.float32)
