@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel pass")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank, to exercise the collective path")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="ppcr_set_option knob applied to every handle (experiments; the default run sets none)")
     ap.add_argument("--lanes", type=int, default=4,
                     help="pairs in flight per GPU when --pairs-per-gpu > 1 (ppcr_align_many host worker threads)")
     ap.add_argument("--pairs-per-gpu", type=int, default=1,
@@ -117,6 +119,9 @@ def main():
     for p in my_pairs:
         src, tgt, Rgt, tgt_t = synth.make_pair(n, cfg=a.config, pair=p)
         c = _lib.Context(local_rank)
+        for kv in a.opt:
+            k, v = kv.split("=")
+            c.set_option(k, int(v))
         c.set_params(cfg["radius"], cfg["max_neighbours"], cfg["dof"], 3)
         c.set_target(tgt)
         c.set_source(src)

@@ -221,6 +221,7 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *   "fused"        1 K1 epilogue writes per-row partials (experiment, measured slower), 0 off (default);
  *   "grid_xf"      x slices per grid cell, 1/2/4/8 (default 4; set before the target): every stencil row is clipped
  *                  to the x window the search sphere needs in that row;
+ *   "brick_x"      x extent in cells of the 4x4 (y,z) bricks the source is ordered by: 1 (default), 2 or 4;
  *   "short_lists"  1 once the temporal cut-off is valid K1 runs with 16-slot lists and four workgroups per CU
  *                  (default), 0 always 32 slots / three workgroups;
  *   "emit_xyz"     1 K1 also writes the neighbours' coordinates so that K23 streams instead of gathering

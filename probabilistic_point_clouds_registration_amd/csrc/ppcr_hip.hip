@@ -177,6 +177,7 @@ struct ppcr_ctx {
     bool have_companion = false, have_ground_truth = false, have_previous = false;
     DevBuf<double> mse_part;
     int opt_short_lists = 1;
+    int opt_brick_xshift = 0;    // log2 of the source bricks' x extent in cells (0: 4x4 yz columns walked along x)
     int opt_xcd_remap = 0;
     int opt_grid_xf = 4;         // x slices per grid cell (GridDesc::xr)
     int opt_emit_xyz = 0;        // K1 also leaves the neighbours' coordinates (k-major SoA) for K23 to stream: measured neutral
@@ -337,13 +338,15 @@ int sort_by_cell(ppcr_ctx *c, const GridDesc &g, const float4 *in, int n, float4
         {
             ProfScope ps(c, K_CELL_KEY);
             if (brick_order)
-                brick_key_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(in, n, g, c->keys_a.p, c->vals_a.p);
+                brick_key_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(in, n, g, c->keys_a.p, c->vals_a.p, c->opt_brick_xshift);
             else
                 cell_key_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(in, n, g, c->keys_a.p, c->vals_a.p);
         }
         PPCR_TRY(check_launch(c, "cell_key_kernel"));
         long long nkeys = g.ncells;
-        if (brick_order) nkeys = 64ll * (((g.n[0] >> g.xr_shift) + 3) / 4) * ((g.n[1] + 3) / 4) * ((g.n[2] + 3) / 4);
+        if (brick_order)
+            nkeys = (16ll << c->opt_brick_xshift) * (((g.n[0] >> g.xr_shift) + (1 << c->opt_brick_xshift) - 1) >> c->opt_brick_xshift) *
+                    ((g.n[1] + 3) / 4) * ((g.n[2] + 3) / 4);
         int end_bit = 1;
         while (end_bit < 32 && (1ll << end_bit) < nkeys) end_bit++;
         size_t tmp_bytes = 0;
@@ -1284,6 +1287,12 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
         if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, PPCR_ERR_INVALID, "grid_xf must be 1, 2, 4 or 8");
         if (c->have_tgt) return fail(c, PPCR_ERR_STATE, "grid_xf must be set before the target cloud");
         c->opt_grid_xf = value;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "brick_x") == 0) {
+        if (value != 1 && value != 2 && value != 4) return fail(c, PPCR_ERR_INVALID, "brick_x must be 1, 2 or 4");
+        c->opt_brick_xshift = value == 1 ? 0 : (value == 2 ? 1 : 2);
+        c->src_sorted = false;
         return PPCR_OK;
     }
     if (std::strcmp(key, "short_lists") == 0) {
