@@ -213,7 +213,7 @@ int ppcr_profile_enable(ppcr_ctx *ctx, int enable); /* also clears accumulated s
 int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_out);
 
 /* Tuning / debugging knobs (never change results): key is one of
- *   "sort_source"  0 keep caller order, 1 brick/snake order (default), 2 x-fastest cell order;
+ *   "sort_source"  0 keep caller order, 1 brick order, boustrophedon (default; see "brick_x"), 2 x-fastest cell order;
  *   "nn_variant"   0/3 LDS-tiled kernel (default), 2 per-lane global scan + LDS list, 1 sorted register list,
  *                  4..7 tile-shape experiments (max_neighbours 9..10 only);
  *   "temporal"     1 start each query's cut-off from its previous m-th distance (default), 0 off;

@@ -508,12 +508,12 @@ void launch_topm(ppcr_ctx *c, float r2, int m, const FusedRows &fm, const Pendin
                                                                               c->dm2.p, dm2_in, vb_none, nxyz)
 #define PPCR_TILE(Cc, B, CAPc) PPCR_TILE_F(Cc, B, CAPc, false)
     if (c->opt_nn_variant == 0 || c->opt_nn_variant == 3) {
-        // LDS budget per 256-query block: halo CAP*16 B + list C*512 B (+1.1 KB tables), three blocks per CU.
-        // CAP must hold the halo of two adjacent 4x4x4 bricks AFTER the source has drifted by a cell:
-        // (8+1+2)x(4+1+2)x(4+1+2) cells ~ 2055 candidates at the benchmark density; with 2048 the kernel
-        // slows from 249 to 341 us as the source moves.  Measured at 1M<->1M (fresh / drifted source):
-        // CAP 2048: 249/341 us, 2112: 320/371, 2176: 231/246, 2240: 230/246, 2272: 302/318, 2304: 304/318.
-        // (C below 32 makes list compactions frequent: C = 24 doubled the kernel time.)
+        // LDS budget per 256-query block: halo CAP*13 B (x, y, z + a row-id byte) + list C*512 B (+1.1 KB tables).
+        // CAP was sized when the source was ordered in 4x4x4 bricks (256 consecutive queries straddling two of them
+        // AFTER a drift of one cell: (8+1+2)x(4+1+2)x(4+1+2) cells ~ 2055 candidates at the benchmark density;
+        // measured then, fresh / drifted source: CAP 2048: 249/341 us, 2176: 231/246, 2240: 230/246, 2272: 302/318).
+        // With the column order (brick_x = 1) typical halos are ~1000-1400 candidates; the margin keeps denser clouds
+        // out of the subdivided passes.  The first association (no cut-off yet) needs C = 32 (C = 24 doubled its time).
         constexpr int C = (M <= 24) ? 32 : 48;
         constexpr int CAP = (M <= 24) ? 2240 : 2048;
         if (fm.enabled) {
