@@ -214,23 +214,13 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
 
 /* Tuning / debugging knobs (never change results): key is one of
  *   "sort_source"  0 keep caller order, 1 brick order, boustrophedon (default; see "brick_x"), 2 x-fastest cell order;
- *   "nn_variant"   0/3 LDS-tiled kernel (default), 2 per-lane global scan + LDS list, 1 sorted register list,
- *                  4..7 tile-shape experiments (max_neighbours 9..10 only);
  *   "temporal"     1 start each query's cut-off from its previous m-th distance (default), 0 off;
  *   "mailbox"      1 deliver the moments through pinned host memory and spin (default), 0 copy + synchronise;
- *   "fused"        1 K1 epilogue writes per-row partials (experiment, measured slower), 0 off (default);
  *   "grid_xf"      x slices per grid cell, 1/2/4/8 (default 4; set before the target): every stencil row is clipped
  *                  to the x window the search sphere needs in that row;
  *   "brick_x"      x extent in cells of the 4x4 (y,z) bricks the source is ordered by: 1 (default), 2 or 4;
  *   "short_lists"  1 once the temporal cut-off is valid K1 runs with 16-slot lists and four workgroups per CU
  *                  (default), 0 always 32 slots / three workgroups;
- *   "emit_xyz"     1 K1 also writes the neighbours' coordinates so that K23 streams instead of gathering
- *                  (experiment, measured neutral: K23 is instruction-bound, not gather-bound), 0 off (default);
- *   "xcd_remap"    1 give each XCD a contiguous eighth of the source bricks (experiment, measured neutral), 0 off;
- *   "verlet"       1 keep per-query skin lists (all targets within radius*(1+skin)) and answer later associations
- *                  from them while the accumulated motion stays inside the skin (experiment, measured slower than
- *                  the direct scan: per-lane gathers), 0 off (default);
- *   "verlet_skin_permille"  skin as a fraction of the radius in 1/1000 (default 200);
  *   "stamps"       1 collect per-phase cycle counts of the tiled kernel (diagnostic). */
 int ppcr_set_option(ppcr_ctx *ctx, const char *key, int value);
 

@@ -298,13 +298,6 @@ class Context:
         self._ck(self._L.ppcr_mse_previous(self._h, C.byref(v)))
         return v.value
 
-    def counters(self):
-        """Diagnostic: (Verlet builds, Verlet uses, plain grid scans) performed by this handle."""
-        out = (C.c_longlong * 3)()
-        self._L.ppcr_debug_get_counters.argtypes = [C.c_void_p, C.c_void_p]
-        self._ck(self._L.ppcr_debug_get_counters(self._h, out))
-        return tuple(int(v) for v in out)
-
     def synchronize(self):
         self._ck(self._L.ppcr_synchronize(self._h))
 

@@ -39,7 +39,6 @@ enum KernelId {
     K_GATHER,
     K_CELL_START,
     K_NN_TOPM,
-    K_VERLET_BUILD,
     K_NN_COUNT,
     K_NN_SCAN,
     K_NN_FILL,
@@ -54,7 +53,7 @@ enum KernelId {
 };
 const char *const kKernelNames[K_NUM] = {
     "repack_kernel",   "bbox_kernel",    "cell_key_kernel",   "radix_sort",       "gather_points_kernel",
-    "cell_start_kernel", "nn_topm_kernel", "verlet_build_kernel", "nn_count_kernel",  "nn_scan",          "nn_fill_kernel",
+    "cell_start_kernel", "nn_topm_kernel", "nn_count_kernel",  "nn_scan",          "nn_fill_kernel",
     "nn_select_kernel", "csr_compact_kernel", "ell_count_sum_kernel", "weights_kernel", "accumulate_kernel",
     "reduce_partials_kernel", "transform_kernel"};
 
@@ -102,9 +101,7 @@ struct ppcr_ctx {
     double dof = 5.0;
     int dim = 3;
     int opt_sort_source = 1;
-    int opt_nn_variant = 0;
     int opt_stamps = 0;
-    int opt_fused = 0;  // split K23 (K1 epilogue writes per-row partials): measured slower, see FusedRows
     DevBuf<unsigned long long> d_stamps;
 
     // clouds
@@ -141,8 +138,6 @@ struct ppcr_ctx {
     // reductions
     DevBuf<double> partials, d_sums;
     DevBuf<unsigned> d_ticket;
-    bool fused_sums_pending = false;  // K1 wrote per-row partials for theta0: the first solve step only streams them
-    DevBuf<double> rowpart;           // [6][ns]
     bool move_pending = false;        // a source move that the next tiled K1 will apply in its prologue
     double pending_T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     double *h_sums = nullptr;          // pinned
@@ -167,8 +162,6 @@ struct ppcr_ctx {
     double prof_ms[K_NUM] = {0};
     int64_t prof_n[K_NUM] = {0};
 
-    // Verlet (skin) lists: second grid with cells >= r + skin, its own sorted copy of the target, the lists, and
-    // the rigid motion accumulated since they were built
     double dbg_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics of the last ppcr_align (ppcr_debug_get_host_times)
     // reporting clouds (the step after each iteration: cc:110-129): a full-resolution companion that follows every
     // move of the source, the ground truth and the previous-iteration snapshot, all in the caller's index order
@@ -178,31 +171,11 @@ struct ppcr_ctx {
     DevBuf<double> mse_part;
     int opt_short_lists = 1;
     int opt_brick_xshift = 0;    // log2 of the source bricks' x extent in cells (0: 4x4 yz columns walked along x)
-    int opt_xcd_remap = 0;
     int opt_grid_xf = 4;         // x slices per grid cell (GridDesc::xr)
-    int opt_emit_xyz = 0;        // K1 also leaves the neighbours' coordinates (k-major SoA) for K23 to stream: measured neutral
-    DevBuf<float> nbr_xyz;
-    bool nbr_xyz_valid = false;  // nbr_xyz matches the current ELL association
-    int opt_verlet = 0;      // measured slower than the direct tiled scan on gfx950, kept as an option
-    double skin_frac = 0.2;  // skin = skin_frac * radius
     float tgt_lo[3] = {0, 0, 0}, tgt_hi[3] = {0, 0, 0};
-    bool grid2_valid = false;
-    double grid2_cell_radius = -1;
-    GridDesc grid2{};
-    DevBuf<int> cell_start2;
-    DevBuf<float4> tgt_sorted2;
-    DevBuf<int> vl_nbr, vl_cnt;
-    bool vl_valid = false;
-    double vl_skin = 0;
-    double T_since[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    float vl_src_lo[3] = {0, 0, 0}, vl_src_hi[3] = {0, 0, 0};
-    int vl_moves_since = 0;
-    double last_move_T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};  // most recent rigid move of the source
-    bool moved_since_assoc = false;                                  // ... applied after the last association
-    int64_t stat_verlet_builds = 0, stat_verlet_uses = 0, stat_direct = 0;
-    // which copy of the target the association's positions index: 0 caller order, 1 grid-sorted, 2 grid2-sorted
+    // which copy of the target the association's positions index: 0 caller order, 1 grid-sorted
     int assoc_space = 0;
-    const float4 *tgt_space(int sp) const { return sp == 2 ? tgt_sorted2.p : (sp == 1 ? tgt_sorted.p : tgt_raw.p); }
+    const float4 *tgt_space(int sp) const { return sp == 1 ? tgt_sorted.p : tgt_raw.p; }
     const float4 *tgt_cur() const { return tgt_space(assoc_space); }
 };
 
@@ -269,9 +242,7 @@ int check_launch(ppcr_ctx *c, const char *what)
 
 void invalidate_association(ppcr_ctx *c)
 {
-    c->fused_sums_pending = false;
     c->assoc = ppcr_ctx::ASSOC_NONE;
-    c->nbr_xyz_valid = false;
     c->nnz = -1;
     c->csr_cache_valid = false;
 }
@@ -448,8 +419,6 @@ int ensure_grid(ppcr_ctx *c)
     if (c->grid_valid && c->grid_radius == c->radius) return PPCR_OK;
     if (!(c->radius > 0) || !std::isfinite(c->radius)) return fail(c, PPCR_ERR_INVALID, "radius must be positive and finite");
     invalidate_association(c);
-    c->vl_valid = false;
-    c->grid2_valid = false;
     const int n = (int)c->nt;
     PPCR_TRY(cloud_bbox(c, c->tgt_raw.p, n, c->tgt_lo, c->tgt_hi));
     for (int a = 0; a < 3; a++) c->origin[a] = 0.5 * ((double)c->tgt_lo[a] + (double)c->tgt_hi[a]);
@@ -463,20 +432,6 @@ int ensure_grid(ppcr_ctx *c)
     return PPCR_OK;
 }
 
-// second grid for the Verlet builds: cells cover r + skin
-int ensure_grid2(ppcr_ctx *c, double cell_radius)
-{
-    if (c->grid2_valid && c->grid2_cell_radius == cell_radius) return PPCR_OK;
-    const int n = (int)c->nt;
-    c->vl_valid = false;
-    make_grid_desc(n, c->tgt_lo, c->tgt_hi, cell_radius, c->opt_grid_xf, c->grid2);
-    HIP_TRY(c, c->tgt_sorted2.reserve((size_t)std::max(n, 1)));
-    PPCR_TRY(sort_by_cell(c, c->grid2, c->tgt_raw.p, n, c->tgt_sorted2.p, &c->cell_start2));
-    c->grid2_valid = true;
-    c->grid2_cell_radius = cell_radius;
-    return PPCR_OK;
-}
-
 int ensure_source_sorted(ppcr_ctx *c)
 {
     if (!c->have_src) return fail(c, PPCR_ERR_STATE, "source cloud not set");
@@ -487,68 +442,37 @@ int ensure_source_sorted(ppcr_ctx *c)
     std::swap(c->src, c->src_alt);
     c->src_sorted = true;
     c->dm2_valid = false;  // row order changed
-    c->vl_valid = false;
     return PPCR_OK;
 }
 
-// nn_variant: 0/3 = LDS-tiled halo + med3 selection (default), 2 = per-lane global scan + LDS list,
-// 1 = sorted register list inside the scan loop (first version, kept for A/B measurements)
+// K1 launch.  LDS budget per 256-query block: halo CAP*13 B (x, y, z + a row-id byte) + list C*512 B (+1.1 KB tables).
+// With the column order of the source typical halos are ~1000-1400 candidates at the benchmark density; the margin
+// keeps denser clouds out of the subdivided passes (measured when the source was ordered in 4x4x4 bricks, fresh /
+// drifted: CAP 2048: 249/341 us, 2176: 231/246, 2240: 230/246, 2272: 302/318).  The first association (no cut-off
+// yet) needs C = 32 (C = 24 doubled its time).
 template <int M>
-void launch_topm(ppcr_ctx *c, float r2, int m, const FusedRows &fm, const PendingMove &pm)
+void launch_tile(ppcr_ctx *c, float r2, int m, const PendingMove &pm)
 {
     unsigned long long *st = c->opt_stamps ? c->d_stamps.p : nullptr;
     const int dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
-    const VerletBuild vb_none{0, nullptr, nullptr};
-    float *nxyz = (c->opt_emit_xyz && !fm.enabled && (c->opt_nn_variant == 0 || c->opt_nn_variant == 3) && c->nbr_xyz.p) ? c->nbr_xyz.p : nullptr;
-    c->nbr_xyz_valid = nxyz != nullptr;
-#define PPCR_TILE_F(Cc, B, CAPc, F)                                                                                 \
-    nn_tile_kernel<M, Cc, B, CAPc, F><<<nblocks(c->ns, B), B, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p, \
-                                                                              c->cell_start.p, c->grid, r2, m,      \
-                                                                              c->nbr.p, c->cnt.p, st, fm, pm,      \
-                                                                              c->dm2.p, dm2_in, vb_none, nxyz)
-#define PPCR_TILE(Cc, B, CAPc) PPCR_TILE_F(Cc, B, CAPc, false)
-    if (c->opt_nn_variant == 0 || c->opt_nn_variant == 3) {
-        // LDS budget per 256-query block: halo CAP*13 B (x, y, z + a row-id byte) + list C*512 B (+1.1 KB tables).
-        // CAP was sized when the source was ordered in 4x4x4 bricks (256 consecutive queries straddling two of them
-        // AFTER a drift of one cell: (8+1+2)x(4+1+2)x(4+1+2) cells ~ 2055 candidates at the benchmark density;
-        // measured then, fresh / drifted source: CAP 2048: 249/341 us, 2176: 231/246, 2240: 230/246, 2272: 302/318).
-        // With the column order (brick_x = 1) typical halos are ~1000-1400 candidates; the margin keeps denser clouds
-        // out of the subdivided passes.  The first association (no cut-off yet) needs C = 32 (C = 24 doubled its time).
-        constexpr int C = (M <= 24) ? 32 : 48;
-        constexpr int CAP = (M <= 24) ? 2240 : 2048;
-        if (fm.enabled) {
-            if constexpr (M == 10) PPCR_TILE_F(C, 256, CAP, true);  // experiment: only instantiated for M = 10
-        } else if (c->opt_xcd_remap) {
-            nn_tile_kernel<M, C, 256, CAP, false, true><<<nblocks(c->ns, 256), 256, 0, c->stream>>>(
-                c->src.p, (int)c->ns, c->tgt_sorted.p, c->cell_start.p, c->grid, r2, m, c->nbr.p, c->cnt.p, st, fm, pm,
-                c->dm2.p, dm2_in, vb_none, nxyz);
-        } else if (dm2_in && c->opt_short_lists && M <= 12) {
-            // steady state: the temporal cut-off keeps every list near m entries, so half the list capacity does
-            // (an overflowing lane re-runs with in-loop compaction as always); with the one-byte row ids that
-            // brings the workgroup under 40 KB of LDS and 128 VGPRs: FOUR workgroups per CU instead of three
-            if constexpr (M <= 12) PPCR_TILE(16, 256, CAP);
-        } else {
-            PPCR_TILE(C, 256, CAP);
+    constexpr int C = (M <= 24) ? 32 : 48;
+    constexpr int CAP = (M <= 24) ? 2240 : 2048;
+#define PPCR_TILE(Cc)                                                                                                   \
+    nn_tile_kernel<M, Cc, 256, CAP><<<nblocks(c->ns, 256), 256, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p, \
+                                                                                c->cell_start.p, c->grid, r2, m,      \
+                                                                                c->nbr.p, c->cnt.p, st, pm, c->dm2.p, \
+                                                                                dm2_in)
+    if constexpr (M <= 12) {
+        // steady state: the temporal cut-off keeps every list near m entries, so half the list capacity does
+        // (an overflowing lane re-runs with in-loop compaction as always); with the one-byte row ids that
+        // brings the workgroup under 40 KB of LDS and 128 VGPRs: FOUR workgroups per CU instead of three
+        if (dm2_in && c->opt_short_lists) {
+            PPCR_TILE(16);
+            return;
         }
-    } else if (c->opt_nn_variant >= 4 && c->opt_nn_variant <= 7) {  // block-shape experiments (M = 10 only)
-        if constexpr (M == 10) {
-            // measured (fresh source, cut-off active, default = 153 us): CAP 1536 -> 231 us (halos stop fitting);
-            // list capacity 16 -> 819-919 us (lists overflow and lanes re-run); capacity 12 + CAP 1280 -> 2.2 ms
-            if (c->opt_nn_variant == 4) PPCR_TILE(32, 256, 2048);
-            if (c->opt_nn_variant == 5) PPCR_TILE(32, 256, 1536);
-            if (c->opt_nn_variant == 6) PPCR_TILE(16, 256, 2240);
-            if (c->opt_nn_variant == 7) PPCR_TILE(32, 256, 3072);
-        }
-    } else if (c->opt_nn_variant == 1) {
-        nn_topm_kernel<M><<<nblocks(c->ns), kBlock, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p,
-                                                                     c->cell_start.p, c->grid, r2, m, c->nbr.p,
-                                                                     c->cnt.p);
-    } else {
-        constexpr int C = (M <= 24) ? 32 : 48;
-        nn_list_kernel<M, C><<<nblocks(c->ns), kBlock, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p,
-                                                                        c->cell_start.p, c->grid, r2, m, c->nbr.p,
-                                                                        c->cnt.p);
     }
+    PPCR_TILE(C);
+#undef PPCR_TILE
 }
 
 constexpr int kAccumRows = 1;     // rows per lane of accumulate_ell_kernel
@@ -557,15 +481,10 @@ constexpr int kAccumBlock = 256;  // threads per block of accumulate_ell_kernel 
 template <int W>
 void launch_accumulate_ell(ppcr_ctx *c, int nb, const Pose &P, const Model &md)
 {
-    if (c->nbr_xyz_valid) {
-        accumulate_ell_kernel<W, kAccumRows, kAccumBlock, true><<<nb, kAccumBlock, 0, c->stream>>>(
-            c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md, c->partials.p, c->ell_width, c->nbr_xyz.p);
-        return;
-    }
     // the two models the reference's CLI reaches by default are compiled in (Gaussian -u; t with dof 5, dim 3:
     // v + dim = 8); any other dof takes the run-time form of the same arithmetic
 #define PPCR_K23(TMc)                                                                                              \
-    accumulate_ell_kernel<W, kAccumRows, kAccumBlock, false, TMc><<<nb, kAccumBlock, 0, c->stream>>>(              \
+    accumulate_ell_kernel<W, kAccumRows, kAccumBlock, TMc><<<nb, kAccumBlock, 0, c->stream>>>(              \
         c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md, c->partials.p, c->ell_width)
     if (md.is_normal) PPCR_K23(0);
     else if (md.vpd_int == 8) PPCR_K23(8);
@@ -573,94 +492,23 @@ void launch_accumulate_ell(ppcr_ctx *c, int nb, const Pose &P, const Model &md)
 #undef PPCR_K23
 }
 
-bool tile_variant(const ppcr_ctx *c) { return c->opt_nn_variant == 0 || c->opt_nn_variant == 3; }
 int flush_pending_move(ppcr_ctx *c);
 
-constexpr int kVerletCap = 48;  // entries per Verlet list (rows with more fall back to scanning the grid)
-
-// largest distance any point of the box [lo, hi] travels under the rigid transform T (|T x - x| is convex in x,
-// so the maximum over a box is attained at a corner)
-double max_displacement(const double T[12], const float lo[3], const float hi[3])
-{
-    double worst = 0;
-    for (int k = 0; k < 8; k++) {
-        const double x[3] = {(k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2]};
-        double d2 = 0;
-        for (int a = 0; a < 3; a++) {
-            const double y = T[4 * a] * x[0] + T[4 * a + 1] * x[1] + T[4 * a + 2] * x[2] + T[4 * a + 3];
-            d2 += (y - x[a]) * (y - x[a]);
-        }
-        worst = std::max(worst, std::sqrt(d2));
-    }
-    return worst;
-}
-
-PendingMove no_move()
-{
-    PendingMove pm;
-    std::memset(&pm, 0, sizeof(pm));
-    return pm;
-}
-
-// BUILD: all targets within radius + skin of every query (tile kernel on the second grid, list capacity
-// kVerletCap); also records the source bounding box the displacement bound is evaluated on
-int verlet_build(ppcr_ctx *c, double skin, const PendingMove &pm)
-{
-    const int ns = (int)c->ns;
-    PPCR_TRY(ensure_grid2(c, c->radius + skin));
-    HIP_TRY(c, c->vl_nbr.reserve((size_t)kVerletCap * (size_t)ns));
-    HIP_TRY(c, c->vl_cnt.reserve((size_t)ns));
-    const double rs = c->radius + skin;
-    const float rs2 = (float)(rs * rs);
-    FusedRows fm;
-    std::memset(&fm, 0, sizeof(fm));
-    const VerletBuild vb{1, c->vl_nbr.p, c->vl_cnt.p};
-    {
-        ProfScope ps(c, K_VERLET_BUILD);
-        nn_tile_kernel<32, kVerletCap, 256, 3072, false><<<nblocks(ns), 256, 0, c->stream>>>(
-            c->src.p, ns, c->tgt_sorted2.p, c->cell_start2.p, c->grid2, rs2, kVerletCap, c->nbr.p, c->cnt.p, nullptr, fm, pm,
-            nullptr, 0, vb);
-    }
-    PPCR_TRY(check_launch(c, "nn_tile_kernel (verlet build)"));
-    PPCR_TRY(cloud_bbox(c, c->src.p, ns, c->vl_src_lo, c->vl_src_hi));
-    const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    std::memcpy(c->T_since, I, sizeof(I));
-    c->vl_moves_since = 0;
-    c->vl_skin = skin;
-    c->vl_valid = true;
-    c->stat_verlet_builds++;
-    return PPCR_OK;
-}
-
-template <int M>
-void launch_verlet_use(ppcr_ctx *c, float r2, int m, const PendingMove &pm)
-{
-    const VerletUse vu{c->vl_nbr.p, c->vl_cnt.p};
-    const int dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
-    nn_verlet_kernel<M><<<nblocks(c->ns), kBlock, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted2.p, c->cell_start2.p,
-                                                                       c->grid2, r2, m, c->nbr.p, c->cnt.p, vu, pm, c->dm2.p,
-                                                                       dm2_in);
-}
-
-// fused_theta (nullable): {R, t} of the state the first IRLS half-step is evaluated at; when given and
-// the tiled kernel runs, K1 also produces the moments (c->fused_sums_pending) and K23 is skipped once
-int associate_impl(ppcr_ctx *c, const Mat3 *fused_R = nullptr, const double *fused_t = nullptr)
+// K1 (or the generic count/scan/fill path for unbounded searches and max_neighbours > 32)
+int associate_impl(ppcr_ctx *c)
 {
     PPCR_TRY(ensure_grid(c));
     if (!c->src_sorted) PPCR_TRY(flush_pending_move(c));  // the one-time spatial sort reads the source
     PPCR_TRY(ensure_source_sorted(c));
     invalidate_association(c);
-    c->fused_sums_pending = false;
     const int ns = (int)c->ns;
     const float r2 = (float)(c->radius * c->radius);  // PCL: static_cast<float>(radius * radius)
     const bool unbounded = (c->max_nb <= 0 || (int64_t)c->max_nb >= c->nt);
-    const bool tiled = !unbounded && c->max_nb <= kEllMaxWidth && tile_variant(c) && ns > 0;
+    const bool tiled = !unbounded && c->max_nb <= kEllMaxWidth && ns > 0;
     PendingMove pm;
     std::memset(&pm, 0, sizeof(pm));
-    double pending_copy[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     if (c->move_pending && tiled) {
         // the deferred source move rides in this kernel's prologue
-        std::memcpy(pending_copy, c->pending_T, sizeof(pending_copy));
         pm.enabled = 1;
         for (int a = 0; a < 3; a++) {
             for (int b = 0; b < 3; b++) pm.P.R[3 * a + b] = c->pending_T[4 * a + b];
@@ -676,85 +524,21 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fused_R = nullptr, const double *fus
         HIP_TRY(c, c->nbr.reserve((size_t)m * (size_t)std::max(ns, 1)));
         HIP_TRY(c, c->cnt.reserve((size_t)std::max(ns, 1)));
         HIP_TRY(c, c->dm2.reserve((size_t)std::max(ns, 1)));
-        c->nbr_xyz_valid = false;
-        if (c->opt_emit_xyz && tiled) HIP_TRY(c, c->nbr_xyz.reserve((size_t)3 * (size_t)m * (size_t)std::max(ns, 1)));
         // dm2 is only trusted when the source moved by nothing but the deferred rigid move applied in this
         // very kernel since the association that wrote it
         if (!tiled) c->dm2_valid = false;
-        FusedRows fm;
-        std::memset(&fm, 0, sizeof(fm));
-        if (fused_R && c->opt_fused && m > 8 && m <= 10 && ns > 0 && c->nt > 0 && tile_variant(c)) {
-            HIP_TRY(c, c->rowpart.reserve((size_t)6 * (size_t)ns));
-            fm.enabled = 1;
-            fm.P = make_pose(c, *fused_R, fused_t);
-            fm.md = make_model(c);
-            fm.rowpart = c->rowpart.p;
-        }
-        // ---- Verlet (skin) lists: reuse / rebuild / plain scan --------------------------------------------
-        bool use_lists = false, build_lists = false;
-        const double skin = c->skin_frac * c->radius;
-        if (tiled && c->opt_verlet && !fm.enabled && m <= 20 && c->nt > 0) {
-            double Ttot[12];
-            if (pm.enabled) compose(pending_copy, c->T_since, Ttot);
-            else std::memcpy(Ttot, c->T_since, sizeof(Ttot));
-            if (c->vl_valid && c->vl_skin == skin) {
-                double corner = 0;
-                for (int a = 0; a < 3; a++) corner = std::max(corner, (double)std::max(std::fabs(c->vl_src_lo[a]), std::fabs(c->vl_src_hi[a])));
-                // float re-rounding of the moved source, one ulp-ish per applied move
-                const double slack = (c->vl_moves_since + 1) * 2.4e-7 * corner * 1.8 + 1e-5 * c->radius;
-                use_lists = max_displacement(Ttot, c->vl_src_lo, c->vl_src_hi) * 1.00001 + slack <= skin;
-            }
-            if (!use_lists && c->moved_since_assoc) {
-                // worth a rebuild only if the motion per iteration is small against the skin
-                float lo[3], hi[3];
-                for (int a = 0; a < 3; a++) {
-                    lo[a] = c->vl_valid ? c->vl_src_lo[a] : c->tgt_lo[a] - (float)c->radius;
-                    hi[a] = c->vl_valid ? c->vl_src_hi[a] : c->tgt_hi[a] + (float)c->radius;
-                }
-                build_lists = max_displacement(c->last_move_T, lo, hi) * 3.0 <= skin;
-            }
-            if (use_lists) {
-                std::memcpy(c->T_since, Ttot, sizeof(Ttot));
-                if (pm.enabled) c->vl_moves_since++;
-            }
-        }
-        c->moved_since_assoc = false;
-        if (build_lists) {
-            PPCR_TRY(verlet_build(c, skin, pm));  // applies the pending move in its prologue
-            if (pm.enabled) c->dm2_valid = false;  // the source moved in a kernel that does not maintain dm2
-            pm = no_move();
-            use_lists = true;
-        }
-        if (ns > 0 && use_lists) {
+        if (ns > 0) {
             ProfScope ps(c, K_NN_TOPM);
-            if (m <= 4) launch_verlet_use<4>(c, r2, m, pm);
-            else if (m <= 5) launch_verlet_use<5>(c, r2, m, pm);
-            else if (m <= 8) launch_verlet_use<8>(c, r2, m, pm);
-            else if (m <= 10) launch_verlet_use<10>(c, r2, m, pm);
-            else if (m <= 16) launch_verlet_use<16>(c, r2, m, pm);
-            else launch_verlet_use<20>(c, r2, m, pm);
-            c->stat_verlet_uses++;
-            c->assoc_space = 2;
-        } else if (ns > 0) {
-            ProfScope ps(c, K_NN_TOPM);
-            if (m <= 4) launch_topm<4>(c, r2, m, fm, pm);
-            else if (m <= 5) launch_topm<5>(c, r2, m, fm, pm);
-            else if (m <= 8) launch_topm<8>(c, r2, m, fm, pm);
-            else if (m <= 10) launch_topm<10>(c, r2, m, fm, pm);
-            else if (m <= 16) launch_topm<16>(c, r2, m, fm, pm);
-            else if (m <= 20) launch_topm<20>(c, r2, m, fm, pm);
-            else launch_topm<32>(c, r2, m, fm, pm);
-            c->stat_direct++;
-            c->assoc_space = 1;
-            if (pm.enabled) {  // the lists (if any) stay in step with the motion applied to the source
-                compose(pending_copy, c->T_since, c->T_since);
-                c->vl_moves_since++;
-            }
-        } else {
-            c->assoc_space = 1;
+            if (m <= 4) launch_tile<4>(c, r2, m, pm);
+            else if (m <= 5) launch_tile<5>(c, r2, m, pm);
+            else if (m <= 8) launch_tile<8>(c, r2, m, pm);
+            else if (m <= 10) launch_tile<10>(c, r2, m, pm);
+            else if (m <= 16) launch_tile<16>(c, r2, m, pm);
+            else if (m <= 20) launch_tile<20>(c, r2, m, pm);
+            else launch_tile<32>(c, r2, m, pm);
         }
-        PPCR_TRY(check_launch(c, "nn_topm_kernel"));
-        c->fused_sums_pending = fm.enabled != 0;
+        c->assoc_space = 1;
+        PPCR_TRY(check_launch(c, "nn_tile_kernel"));
         c->dm2_valid = tiled;
         c->assoc = ppcr_ctx::ASSOC_ELL;
         c->ell_width = m;
@@ -1018,28 +802,6 @@ int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PP
     return fold_and_deliver(c, nb, sums);
 }
 
-// first IRLS half-step after a fused association: the per-row partials K1 left behind are streamed into moments
-int run_moments_from_rows(ppcr_ctx *c, double sums[PPCR_NSUMS])
-{
-    const int ns = (int)c->ns;
-    const int nb = std::max(1, std::min(kAccumMaxBlocks, nblocks(ns)));
-    HIP_TRY(c, c->partials.reserve((size_t)nb * kNSums));
-    HIP_TRY(c, c->d_sums.reserve(kNSums));
-    if (!c->d_ticket.p) {
-        HIP_TRY(c, c->d_ticket.reserve(1));
-        HIP_TRY(c, hipMemsetAsync(c->d_ticket.p, 0, sizeof(unsigned), c->stream));
-    }
-    Pose P;
-    std::memset(&P, 0, sizeof(P));
-    for (int a = 0; a < 3; a++) P.c[a] = c->origin[a];
-    {
-        ProfScope ps(c, K_ACCUMULATE);
-        moments_from_rows_kernel<<<nb, kBlock, 0, c->stream>>>(c->src.p, c->rowpart.p, ns, P, c->partials.p);
-    }
-    PPCR_TRY(check_launch(c, "moments_from_rows_kernel"));
-    return fold_and_deliver(c, nb, sums);
-}
-
 int apply_transform_now(ppcr_ctx *c, const double T[12]);
 
 // make the device copy of the source current (a move deferred to the next tiled K1 is applied now)
@@ -1055,8 +817,6 @@ int apply_transform_impl(ppcr_ctx *c, const double T[12], bool defer = false)
 {
     if (!c->have_src) return fail(c, PPCR_ERR_STATE, "source cloud not set");
     PPCR_TRY(flush_pending_move(c));
-    std::memcpy(c->last_move_T, T, sizeof(c->last_move_T));
-    c->moved_since_assoc = true;
     if (c->have_companion && c->n_companion > 0) {
         // the full-resolution copy moves with the same f64 -> f32 arithmetic, at once (it is off the hot path)
         Pose P;
@@ -1079,8 +839,6 @@ int apply_transform_impl(ppcr_ctx *c, const double T[12], bool defer = false)
 int apply_transform_now(ppcr_ctx *c, const double T[12])
 {
     c->dm2_valid = false;  // the source moved outside a tiled K1: the temporal cut-off starts over
-    compose(T, c->T_since, c->T_since);  // Verlet lists stay in step with every motion applied to the source
-    c->vl_moves_since++;
     Pose P;
     for (int a = 0; a < 3; a++) {
         for (int b = 0; b < 3; b++) P.R[3 * a + b] = T[4 * a + b];
@@ -1103,13 +861,7 @@ int solve_impl(ppcr_ctx *c, const double q0[4], const double t0[3], int max_step
     Mat3 R = quat_to_rot(q0);
     Vec3 t{{t0[0], t0[1], t0[2]}};
     double sums[PPCR_NSUMS];
-    if (c->fused_sums_pending) {
-        // K1's epilogue already evaluated the weights at (q0, t0) and left six per-row partials: stream them
-        c->fused_sums_pending = false;
-        PPCR_TRY(run_moments_from_rows(c, sums));
-    } else {
-        PPCR_TRY(run_accumulate(c, R, t.v, sums));
-    }
+    PPCR_TRY(run_accumulate(c, R, t.v, sums));
     double cost_old = 0.5 * sums[16];
     cost_out[0] = cost_out[1] = cost_old;
     int steps = 0;
@@ -1205,14 +957,9 @@ int ppcr_destroy(ppcr_ctx *c)
     c->src.release();
     c->src_alt.release();
     c->cell_start.release();
-    c->cell_start2.release();
-    c->tgt_sorted2.release();
-    c->vl_nbr.release();
-    c->nbr_xyz.release();
     c->companion.release();
     c->ground_truth.release();
     c->previous.release();
-    c->vl_cnt.release();
     c->keys_a.release();
     c->keys_b.release();
     c->vals_a.release();
@@ -1230,11 +977,11 @@ int ppcr_destroy(ppcr_ctx *c)
     c->d_total.release();
     c->d_stamps.release();
     c->partials.release();
-    c->rowpart.release();
     c->d_sums.release();
     c->d_ticket.release();
     c->d_w.release();
     c->d_s.release();
+    c->mse_part.release();
     if (c->h_sums) (void)hipHostFree(c->h_sums);
     if (c->h_total) (void)hipHostFree(c->h_total);
     if (c->h_mbox) (void)hipHostFree(c->h_mbox);
@@ -1274,15 +1021,6 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
         c->opt_sort_source = value;  // 0 = keep caller order, 1 = brick/snake order (default), 2 = x-fastest cell order
         return PPCR_OK;
     }
-    if (std::strcmp(key, "nn_variant") == 0) {
-        c->opt_nn_variant = value;
-        return PPCR_OK;
-    }
-    if (std::strcmp(key, "verlet") == 0) {  // 1: Verlet (skin) neighbour lists while the source moves little (default)
-        c->opt_verlet = value ? 1 : 0;
-        c->vl_valid = false;
-        return PPCR_OK;
-    }
     if (std::strcmp(key, "grid_xf") == 0) {
         if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, PPCR_ERR_INVALID, "grid_xf must be 1, 2, 4 or 8");
         if (c->have_tgt) return fail(c, PPCR_ERR_STATE, "grid_xf must be set before the target cloud");
@@ -1299,31 +1037,12 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
         c->opt_short_lists = value ? 1 : 0;
         return PPCR_OK;
     }
-    if (std::strcmp(key, "emit_xyz") == 0) {
-        c->opt_emit_xyz = value ? 1 : 0;
-        c->nbr_xyz_valid = false;
-        return PPCR_OK;
-    }
-    if (std::strcmp(key, "xcd_remap") == 0) {
-        c->opt_xcd_remap = value ? 1 : 0;
-        return PPCR_OK;
-    }
-    if (std::strcmp(key, "verlet_skin_permille") == 0) {  // skin as a fraction of the radius, in 1/1000 (default 200)
-        if (value < 1 || value > 1000) return fail(c, PPCR_ERR_INVALID, "verlet_skin_permille must be in [1, 1000]");
-        c->skin_frac = value / 1000.0;
-        c->vl_valid = false;
-        return PPCR_OK;
-    }
     if (std::strcmp(key, "mailbox") == 0) {
         c->opt_mailbox = value ? 1 : 0;
         return PPCR_OK;
     }
     if (std::strcmp(key, "temporal") == 0) {  // 1: start each query's cut-off from its previous m-th distance (default)
         c->opt_temporal = value ? 1 : 0;
-        return PPCR_OK;
-    }
-    if (std::strcmp(key, "fused") == 0) {  // 1: K1 epilogue + stream kernel replace K23 for the first step (experiment, M = 10)
-        c->opt_fused = value ? 1 : 0;
         return PPCR_OK;
     }
     if (std::strcmp(key, "stamps") == 0) {  // diagnostic: per-phase cycle totals of nn_tile_kernel
@@ -1342,8 +1061,6 @@ static int set_target_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, in
     c->nt = n;
     c->have_tgt = true;
     c->grid_valid = false;
-    c->grid2_valid = false;
-    c->vl_valid = false;
     c->origin_valid = false;
     c->dm2_valid = false;
     c->assoc_space = 0;
@@ -1355,7 +1072,6 @@ static int set_source_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, in
 {
     c->move_pending = false;  // a deferred move of the previous source dies with it
     c->dm2_valid = false;
-    c->vl_valid = false;
     PPCR_TRY(upload_cloud(c, p, dev, n, stride, c->src));
     c->ns = n;
     c->have_src = true;
@@ -1481,7 +1197,6 @@ int ppcr_set_association(ppcr_ctx *c, const int32_t *row_ptr, const int32_t *col
         HIP_TRY(c, hipMemcpyAsync(c->cnt.p, h_cnt.data(), h_cnt.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->assoc = ppcr_ctx::ASSOC_ELL;
-        c->nbr_xyz_valid = false;
         c->ell_width = w;
     } else {
         std::vector<int> h_rp((size_t)ns + 1, 0), h_nbr((size_t)std::max<int64_t>(nnz, 1));
@@ -1501,7 +1216,6 @@ int ppcr_set_association(ppcr_ctx *c, const int32_t *row_ptr, const int32_t *col
         HIP_TRY(c, hipMemcpyAsync(c->nbr.p, h_nbr.data(), h_nbr.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->assoc = ppcr_ctx::ASSOC_CSR;
-        c->nbr_xyz_valid = false;
     }
     c->nnz = nnz;
     c->csr_cache_valid = true;
@@ -1645,8 +1359,7 @@ int ppcr_iterate(ppcr_ctx *c, const double q0[4], const double t0[3], int inner_
         const double qn = q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3];
         if (!(qn > 0) || !std::isfinite(qn)) return fail(c, PPCR_ERR_INVALID, "initial rotation quaternion has zero or non-finite norm");
     }
-    const Mat3 R0 = quat_to_rot(q0);
-    PPCR_TRY(associate_impl(c, &R0, t0));
+    PPCR_TRY(associate_impl(c));
     PPCR_TRY(solve_impl(c, q0, t0, inner_steps, f_tol, T_out, cost_out, steps_out));
     return apply_transform_impl(c, T_out, /*defer=*/true);
 }
@@ -1662,7 +1375,6 @@ int ppcr_align(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_d
         const double qn = q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3];
         if (!(qn > 0) || !std::isfinite(qn)) return fail(c, PPCR_ERR_INVALID, "initial rotation quaternion has zero or non-finite norm");
     }
-    const Mat3 R0 = quat_to_rot(q0);
     ConvergenceRule rule;
     double Tcum[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     for (double &v : c->dbg_host) v = 0;
@@ -1672,7 +1384,7 @@ int ppcr_align(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_d
         int st = 0;
         const auto ti0 = std::chrono::steady_clock::now();
         const double w_before = c->dbg_host[1];
-        PPCR_TRY(associate_impl(c, &R0, t0));
+        PPCR_TRY(associate_impl(c));
         const auto ti1 = std::chrono::steady_clock::now();
         c->dbg_host[5] = std::max(c->dbg_host[5], std::chrono::duration<double>(ti1 - ti0).count());
         const double fold0 = c->dbg_host[6];
@@ -1741,22 +1453,12 @@ int ppcr_debug_get_stamps(ppcr_ctx *c, unsigned long long out[8])
     return PPCR_OK;
 }
 
-// diagnostic: {verlet builds, verlet uses, plain scans} since the handle was created
 // diagnostic: host-side time of the last ppcr_align: {iterations, total wait (s), max wait, total launch+solve, max,
 // max associate call, max reduce launch call, max (accumulate launch + host solve)}
 int ppcr_debug_get_host_times(ppcr_ctx *c, double out[8])
 {
     CTX_ENTER(c);
     for (int k = 0; k < 8; k++) out[k] = c->dbg_host[k];
-    return PPCR_OK;
-}
-
-int ppcr_debug_get_counters(ppcr_ctx *c, long long out[3])
-{
-    CTX_ENTER(c);
-    out[0] = c->stat_verlet_builds;
-    out[1] = c->stat_verlet_uses;
-    out[2] = c->stat_direct;
     return PPCR_OK;
 }
 

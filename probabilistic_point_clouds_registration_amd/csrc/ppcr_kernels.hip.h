@@ -227,54 +227,6 @@ __device__ __forceinline__ void for_each_candidate(float4 q, const GridDesc &g,
     }
 }
 
-template <int M>
-__global__ __launch_bounds__(kBlock) void nn_topm_kernel(const float4 *__restrict__ src, int ns,
-                                                         const float4 *__restrict__ tgt,
-                                                         const int *__restrict__ cell_start, GridDesc g,
-                                                         float r2, int m, int *__restrict__ nbr,
-                                                         int *__restrict__ cnt)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= ns) return;
-    const float4 q = src[i];
-    unsigned long long key[M];
-    int pos[M];
-#pragma unroll
-    for (int j = 0; j < M; j++) {
-        key[j] = ~0ull;
-        pos[j] = -1;
-    }
-    for_each_candidate(q, g, cell_start, tgt, [&](int p, float4 t) {
-        const float d2 = dist2_flann(q, t);
-        if (d2 < r2) {
-            unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(t.w);
-            if (k < key[M - 1]) {
-                int pp = p;
-                // bubble the new key through the ascending list; the largest falls off the end
-#pragma unroll
-                for (int j = 0; j < M; j++) {
-                    const bool lt = k < key[j];
-                    const unsigned long long kk = lt ? key[j] : k;
-                    const int pk = lt ? pos[j] : pp;
-                    key[j] = lt ? k : key[j];
-                    pos[j] = lt ? pp : pos[j];
-                    k = kk;
-                    pp = pk;
-                }
-            }
-        }
-    });
-    int c = 0;
-#pragma unroll
-    for (int j = 0; j < M; j++) {
-        if (j < m) {
-            nbr[(size_t)j * ns + i] = pos[j];
-            c += (pos[j] >= 0) ? 1 : 0;
-        }
-    }
-    cnt[i] = c;
-}
-
 // ---------------------------------------------------------------------------------------------
 // K1, list variant (default).  Measured on MI355X: the candidate scan alone costs ~90 us at
 // 1M<->1M while keeping a sorted top-m list inside the scan loop costs another ~320 us (every
@@ -313,80 +265,6 @@ __device__ __forceinline__ unsigned pick(const unsigned (&K)[M], int j)
 #pragma unroll
     for (int a = 0; a < M; a++) r = (a == j) ? K[a] : r;
     return r;
-}
-
-template <int M, int C>
-__global__ __launch_bounds__(kBlock) void nn_list_kernel(const float4 *__restrict__ src, int ns,
-                                                         const float4 *__restrict__ tgt,
-                                                         const int *__restrict__ cell_start, GridDesc g,
-                                                         float r2, int m, int *__restrict__ nbr,
-                                                         int *__restrict__ cnt)
-{
-    static_assert(C > M, "a compaction must leave room in the list");
-    __shared__ int lpos[C * kBlock];
-    const int tid = threadIdx.x;
-    const int i = blockIdx.x * kBlock + tid;
-    if (i >= ns) return;  // lists are lane-private: no block-level synchronisation anywhere
-    const float4 q = src[i];
-    int n = 0;
-    unsigned thr = 0xFFFFFFFFu;
-
-    // reduce the lane's list to its top-m by (d2, original index); n > m on entry
-    auto select_top_m = [&]() {
-        unsigned K[M];
-#pragma unroll
-        for (int j = 0; j < M; j++) K[j] = 0xFFFFFFFFu;
-        for (int t = 0; t < n; t++) {
-            const float4 c = tgt[lpos[t * kBlock + tid]];
-            sorted_insert<M>(K, __float_as_uint(dist2_flann(q, c)));
-        }
-        const unsigned T = pick<M>(K, m - 1);
-        int w = 0, c_eq = 0;
-        for (int t = 0; t < n; t++) {
-            const int p = lpos[t * kBlock + tid];
-            const unsigned b = __float_as_uint(dist2_flann(q, tgt[p]));
-            if (b <= T) {
-                lpos[w * kBlock + tid] = p;
-                w++;
-                c_eq += (b == T) ? 1 : 0;
-            }
-        }
-        if (w > m) {  // more ties at the cut-off than room: lowest original indices win
-            const int need = m - (w - c_eq);
-#pragma unroll
-            for (int j = 0; j < M; j++) K[j] = 0xFFFFFFFFu;
-            for (int t = 0; t < w; t++) {
-                const float4 c = tgt[lpos[t * kBlock + tid]];
-                if (__float_as_uint(dist2_flann(q, c)) == T) sorted_insert<M>(K, (unsigned)__float_as_int(c.w));
-            }
-            const unsigned T2 = pick<M>(K, need - 1);
-            int w2 = 0;
-            for (int t = 0; t < w; t++) {
-                const int p = lpos[t * kBlock + tid];
-                const float4 c = tgt[p];
-                const unsigned b = __float_as_uint(dist2_flann(q, c));
-                if (b < T || (unsigned)__float_as_int(c.w) <= T2) {
-                    lpos[w2 * kBlock + tid] = p;
-                    w2++;
-                }
-            }
-            w = w2;
-        }
-        n = w;
-        thr = T;
-    };
-
-    for_each_candidate(q, g, cell_start, tgt, [&](int p, float4 t) {
-        const float d2 = dist2_flann(q, t);
-        if (d2 < r2 && __float_as_uint(d2) <= thr) {
-            lpos[n * kBlock + tid] = p;
-            n++;
-            if (n == C) select_top_m();
-        }
-    });
-    if (n > m) select_top_m();
-    for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = lpos[j * kBlock + tid];
-    cnt[i] = n;
 }
 
 __device__ __forceinline__ double log_prob(const Model &md, double s)
@@ -521,95 +399,6 @@ __device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__
     }
 }
 
-
-// Split K23.  When the state theta0 of the first IRLS half-step is known at association time (it always is
-// inside align()/iterate()), nn_tile_kernel<FUSED> finishes each row while its winners are still in LDS and
-// writes SIX per-row quantities (no gathers, only short-lived temporaries):
-//     rowpart[0][i] = W_i = sum_k w_ik          rowpart[1..3][i] = sum_k w_ik (y_k - c)
-//     rowpart[4][i] = sum_k w_ik s_ik           rowpart[5][i]    = sum_k w_ik |y_k - c|^2
-// and moments_from_rows_kernel (a plain stream over src + rowpart, 23 us) forms the 19 moments.
-// MEASURED NEGATIVE on MI355X (1M<->1M, m = 10), kept behind option "fused" (off by default):
-//   v1, all 19 moments accumulated inside K1: 226 VGPRs, 2 waves/SIMD: 797 us vs 260 + 80 + 14 us separate;
-//   v2, this row-partial form: 197 VGPRs (2 waves/SIMD) 288 + 23 us, or forced to 168 VGPRs with 104 B of
-//       scratch 248 + 23 us, against 179 + 58 us for K1 + the standalone accumulate_ell_kernel.
-// The f64 per-row arithmetic (~450 instructions per lane) is simply cheaper in its own kernel at 4 waves/SIMD
-// than inside K1, whose register budget is already spent on the scan.
-struct FusedRows {
-    int enabled;
-    Pose P;
-    Model md;
-    double *rowpart;  // [6][ns]
-};
-
-template <class S>
-__device__ __forceinline__ void row_partials(const S &src, int n, float4 xf, const Pose &P, const Model &md,
-                                             double *__restrict__ rowpart, int ns, int i)
-{
-    double Wi = 0, wy0 = 0, wy1 = 0, wy2 = 0, gs = 0, gyy = 0;
-    if (n > 0) {
-        double xr[3];
-        rotate_point(P, xf, xr);
-        double smin = INFINITY;
-        for (int j = 0; j < n; j++) {
-            const double sj = sq_residual(src.get(src.load(j)), xr);
-            smin = sj < smin ? sj : smin;
-        }
-        const double lp_max = (md.is_normal || md.vpd_int) ? 0.0 : log_prob(md, smin);
-        double Z = 0, G = 0, Gs = 0, Gyy = 0, Gy0 = 0, Gy1 = 0, Gy2 = 0;
-        for (int j = 0; j < n; j++) {
-            const float4 y = src.get(src.load(j));
-            const double sj = sq_residual(y, xr);
-            const double inv_vs = md.is_normal ? 0.0 : fast_rcp(md.v + sj);
-            const double e = rel_likelihood(md, sj, smin, lp_max, inv_vs);
-            Z += e;
-            const double gk = md.is_normal ? e : e * (md.vpd * inv_vs);
-            const double yc0 = (double)y.x - P.c[0], yc1 = (double)y.y - P.c[1], yc2 = (double)y.z - P.c[2];
-            G += gk;
-            Gs = fma(gk, sj, Gs);
-            Gy0 = fma(gk, yc0, Gy0);
-            Gy1 = fma(gk, yc1, Gy1);
-            Gy2 = fma(gk, yc2, Gy2);
-            Gyy = fma(gk, yc0 * yc0 + yc1 * yc1 + yc2 * yc2, Gyy);
-        }
-        const double iz = fast_rcp(Z);
-        Wi = G * iz, wy0 = Gy0 * iz, wy1 = Gy1 * iz, wy2 = Gy2 * iz, gs = Gs * iz, gyy = Gyy * iz;
-    }
-    rowpart[(size_t)0 * ns + i] = Wi;
-    rowpart[(size_t)1 * ns + i] = wy0;
-    rowpart[(size_t)2 * ns + i] = wy1;
-    rowpart[(size_t)3 * ns + i] = wy2;
-    rowpart[(size_t)4 * ns + i] = gs;
-    rowpart[(size_t)5 * ns + i] = gyy;
-}
-
-// second half of the split K23: stream src + rowpart, form the 19 moments, block-reduce
-__global__ __launch_bounds__(kBlock) void moments_from_rows_kernel(const float4 *__restrict__ src,
-                                                                   const double *__restrict__ rowpart, int ns, Pose P,
-                                                                   double *__restrict__ partials)
-{
-    RowAcc acc;
-#pragma unroll
-    for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < ns; i += gridDim.x * kBlock) {
-        const float4 xf = src[i];
-        const double Wi = rowpart[i];
-        const double wy[3] = {rowpart[(size_t)ns + i], rowpart[(size_t)2 * ns + i], rowpart[(size_t)3 * ns + i]};
-        const double gs = rowpart[(size_t)4 * ns + i], gyy = rowpart[(size_t)5 * ns + i];
-        const double xc[3] = {(double)xf.x - P.c[0], (double)xf.y - P.c[1], (double)xf.z - P.c[2]};
-        acc.a[0] += Wi;
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            acc.a[1 + d] = fma(Wi, xc[d], acc.a[1 + d]);
-            acc.a[4 + d] += wy[d];
-#pragma unroll
-            for (int b = 0; b < 3; b++) acc.a[7 + 3 * d + b] = fma(xc[d], wy[b], acc.a[7 + 3 * d + b]);
-        }
-        acc.a[16] += gs;
-        acc.a[17] = fma(Wi, xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2], acc.a[17]);
-        acc.a[18] += gyy;
-    }
-    block_reduce_store<kBlock>(acc, partials);
-}
 
 // ---------------------------------------------------------------------------------------------
 // K1, tiled variant (default).  rocprofv3 on the list variant: the scan is bound by the texture
@@ -758,27 +547,14 @@ struct PendingMove {
     Pose P;
 };
 
-// Verlet (skin) neighbour lists.  BUILD (rare): nn_tile_kernel run with the skin radius r + delta collects, for
-// every query, ALL targets within r + delta (no cut-off, no top-m) into vl_nbr[k][i] / vl_cnt[i] (-1: more than the
-// list holds).  USE (every iteration while no query has moved farther than delta since the build — the host checks
-// that from the accumulated rigid transform): nn_verlet_kernel re-tests only those stored candidates.  Any target
-// within r of a query's current position was within r + delta of its build position, so the exact in-radius set,
-// and with it the exact top-m, is contained in the list: results are bit-identical to a full scan.
-struct VerletBuild {
-    int enabled;
-    int *vl_nbr;  // [C][ns]
-    int *vl_cnt;  // [ns]
-};
-
-template <int M, int C, int BLOCK, int CAP, bool FUSED, bool XCD_REMAP = false>
+template <int M, int C, int BLOCK, int CAP>
 __global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt,
                                                          const int *__restrict__ cell_start, GridDesc g,
                                                          float r2, int m, int *__restrict__ nbr,
                                                          int *__restrict__ cnt,
-                                                         unsigned long long *__restrict__ stamps, FusedRows fm,
-                                                         PendingMove pm, unsigned *__restrict__ dm2, int dm2_valid,
-                                                         VerletBuild vb, float *__restrict__ nxyz = nullptr)
+                                                         unsigned long long *__restrict__ stamps,
+                                                         PendingMove pm, unsigned *__restrict__ dm2, int dm2_valid)
 {
     static_assert(C > M, "a compaction must leave room in the list");
     static_assert(CAP % 4 == 0 && CAP <= 65536 && C * 64 <= 3 * CAP && kTileRows <= 256, "the global fallback aliases the candidate buffer");
@@ -813,15 +589,7 @@ __global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with its own L2.  The
-    // source is in brick order, so neighbouring blocks share most of their target halo: give every XCD one
-    // contiguous eighth of the bricks instead of every eighth brick.
-    int bid = blockIdx.x;
-    if (XCD_REMAP) {
-        const int nb = gridDim.x, x = bid & 7, j = bid >> 3;
-        bid = x * (nb >> 3) + min(x, nb & 7) + j;
-    }
-    const int i = bid * BLOCK + tid;
+    const int i = blockIdx.x * BLOCK + tid;
     const bool valid = i < ns;
     float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     float moved = 0.f;  // how far this query travelled since the association that produced dm2
@@ -1099,13 +867,6 @@ __global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float
                     }
                 };
                 scan_runs(std::false_type{});
-                if (vb.enabled) {
-                    // Verlet build: the list IS the result (r2 here is the skin radius squared)
-                    const int nv = (n > C) ? 0 : n;
-                    for (int j = 0; j < nv; j++) vb.vl_nbr[(size_t)j * ns + i] = L.pos_of(L.load(j));
-                    vb.vl_cnt[i] = (n > C) ? -1 : n;
-                    done = true;
-                } else {
                 if (n > C) {  // list overflow (slot C-1 was overwritten): redo this lane with in-loop compaction
                     n = 0;
                     thr = lim0;
@@ -1121,25 +882,10 @@ __global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float
                     for_each_entry(L, q, n, [&](int, int, unsigned b) { tm = max(tm, b); });
                 }
                 stamp(4);
-                if (nxyz) {
-                    // the winners' coordinates are in LDS right now: leave them next to the indices
-                    // (k-major SoA) so that K23 streams them instead of gathering 16 B out of 128-B lines
-                    for (int j = 0; j < n; j++) {
-                        const int e = L.load(j);
-                        const float4 y = L.get(e);
-                        nbr[(size_t)j * ns + i] = L.pos_of(e);
-                        nxyz[(size_t)(3 * j + 0) * ns + i] = y.x;
-                        nxyz[(size_t)(3 * j + 1) * ns + i] = y.y;
-                        nxyz[(size_t)(3 * j + 2) * ns + i] = y.z;
-                    }
-                } else {
-                    for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = L.pos_of(L.load(j));
-                }
+                for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = L.pos_of(L.load(j));
                 cnt[i] = n;
                 if (dm2) dm2[i] = tm;
                 done = true;
-                if constexpr (FUSED) row_partials(L, n, q, fm.P, fm.md, fm.rowpart, ns, i);  // winners still in LDS
-                }
                 stamp(5);
             }
             done_mask |= pass_mask;
@@ -1151,18 +897,6 @@ __global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float
             if (!done && wave == w0) {
                 const GlobalCands<64> G{tgt, s_glist, lane};
                 unsigned thr = thr0;
-                if (vb.enabled) {
-                    for_each_candidate(q, g, cell_start, tgt, [&](int p, float4 t) {
-                        if (dist2_flann(q, t) < r2) {
-                            G.store(min(n, C - 1), p);
-                            n++;
-                        }
-                    });
-                    const int nv = (n > C) ? 0 : n;
-                    for (int j = 0; j < nv; j++) vb.vl_nbr[(size_t)j * ns + i] = G.load(j);
-                    vb.vl_cnt[i] = (n > C) ? -1 : n;
-                    done = true;
-                } else {
                 for_each_candidate(q, g, cell_start, tgt, [&](int p, float4 t) {
                     const float d2 = dist2_flann(q, t);
                     if (d2 < r2 && __float_as_uint(d2) <= thr) {
@@ -1179,21 +913,10 @@ __global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float
                     tm = 0;
                     for_each_entry(G, q, n, [&](int, int, unsigned b) { tm = max(tm, b); });
                 }
-                for (int j = 0; j < n; j++) {
-                    const int e = G.load(j);
-                    nbr[(size_t)j * ns + i] = e;
-                    if (nxyz) {
-                        const float4 y = G.get(e);
-                        nxyz[(size_t)(3 * j + 0) * ns + i] = y.x;
-                        nxyz[(size_t)(3 * j + 1) * ns + i] = y.y;
-                        nxyz[(size_t)(3 * j + 2) * ns + i] = y.z;
-                    }
-                }
+                for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = G.load(j);
                 cnt[i] = n;
                 if (dm2) dm2[i] = tm;
                 done = true;
-                if constexpr (FUSED) row_partials(G, n, q, fm.P, fm.md, fm.rowpart, ns, i);
-                }
             }
             done_mask |= pass_mask;
             lds_barrier();
@@ -1201,169 +924,6 @@ __global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float
         }
       }
     flush_stamps();
-}
-
-// Verlet USE: one lane per query, no grid, no halo, no LDS, no barrier.  (A first version kept an LDS list and
-// re-gathered its entries in the selection passes: a dependent load chain, 148 us — no faster than the scan.)
-// Rows whose list overflowed at build time (vl_cnt < 0) walk the grid instead.
-struct VerletUse {
-    const int *vl_nbr;  // [cap][ns]
-    const int *vl_cnt;  // [ns]
-};
-
-template <int M>
-__global__ __launch_bounds__(kBlock) void nn_verlet_kernel(float4 *__restrict__ src, int ns,
-                                                           const float4 *__restrict__ tgt,
-                                                           const int *__restrict__ cell_start, GridDesc g, float r2,
-                                                           int m, int *__restrict__ nbr, int *__restrict__ cnt,
-                                                           VerletUse vu, PendingMove pm, unsigned *__restrict__ dm2,
-                                                           int dm2_valid)
-{
-    constexpr int CL = 32;  // in-radius entries cached per lane (more: the lane takes the two-pass route)
-    __shared__ unsigned s_b[CL * kBlock];      // d2 bits of the in-radius candidates, [slot][lane]
-    __shared__ unsigned char s_k[CL * kBlock];  // their index in the stored list
-    const int tid = threadIdx.x;
-    const int i = blockIdx.x * kBlock + tid;
-    if (i >= ns) return;  // lane-private LDS slots only: no barrier
-    float4 q = src[i];
-    float moved = 0.f;
-    if (pm.enabled) {
-        const float4 q0 = q;
-        q = move_point(q, pm.P);
-        src[i] = q;
-        const float ex = q.x - q0.x, ey = q.y - q0.y, ez = q.z - q0.z;
-        moved = sqrtf(ex * ex + ey * ey + ez * ez);
-    }
-    unsigned thr0 = 0xFFFFFFFFu;  // temporal cut-off, as in nn_tile_kernel
-    if (dm2_valid) {
-        const unsigned prev = dm2[i];
-        if (prev != 0xFFFFFFFFu) {
-            const float bound = sqrtf(__uint_as_float(prev)) + moved;
-            const float t2 = bound * bound * 1.00001f + 1e-30f;
-            thr0 = (t2 < r2) ? __float_as_uint(t2) : 0xFFFFFFFFu;
-        }
-    }
-    const unsigned lim0 = min(thr0, __float_as_uint(r2) - 1u);
-    const int nv = vu.vl_cnt[i];
-
-    // generic exact answer by walking the candidates twice (plus twice more for exact ties); used for rows
-    // whose stored list overflowed (they walk the grid) and for lanes with more than CL in-radius entries
-    auto answer = [&](auto &&for_all) {
-        unsigned K[M];
-#pragma unroll
-        for (int j = 0; j < M; j++) K[j] = 0xFFFFFFFFu;
-        int inside = 0;
-        for_all([&](int, float4 t) {
-            const unsigned b = __float_as_uint(dist2_flann(q, t));
-            if (b <= lim0) {
-                sorted_insert<M>(K, b);
-                inside++;
-            }
-        });
-        const bool full = inside >= m;
-        const unsigned T = full ? pick<M>(K, m - 1) : lim0;
-        int j = 0;
-        for_all([&](int p, float4 t) {
-            if (__float_as_uint(dist2_flann(q, t)) <= T) {
-                if (j < m) nbr[(size_t)j * ns + i] = p;
-                j++;
-            }
-        });
-        if (j > m) {  // more ties at the cut-off than room: the lowest original target indices win
-            int c_less = 0;
-#pragma unroll
-            for (int a = 0; a < M; a++) K[a] = 0xFFFFFFFFu;
-            for_all([&](int, float4 t) {
-                const unsigned b = __float_as_uint(dist2_flann(q, t));
-                if (b < T) c_less++;
-                else if (b == T) sorted_insert<M>(K, (unsigned)__float_as_int(t.w));
-            });
-            const unsigned T2 = pick<M>(K, m - c_less - 1);
-            j = 0;
-            for_all([&](int p, float4 t) {
-                const unsigned b = __float_as_uint(dist2_flann(q, t));
-                if (b < T || (b == T && (unsigned)__float_as_int(t.w) <= T2)) {
-                    if (j < m) nbr[(size_t)j * ns + i] = p;
-                    j++;
-                }
-            });
-        }
-        cnt[i] = min(j, m);
-        if (dm2) dm2[i] = full ? T : 0xFFFFFFFFu;
-    };
-    auto walk_list = [&](auto &&f) {  // stored candidates: eight index loads, then eight gathers, in flight
-        int k = 0;
-        for (; k < nv; k += 8) {
-            int p[8];
-            float4 t[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) p[u] = (k + u < nv) ? vu.vl_nbr[(size_t)(k + u) * ns + i] : 0;
-#pragma unroll
-            for (int u = 0; u < 8; u++) t[u] = tgt[p[u]];
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (k + u < nv) f(k + u, p[u], t[u]);
-        }
-    };
-
-    if (nv < 0) {
-        answer([&](auto &&f) { for_each_candidate(q, g, cell_start, tgt, f); });  // list overflowed at build time
-        return;
-    }
-    // Fast route: ONE pass of gathers.  d2 bits and list index of every in-radius candidate are parked in LDS while
-    // the bits also go through the sorted register list; afterwards the winners (bits <= T) re-read only their
-    // position from the stored list.
-    unsigned K[M];
-#pragma unroll
-    for (int j = 0; j < M; j++) K[j] = 0xFFFFFFFFu;
-    int n = 0;
-    walk_list([&](int k, int, float4 t) {
-        const unsigned b = __float_as_uint(dist2_flann(q, t));
-        if (b <= lim0) {
-            const int slot = min(n, CL - 1);
-            s_b[slot * kBlock + tid] = b;
-            s_k[slot * kBlock + tid] = (unsigned char)k;
-            sorted_insert<M>(K, b);
-            n++;
-        }
-    });
-    if (n > CL) {  // more in-radius entries than the LDS cache holds: exact two-pass route over the stored list
-        answer([&](auto &&f) { walk_list([&](int, int p, float4 t) { f(p, t); }); });
-        return;
-    }
-    const bool full = n >= m;
-    const unsigned T = full ? pick<M>(K, m - 1) : lim0;
-    int j = 0, c_less = 0;
-    for (int e = 0; e < n; e++) {
-        const unsigned b = s_b[e * kBlock + tid];
-        if (b <= T) {
-            if (j < m) nbr[(size_t)j * ns + i] = vu.vl_nbr[(size_t)s_k[e * kBlock + tid] * ns + i];
-            j++;
-            c_less += (b < T) ? 1 : 0;
-        }
-    }
-    if (j > m) {  // exact ties at the cut-off (rare): lowest original target indices win
-#pragma unroll
-        for (int a = 0; a < M; a++) K[a] = 0xFFFFFFFFu;
-        for (int e = 0; e < n; e++)
-            if (s_b[e * kBlock + tid] == T) {
-                const int p = vu.vl_nbr[(size_t)s_k[e * kBlock + tid] * ns + i];
-                sorted_insert<M>(K, (unsigned)__float_as_int(tgt[p].w));
-            }
-        const unsigned T2 = pick<M>(K, m - c_less - 1);
-        j = 0;
-        for (int e = 0; e < n; e++) {
-            const unsigned b = s_b[e * kBlock + tid];
-            if (b > T) continue;
-            const int p = vu.vl_nbr[(size_t)s_k[e * kBlock + tid] * ns + i];
-            if (b < T || (unsigned)__float_as_int(tgt[p].w) <= T2) {
-                if (j < m) nbr[(size_t)j * ns + i] = p;
-                j++;
-            }
-        }
-    }
-    cnt[i] = min(j, m);
-    if (dm2) dm2[i] = full ? T : 0xFFFFFFFFu;
 }
 
 // Generic path (unbounded, or max_neighbours above the register-list variants):
@@ -1552,17 +1112,14 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(A a, const float4 *_
 // gathers in flight; the rows are then finished from registers in a single sweep (never re-read).  The
 // grid covers every row exactly once (no grid-stride loop).  Measured at 1M rows, W = 10: ROWS = 1
 // (124 VGPRs, 4 waves/SIMD) 58.6 us; ROWS = 2 (168 VGPRs, 3 waves/SIMD) 67 us; forcing 96 VGPRs spills: 74 us.
-// XYZ = true: the neighbours' coordinates were left by K1 in nxyz (k-major SoA, [3k + c][ns]) and are streamed
-// with coalesced loads; nbr and tgt are not touched.
-template <int W, int ROWS, int BLOCK, bool XYZ = false, int TM = -1>
+template <int W, int ROWS, int BLOCK, int TM = -1>
 __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__restrict__ nbr,
                                                                 const int *__restrict__ cnt,
                                                                 const float4 *__restrict__ src,
                                                                 const float4 *__restrict__ tgt, int ns, Pose P,
-                                                                Model md, double *__restrict__ partials, int width,
-                                                                const float *__restrict__ nxyz = nullptr)
+                                                                Model md, double *__restrict__ partials, int width)
 {
-    // width = slots the association really has per row (<= W): slots beyond it do not exist in nbr / nxyz
+    // width = slots the association really has per row (<= W): slots beyond it do not exist in nbr
     RowAcc acc;
 #pragma unroll
     for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
@@ -1570,23 +1127,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
     int n[ROWS];
     float4 xf[ROWS];
     float yx[ROWS][W], yy[ROWS][W], yz[ROWS][W];
-    if constexpr (XYZ) {
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            const int i = base + r * BLOCK;
-            const bool ok = i < ns;
-            const int ic = ok ? i : 0;
-            n[r] = ok ? cnt[ic] : 0;
-            xf[r] = src[ic];
-#pragma unroll
-            for (int k = 0; k < W; k++) {  // slots >= cnt hold stale data: masked below
-                const int kc = k < width ? k : 0;
-                yx[r][k] = nxyz[(size_t)(3 * kc + 0) * ns + ic];
-                yy[r][k] = nxyz[(size_t)(3 * kc + 1) * ns + ic];
-                yz[r][k] = nxyz[(size_t)(3 * kc + 2) * ns + ic];
-            }
-        }
-    } else {
+    {
         int idx[ROWS][W];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {

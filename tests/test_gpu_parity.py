@@ -553,11 +553,7 @@ def test_temporal_cutoff_and_deferred_move_change_nothing(ctx):
     src, tgt, _, _ = synth.make_pair(30000, cfg=2, stride=3)
     a, b = _lib.Context(0), _lib.Context(0)
     try:
-        a.set_option("verlet", 1)        # skin lists on top (off by default: measured slower, must still be exact)
-        b.set_option("emit_xyz", 1)      # K23 streams coordinates left by K1 (off by default: measured neutral)
-        b.set_option("xcd_remap", 1)
         b.set_option("temporal", 0)
-        b.set_option("verlet", 0)
         for c in (a, b):
             c.set_params(1.0, 10, 5.0, 3)
             c.set_target(tgt)
@@ -575,9 +571,6 @@ def test_temporal_cutoff_and_deferred_move_change_nothing(ctx):
             np.testing.assert_array_equal(ra[1], ocol)
             po.transform_cloud(cur, np.vstack([Ta, [0, 0, 0, 1]]))
             np.testing.assert_array_equal(a.get_source(), cur)
-        builds, uses, direct = a.counters()
-        assert builds >= 1 and uses >= 3, (builds, uses, direct)      # the Verlet path really ran in context a
-        assert b.counters()[:2] == (0, 0)
         # a big jump (cut-off bound = previous distance + displacement must still hold)
         jump = np.eye(4)
         jump[:3, :3] = synth.rodrigues([0.2, 1.0, -0.3], 0.4)
@@ -862,8 +855,8 @@ def test_device_pointer_inputs(ctx):
         hip.hipFree(d_src)
 
 
-@pytest.mark.parametrize("opts", [dict(nn_variant=1), dict(nn_variant=2), dict(short_lists=0), dict(mailbox=0),
-                                  dict(fused=1), dict(sort_source=0), dict(sort_source=2), dict(temporal=0, short_lists=0)])
+@pytest.mark.parametrize("opts", [dict(short_lists=0), dict(mailbox=0), dict(sort_source=0), dict(sort_source=2),
+                                  dict(temporal=0, short_lists=0)])
 def test_every_tuning_option_keeps_the_result(ctx, opts):
     """ppcr_set_option knobs never change results: the association of every iteration is identical and the transforms
     agree to rounding with the default configuration."""

@@ -7,9 +7,7 @@ from probabilistic_point_clouds_registration_amd import _lib, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 src, tgt, _, _ = synth.make_pair(n, cfg=3)
 c = _lib.Context(0)
-c.set_option('nn_variant', int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-c.set_option('temporal', int(sys.argv[3]) if len(sys.argv) > 3 else 1)
-for kv in sys.argv[4:]:
+for kv in sys.argv[2:]:
     k, v = kv.split('=')
     c.set_option(k, int(v))
 c.set_params(1.0, 10, 5.0, 3); c.set_target(tgt); c.set_source(src)

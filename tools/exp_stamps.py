@@ -9,8 +9,6 @@ m = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 src, tgt, _, _ = synth.make_pair(n, cfg=3)
 c = _lib.Context(0)
 c.set_params(1.0, m, 5.0, 3); c.set_target(tgt); c.set_source(src)
-fused = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-c.set_option("fused", fused)
 c.associate(); c.synchronize()
 c.set_option("stamps", 1)
 L = _lib.load(); L.ppcr_debug_get_stamps.argtypes = [C.c_void_p, C.c_void_p]

@@ -10,7 +10,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ
            "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" \
            "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_THREAD_CYCLES_VALU"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --output-format csv --pmc $set -d $OUT/p$i -o p$i -- python3 $R/tools/exp_iter.py 1000000 0 1 > $OUT/log$i.txt 2>&1
+  rocprofv3 --kernel-trace --output-format csv --pmc $set -d $OUT/p$i -o p$i -- python3 $R/tools/exp_iter.py 1000000 > $OUT/log$i.txt 2>&1
 done
 python3 $R/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
 grep -E "^nn_tile|^accumulate_ell" -A28 $OUT/summary.txt | head -90
