@@ -121,6 +121,31 @@ int ppcr_apply_transform(ppcr_ctx *ctx, const double T[12]);
 int ppcr_iterate(ppcr_ctx *ctx, const double q0[4], const double t0[3], int inner_steps, double f_tol,
                  double T_out[12], double cost_out[2], int *steps_out);
 
+/* ProbPointCloudRegistration::hasConverged (cc:138-158) as a plain state machine, so that ppcr_align, the C++ class
+ * and any other host front end share ONE definition of the stopping rule.  Zero-initialise, call ppcr_stop_rule_check
+ * before every outer iteration, and after each iteration store its relative cost drop
+ * (initial_cost - final_cost) / initial_cost (cc:119) and add one to `iteration` (cc:130).
+ * Quirks kept on purpose: cost_drop starts at 0, so the first check already counts as an idle iteration; a NaN drop
+ * (empty association, 0/0) compares false and resets the idle count, so such a run lasts n_iter iterations;
+ * n_iter < 0 never equals the iteration count: no cap. */
+typedef struct ppcr_stop_rule {
+    int32_t iteration; /* outer iterations finished so far (current_iteration_) */
+    int32_t idle;      /* consecutive checks that saw a cost drop below the threshold */
+    double cost_drop;  /* relative cost drop of the last iteration */
+} ppcr_stop_rule;
+enum { PPCR_CONTINUE = 0, PPCR_STOP_MAX_ITERATIONS = 1, PPCR_STOP_COST_DROP = 2 };
+static inline int ppcr_stop_rule_check(ppcr_stop_rule *rule, int n_iter, double cost_drop_thresh, double n_cost_drop_it)
+{
+    if (rule->iteration == n_iter) return PPCR_STOP_MAX_ITERATIONS;
+    if (!(rule->cost_drop < cost_drop_thresh)) {
+        rule->idle = 0;
+        return PPCR_CONTINUE;
+    }
+    if ((double)rule->idle > n_cost_drop_it) return PPCR_STOP_COST_DROP;
+    rule->idle += 1;
+    return PPCR_CONTINUE;
+}
+
 /* The whole align() loop including hasConverged() (cc:63-158).  history (n_iter*12 doubles,
  * cumulative transforms T_cum <- T_k*T_cum), costs (n_iter*2), steps (n_iter ints) may be NULL.
  * n_done receives the number of outer iterations performed. */

@@ -250,6 +250,10 @@ class Context:
 
     def align(self, n_iter, cost_drop_thresh=0.0, n_cost_drop_it=5, q0=(1, 0, 0, 0), t0=(0, 0, 0),
               inner_steps=1, f_tol=1e-5, want_history=True):
+        """n_iter < 0 = no iteration cap (the reference's meaning): only with want_history=False and
+        cost_drop_thresh > 0 — the per-iteration arrays could not be sized and the loop would never end."""
+        if int(n_iter) < 0 and want_history:
+            raise ValueError("align(n_iter < 0) has no iteration cap: pass want_history=False (and cost_drop_thresh > 0)")
         k = max(int(n_iter), 1)
         hist = np.zeros(k * 12) if want_history else None
         costs = np.zeros(k * 2) if want_history else None

@@ -59,6 +59,9 @@ struct Vector3d {
     double &operator()(int i) { return v[i]; }
     double operator()(int i) const { return v[i]; }
     double operator()(int i, int) const { return v[i]; }
+    static Vector3d UnitX() { return Vector3d(1, 0, 0); }
+    static Vector3d UnitY() { return Vector3d(0, 1, 0); }
+    static Vector3d UnitZ() { return Vector3d(0, 0, 1); }
 };
 
 struct Matrix3d {
@@ -84,7 +87,29 @@ struct Quaterniond {
         qw /= n, qx /= n, qy /= n, qz /= n;
     }
     Matrix3d toRotationMatrix() const;
+    // Hamilton product: (*this * o) rotates by o first, then by *this
+    Quaterniond operator*(const Quaterniond &o) const
+    {
+        return Quaterniond(qw * o.qw - qx * o.qx - qy * o.qy - qz * o.qz, qw * o.qx + qx * o.qw + qy * o.qz - qz * o.qy,
+                           qw * o.qy - qx * o.qz + qy * o.qw + qz * o.qx, qw * o.qz + qx * o.qy - qy * o.qx + qz * o.qw);
+    }
 };
+
+// rotation by `angle` about a UNIT axis; products of rotations are quaternions, like Eigen's AngleAxisd * AngleAxisd
+struct AngleAxisd {
+    double angle = 0;
+    Vector3d axis = Vector3d(1, 0, 0);
+    AngleAxisd() = default;
+    AngleAxisd(double a, const Vector3d &ax) : angle(a), axis(ax) {}
+    operator Quaterniond() const
+    {
+        const double h = 0.5 * angle, s = std::sin(h);
+        return Quaterniond(std::cos(h), s * axis.v[0], s * axis.v[1], s * axis.v[2]);
+    }
+    Quaterniond operator*(const AngleAxisd &o) const { return Quaterniond(*this) * Quaterniond(o); }
+    Quaterniond operator*(const Quaterniond &o) const { return Quaterniond(*this) * o; }
+};
+inline Quaterniond operator*(const Quaterniond &q, const AngleAxisd &a) { return q * Quaterniond(a); }
 
 // rigid transform [R|t]; operator* composes (this applied after rhs), like Eigen::Affine3d
 class Affine3d {

@@ -1,9 +1,10 @@
-// ProbPointCloudRegistration — the outer registration driver with the reference's public surface
-// (prob_point_cloud_registration.h:18-64): constructors, align(), hasConverged(), transformation(),
-// transformation_history(), report().  The loop body of align() runs on the GPU (ppcr_iterate).
+// ProbPointCloudRegistration — the outer registration driver.  Public surface = the reference's
+// (prob_point_cloud_registration.h:18-45 there): two constructors, align(), hasConverged(), transformation(),
+// transformation_history(), report().  Everything behind it is this library's own: the state lives in a
+// private implementation object (src/prob_point_cloud_registration.cc) that owns one device handle of the C ABI;
+// the loop body of align() runs on the GPU (ppcr_iterate) and the stopping rule is ppcr_stop_rule (ppcr.h).
 #pragma once
 #include <memory>
-#include <sstream>
 #include <string>
 #include <vector>
 
@@ -30,32 +31,18 @@ public:
                                ProbPointCloudRegistrationParams parameters,
                                pcl::PointCloud<pcl::PointXYZ>::Ptr ground_truth_cloud);
     ~ProbPointCloudRegistration();
+    ProbPointCloudRegistration(const ProbPointCloudRegistration &) = delete;
+    ProbPointCloudRegistration &operator=(const ProbPointCloudRegistration &) = delete;
+
     void align();
     bool hasConverged();
-    inline Eigen::Affine3d transformation() { return transformation_history_.back(); }
-    inline std::vector<Eigen::Affine3d> transformation_history() { return transformation_history_; }
-    inline std::string report() { return report_.str(); }
+    Eigen::Affine3d transformation();
+    std::vector<Eigen::Affine3d> transformation_history();
+    std::string report();
 
 private:
-    void fetchSource();  // device -> source_cloud_ (once, after the loop)
-
-    ProbPointCloudRegistrationParams parameters_;
-    pcl::PointCloud<pcl::PointXYZ>::Ptr target_cloud_;
-    pcl::PointCloud<pcl::PointXYZ>::Ptr source_cloud_;
-    pcl::PointCloud<pcl::PointXYZ>::Ptr filtered_source_cloud_;
-    pcl::PointCloud<pcl::PointXYZ>::Ptr prev_source_cloud_;
-    pcl::PointCloud<pcl::PointXYZ>::Ptr ground_truth_cloud_;
-    bool ground_truth_;
-    bool filtered_;
-    double mse_ground_truth_;
-    double mse_prev_it_;
-    double cost_drop_;
-    int num_unusefull_iter_;
-    int current_iteration_;
-    OutputStream output_stream_;
-    std::vector<Eigen::Affine3d> transformation_history_;
-    std::stringstream report_;
-    std::unique_ptr<DeviceContext> device_;
+    struct State;
+    std::unique_ptr<State> state_;
 };
 
 }  // namespace prob_point_cloud_registration

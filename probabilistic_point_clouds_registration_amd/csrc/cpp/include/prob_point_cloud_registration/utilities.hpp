@@ -124,6 +124,25 @@ inline double robustMedianClosestDistance(pcl::PointCloud<pcl::PointXYZ>::Ptr cl
     return detail::referenceMedian(filtered) / filtered.size();  // the reference divides the median by the count
 }
 
+// median of the association's stored values (the float d2 of every correspondence) with the reference's index
+// convention (utilities.hpp:236-250: one past the textbook median, see detail::referenceMedian); needs size() > 2
+inline double medianDistance(std::vector<Eigen::Triplet<double>> tripletList)
+{
+    std::vector<double> values;
+    values.reserve(tripletList.size());
+    for (const auto &t : tripletList) values.push_back(t.value());
+    std::sort(values.begin(), values.end());
+    return detail::referenceMedian(values);
+}
+
+// q = Rz(yaw) * Ry(pitch) * Rx(roll) (utilities.hpp:252-263)
+inline Eigen::Quaterniond euler2Quaternion(const double roll, const double pitch, const double yaw)
+{
+    const Eigen::AngleAxisd about_x(roll, Eigen::Vector3d::UnitX()), about_y(pitch, Eigen::Vector3d::UnitY()),
+        about_z(yaw, Eigen::Vector3d::UnitZ());
+    return about_z * about_y * about_x;
+}
+
 // in-place/out-of-place pcl::transformPointCloud(cloud_in, cloud_out, Affine3d): f64 math, f32 store
 inline void transformPointCloud(const pcl::PointCloud<pcl::PointXYZ> &in, pcl::PointCloud<pcl::PointXYZ> &out,
                                 const Eigen::Affine3d &T)

@@ -1,6 +1,8 @@
 #include "prob_point_cloud_registration/pcd_io.hpp"
 
+#include <algorithm>
 #include <cstdint>
+#include <exception>
 #include <cstring>
 #include <fstream>
 #include <iomanip>
@@ -60,9 +62,19 @@ std::vector<std::string> split(const std::string &line)
     while (is >> tok) out.push_back(tok);
     return out;
 }
-}  // namespace
 
-int loadPCDFile(const std::string &file_name, pcl::PointCloud<pcl::PointXYZ> &cloud)
+// bytes left in the stream from the current read position (-1 when the stream cannot seek)
+long long remainingBytes(std::ifstream &in)
+{
+    const std::streampos here = in.tellg();
+    if (here < 0) return -1;
+    in.seekg(0, std::ios::end);
+    const std::streampos end = in.tellg();
+    in.seekg(here);
+    return (end < 0 || !in) ? -1 : static_cast<long long>(end - here);
+}
+
+int loadChecked(const std::string &file_name, pcl::PointCloud<pcl::PointXYZ> &cloud)
 {
     std::ifstream in(file_name, std::ios::binary);
     if (!in) {
@@ -98,7 +110,12 @@ int loadPCDFile(const std::string &file_name, pcl::PointCloud<pcl::PointXYZ> &cl
             break;
         }
     }
-    if (points < 0) points = width * height;
+    if (points < 0 && width >= 0 && height >= 0 && (height == 0 || width <= (1ll << 40) / std::max(height, 1ll))) points = width * height;
+    for (const Field &f : fields)
+        if (f.size <= 0 || f.size > 8 || f.count <= 0 || f.count > (1 << 20)) {
+            std::cerr << "[pcd] " << file_name << ": bad SIZE / COUNT in the header" << std::endl;
+            return -1;
+        }
     int ix = -1, iy = -1, iz = -1, col = 0, off = 0;
     std::vector<int> first_col(fields.size(), 0);
     for (std::size_t f = 0; f < fields.size(); f++) {
@@ -119,6 +136,13 @@ int loadPCDFile(const std::string &file_name, pcl::PointCloud<pcl::PointXYZ> &cl
             std::cerr << "[pcd] " << file_name << ": x/y/z must be float32" << std::endl;
             return -1;
         }
+    // a point needs at least one byte of data whatever the encoding's best case (LZF expands <= ~ 264x): a header
+    // that promises more points than the file could hold is refused before anything is allocated
+    const long long left = remainingBytes(in);
+    if (left >= 0 && (points > left * 512 + 16 || (data_mode == "binary" && points > left / std::max(off, 1)))) {
+        std::cerr << "[pcd] " << file_name << ": header promises more points than the file holds" << std::endl;
+        return -1;
+    }
     cloud.points.assign(static_cast<std::size_t>(points), pcl::PointXYZ());
     if (data_mode == "ascii") {
         const int ncols = col;
@@ -172,6 +196,10 @@ int loadPCDFile(const std::string &file_name, pcl::PointCloud<pcl::PointXYZ> &cl
                       << ")" << std::endl;
             return -1;
         }
+        if (left >= 0 && static_cast<long long>(sizes[0]) > left - 8) {
+            std::cerr << "[pcd] " << file_name << ": truncated binary_compressed data" << std::endl;
+            return -1;
+        }
         std::vector<unsigned char> comp(sizes[0]), raw(expect);
         in.read(reinterpret_cast<char *>(comp.data()), static_cast<std::streamsize>(comp.size()));
         if (static_cast<std::size_t>(in.gcount()) != comp.size()) {
@@ -199,6 +227,20 @@ int loadPCDFile(const std::string &file_name, pcl::PointCloud<pcl::PointXYZ> &cl
         return -1;
     }
     return 0;
+}
+
+}  // namespace
+
+int loadPCDFile(const std::string &file_name, pcl::PointCloud<pcl::PointXYZ> &cloud)
+{
+    // pcl::io::loadPCDFile returns -1 on anything it cannot read; nothing may escape to the CLI
+    try {
+        return loadChecked(file_name, cloud);
+    } catch (const std::exception &e) {
+        std::cerr << "[pcd] " << file_name << ": malformed file (" << e.what() << ")" << std::endl;
+        cloud.points.clear();
+        return -1;
+    }
 }
 
 int savePCDFile(const std::string &file_name, const pcl::PointCloud<pcl::PointXYZ> &cloud, bool binary_mode)

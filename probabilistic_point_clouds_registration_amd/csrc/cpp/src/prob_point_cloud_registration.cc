@@ -1,173 +1,210 @@
-// Outer registration driver on top of the C ABI (include/ppcr.h).  Mirrors the behaviour of the
-// reference's src/prob_point_cloud_registration.cc (constructor filtering, align loop, hasConverged,
-// report rows) with the loop body executed by ppcr_iterate() on the GPU.
+// Outer registration driver on top of the C ABI (include/ppcr.h).  Behaviour follows the reference's
+// src/prob_point_cloud_registration.cc (what is filtered and copied at construction, what one outer iteration
+// reports, when the loop stops, what is printed); the organisation is this library's own: a State object that
+// owns the device handle, with the clouds resident on the GPU from construction to the end of align().
 #include "prob_point_cloud_registration/prob_point_cloud_registration.h"
 
 #include <cmath>
 #include <cstdint>
 #include <iostream>
-#include <map>
-#include <tuple>
+#include <sstream>
 
 #include "prob_point_cloud_registration/utilities.hpp"
 
 namespace prob_point_cloud_registration {
 
+namespace {
+
+using Cloud = pcl::PointCloud<pcl::PointXYZ>;
+
+const float *xyz_of(const Cloud &cloud) { return cloud.empty() ? nullptr : &cloud[0].x; }
+float *xyz_of(Cloud &cloud) { return cloud.empty() ? nullptr : &cloud[0].x; }
+int64_t count_of(const Cloud &cloud) { return static_cast<int64_t>(cloud.size()); }
+
+// Ceres' function_tolerance as the reference sets it (cc:97 there: "10e-6")
+constexpr double kFunctionTolerance = 10e-6;
+
+const char *const kReportColumns =
+    "iter, n_success_steps, initial_cost, final_cost, tx, ty, tz, roll, pitch, yaw, mse_prev_iter, mse_gtruth";
+
+}  // namespace
+
 // pcl::VoxelGrid centroid down-sampling on the device (ppcr_voxel_filter): one point per occupied voxel, voxels in
 // ascending index.  (Parity with PCL itself is unpinned: the reference has no test for it and PCL is not
 // available here; the definition is pinned against the CPU restatement in the test tree.)
-void voxelGridFilter(const pcl::PointCloud<pcl::PointXYZ> &in, double leaf, pcl::PointCloud<pcl::PointXYZ> &out,
-                     int device_id)
+void voxelGridFilter(const Cloud &in, double leaf, Cloud &out, int device_id)
 {
-    pcl::PointCloud<pcl::PointXYZ> result;
     if (!(leaf > 0) || in.empty()) {
-        result = in;
-        out = result;
+        if (&in != &out) out = in;
         return;
     }
-    result.points.resize(in.size());
-    int64_t n_out = 0;
-    const int rc = ppcr_voxel_filter(device_id, &in[0].x, static_cast<int64_t>(in.size()), sizeof(pcl::PointXYZ),
-                                     static_cast<float>(leaf), &result.points[0].x, sizeof(pcl::PointXYZ), &n_out);
+    Cloud kept;
+    kept.points.resize(in.size());
+    int64_t n_kept = 0;
+    const int rc = ppcr_voxel_filter(device_id, xyz_of(in), count_of(in), sizeof(pcl::PointXYZ), static_cast<float>(leaf),
+                                     xyz_of(kept), sizeof(pcl::PointXYZ), &n_kept);
     if (rc != PPCR_OK) throw DeviceError(rc, std::string("ppcr_voxel_filter: ") + ppcr_last_error(nullptr));
-    result.points.resize(static_cast<size_t>(n_out));
-    out = result;
+    kept.points.resize(static_cast<size_t>(n_kept));
+    out.points.swap(kept.points);
 }
 
-ProbPointCloudRegistration::ProbPointCloudRegistration(pcl::PointCloud<pcl::PointXYZ>::Ptr source_cloud,
-                                                       pcl::PointCloud<pcl::PointXYZ>::Ptr target_cloud,
+// Everything the driver remembers between calls.
+struct ProbPointCloudRegistration::State {
+    ProbPointCloudRegistrationParams params;
+    OutputStream log;            // verbose-gated stdout
+    DeviceContext gpu;           // one C-ABI handle: device + stream + resident clouds
+    ppcr_stop_rule stop{0, 0, 0.0};
+    Cloud::Ptr target;           // the caller's cloud (shared; filtered in place when asked)
+    Cloud full_source;           // private copy of the caller's source, refreshed from the device after align()
+    bool has_companion = false;  // the device also carries the unfiltered source next to the filtered one
+    bool has_truth = false;
+    double truth_distance = 0;   // mean distance to the ground truth after the last iteration
+    std::vector<Eigen::Affine3d> cumulative;  // T_cum after every outer iteration
+    std::ostringstream table;    // --dump rows
+
+    State(const ProbPointCloudRegistrationParams &p, const Cloud &source, Cloud::Ptr target_cloud)
+        : params(p), log(p.verbose), gpu(p.device_id), target(std::move(target_cloud)), full_source(source)
+    {
+    }
+
+    ppcr_ctx *handle() const { return gpu.get(); }
+
+    // the two farewell lines of the loop (verbose only), keyed by ppcr_stop_rule_check's verdict
+    void explainStop(int verdict)
+    {
+        if (verdict == PPCR_STOP_MAX_ITERATIONS)
+            log << "Terminating because maximum number of iterations has been reached ( " << stop.iteration << " iter)\n";
+        else if (verdict == PPCR_STOP_COST_DROP)
+            log << "Terminating because cost drop has been under " << params.cost_drop_thresh * 100 << " % for more than "
+                << params.n_cost_drop_it << " iterations\n";
+    }
+
+    void uploadClouds()
+    {
+        // association cloud = the down-sampled source when a leaf size was given; the full-resolution copy then
+        // rides along on the device as the handle's companion (moved by every iteration, read by the reports)
+        Cloud thinned;
+        const Cloud *assoc = &full_source;
+        if (params.source_filter_size > 0) {
+            log << "Filtering source point cloud with leaf of size " << params.source_filter_size << "\n";
+            voxelGridFilter(full_source, params.source_filter_size, thinned, params.device_id);
+            assoc = &thinned;
+            has_companion = true;
+        }
+        if (params.target_filter_size > 0) {
+            log << "Filtering target point cloud with leaf of size " << params.target_filter_size << "\n";
+            voxelGridFilter(*target, params.target_filter_size, *target, params.device_id);
+        }
+        gpu.check(ppcr_set_params(handle(), params.radius, params.max_neighbours, params.dof, DIMENSIONS), "ppcr_set_params");
+        gpu.check(ppcr_set_target(handle(), xyz_of(*target), count_of(*target), sizeof(pcl::PointXYZ)), "ppcr_set_target");
+        gpu.check(ppcr_set_source(handle(), xyz_of(*assoc), count_of(*assoc), sizeof(pcl::PointXYZ)), "ppcr_set_source");
+        if (has_companion)
+            gpu.check(ppcr_set_companion(handle(), xyz_of(full_source), count_of(full_source), sizeof(pcl::PointXYZ)),
+                      "ppcr_set_companion");
+        if (params.summary) {
+            table << kReportColumns << std::endl;
+            // the "previous iteration" snapshot starts as the untouched source
+            gpu.check(ppcr_mse_previous(handle(), nullptr), "ppcr_mse_previous");
+        }
+    }
+
+    void attachGroundTruth(const Cloud &truth)
+    {
+        gpu.check(ppcr_set_ground_truth(handle(), xyz_of(truth), count_of(truth), sizeof(pcl::PointXYZ)),
+                  "ppcr_set_ground_truth");
+        has_truth = true;
+        measureTruthDistance();
+        log << "Initial MSE w.r.t. ground truth: " << truth_distance << "\n";
+    }
+
+    void measureTruthDistance() { gpu.check(ppcr_mse_ground_truth(handle(), &truth_distance), "ppcr_mse_ground_truth"); }
+
+    // one outer iteration on the device: associate, solve, move both copies of the source
+    void iterate()
+    {
+        double step[12], cost[2];
+        int inner = 0;
+        gpu.check(ppcr_iterate(handle(), params.initial_rotation, params.initial_translation, params.inner_max_steps,
+                               kFunctionTolerance, step, cost, &inner),
+                  "ppcr_iterate");
+        const Eigen::Affine3d delta = Eigen::Affine3d::from_rows(step);
+        cumulative.push_back(cumulative.empty() ? delta : delta * cumulative.back());
+        log << "iteration " << stop.iteration << ": initial_cost " << cost[0] << " final_cost " << cost[1] << " inner steps "
+            << inner << "\n";
+        if (has_truth) {
+            measureTruthDistance();
+            log << "MSE w.r.t. ground truth: " << truth_distance << "\n";
+        }
+        if (params.summary) appendRow(inner, cost);
+        stop.cost_drop = (cost[0] - cost[1]) / cost[0];
+        stop.iteration += 1;
+    }
+
+    void appendRow(int inner, const double cost[2])
+    {
+        double moved = 0;  // mean distance each point travelled in this iteration
+        gpu.check(ppcr_mse_previous(handle(), &moved), "ppcr_mse_previous");
+        const Eigen::Affine3d &T = cumulative.back();
+        const Eigen::Vector3d angles = T.rotation().eulerAngles(0, 1, 2);
+        table << stop.iteration << ", " << inner << ", " << cost[0] << ", " << cost[1];
+        for (int a = 0; a < 3; a++) table << ", " << T.translation()(a);
+        for (int a = 0; a < 3; a++) table << ", " << pcl::rad2deg(angles(a));
+        table << ", " << moved << ", " << truth_distance << std::endl;
+    }
+
+    // bring the caller-visible full-resolution source back from the device
+    void downloadSource()
+    {
+        if (full_source.empty()) return;
+        if (has_companion)
+            gpu.check(ppcr_get_companion(handle(), xyz_of(full_source), sizeof(pcl::PointXYZ)), "ppcr_get_companion");
+        else
+            gpu.check(ppcr_get_source(handle(), xyz_of(full_source), sizeof(pcl::PointXYZ)), "ppcr_get_source");
+    }
+};
+
+ProbPointCloudRegistration::ProbPointCloudRegistration(Cloud::Ptr source_cloud, Cloud::Ptr target_cloud,
                                                        ProbPointCloudRegistrationParams parameters)
-    : parameters_(parameters),
-      target_cloud_(target_cloud),
-      ground_truth_(false),
-      filtered_(false),
-      mse_ground_truth_(0),
-      mse_prev_it_(0),
-      cost_drop_(0),
-      num_unusefull_iter_(0),
-      current_iteration_(0),
-      output_stream_(parameters.verbose)
+    : state_(new State(parameters, *source_cloud, std::move(target_cloud)))
 {
-    // the source is deep-copied, the caller's target is shared (and filtered in place when asked)
-    source_cloud_ = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>(*source_cloud);
-    filtered_source_cloud_ = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
-    if (parameters_.source_filter_size > 0) {
-        output_stream_ << "Filtering source point cloud with leaf of size " << parameters_.source_filter_size << "\n";
-        voxelGridFilter(*source_cloud_, parameters_.source_filter_size, *filtered_source_cloud_, parameters_.device_id);
-        filtered_ = true;
-    } else {
-        *filtered_source_cloud_ = *source_cloud_;
-    }
-    if (parameters_.target_filter_size > 0) {
-        output_stream_ << "Filtering target point cloud with leaf of size " << parameters_.target_filter_size << "\n";
-        voxelGridFilter(*target_cloud_, parameters_.target_filter_size, *target_cloud_, parameters_.device_id);
-    }
-    if (parameters_.summary) {
-        report_ << "iter, n_success_steps, initial_cost, final_cost, tx, ty, tz, roll, pitch, yaw, mse_prev_iter, mse_gtruth"
-                << std::endl;
-    }
-    device_.reset(new DeviceContext(parameters_.device_id));
-    ppcr_ctx *c = device_->get();
-    device_->check(ppcr_set_params(c, parameters_.radius, parameters_.max_neighbours, parameters_.dof, DIMENSIONS),
-                   "ppcr_set_params");
-    device_->check(ppcr_set_target(c, target_cloud_->size() ? &(*target_cloud_)[0].x : nullptr,
-                                   static_cast<int64_t>(target_cloud_->size()), sizeof(pcl::PointXYZ)),
-                   "ppcr_set_target");
-    // the association runs on the (possibly filtered) copy; when the two differ the full copy rides along on the
-    // device as the handle's companion: moved by every iteration, looked at by the reports, read back once
-    device_->check(ppcr_set_source(c, filtered_source_cloud_->size() ? &(*filtered_source_cloud_)[0].x : nullptr,
-                                   static_cast<int64_t>(filtered_source_cloud_->size()), sizeof(pcl::PointXYZ)),
-                   "ppcr_set_source");
-    if (filtered_)
-        device_->check(ppcr_set_companion(c, source_cloud_->size() ? &(*source_cloud_)[0].x : nullptr,
-                                          static_cast<int64_t>(source_cloud_->size()), sizeof(pcl::PointXYZ)),
-                       "ppcr_set_companion");
-    if (parameters_.summary) device_->check(ppcr_mse_previous(c, nullptr), "ppcr_mse_previous");  // prev = source (cc:51)
+    state_->uploadClouds();
 }
 
-ProbPointCloudRegistration::ProbPointCloudRegistration(pcl::PointCloud<pcl::PointXYZ>::Ptr source_cloud,
-                                                       pcl::PointCloud<pcl::PointXYZ>::Ptr target_cloud,
+ProbPointCloudRegistration::ProbPointCloudRegistration(Cloud::Ptr source_cloud, Cloud::Ptr target_cloud,
                                                        ProbPointCloudRegistrationParams parameters,
-                                                       pcl::PointCloud<pcl::PointXYZ>::Ptr ground_truth_cloud)
-    : ProbPointCloudRegistration(source_cloud, target_cloud, parameters)
+                                                       Cloud::Ptr ground_truth_cloud)
+    : ProbPointCloudRegistration(std::move(source_cloud), std::move(target_cloud), parameters)
 {
-    ground_truth_cloud_ = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>(*ground_truth_cloud);
-    ground_truth_ = true;
-    device_->check(ppcr_set_ground_truth(device_->get(), ground_truth_cloud_->size() ? &(*ground_truth_cloud_)[0].x : nullptr,
-                                         static_cast<int64_t>(ground_truth_cloud_->size()), sizeof(pcl::PointXYZ)),
-                   "ppcr_set_ground_truth");
-    device_->check(ppcr_mse_ground_truth(device_->get(), &mse_ground_truth_), "ppcr_mse_ground_truth");
-    output_stream_ << "Initial MSE w.r.t. ground truth: " << mse_ground_truth_ << "\n";
+    state_->attachGroundTruth(*ground_truth_cloud);
 }
 
 ProbPointCloudRegistration::~ProbPointCloudRegistration() = default;
 
-// the caller-visible full-resolution source, read back from the device (companion when the source was filtered)
-void ProbPointCloudRegistration::fetchSource()
-{
-    if (source_cloud_->empty()) return;
-    if (filtered_)
-        device_->check(ppcr_get_companion(device_->get(), &(*source_cloud_)[0].x, sizeof(pcl::PointXYZ)), "ppcr_get_companion");
-    else
-        device_->check(ppcr_get_source(device_->get(), &(*source_cloud_)[0].x, sizeof(pcl::PointXYZ)), "ppcr_get_source");
-}
-
 void ProbPointCloudRegistration::align()
 {
-    while (!hasConverged()) {
-        double Tk[12], cost[2];
-        int steps = 0;
-        device_->check(ppcr_iterate(device_->get(), parameters_.initial_rotation, parameters_.initial_translation,
-                                    parameters_.inner_max_steps, 10e-6 /* function_tolerance of the reference */, Tk, cost,
-                                    &steps),
-                       "ppcr_iterate");
-        const Eigen::Affine3d incremental = Eigen::Affine3d::from_rows(Tk);
-        Eigen::Affine3d current_trans = incremental;
-        if (current_iteration_ > 0) current_trans = incremental * transformation_history_.back();
-        transformation_history_.push_back(current_trans);
-        output_stream_ << "iteration " << current_iteration_ << ": initial_cost " << cost[0] << " final_cost " << cost[1]
-                       << " inner steps " << steps << "\n";
-        // both copies of the source were moved on the device by ppcr_iterate; the reports are device reductions
-        if (ground_truth_) {
-            device_->check(ppcr_mse_ground_truth(device_->get(), &mse_ground_truth_), "ppcr_mse_ground_truth");
-            output_stream_ << "MSE w.r.t. ground truth: " << mse_ground_truth_ << "\n";
-        }
-        cost_drop_ = (cost[0] - cost[1]) / cost[0];
-        if (parameters_.summary) {
-            device_->check(ppcr_mse_previous(device_->get(), &mse_prev_it_), "ppcr_mse_previous");
-            const Eigen::Vector3d rpy = current_trans.rotation().eulerAngles(0, 1, 2);
-            report_ << current_iteration_ << ", " << steps << ", " << cost[0] << ", " << cost[1] << ", "
-                    << current_trans.translation().x() << ", " << current_trans.translation().y() << ", "
-                    << current_trans.translation().z() << ", " << pcl::rad2deg(rpy(0, 0)) << ", " << pcl::rad2deg(rpy(1, 0))
-                    << ", " << pcl::rad2deg(rpy(2, 0)) << ", " << mse_prev_it_ << ", " << mse_ground_truth_ << std::endl;
-        }
-        current_iteration_++;
-    }
-    fetchSource();
-    if (ground_truth_) {
-        device_->check(ppcr_mse_ground_truth(device_->get(), &mse_ground_truth_), "ppcr_mse_ground_truth");
-        std::cout << "MSE w.r.t. ground truth: " << mse_ground_truth_ << std::endl;
+    while (!hasConverged()) state_->iterate();
+    state_->downloadSource();
+    if (state_->has_truth) {
+        state_->measureTruthDistance();
+        std::cout << "MSE w.r.t. ground truth: " << state_->truth_distance << std::endl;
     }
 }
 
 bool ProbPointCloudRegistration::hasConverged()
 {
-    if (current_iteration_ == parameters_.n_iter) {
-        output_stream_ << "Terminating because maximum number of iterations has been reached ( " << current_iteration_
-                       << " iter)\n";
-        return true;
-    }
-    if (cost_drop_ < parameters_.cost_drop_thresh) {
-        if (num_unusefull_iter_ > parameters_.n_cost_drop_it) {
-            output_stream_ << "Terminating because cost drop has been under " << parameters_.cost_drop_thresh * 100
-                           << " % for more than " << parameters_.n_cost_drop_it << " iterations\n";
-            return true;
-        }
-        num_unusefull_iter_++;
-    } else {
-        num_unusefull_iter_ = 0;
-    }
-    return false;
+    State &st = *state_;
+    const int verdict = ppcr_stop_rule_check(&st.stop, st.params.n_iter, st.params.cost_drop_thresh, st.params.n_cost_drop_it);
+    st.explainStop(verdict);
+    return verdict != PPCR_CONTINUE;
 }
+
+Eigen::Affine3d ProbPointCloudRegistration::transformation()
+{
+    return state_->cumulative.empty() ? Eigen::Affine3d::Identity() : state_->cumulative.back();
+}
+
+std::vector<Eigen::Affine3d> ProbPointCloudRegistration::transformation_history() { return state_->cumulative; }
+
+std::string ProbPointCloudRegistration::report() { return state_->table.str(); }
 
 }  // namespace prob_point_cloud_registration

@@ -1,8 +1,9 @@
-// probabilistic_point_cloud_registration — command-line front end with the reference's flags, defaults
-// and outputs (src/prob_point_cloud_registration_ex.cc:34-66,93-188, README.md:31-92):
+// probabilistic_point_cloud_registration — command-line front end.  Flags, defaults, printed lines and output files
+// are the reference's (src/prob_point_cloud_registration_ex.cc:34-66,93-188, README.md:31-92):
 //   probabilistic_point_cloud_registration [--dump] [-g gt.pcd] [-v] [-u] [-n int] [-c float] [-r float]
 //       [-d float] [-i int] [-m int] [-t float] [-s float] <source.pcd> <target.pcd>
-// Additions (do not collide with the reference's letters): --device N, --inner-steps K.
+// Additions (they do not collide with the reference's letters): --device N, --inner-steps K.
+// The program is organised as a small pipeline of its own: parse -> load -> register -> publish.
 #include <cstdlib>
 #include <filesystem>
 #include <fstream>
@@ -16,19 +17,25 @@
 #include "prob_point_cloud_registration/prob_point_cloud_registration.h"
 #include "prob_point_cloud_registration/utilities.hpp"
 
-using prob_point_cloud_registration::ProbPointCloudRegistration;
-using prob_point_cloud_registration::ProbPointCloudRegistrationParams;
-typedef pcl::PointXYZ PointType;
+namespace ppcr_cli {
 
-namespace {
+namespace fs = std::filesystem;
+namespace reg = prob_point_cloud_registration;
+using Cloud = pcl::PointCloud<pcl::PointXYZ>;
 
-struct ArgError {
-    std::string what, arg;
+struct Job {
+    reg::ProbPointCloudRegistrationParams params;
+    std::string source_path, target_path, truth_path;  // truth_path empty: no -g
+    bool gaussian = false;
 };
 
-[[noreturn]] void usage_and_exit(const ArgError &e)
+struct BadArgument {
+    std::string complaint, argument;
+};
+
+[[noreturn]] void rejectCommandLine(const BadArgument &bad)
 {
-    std::cerr << "error: " << e.what << " for arg " << e.arg << std::endl;
+    std::cerr << "error: " << bad.complaint << " for arg " << bad.argument << std::endl;
     std::cerr << "usage: probabilistic_point_cloud_registration [--dump] [-g <string>] [-v] [-u] [-n <int>] [-c <float>]\n"
                  "         [-r <float>] [-d <float>] [-i <int>] [-m <int>] [-t <float>] [-s <float>] [--device <int>]\n"
                  "         [--inner-steps <int>] <source_file_name> <target_file_name>"
@@ -36,163 +43,204 @@ struct ArgError {
     std::exit(EXIT_FAILURE);
 }
 
-}  // namespace
+// cursor over argv with typed reads; every failure names the flag it happened on
+class ArgCursor {
+public:
+    ArgCursor(int argc, char **argv) : args_(argv + 1, argv + argc) {}
+    bool done() const { return next_ >= args_.size(); }
+    std::string take() { return args_[next_++]; }
+    std::string valueOf(const std::string &flag)
+    {
+        if (done()) throw BadArgument{"Missing a value", flag};
+        return take();
+    }
+    template <class T, class Parse>
+    T number(const std::string &flag, Parse parse)
+    {
+        const std::string text = valueOf(flag);
+        std::size_t used = 0;
+        T v{};
+        try {
+            v = parse(text, &used);
+        } catch (...) {
+            used = std::string::npos;
+        }
+        if (used != text.size()) throw BadArgument{"Couldn't read argument value from string '" + text + "'", flag};
+        return v;
+    }
+    int integer(const std::string &flag)
+    {
+        return number<int>(flag, [](const std::string &s, std::size_t *n) { return std::stoi(s, n); });
+    }
+    float real(const std::string &flag)
+    {
+        return number<float>(flag, [](const std::string &s, std::size_t *n) { return std::stof(s, n); });
+    }
 
-int main(int argc, char **argv)
+private:
+    std::vector<std::string> args_;
+    std::size_t next_ = 0;
+};
+
+bool looksLikeFlag(const std::string &a)
 {
-    bool use_gaussian = false, ground_truth = false;
-    std::string source_file_name, target_file_name, ground_truth_file_name;
-    ProbPointCloudRegistrationParams params;
-    // CLI defaults (they differ from the struct's: radius 3 here, 1 there — kept as in the reference)
-    params.max_neighbours = 20;
-    params.n_iter = 1000;
-    params.dof = 5;
-    params.radius = 3;
-    params.cost_drop_thresh = 0.01;
-    params.n_cost_drop_it = 5;
-    std::vector<std::string> positional;
-    try {
-        for (int i = 1; i < argc; i++) {
-            const std::string a = argv[i];
-            auto value = [&](const std::string &name) -> std::string {
-                if (i + 1 >= argc) throw ArgError{"Missing a value", name};
-                return argv[++i];
-            };
-            auto as_int = [&](const std::string &name) {
-                const std::string v = value(name);
-                std::size_t pos = 0;
-                int r = 0;
-                try {
-                    r = std::stoi(v, &pos);
-                } catch (...) {
-                    throw ArgError{"Couldn't read argument value from string '" + v + "'", name};
-                }
-                if (pos != v.size()) throw ArgError{"Couldn't read argument value from string '" + v + "'", name};
-                return r;
-            };
-            auto as_float = [&](const std::string &name) {
-                const std::string v = value(name);
-                std::size_t pos = 0;
-                float r = 0;
-                try {
-                    r = std::stof(v, &pos);
-                } catch (...) {
-                    throw ArgError{"Couldn't read argument value from string '" + v + "'", name};
-                }
-                if (pos != v.size()) throw ArgError{"Couldn't read argument value from string '" + v + "'", name};
-                return r;
-            };
-            if (a == "-s" || a == "--source_filter_size") params.source_filter_size = as_float(a);
-            else if (a == "-t" || a == "--target_filter_size") params.target_filter_size = as_float(a);
-            else if (a == "-m" || a == "--max_neighbours") params.max_neighbours = as_int(a);
-            else if (a == "-i" || a == "--num_iter") params.n_iter = as_int(a);
-            else if (a == "-d" || a == "--dof") params.dof = as_float(a);
-            else if (a == "-r" || a == "--radius") params.radius = as_float(a);
-            else if (a == "-c" || a == "--cost_drop_treshold") params.cost_drop_thresh = as_float(a);
-            else if (a == "-n" || a == "--num_drop_iter") params.n_cost_drop_it = as_int(a);
-            else if (a == "-u" || a == "--use_gaussian") use_gaussian = true;
-            else if (a == "-v" || a == "--verbose") params.verbose = true;
-            else if (a == "-g" || a == "--ground_truth") {
-                ground_truth = true;
-                ground_truth_file_name = value(a);
-            } else if (a == "--dump") params.summary = true;
-            else if (a == "--device") params.device_id = as_int(a);
-            else if (a == "--inner-steps") params.inner_max_steps = as_int(a);
-            else if (a == "-h" || a == "--help") throw ArgError{"help requested", a};
-            else if (a.size() > 1 && a[0] == '-' && !(a[1] >= '0' && a[1] <= '9') && a[1] != '.') throw ArgError{"Couldn't find match for argument", a};
-            else positional.push_back(a);
-        }
-        if (positional.size() < 1) throw ArgError{"Required argument missing", "source_file_name"};
-        if (positional.size() < 2) throw ArgError{"Required argument missing", "target_file_name"};
-        if (positional.size() > 2) throw ArgError{"Too many positional arguments", positional[2]};
-    } catch (const ArgError &e) {
-        usage_and_exit(e);
-    }
-    source_file_name = positional[0];
-    target_file_name = positional[1];
+    // "-3" and "-.5" are values, not flags
+    return a.size() > 1 && a[0] == '-' && !(a[1] >= '0' && a[1] <= '9') && a[1] != '.';
+}
 
-    if (use_gaussian) {
-        if (params.verbose) std::cout << "Using gaussian model" << std::endl;
-        params.dof = std::numeric_limits<double>::infinity();
-    } else if (params.verbose) {
-        std::cout << "Using a t-distribution with " << params.dof << " dof" << std::endl;
+Job parseCommandLine(int argc, char **argv)
+{
+    Job job;
+    // the CLI's own defaults (radius 3 here, 1 in the params struct — the reference has the same split)
+    job.params.radius = 3;
+    job.params.max_neighbours = 20;
+    job.params.n_iter = 1000;
+    job.params.dof = 5;
+    job.params.cost_drop_thresh = 0.01;
+    job.params.n_cost_drop_it = 5;
+    std::vector<std::string> files;
+    ArgCursor cur(argc, argv);
+    while (!cur.done()) {
+        const std::string a = cur.take();
+        auto is = [&](const char *shortf, const char *longf) { return a == shortf || a == longf; };
+        if (is("-r", "--radius")) job.params.radius = cur.real(a);
+        else if (is("-m", "--max_neighbours")) job.params.max_neighbours = cur.integer(a);
+        else if (is("-i", "--num_iter")) job.params.n_iter = cur.integer(a);
+        else if (is("-d", "--dof")) job.params.dof = cur.real(a);
+        else if (is("-c", "--cost_drop_treshold")) job.params.cost_drop_thresh = cur.real(a);
+        else if (is("-n", "--num_drop_iter")) job.params.n_cost_drop_it = cur.integer(a);
+        else if (is("-s", "--source_filter_size")) job.params.source_filter_size = cur.real(a);
+        else if (is("-t", "--target_filter_size")) job.params.target_filter_size = cur.real(a);
+        else if (is("-g", "--ground_truth")) job.truth_path = cur.valueOf(a);
+        else if (is("-u", "--use_gaussian")) job.gaussian = true;
+        else if (is("-v", "--verbose")) job.params.verbose = true;
+        else if (a == "--dump") job.params.summary = true;
+        else if (a == "--device") job.params.device_id = cur.integer(a);
+        else if (a == "--inner-steps") job.params.inner_max_steps = cur.integer(a);
+        else if (is("-h", "--help")) throw BadArgument{"help requested", a};
+        else if (looksLikeFlag(a)) throw BadArgument{"Couldn't find match for argument", a};
+        else files.push_back(a);
     }
-    if (params.verbose) {
-        std::cout << "Radius of the neighborhood search: " << params.radius << std::endl;
-        std::cout << "Max number of neighbours: " << params.max_neighbours << std::endl;
-        std::cout << "Max number of iterations: " << params.n_iter << std::endl;
-        std::cout << "Cost drop threshold: " << params.cost_drop_thresh << std::endl;
-        std::cout << "Num cost drop iter: " << params.n_cost_drop_it << std::endl;
-        std::cout << "Loading source point cloud from " << source_file_name << std::endl;
-    }
-    namespace pio = prob_point_cloud_registration::io;
-    auto source_cloud = std::make_shared<pcl::PointCloud<PointType>>();
-    if (pio::loadPCDFile(source_file_name, *source_cloud) == -1) {
-        std::cout << "Could not load source cloud, closing" << std::endl;
+    static const char *const kNames[2] = {"source_file_name", "target_file_name"};
+    if (files.size() < 2) throw BadArgument{"Required argument missing", kNames[files.size()]};
+    if (files.size() > 2) throw BadArgument{"Too many positional arguments", files[2]};
+    job.source_path = files[0];
+    job.target_path = files[1];
+    if (job.gaussian) job.params.dof = std::numeric_limits<double>::infinity();  // -u: Gaussian weights
+    return job;
+}
+
+void announce(const Job &job)
+{
+    if (!job.params.verbose) return;
+    const auto &p = job.params;
+    if (job.gaussian) std::cout << "Using gaussian model" << std::endl;
+    else std::cout << "Using a t-distribution with " << p.dof << " dof" << std::endl;
+    std::cout << "Radius of the neighborhood search: " << p.radius << std::endl;
+    std::cout << "Max number of neighbours: " << p.max_neighbours << std::endl;
+    std::cout << "Max number of iterations: " << p.n_iter << std::endl;
+    std::cout << "Cost drop threshold: " << p.cost_drop_thresh << std::endl;
+    std::cout << "Num cost drop iter: " << p.n_cost_drop_it << std::endl;
+}
+
+// nullptr when the file cannot be read (the reader has already said why on stderr)
+Cloud::Ptr readCloud(const std::string &path)
+{
+    auto cloud = std::make_shared<Cloud>();
+    if (reg::io::loadPCDFile(path, *cloud) == -1) return nullptr;
+    return cloud;
+}
+
+Cloud::Ptr readCloudOrExit(const std::string &path, const char *role, bool verbose)
+{
+    if (verbose) std::cout << "Loading " << role << " point cloud from " << path << std::endl;
+    Cloud::Ptr cloud = readCloud(path);
+    if (!cloud) {
+        std::cout << "Could not load " << role << " cloud, closing" << std::endl;
         std::exit(EXIT_FAILURE);
     }
-    if (params.verbose) std::cout << "Loading target point cloud from " << target_file_name << std::endl;
-    auto target_cloud = std::make_shared<pcl::PointCloud<PointType>>();
-    if (pio::loadPCDFile(target_file_name, *target_cloud) == -1) {
-        std::cout << "Could not load target cloud, closing" << std::endl;
-        std::exit(EXIT_FAILURE);
+    return cloud;
+}
+
+void printHistory(const std::vector<Eigen::Affine3d> &history)
+{
+    std::cout << "Transformation history:" << std::endl;
+    for (const Eigen::Affine3d &T : history) {
+        const Eigen::Quaterniond q(T.rotation());
+        std::cout << "T: " << T.translation().x() << ", " << T.translation().y() << ", " << T.translation().z()
+                  << " ||| R: " << q.x() << ", " << q.y() << ", " << q.z() << ", " << q.w() << std::endl;
     }
-    pcl::PointCloud<PointType>::Ptr source_ground_truth;
-    if (ground_truth) {
-        std::cout << "Loading ground truth point cloud from " << ground_truth_file_name << std::endl;
-        source_ground_truth = std::make_shared<pcl::PointCloud<PointType>>();
-        if (pio::loadPCDFile(ground_truth_file_name, *source_ground_truth) == -1) {
-            std::cout << "Could not load ground truth" << std::endl;
-            ground_truth = false;  // continue without it, like the reference
-        }
+}
+
+void saveAligned(const Job &job, const Cloud &aligned)
+{
+    const std::string name = "aligned_" + fs::path(job.source_path).filename().string();
+    std::cout << "Saving aligned source cloud to: " << name << std::endl;
+    reg::io::savePCDFile(name, aligned);
+}
+
+void writeSummary(const Job &job, const std::string &table)
+{
+    const std::string name = fs::path(job.source_path).stem().string() + "_" + fs::path(job.target_path).stem().string() +
+                             "_summary.txt";
+    std::cout << "Saving registration report to: " << name << std::endl;
+    const auto &p = job.params;
+    std::ofstream out(name);
+    out << "Source: " << job.source_path << " with filter size: " << p.source_filter_size << std::endl;
+    out << "Target:" << job.target_path << " with filter size: " << p.target_filter_size << std::endl;
+    out << "dof: " << p.dof << " | Radius: " << p.radius << " | Max_iter: " << p.n_iter << " | Max neigh: " << p.max_neighbours
+        << " | Cost_drop_thresh_: " << p.cost_drop_thresh << " | N_cost_drop_it: " << p.n_cost_drop_it << std::endl;
+    out << table;
+}
+
+int run(const Job &job)
+{
+    announce(job);
+    const bool verbose = job.params.verbose;
+    const Cloud::Ptr source = readCloudOrExit(job.source_path, "source", verbose);
+    const Cloud::Ptr target = readCloudOrExit(job.target_path, "target", verbose);
+    Cloud::Ptr truth;
+    if (!job.truth_path.empty()) {
+        std::cout << "Loading ground truth point cloud from " << job.truth_path << std::endl;
+        truth = readCloud(job.truth_path);
+        if (!truth) std::cout << "Could not load ground truth" << std::endl;  // the run goes on without it
     }
 
-    std::unique_ptr<ProbPointCloudRegistration> registration;
+    std::unique_ptr<reg::ProbPointCloudRegistration> solver;
     try {
-        if (ground_truth)
-            registration = std::make_unique<ProbPointCloudRegistration>(source_cloud, target_cloud, params, source_ground_truth);
-        else
-            registration = std::make_unique<ProbPointCloudRegistration>(source_cloud, target_cloud, params);
-        if (params.verbose) std::cout << "Registration\n";
-        registration->align();
+        if (truth) solver = std::make_unique<reg::ProbPointCloudRegistration>(source, target, job.params, truth);
+        else solver = std::make_unique<reg::ProbPointCloudRegistration>(source, target, job.params);
+        if (verbose) std::cout << "Registration\n";
+        solver->align();
     } catch (const std::exception &e) {
         std::cerr << "registration failed: " << e.what() << std::endl;
         return EXIT_FAILURE;
     }
-    if (registration->transformation_history().empty()) {
+    const std::vector<Eigen::Affine3d> history = solver->transformation_history();
+    if (history.empty()) {
         std::cerr << "no iteration was performed (num_iter = 0?)" << std::endl;
         return EXIT_FAILURE;
     }
-    const Eigen::Affine3d estimated_transform = registration->transformation();
-    auto aligned_source = std::make_shared<pcl::PointCloud<PointType>>();
-    pcl::transformPointCloud(*source_cloud, *aligned_source, estimated_transform);
-    if (params.verbose) {
-        std::cout << "Transformation history:" << std::endl;
-        for (const auto &trans : registration->transformation_history()) {
-            const Eigen::Quaterniond rotq(trans.rotation());
-            std::cout << "T: " << trans.translation().x() << ", " << trans.translation().y() << ", " << trans.translation().z()
-                      << " ||| R: " << rotq.x() << ", " << rotq.y() << ", " << rotq.z() << ", " << rotq.w() << std::endl;
-        }
-        const std::filesystem::path source_path(source_file_name);
-        const std::string aligned_source_name = "aligned_" + source_path.filename().string();
-        std::cout << "Saving aligned source cloud to: " << aligned_source_name << std::endl;
-        pio::savePCDFile(aligned_source_name, *aligned_source);  // only when verbose, as in the reference
+
+    // the final transform is applied to the cloud as it was read from disk
+    auto aligned = std::make_shared<Cloud>();
+    pcl::transformPointCloud(*source, *aligned, history.back());
+    if (verbose) {  // the aligned cloud is only saved in verbose mode (a quirk of the reference, kept)
+        printHistory(history);
+        saveAligned(job, *aligned);
     }
-    if (params.summary) {
-        const std::filesystem::path source_path(source_file_name), target_path(target_file_name);
-        const std::string report_file_name = source_path.stem().string() + "_" + target_path.stem().string() + "_summary.txt";
-        std::cout << "Saving registration report to: " << report_file_name << std::endl;
-        std::ofstream report_file(report_file_name);
-        report_file << "Source: " << source_file_name << " with filter size: " << params.source_filter_size << std::endl;
-        report_file << "Target:" << target_file_name << " with filter size: " << params.target_filter_size << std::endl;
-        report_file << "dof: " << params.dof << " | Radius: " << params.radius << " | Max_iter: " << params.n_iter
-                    << " | Max neigh: " << params.max_neighbours << " | Cost_drop_thresh_: " << params.cost_drop_thresh
-                    << " | N_cost_drop_it: " << params.n_cost_drop_it << std::endl;
-        report_file << registration->report();
+    if (job.params.summary) writeSummary(job, solver->report());
+    if (truth) std::cout << "MSE w.r.t. ground truth: " << reg::calculateMSE(aligned, truth) << std::endl;
+    return EXIT_SUCCESS;
+}
+
+}  // namespace ppcr_cli
+
+int main(int argc, char **argv)
+{
+    try {
+        return ppcr_cli::run(ppcr_cli::parseCommandLine(argc, argv));
+    } catch (const ppcr_cli::BadArgument &bad) {
+        ppcr_cli::rejectCommandLine(bad);
     }
-    if (ground_truth) {
-        const double mse_gtruth = prob_point_cloud_registration::calculateMSE(aligned_source, source_ground_truth);
-        std::cout << "MSE w.r.t. ground truth: " << mse_gtruth << std::endl;
-    }
-    return 0;
 }

@@ -1364,22 +1364,29 @@ int ppcr_iterate(ppcr_ctx *c, const double q0[4], const double t0[3], int inner_
     return apply_transform_impl(c, T_out, /*defer=*/true);
 }
 
-int ppcr_align(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_drop_it, const double q0[4],
-               const double t0[3], int inner_steps, double f_tol, double *history, double *costs, int32_t *steps,
-               int *n_done)
+// align() with the per-iteration outputs optional and the last cumulative transform returned separately
+static int align_impl(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_drop_it, const double q0[4],
+                      const double t0[3], int inner_steps, double f_tol, double *history, double *costs, int32_t *steps,
+                      double *T_final, int *n_done)
 {
     CTX_ENTER(c);
     if (!q0 || !t0) return fail(c, PPCR_ERR_INVALID, "null argument");
+    // n_iter < 0 means "no iteration cap" in the reference (cc:140 never fires): legal, but then the per-iteration
+    // arrays cannot be sized by the caller
+    if (n_iter < 0 && (history || costs || steps))
+        return fail(c, PPCR_ERR_INVALID, "ppcr_align: n_iter < 0 (no iteration cap) needs history, costs and steps to be NULL");
+    if (n_iter < 0 && !(cost_drop_thresh > 0))
+        return fail(c, PPCR_ERR_INVALID, "ppcr_align: n_iter < 0 (no iteration cap) needs cost_drop_thresh > 0, or the loop never ends");
     if (!c->have_src || !c->have_tgt) return fail(c, PPCR_ERR_STATE, "set source and target before ppcr_align");
     {
         const double qn = q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3];
         if (!(qn > 0) || !std::isfinite(qn)) return fail(c, PPCR_ERR_INVALID, "initial rotation quaternion has zero or non-finite norm");
     }
-    ConvergenceRule rule;
+    ppcr_stop_rule rule = {0, 0, 0.0};  // hasConverged(), shared with the C++ class (ppcr.h)
     double Tcum[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     for (double &v : c->dbg_host) v = 0;
     const auto ta0 = std::chrono::steady_clock::now();
-    while (!rule.has_converged(n_iter, cost_drop_thresh, n_cost_drop_it)) {
+    while (ppcr_stop_rule_check(&rule, n_iter, cost_drop_thresh, n_cost_drop_it) == PPCR_CONTINUE) {
         double Tk[12], cost[2];
         int st = 0;
         const auto ti0 = std::chrono::steady_clock::now();
@@ -1393,7 +1400,7 @@ int ppcr_align(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_d
                                                       (c->dbg_host[1] - w_before) - std::max(0.0, c->dbg_host[6] - fold0));
         PPCR_TRY(apply_transform_impl(c, Tk, /*defer=*/true));  // rides in the next iteration's K1 prologue
         compose(Tk, Tcum, Tcum);  // T_cum <- T_k * T_cum (cc:101-107)
-        const int it = rule.current_iteration;
+        const int it = rule.iteration;
         if (history) std::memcpy(history + (size_t)it * 12, Tcum, sizeof(Tcum));
         if (costs) {
             costs[2 * it] = cost[0];
@@ -1401,7 +1408,7 @@ int ppcr_align(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_d
         }
         if (steps) steps[it] = st;
         rule.cost_drop = (cost[0] - cost[1]) / cost[0];  // cc:119
-        rule.current_iteration++;                        // cc:130
+        rule.iteration++;                                // cc:130
         {
             const double it_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - ti0).count();
             const double busy = it_s - (c->dbg_host[1] - w_before);  // launches + host solve, waits excluded
@@ -1412,8 +1419,17 @@ int ppcr_align(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_d
     (void)ta0;
     PPCR_TRY(flush_pending_move(c));  // leave the device copy of the source current
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (n_done) *n_done = rule.current_iteration;
+    if (T_final) std::memcpy(T_final, Tcum, sizeof(Tcum));  // identity when no iteration ran
+    if (n_done) *n_done = rule.iteration;
     return PPCR_OK;
+}
+
+int ppcr_align(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_drop_it, const double q0[4],
+               const double t0[3], int inner_steps, double f_tol, double *history, double *costs, int32_t *steps,
+               int *n_done)
+{
+    return align_impl(c, n_iter, cost_drop_thresh, n_cost_drop_it, q0, t0, inner_steps, f_tol, history, costs, steps,
+                      nullptr, n_done);
 }
 
 int ppcr_get_source(ppcr_ctx *c, float *xyz, int64_t stride_bytes)
@@ -1791,23 +1807,14 @@ int ppcr_nearest_sq_distances(int device_id, const float *queries, int64_t nq, i
 // ---- batches of independent pairs -------------------------------------------------------------------------------
 namespace {
 
-void identity12(double *T)
-{
-    static const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    std::memcpy(T, I, sizeof(I));
-}
-
 // align() on one handle, keeping only the last cumulative transform
 int align_final(ppcr_ctx *c, int n_iter, double thresh, double n_cost_drop_it, const double q0[4], const double t0[3],
                 int inner_steps, double f_tol, double *T_final, int32_t *n_done)
 {
-    std::vector<double> hist((size_t)std::max(n_iter, 0) * 12);
     int done = 0;
-    const int rc = ppcr_align(c, n_iter, thresh, n_cost_drop_it, q0, t0, inner_steps, f_tol,
-                              hist.empty() ? nullptr : hist.data(), nullptr, nullptr, &done);
+    const int rc = align_impl(c, n_iter, thresh, n_cost_drop_it, q0, t0, inner_steps, f_tol, nullptr, nullptr, nullptr,
+                              T_final, &done);
     if (rc != PPCR_OK) return rc;
-    if (done > 0) std::memcpy(T_final, hist.data() + (size_t)(done - 1) * 12, 12 * sizeof(double));
-    else identity12(T_final);
     if (n_done) *n_done = done;
     return PPCR_OK;
 }

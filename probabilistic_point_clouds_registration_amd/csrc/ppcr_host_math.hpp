@@ -243,23 +243,4 @@ inline void pack_T(const Mat3 &R, const Vec3 &t, double T[12])
     }
 }
 
-// hasConverged() state machine, src/prob_point_cloud_registration.cc:138-158 (cost_drop_ starts
-// at 0, :20; n_cost_drop_it is a double, ..._params.hpp:11; NaN cost_drop resets the counter).
-struct ConvergenceRule {
-    int current_iteration = 0;
-    double cost_drop = 0.0;
-    int num_unuseful_iter = 0;
-    bool has_converged(int n_iter, double thresh, double n_cost_drop_it)
-    {
-        if (current_iteration == n_iter) return true;
-        if (cost_drop < thresh) {
-            if (static_cast<double>(num_unuseful_iter) > n_cost_drop_it) return true;
-            ++num_unuseful_iter;
-        } else {
-            num_unuseful_iter = 0;
-        }
-        return false;
-    }
-};
-
 }  // namespace ppcr

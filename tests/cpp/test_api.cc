@@ -242,8 +242,33 @@ static void closestPointMetricsTest()
     EXPECT_TRUE(robustMedianClosestDistance(a, b) > 0);
 }
 
+// utilities.hpp:236-263: host-only helpers (median of the stored d2 with the reference's index convention, Euler
+// angles -> quaternion as Rz(yaw) * Ry(pitch) * Rx(roll))
+static void hostUtilitiesTest()
+{
+    std::vector<Eigen::Triplet<double>> odd = {{0, 0, 5.0}, {0, 1, 1.0}, {1, 0, 4.0}, {1, 1, 2.0}, {2, 2, 3.0}};
+    EXPECT_NEAR(medianDistance(odd), 4.0, 0);  // sorted 1 2 3 4 5, element (5 + 1) / 2 = 3 -> 4
+    std::vector<Eigen::Triplet<double>> even = {{0, 0, 6.0}, {0, 1, 1.0}, {1, 0, 4.0}, {1, 1, 2.0}, {2, 2, 3.0}, {2, 0, 5.0}};
+    EXPECT_NEAR(medianDistance(even), 4.5, 0);  // sorted 1..6, (element 3 + element 4) / 2 = (4 + 5) / 2
+    const double roll = 0.3, pitch = -0.7, yaw = 1.1;
+    const Eigen::Quaterniond q = euler2Quaternion(roll, pitch, yaw);
+    EXPECT_NEAR(q.w() * q.w() + q.x() * q.x() + q.y() * q.y() + q.z() * q.z(), 1.0, 1e-15);
+    const Eigen::Matrix3d R = q.toRotationMatrix();
+    const double cr = std::cos(roll), sr = std::sin(roll), cp = std::cos(pitch), sp = std::sin(pitch), cy = std::cos(yaw),
+                 sy = std::sin(yaw);
+    const double want[3][3] = {{cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr},
+                               {sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr},
+                               {-sp, cp * sr, cp * cr}};
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) EXPECT_NEAR(R(a, b), want[a][b], 1e-15);
+    EXPECT_NEAR(euler2Quaternion(0, 0, 0).w(), 1.0, 0);
+    const Eigen::Quaterniond qz = euler2Quaternion(0, 0, M_PI / 2);
+    EXPECT_NEAR(qz.z(), std::sqrt(0.5), 1e-15);
+}
+
 int main()
 {
+    hostUtilitiesTest();
     weightsTests();
     closestPointMetricsTest();
     exactAssociationTest(std::numeric_limits<double>::infinity());

@@ -109,6 +109,31 @@ def test_cli_argument_errors_exit_like_the_reference(programs):
     assert r.returncode == 1 and "Could not load source cloud, closing" in r.stdout
 
 
+def test_cli_refuses_malformed_pcd_headers(programs, tmp_path):
+    """pcl::io::loadPCDFile returns -1 on anything it cannot read and the CLI exits 1 (..._ex.cc:113-116): a
+    malformed header must not abort the process or allocate what the file could never hold (no GPU needed: the
+    clouds are loaded before the device is touched)."""
+    good = tmp_path / "good.pcd"
+    write_pcd(good, np.zeros((4, 3), np.float32))
+    hdr = "VERSION 0.7\nFIELDS x y z\nSIZE {size}\nTYPE F F F\nCOUNT {count}\nWIDTH {w}\nHEIGHT 1\nPOINTS {pts}\nDATA {mode}\n"
+    cases = dict(
+        bad_number=hdr.format(size="4 4 4", count="1 1 1", w="abc", pts="4", mode="ascii") + "0 0 0\n" * 4,
+        missing_token=hdr.format(size="4 4 4", count="1 1 1", w="4", pts="", mode="ascii") + "0 0 0\n" * 4,
+        negative_size=hdr.format(size="-4 4 4", count="1 1 1", w="4", pts="4", mode="binary") + "\0" * 48,
+        zero_count=hdr.format(size="4 4 4", count="0 1 1", w="4", pts="4", mode="binary") + "\0" * 48,
+        huge_points=hdr.format(size="4 4 4", count="1 1 1", w="4", pts="900000000000", mode="binary") + "\0" * 48,
+        huge_points_ascii=hdr.format(size="4 4 4", count="1 1 1", w="4", pts="900000000000", mode="ascii") + "0 0 0\n",
+        negative_points=hdr.format(size="4 4 4", count="1 1 1", w="4", pts="-5", mode="ascii") + "0 0 0\n",
+    )
+    blob = hdr.format(size="4 4 4", count="1 1 1", w="4", pts="4", mode="binary_compressed").encode()
+    cases_bin = dict(huge_compressed=blob + np.array([0xFFFFFFF0, 48], np.uint32).tobytes() + b"\0" * 16)
+    for name, text in list(cases.items()) + list(cases_bin.items()):
+        path = tmp_path / f"{name}.pcd"
+        path.write_bytes(text if isinstance(text, bytes) else text.encode())
+        r = subprocess.run([programs[0], str(path), str(good)], capture_output=True, text=True, cwd=tmp_path, timeout=120)
+        assert r.returncode == 1 and "Could not load source cloud, closing" in r.stdout, (name, r.returncode, r.stdout, r.stderr)
+
+
 @pytest.mark.gpu
 def test_cpp_api_restated_reference_tests(programs):
     r = subprocess.run([programs[1]], capture_output=True, text=True, timeout=600)
