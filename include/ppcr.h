@@ -134,17 +134,8 @@ typedef struct ppcr_stop_rule {
     double cost_drop;  /* relative cost drop of the last iteration */
 } ppcr_stop_rule;
 enum { PPCR_CONTINUE = 0, PPCR_STOP_MAX_ITERATIONS = 1, PPCR_STOP_COST_DROP = 2 };
-static inline int ppcr_stop_rule_check(ppcr_stop_rule *rule, int n_iter, double cost_drop_thresh, double n_cost_drop_it)
-{
-    if (rule->iteration == n_iter) return PPCR_STOP_MAX_ITERATIONS;
-    if (!(rule->cost_drop < cost_drop_thresh)) {
-        rule->idle = 0;
-        return PPCR_CONTINUE;
-    }
-    if ((double)rule->idle > n_cost_drop_it) return PPCR_STOP_COST_DROP;
-    rule->idle += 1;
-    return PPCR_CONTINUE;
-}
+/* returns PPCR_CONTINUE or the reason to stop; pure host arithmetic (no device is touched) */
+int ppcr_stop_rule_check(ppcr_stop_rule *rule, int n_iter, double cost_drop_thresh, double n_cost_drop_it);
 
 /* The whole align() loop including hasConverged() (cc:63-158).  history (n_iter*12 doubles,
  * cumulative transforms T_cum <- T_k*T_cum), costs (n_iter*2), steps (n_iter ints) may be NULL.

@@ -22,8 +22,19 @@ SYMBOLS = [
     "ppcr_iterate", "ppcr_align", "ppcr_get_source", "ppcr_synchronize", "ppcr_profile_enable",
     "ppcr_profile_get", "ppcr_set_option", "ppcr_batch_run", "ppcr_align_many", "ppcr_set_companion",
     "ppcr_get_companion", "ppcr_set_ground_truth", "ppcr_mse_ground_truth", "ppcr_mse_previous", "ppcr_voxel_filter",
-    "ppcr_nearest_sq_distances",
+    "ppcr_nearest_sq_distances", "ppcr_stop_rule_check",
 ]
+
+
+class StopRule(C.Structure):
+    """ppcr_stop_rule: the hasConverged() state machine shared by ppcr_align and the C++ class."""
+    _fields_ = [("iteration", C.c_int32), ("idle", C.c_int32), ("cost_drop", C.c_double)]
+
+    def check(self, n_iter, cost_drop_thresh, n_cost_drop_it):
+        """0 = continue, 1 = iteration cap reached, 2 = cost drop below the threshold for too long."""
+        L = load()
+        L.ppcr_stop_rule_check.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+        return int(L.ppcr_stop_rule_check(C.byref(self), int(n_iter), float(cost_drop_thresh), float(n_cost_drop_it)))
 
 
 class KernelStat(C.Structure):

@@ -1364,6 +1364,19 @@ int ppcr_iterate(ppcr_ctx *c, const double q0[4], const double t0[3], int inner_
     return apply_transform_impl(c, T_out, /*defer=*/true);
 }
 
+int ppcr_stop_rule_check(ppcr_stop_rule *rule, int n_iter, double cost_drop_thresh, double n_cost_drop_it)
+{
+    if (!rule) return PPCR_ERR_INVALID;
+    if (rule->iteration == n_iter) return PPCR_STOP_MAX_ITERATIONS;  // cc:140
+    if (!(rule->cost_drop < cost_drop_thresh)) {                     // also taken by a NaN drop (cc:154-156)
+        rule->idle = 0;
+        return PPCR_CONTINUE;
+    }
+    if ((double)rule->idle > n_cost_drop_it) return PPCR_STOP_COST_DROP;  // cc:146
+    rule->idle += 1;
+    return PPCR_CONTINUE;
+}
+
 // align() with the per-iteration outputs optional and the last cumulative transform returned separately
 static int align_impl(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_drop_it, const double q0[4],
                       const double t0[3], int inner_steps, double f_tol, double *history, double *costs, int32_t *steps,

@@ -82,3 +82,49 @@ def test_host_solver_matches_oracle(lib):
         assert abs(_lib.cost_from_moments(S, c, R, t) - po.cost_from_sums(S, c, Ro, to)) < 1e-12 * (S[17] + S[18])
     R, t, rc = _lib.solve_moments(np.zeros(19), np.zeros(3))
     assert rc == 1 and np.allclose(R, np.eye(3)) and np.allclose(t, 0)
+
+
+def test_stop_rule_is_the_references_has_converged(lib):
+    """ppcr_stop_rule_check (one definition for ppcr_align, the C++ class and this binding) against a line-by-line
+    model of hasConverged (src/prob_point_cloud_registration.cc:138-158) on random cost-drop sequences, including
+    NaN drops, negative n_iter (no cap) and fractional n_cost_drop_it (a double in the params struct)."""
+    rng = np.random.default_rng(7)
+
+    class Model:  # the reference's members and control flow
+        def __init__(self):
+            self.current_iteration, self.cost_drop, self.num_unuseful = 0, 0.0, 0
+
+        def has_converged(self, n_iter, thresh, n_it):
+            if self.current_iteration == n_iter:
+                return 1
+            if self.cost_drop < thresh:
+                if self.num_unuseful > n_it:
+                    return 2
+                self.num_unuseful += 1
+            else:
+                self.num_unuseful = 0
+            return 0
+
+    for trial in range(300):
+        n_iter = int(rng.integers(-1, 40))
+        thresh = float(rng.choice([0.0, 0.01, 0.5, 2.0]))
+        n_it = float(rng.choice([0, 1, 2.5, 5]))
+        rule, model = _lib.StopRule(), Model()
+        for step in range(60):
+            a, b = rule.check(n_iter, thresh, n_it), model.has_converged(n_iter, thresh, n_it)
+            assert a == b, (trial, step, a, b)
+            if a:
+                break
+            drop = float(rng.choice([rng.uniform(-0.2, 1.0), 0.0, float("nan"), 1e-3]))
+            rule.cost_drop = model.cost_drop = drop
+            rule.iteration += 1
+            model.current_iteration += 1
+        assert rule.iteration == model.current_iteration and rule.idle == model.num_unuseful
+    # the default thresholds cannot stop before six iterations (cost_drop starts at 0: the first check is idle already)
+    rule = _lib.StopRule()
+    n = 0
+    while rule.check(1000, 0.01, 5) == 0:
+        rule.cost_drop = 0.0
+        rule.iteration += 1
+        n += 1
+    assert n == 6
