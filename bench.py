@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
-"""Benchmark of the registration hot path on MI355X (contract: see the task statement / DESIGN.md §7).
+"""Benchmark of the registration hot path on MI355X (contract: see the task statement / DESIGN.md §5).
 
 A "step" is one outer registration iteration over one source/target pair:
-    radius-NN association (K1) -> t/Gaussian weights + weighted moments (K23) -> host 3x3 SVD
-    -> in-place move of the source (K4),
-i.e. BASELINE.json's metric "registration iterations/sec (1M<->1M pts, r=1.0, m=10)" with one inner
-IRLS step per association, early termination disabled (cost_drop_thresh = 0).
-Clouds are resident in HBM before the timed region starts.
+    radius-NN association (K1) -> t/Gaussian weights + weighted moments (K23) -> 3x3 SVD -> in-place move of
+    the source (K4, folded into the next K1),
+i.e. BASELINE.json's metric "registration iterations/sec (1M<->1M pts, r=1.0, m=10)" with one inner IRLS step per
+association, early termination disabled (cost_drop_thresh = 0).  Clouds are resident in HBM
+before a timed window starts.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank registers its own
-independent 1M<->1M pair (weak scaling, no data-path collective); the only collective is the final
-all_gather of the 3x4 transforms over RCCL, inside the timed region.
+Timed region: `--windows` (default 5) windows; every window re-uploads the source (fresh start), runs `--warmup`
+untimed iterations, and then times EXACTLY `--steps` iterations between barrier + synchronize on both sides (max over
+ranks).  `value` is the MEDIAN window; min / max are reported next to it.
+
+--gpus N without a torchrun environment: this process starts N ranks itself (torch.distributed.run as a child
+process, before anything here touches a GPU) and exits with the child's status.  N ranks always means N GPUs: the
+line never reports an n_gpus other than the one asked for.
+  config 3 (default) / 4 / 2: every rank registers its own pair (weak scaling);
+  config 5 (BASELINE configs[4]): 64 pairs of 250k, 64 / N per rank (strong scaling), the gathered transforms
+  checked on rank 0 against a single-rank run of every pair.
+The only collective of the job is the final all_gather of the transforms over RCCL, inside the timed window.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,9 +35,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from probabilistic_point_clouds_registration_amd import _lib, batch, synth  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+REF_F_TOL = 10e-6      # function_tolerance of the reference (src/prob_point_cloud_registration.cc:97)
 
 
 def parse():
@@ -35,22 +44,49 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config number (3 = 1M headline, 4 = Gaussian)")
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps iterations (value = median)")
+    ap.add_argument("--config", type=int, default=3,
+                    help="BASELINE.json config number (3 = 1M headline, 4 = Gaussian, 2 = 100k, 5 = 64 x 250k batch)")
     ap.add_argument("--n", type=int, default=None, help="override the cloud size (debugging)")
     ap.add_argument("--inner-steps", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0,
                     help="outer iterations of the CPU baseline sample (0 = auto: about 6 s of wall time, 3..30)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the cold-start / converged-inner / reference-shaped CPU legs (headline + roofline only)")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel pass")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank, to exercise the collective path")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="ppcr_set_option knob applied to every handle (experiments; the default run sets none)")
     ap.add_argument("--lanes", type=int, default=4,
-                    help="pairs in flight per GPU when --pairs-per-gpu > 1 (ppcr_align_many host worker threads)")
-    ap.add_argument("--pairs-per-gpu", type=int, default=1,
-                    help="independent pairs each rank registers back to back (BASELINE configs[4]: --config 5 --pairs-per-gpu 8)")
+                    help="pairs in flight per GPU when a rank holds several pairs (ppcr_align_many host worker threads)")
+    ap.add_argument("--pairs-per-gpu", type=int, default=0,
+                    help="independent pairs per rank (0 = the config's own: 1, or 64 / N for config 5)")
+    ap.add_argument("--no-verify", action="store_true", help="config 5: skip the single-rank re-run of every pair")
     return ap.parse_args()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(a):
+    """--gpus N > 1 outside torchrun: start the N ranks as a CHILD process tree (never exec from a process that may
+    have touched the GPU; this one has not) and hand its exit status on."""
+    import torch  # device_count() does not initialise the GPU
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} requested but {have} device(s) visible; refusing to run a smaller job "
+              f"under the requested label", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def effective_cores():
@@ -68,8 +104,8 @@ def effective_cores():
 
 
 def cpu_baseline(src, tgt, cfg, iters, inner_steps):
-    """The oracle (kind 'port': OpenMP-generous variant — grid built per call, all loops parallel) timed on
-    this box's host cores on a bounded sample: `iters` outer iterations of the SAME workload."""
+    """The oracle (kind 'port': OpenMP-generous variant — every loop parallel over the host cores) timed on this
+    box on a bounded sample: `iters` outer iterations of the SAME workload."""
     from oracle import binding as po  # checker-side import, only on this leg
     cores, visible, quota = effective_cores()
     threads = max(1, min(po.num_threads(), cores))
@@ -91,17 +127,38 @@ def cpu_baseline(src, tgt, cfg, iters, inner_steps):
                 seconds=dt), res
 
 
-def main():
-    a = parse()
+def cpu_baseline_refshape(src, tgt, cfg, iters=3):
+    """The oracle run the way the REFERENCE runs (SURVEY §8(d) ii): one thread (its search, residual and weight loops
+    are serial, cc:72-81, weight_updater_callback.hpp:42-51), the spatial index rebuilt every outer iteration
+    (cc:66-67) and the inner loop iterated to function_tolerance (cc:96-97).  A bounded sample; still kinder than the
+    reference, which also builds a Ceres problem of nnz residual blocks per iteration."""
+    from oracle import binding as po
+    t0 = time.perf_counter()
+    res = po.align(src, tgt, cfg["radius"], cfg["max_neighbours"], cfg["dof"], iters, cost_drop_thresh=0.0,
+                   inner_max_steps=100, f_tol=REF_F_TOL, threads=1)
+    dt = time.perf_counter() - t0
+    n = len(res["history"])
+    return dict(value=n / dt, unit="iterations/s", cores=1, kind="port",
+                sample=f"{n} outer iterations of the same {src.shape[0]}<->{tgt.shape[0]} workload, one thread, grid "
+                       f"rebuilt every iteration, inner IRLS to f_tol={REF_F_TOL:g} "
+                       f"(mean {float(np.mean(res['inner_steps'])):.1f} inner steps)",
+                seconds=dt, mean_inner_steps=float(np.mean(res["inner_steps"])))
+
+
+def run_rank(a):
+    from probabilistic_point_clouds_registration_amd import _lib, batch, synth
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to mislabel the run")
 
     import torch  # device selection, synchronize, torch.distributed (RCCL)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() < (local_rank + 1):
+        raise SystemExit(f"bench.py: rank {rank} has no device {local_rank}")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or a.force_dist:
@@ -109,15 +166,24 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == a.gpus
 
     cfg = dict(synth.CONFIGS[a.config])
     n = a.n or cfg["n"]
-    # weak scaling: rank r registers its own pair(s): pair p lives on rank p % world (batch.shard_pairs)
-    n_pairs = world * a.pairs_per_gpu
-    my_pairs = batch.shard_pairs(n_pairs, world, rank)
-    ctxs = []
+    batch_cfg = "pairs" in cfg              # config 5: a fixed batch of independent pairs sharded over the ranks
+    if a.pairs_per_gpu > 0:
+        n_pairs = world * a.pairs_per_gpu
+    elif batch_cfg:
+        if cfg["pairs"] % world:
+            raise SystemExit(f"config {a.config}: {cfg['pairs']} pairs do not divide over {world} ranks")
+        n_pairs = cfg["pairs"]
+    else:
+        n_pairs = world
+    pairs_per_gpu = n_pairs // world
+    my_pairs = batch.shard_pairs(n_pairs, world, rank)   # pair p lives on rank p % world
+    ctxs, clouds = [], []
     for p in my_pairs:
-        src, tgt, Rgt, tgt_t = synth.make_pair(n, cfg=a.config, pair=p)
+        src, tgt, _, _ = synth.make_pair(n, cfg=a.config, pair=p)
         c = _lib.Context(local_rank)
         for kv in a.opt:
             k, v = kv.split("=")
@@ -126,8 +192,11 @@ def main():
         c.set_target(tgt)
         c.set_source(src)
         ctxs.append(c)
+        clouds.append((src, tgt))
     ctx = ctxs[0]
-    src, tgt, Rgt, tgt_t = synth.make_pair(n, cfg=a.config, pair=my_pairs[0])   # rank 0's first pair (cpu baseline/parity)
+    src, tgt = clouds[0]   # this rank's first pair (rank 0: cpu baselines / parity)
+    concurrent = len(ctxs) > 1 and a.lanes > 1
+    dev = torch.device("cuda", local_rank)
 
     def barrier():
         for c in ctxs:
@@ -136,49 +205,61 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # warm-up (also builds the grid and sorts the source once)
-    if a.warmup > 0:
-        if len(ctxs) > 1 and a.lanes > 1:
-            # same concurrency as the timed region: the runtime creates its extra hardware queues on first
-            # concurrent use (a one-off ~50 ms stall measured when this ran sequentially)
-            _lib.align_many(ctxs, a.warmup, lanes=a.lanes, cost_drop_thresh=0.0, inner_steps=a.inner_steps)
+    def run_iterations(k, inner, f_tol=1e-5):
+        """k outer iterations on every pair of this rank -> {pair: final cumulative 3x4 of these k iterations}"""
+        out = {}
+        if concurrent:
+            # several resident pairs per GPU: a.lanes of them in flight, each on its own handle/stream
+            T_fin, done = _lib.align_many(ctxs, k, lanes=a.lanes, cost_drop_thresh=0.0, inner_steps=inner, f_tol=f_tol)
+            assert all(int(d) == k for d in done), f"early stop: {list(done)}"
+            for j, p in enumerate(my_pairs):
+                out[p] = T_fin[j]
         else:
-            for c in ctxs:
-                c.align(a.warmup, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
-    if dist is not None:
-        # the collective is warmed up too (communicator set-up and its buffers are not part of a step)
-        batch.gather_transforms({p: np.eye(4)[:3] for p in my_pairs}, n_pairs, dist=dist,
-                                device=torch.device("cuda", local_rank))
-    barrier()
-    gathered = None
-    t0 = time.perf_counter()
-    local = {}
-    if len(ctxs) > 1 and a.lanes > 1:
-        # several resident pairs per GPU: a.lanes of them in flight, each on its own handle/stream
-        T_fin, done = _lib.align_many(ctxs, a.steps, lanes=a.lanes, cost_drop_thresh=0.0, inner_steps=a.inner_steps)
-        assert all(int(d) == a.steps for d in done), f"early stop inside the timed region: {list(done)}"
-        for k, p in enumerate(my_pairs):
-            local[p] = T_fin[k]
-    else:
-        for p, c in zip(my_pairs, ctxs):
-            res = c.align(a.steps, cost_drop_thresh=0.0, inner_steps=a.inner_steps)
-            assert res["n_iter"] == a.steps, f"early stop inside the timed region: {res['n_iter']}"
-            local[p] = res["history"][-1]
-    if dist is not None:
-        # RCCL: the only collective of the job — final gather of the transforms (batch.gather_transforms)
-        gathered = batch.gather_transforms(local, n_pairs, dist=dist, device=torch.device("cuda", local_rank))
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+            for p, c in zip(my_pairs, ctxs):
+                res = c.align(k, cost_drop_thresh=0.0, inner_steps=inner, f_tol=f_tol)
+                assert res["n_iter"] == k, f"early stop: {res['n_iter']}"
+                out[p] = res["history"][-1] if k > 0 else np.eye(4)[:3]
+        return out
 
-    # per-kernel durations with HIP events on the handle's own stream (separate pass so that the event
-    # records cannot perturb the headline number; same workload, same K)
+    def fresh_start(inner, f_tol=1e-5):
+        for c, (s, _) in zip(ctxs, clouds):
+            c.set_source(s)
+        if a.warmup > 0:
+            run_iterations(a.warmup, inner, f_tol)
+
+    if dist is not None:
+        # the collective is warmed up once (communicator set-up and its buffers are not part of a step)
+        batch.gather_transforms({p: np.eye(4)[:3] for p in my_pairs}, n_pairs, dist=dist, device=dev)
+
+    # ---- timed windows --------------------------------------------------------------------------------------------
+    window_s, gathered, local = [], None, None
+    for w in range(max(1, a.windows)):
+        fresh_start(a.inner_steps)
+        barrier()
+        t0 = time.perf_counter()
+        local = run_iterations(a.steps, a.inner_steps)
+        if dist is not None:
+            # RCCL: the only collective of the job — final gather of the transforms
+            gathered = batch.gather_transforms(local, n_pairs, dist=dist, device=dev)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        window_s.append(dt)
+    if dist is None:
+        gathered = batch.gather_transforms(local, n_pairs)
+    dt = float(np.median(window_s))
+
+    # ---- per-kernel durations with HIP events on the handle's own stream (separate pass so that the event records
+    # cannot perturb the headline number; same workload, same warm-up, same K)
     prof = {}
     nnz = ctx.association_size()[1]
     if not a.no_profile:
+        ctx.set_source(src)
+        if a.warmup > 0:
+            ctx.align(a.warmup, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
         ctx.profile_enable(True)
         tp0 = time.perf_counter()
         ctx.align(a.steps, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
@@ -191,9 +272,10 @@ def main():
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
-        return
+        return 0
 
     ns, nt = src.shape[0], tgt.shape[0]
+    model = "Gaussian" if np.isinf(cfg["dof"]) else "t dof=%g" % cfg["dof"]
     out = {
         # BASELINE.json's metric; the label follows the cloud size actually run (configs other than the headline)
         "metric": "registration iterations/sec (%s<->%s pts, r=%.1f, m=%d)" % (
@@ -203,22 +285,27 @@ def main():
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
-        "ms_per_step": 1e3 * dt / (a.steps * a.pairs_per_gpu),
+        "ms_per_step": 1e3 * dt / (a.steps * pairs_per_gpu),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if (batch_cfg and a.pairs_per_gpu == 0) else "weak",
         "vs_baseline": None,
         "dtype": "f32 (distances) + f64 (weights, moments, solve)",
         "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[{a.config - 1}]: {ns}<->{nt} synthetic clouds, radius={cfg['radius']}, "
-                               f"max_neighbours={cfg['max_neighbours']}, "
-                               f"{'Gaussian' if np.isinf(cfg['dof']) else 't dof=%g' % cfg['dof']}, "
+        "config": {"workload": f"BASELINE configs[{a.config - 1}]: "
+                               + (f"batch of {n_pairs} independent pairs of " if n_pairs > 1 else "")
+                               + f"{ns}<->{nt} synthetic clouds, radius={cfg['radius']}, "
+                               f"max_neighbours={cfg['max_neighbours']}, {model}, "
                                f"{a.inner_steps} inner IRLS step(s)/iteration, cost_drop_thresh=0",
-                   "pairs": n_pairs, "lanes_per_gpu": (a.lanes if a.pairs_per_gpu > 1 else 1),
-                   "parallelism": f"{n_pairs} independent pair(s), {a.pairs_per_gpu} per GPU on {world} GPU(s); "
-                                                     "no data-path collective; final RCCL all_gather of the transforms"},
+                   "pairs": n_pairs, "pairs_per_gpu": pairs_per_gpu, "lanes_per_gpu": (a.lanes if concurrent else 1),
+                   "parallelism": f"{n_pairs} independent pair(s), {pairs_per_gpu} per GPU on {world} GPU(s); "
+                                  "no data-path collective; final RCCL all_gather of the transforms"},
+        "windows": {"count": len(window_s), "statistic": "median",
+                    "it_per_s": [n_pairs * a.steps / w for w in window_s],
+                    "min_it_per_s": n_pairs * a.steps / max(window_s), "max_it_per_s": n_pairs * a.steps / min(window_s),
+                    "window_ms": 1e3 * dt},
         "nnz": int(nnz),
     }
-    # roofline of the dominant kernel (K1, nn_topm_kernel): algorithmic bytes B_nn = 16*Ns + 12*Nt + 4*nnz
+    # roofline of the dominant kernel (K1, nn_tile_kernel): algorithmic bytes B_nn = 16*Ns + 12*Nt + 4*nnz
     #  / average launch duration measured with HIP events above
     b_nn = 16.0 * ns + 12.0 * nt + 4.0 * nnz
     b_iter = 72.0 * ns + 12.0 * nt + 52.0 * nnz + (a.inner_steps - 1) * (32.0 * ns + 48.0 * nnz)
@@ -226,51 +313,116 @@ def main():
         k = prof["nn_topm_kernel"]
         avg_ms = k["total_ms"] / max(1, k["launches"])
         ach = b_nn / (avg_ms * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from PMC counters: a separate rocprofv3 --pmc run (profiles/k1_traffic.json)
+        # HBM bytes per launch come from PMC counters, which need their own rocprofv3 --pmc passes
+        # (tools/profile_round.sh); the committed summary of the latest passes is quoted, with its source named
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
         if os.path.exists(tpath) and a.config in (3, 4) and a.n is None:
-            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("traffic_bytes_per_launch")
+            traffic_source = "profiles/k1_traffic.json (%s)" % tj.get("source", "separate rocprofv3 --pmc passes")
         out["roofline"] = {"bound": "hbm", "kernel": "nn_tile_kernel (K1)", "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                           "traffic_source": traffic_source,
                            "avg_kernel_ms": avg_ms, "algorithmic_bytes_per_launch": b_nn,
                            "candidate_tests_per_s": 27 * 3.8147 * ns / (avg_ms * 1e-3)}
     else:
         out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                           "traffic": None}
+                           "traffic": None, "traffic_source": None}
     out["iteration_roofline"] = {"algorithmic_bytes_per_iteration": b_iter,
-                                 "achieved_GBs_per_gpu": b_iter * a.steps * a.pairs_per_gpu / dt / 1e9,
-                                 "frac_of_hbm_peak": b_iter * a.steps * a.pairs_per_gpu / dt / 1e9 / HBM_PEAK_GBS}
+                                 "achieved_GBs_per_gpu": b_iter * a.steps * pairs_per_gpu / dt / 1e9,
+                                 "frac_of_hbm_peak": b_iter * a.steps * pairs_per_gpu / dt / 1e9 / HBM_PEAK_GBS,
+                                 "note": "B_iter is SURVEY §8(d)'s definition (weights and correspondences "
+                                         "materialised); the fused kernels move about half of it"}
     out["kernels_ms_per_launch"] = {k: v["total_ms"] / max(1, v["launches"]) for k, v in prof.items()
                                     if isinstance(v, dict)}
     if "_profiled_pass_ms_per_step" in prof:
         out["profiled_pass_ms_per_step"] = prof["_profiled_pass_ms_per_step"]
 
+    if not a.no_extras:
+        # cold start: the first associations after an upload have no temporal cut-off yet and the source still moves
+        ctx.set_source(src)
+        ctx.synchronize()
+        cold = []
+        for _ in range(5):
+            tc = time.perf_counter()
+            ctx.iterate(inner_steps=a.inner_steps)
+            ctx.synchronize()
+            cold.append(1e3 * (time.perf_counter() - tc))
+        out["cold_ms_per_iteration"] = cold   # it0 also sorts the source into the grid's order (once per upload)
+        # the schedule a drop-in user of the C++ classes / CLI gets: inner IRLS to the reference's function_tolerance
+        ctx.set_source(src)
+        if a.warmup > 0:
+            ctx.align(a.warmup, cost_drop_thresh=0.0, inner_steps=100, f_tol=REF_F_TOL, want_history=False)
+        ctx.synchronize()
+        tc = time.perf_counter()
+        res = ctx.align(a.steps, cost_drop_thresh=0.0, inner_steps=100, f_tol=REF_F_TOL)
+        ctx.synchronize()
+        tc = time.perf_counter() - tc
+        out["converged_inner"] = {"it_per_s": a.steps / tc, "ms_per_iteration": 1e3 * tc / a.steps,
+                                  "mean_inner_steps": float(np.mean(res["inner_steps"])),
+                                  "schedule": f"<=100 IRLS steps per association, f_tol={REF_F_TOL:g} "
+                                              "(the C++ layer's and the reference's default)"}
+
+    if batch_cfg or world > 1 or dist is not None:
+        ok = np.isfinite(gathered).all(axis=(1, 2))
+        out["gathered_transforms"] = int(ok.sum())
+        assert out["gathered_transforms"] == n_pairs, f"gathered {int(ok.sum())} of {n_pairs} transforms"
+        if batch_cfg and not a.no_verify:
+            # every gathered transform against a single-rank, single-stream run of the same pair and schedule
+            worst = 0.0
+            with _lib.Context(local_rank) as chk:
+                chk.set_params(cfg["radius"], cfg["max_neighbours"], cfg["dof"], 3)
+                for p in range(n_pairs):
+                    s, t, _, _ = synth.make_pair(n, cfg=a.config, pair=p)
+                    chk.set_target(t)
+                    chk.set_source(s)
+                    if a.warmup > 0:
+                        chk.align(a.warmup, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
+                    one = chk.align(a.steps, cost_drop_thresh=0.0, inner_steps=a.inner_steps)["history"][-1]
+                    worst = max(worst, float(np.abs(one - gathered[p]).max()))
+            out["batch_verification"] = {"pairs_checked": n_pairs, "max_abs_diff_vs_single_rank_run": worst}
+            assert worst < 1e-9, f"a gathered transform differs from its single-rank run by {worst}"
+
     if world == 1 and not a.no_cpu_baseline:
+        from oracle import binding as po  # noqa: F401  (checker side)
         cb, ora = cpu_baseline(src, tgt, cfg, a.cpu_iters, a.inner_steps)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+        if not a.no_extras:
+            out["cpu_baseline_refshape"] = cpu_baseline_refshape(src, tgt, cfg)
+            if "converged_inner" in out:
+                out["converged_inner"]["speedup_vs_cpu_baseline_refshape"] = (
+                    out["converged_inner"]["it_per_s"] / out["cpu_baseline_refshape"]["value"])
         # parity attached to the timing: GPU vs oracle after the same number of iterations from the same start
-        chk = _lib.Context(local_rank)
-        chk.set_params(cfg["radius"], cfg["max_neighbours"], cfg["dof"], 3)
-        chk.set_target(tgt)
-        chk.set_source(src)
-        n_par = int(ora["n_iter"]) if "n_iter" in ora else len(ora["history"])
-        g = chk.align(n_par, cost_drop_thresh=0.0, inner_steps=a.inner_steps)
-        chk.close()
-        assert g["n_iter"] == len(ora["history"]), (g["n_iter"], len(ora["history"]))
+        with _lib.Context(local_rank) as chk:
+            chk.set_params(cfg["radius"], cfg["max_neighbours"], cfg["dof"], 3)
+            chk.set_target(tgt)
+            chk.set_source(src)
+            n_par = len(ora["history"])
+            g = chk.align(n_par, cost_drop_thresh=0.0, inner_steps=a.inner_steps)
+        assert g["n_iter"] == n_par, (g["n_iter"], n_par)
         out["parity"] = {"iterations": n_par,
                          "rot_err_rad": synth.rotation_angle(g["history"][-1][:, :3], ora["history"][-1][:, :3]),
                          "trans_err_m": float(np.linalg.norm(g["history"][-1][:, 3] - ora["history"][-1][:, 3])),
                          "vs": "oracle (CPU restatement); the reference itself cannot be built (PCL/Ceres absent)"}
-    elif world > 1:
-        out["gathered_transforms"] = int(np.isfinite(gathered).all(axis=(1, 2)).sum()) if gathered is not None else 0
     print(json.dumps(out))
     sys.stdout.flush()
     for c in ctxs:
         c.close()
     if dist is not None:
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return spawn_ranks(a)
+    return run_rank(a)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
