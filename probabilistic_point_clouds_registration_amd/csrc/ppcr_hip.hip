@@ -127,6 +127,9 @@ struct ppcr_ctx {
     enum { ASSOC_NONE, ASSOC_ELL, ASSOC_CSR } assoc = ASSOC_NONE;
     int ell_width = 0;
     DevBuf<int> nbr, cnt, row_ptr;
+    DevBuf<int> ovf_list;        // blocks nn_fast_kernel handed over to nn_tile_cleanup_kernel
+    DevBuf<unsigned> ovf_state;  // two list counters used alternately (ovf_parity): the idle one is cleared by the fast kernel
+    int ovf_parity = 0;
     DevBuf<unsigned> dm2;    // per (sorted) source row: float d2 bits of its m-th neighbour in the last tiled K1
     bool dm2_valid = false;  // dm2 matches the current source order / target / radius / max_neighbours
     int opt_temporal = 1;
@@ -445,11 +448,12 @@ int ensure_source_sorted(ppcr_ctx *c)
     return PPCR_OK;
 }
 
-// K1 launch.  LDS budget per 256-query block: halo CAP*13 B (x, y, z + a row-id byte) + list C*512 B (+1.1 KB tables).
-// With the column order of the source typical halos are ~1000-1400 candidates at the benchmark density; the margin
-// keeps denser clouds out of the subdivided passes (measured when the source was ordered in 4x4x4 bricks, fresh /
-// drifted: CAP 2048: 249/341 us, 2176: 231/246, 2240: 230/246, 2272: 302/318).  The first association (no cut-off
-// yet) needs C = 32 (C = 24 doubled its time).
+// K1 launch: nn_fast_kernel over every block, then nn_tile_cleanup_kernel over the blocks the fast flavour handed over
+// (usually none: the cleanup launch then costs a few microseconds of an empty grid).
+// LDS budget per 256-query block: halo CAP*13 B (x, y, z + a row byte) + list C*512 B (+0.4 KB tables).  With the
+// column order of the source typical halos are ~1000-1400 candidates at the benchmark density; the margin keeps
+// denser clouds and drifted sources in the fast flavour (measured when the source was ordered in 4x4x4 bricks, fresh /
+// drifted: CAP 2048: 249/341 us, 2176: 231/246, 2240: 230/246, 2272: 302/318).
 template <int M>
 void launch_tile(ppcr_ctx *c, float r2, int m, const PendingMove &pm)
 {
@@ -457,22 +461,41 @@ void launch_tile(ppcr_ctx *c, float r2, int m, const PendingMove &pm)
     const int dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
     constexpr int C = (M <= 24) ? 32 : 48;
     constexpr int CAP = (M <= 24) ? 2240 : 2048;
-#define PPCR_TILE(Cc)                                                                                                   \
-    nn_tile_kernel<M, Cc, 256, CAP><<<nblocks(c->ns, 256), 256, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p, \
-                                                                                c->cell_start.p, c->grid, r2, m,      \
-                                                                                c->nbr.p, c->cnt.p, st, pm, c->dm2.p, \
-                                                                                dm2_in)
+    const int nb = nblocks(c->ns, 256);
+    c->ovf_parity ^= 1;
+    unsigned *const ovf_now = c->ovf_state.p + c->ovf_parity, *const ovf_next = c->ovf_state.p + (c->ovf_parity ^ 1);
+#define PPCR_FAST(Cc, STAMPc)                                                                                          \
+    nn_fast_kernel<M, Cc, CAP, STAMPc><<<nb, 256, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p,                \
+                                                                  c->cell_start.p, c->grid, r2, m, c->nbr.p, c->cnt.p, \
+                                                                  pm, c->dm2.p, dm2_in, c->ovf_list.p, ovf_now,         \
+                                                                  ovf_next, st)
+    bool launched = false;
     if constexpr (M <= 12) {
-        // steady state: the temporal cut-off keeps every list near m entries, so half the list capacity does
-        // (an overflowing lane re-runs with in-loop compaction as always); with the one-byte row ids that
-        // brings the workgroup under 40 KB of LDS and 128 VGPRs: FOUR workgroups per CU instead of three
+        // steady state: the temporal cut-off keeps every list near m entries, so half the list capacity does (an
+        // overflowing lane tightens its threshold and scans again): under 40 KB of LDS and 128 VGPRs, FOUR
+        // workgroups per CU instead of three
         if (dm2_in && c->opt_short_lists) {
-            PPCR_TILE(16);
-            return;
+            if constexpr (M == 10) {
+                if (st) PPCR_FAST(16, true);
+                else PPCR_FAST(16, false);
+            } else {
+                PPCR_FAST(16, false);
+            }
+            launched = true;
         }
     }
-    PPCR_TILE(C);
-#undef PPCR_TILE
+    if (!launched) {
+        if constexpr (M == 10) {
+            if (st) PPCR_FAST(C, true);
+            else PPCR_FAST(C, false);
+        } else {
+            PPCR_FAST(C, false);
+        }
+    }
+#undef PPCR_FAST
+    nn_tile_cleanup_kernel<M, C, 256, CAP><<<std::min(nb, 512), 256, 0, c->stream>>>(
+        c->src.p, (int)c->ns, c->tgt_sorted.p, c->cell_start.p, c->grid, r2, m, c->nbr.p, c->cnt.p, c->dm2.p,
+        c->ovf_list.p, ovf_now);
 }
 
 constexpr int kAccumRows = 1;     // rows per lane of accumulate_ell_kernel
@@ -524,6 +547,11 @@ int associate_impl(ppcr_ctx *c)
         HIP_TRY(c, c->nbr.reserve((size_t)m * (size_t)std::max(ns, 1)));
         HIP_TRY(c, c->cnt.reserve((size_t)std::max(ns, 1)));
         HIP_TRY(c, c->dm2.reserve((size_t)std::max(ns, 1)));
+        HIP_TRY(c, c->ovf_list.reserve((size_t)nblocks(std::max(ns, 1), 256)));
+        if (!c->ovf_state.p) {
+            HIP_TRY(c, c->ovf_state.reserve(2));
+            HIP_TRY(c, hipMemsetAsync(c->ovf_state.p, 0, 2 * sizeof(unsigned), c->stream));
+        }
         // dm2 is only trusted when the source moved by nothing but the deferred rigid move applied in this
         // very kernel since the association that wrote it
         if (!tiled) c->dm2_valid = false;
@@ -968,6 +996,8 @@ int ppcr_destroy(ppcr_ctx *c)
     c->bbox_part.release();
     c->nbr.release();
     c->dm2.release();
+    c->ovf_list.release();
+    c->ovf_state.release();
     c->cnt.release();
     c->row_ptr.release();
     c->gen_counts.release();
@@ -1479,6 +1509,17 @@ int ppcr_debug_get_stamps(ppcr_ctx *c, unsigned long long out[8])
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int k = 0; k < 8; k++) out[k] = 0;
     for (size_t i = 0; i < nst; i++) out[i % 8] += h[i];
+    return PPCR_OK;
+}
+
+// diagnostic: the raw per-wave stamp records (8 x u64 per wave) of the last STAMPS launch
+int ppcr_debug_get_stamps_raw(ppcr_ctx *c, unsigned long long *out, size_t n)
+{
+    CTX_ENTER(c);
+    if (!c->d_stamps.p) return fail(c, PPCR_ERR_STATE, "stamps not enabled");
+    if (n > c->d_stamps.cap) return fail(c, PPCR_ERR_INVALID, "more records than the stamp buffer holds");
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_stamps.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return PPCR_OK;
 }
 

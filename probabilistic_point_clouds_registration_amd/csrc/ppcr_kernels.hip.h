@@ -547,36 +547,30 @@ struct PendingMove {
     Pose P;
 };
 
+// GENERAL flavour of K1, run on the workgroups nn_fast_kernel hands over (ovf_list[0 .. *ovf_count)): halos of any
+// shape (up to 128 rows), binary subdivision when a halo does not fit, global-memory scan as the last resort, in-loop
+// list compaction for dense neighbourhoods.  The source has already been moved by the fast kernel and the temporal
+// cut-off is not used here (the fast kernel may have overwritten some of this block's dm2 entries already).
+// Persistent workgroups stride over the list.  The list counters ping-pong: launch k counts in ovf_state[k & 1] and the
+// fast kernel of launch k clears ovf_state[(k + 1) & 1] (last used by launch k - 1, whose cleanup has finished by then in
+// stream order), so nobody needs an atomic ticket (1024 same-address atomics cost this kernel 20 us when it was tried).
 template <int M, int C, int BLOCK, int CAP>
-__global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float4 *__restrict__ src, int ns,
+__global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt,
                                                          const int *__restrict__ cell_start, GridDesc g,
                                                          float r2, int m, int *__restrict__ nbr,
-                                                         int *__restrict__ cnt,
-                                                         unsigned long long *__restrict__ stamps,
-                                                         PendingMove pm, unsigned *__restrict__ dm2, int dm2_valid)
+                                                         int *__restrict__ cnt, unsigned *__restrict__ dm2,
+                                                         const int *__restrict__ ovf_list,
+                                                         const unsigned *__restrict__ ovf_count)
 {
+    const unsigned n_listed = *ovf_count;
+    for (unsigned listed = blockIdx.x; listed < n_listed; listed += gridDim.x) {
+    const int bid = ovf_list[listed];
     static_assert(C > M, "a compaction must leave room in the list");
     static_assert(CAP % 4 == 0 && CAP <= 65536 && C * 64 <= 3 * CAP && kTileRows <= 256, "the global fallback aliases the candidate buffer");
     static_assert(kTileRows == 128, "row table: two rows per lane of one wave");
     constexpr int kWaves = BLOCK / 64;
-    constexpr int kStageUnroll = (C <= 16 ? 4 : 8);  // halo rows in flight per wave (fewer under the 128-VGPR budget of the 16-slot variant: 134 -> 127 us)
-    // diagnostic only (stamps == nullptr in every timed run): per-wave, per-phase cycle counts kept in
-    // registers and written once at exit to stamps[(block * waves + wave) * 8 + phase]
-    unsigned long long t_prev = stamps ? clock64() : 0;
-    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto stamp = [&](int phase) {
-        if (stamps) {
-            const unsigned long long now = clock64();
-#pragma unroll
-            for (int k = 0; k < 8; k++) t_acc[k] += (k == phase) ? now - t_prev : 0ull;
-            t_prev = now;
-        }
-    };
-    auto flush_stamps = [&]() {
-        if (stamps && (threadIdx.x & 63) == 0)
-            for (int k = 0; k < 8; k++) stamps[((size_t)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8 + k] = t_acc[k];
-    };
+    constexpr int kStageUnroll = 8;  // halo rows in flight per wave
     // staged halo, structure-of-arrays: two candidates per ds_read_b64 and per packed-f32 instruction
     __shared__ __attribute__((aligned(16))) float s_halo[3 * CAP + CAP / 4];
     float *const s_x = s_halo, *const s_y = s_halo + CAP, *const s_z = s_halo + 2 * CAP;
@@ -589,31 +583,10 @@ __global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = blockIdx.x * BLOCK + tid;
+    const int i = bid * BLOCK + tid;
     const bool valid = i < ns;
-    float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    float moved = 0.f;  // how far this query travelled since the association that produced dm2
-    if (pm.enabled && valid) {
-        const float4 q0 = q;
-        q = move_point(q, pm.P);
-        src[i] = q;
-        const float ex = q.x - q0.x, ey = q.y - q0.y, ez = q.z - q0.z;
-        moved = sqrtf(ex * ex + ey * ey + ez * ez);
-    }
-    // Temporal cut-off.  dm2[i] holds the float d2 of this query's m-th neighbour in the previous
-    // association (all-ones when it had fewer than m).  Those m targets are now at most dm + |move| away, so
-    // the new m-th distance is <= dm + |move|: a candidate farther than that cannot be among the m closest
-    // and is never appended.  The bound is inflated by 1e-5 (float rounding of d2 is ~4e-7 relative), and the
-    // final selection below is exact as before — only the amount of list traffic changes.
-    unsigned thr0 = 0xFFFFFFFFu;
-    if (dm2_valid && valid) {
-        const unsigned prev = dm2[i];
-        if (prev != 0xFFFFFFFFu) {
-            const float bound = sqrtf(__uint_as_float(prev)) + moved;
-            const float t2 = bound * bound * 1.00001f + 1e-30f;
-            thr0 = (t2 < r2) ? __float_as_uint(t2) : 0xFFFFFFFFu;
-        }
-    }
+    const float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned thr0 = 0xFFFFFFFFu;  // no temporal cut-off in this flavour
     const QueryCells qc = query_cells(q, g);
 
     // this lane's 9 stencil runs [rb, re) in sorted-target positions: issued now, consumed after the
@@ -663,7 +636,6 @@ __global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float
             }
     }
     lds_barrier();
-    stamp(0);
 
     int n = 0;
     bool done = !valid;
@@ -717,7 +689,6 @@ __global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float
         const int offA = incl - lenA - lenB, offB = offA + lenA;
         const int total = __builtin_amdgcn_readlane(incl, 63);
         const bool ok = rows_ok && total <= CAP;
-        stamp(1);
         if (ok) {
             if (wave == w0) {  // one wave publishes the table for the scan phase
                 s_row_gb[2 * lane] = gbA;
@@ -762,7 +733,6 @@ __global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float
                 }
             }
             lds_barrier();
-            stamp(2);
             if (!done && wave >= w0 && wave < w1) {
                 const LdsCands<BLOCK> L{s_x, s_y, s_z, s_rowid, s_row_gb, s_row_off, s_list, tid};
                 // d2 >= +0 and r2 > 0, so "d2 < r2" is "bits(d2) <= bits(r2) - 1" (a NaN d2 has larger bits and
@@ -872,7 +842,6 @@ __global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float
                     thr = lim0;
                     scan_runs(std::true_type{});
                 }
-                stamp(3);
                 unsigned tm = 0xFFFFFFFFu;  // d2 bits of the m-th neighbour (all-ones: fewer than m found)
                 if (n > m) {
                     n = select_top_m<M>(L, tgt, q, n, m, thr);
@@ -881,17 +850,14 @@ __global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float
                     tm = 0;
                     for_each_entry(L, q, n, [&](int, int, unsigned b) { tm = max(tm, b); });
                 }
-                stamp(4);
                 for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = L.pos_of(L.load(j));
                 cnt[i] = n;
                 if (dm2) dm2[i] = tm;
                 done = true;
-                stamp(5);
             }
             done_mask |= pass_mask;
             if (done_mask == (1u << kWaves) - 1u) break;  // common case: nothing left, no trailing barrier
             lds_barrier();                              // the halo buffer is reused by the next pass
-            stamp(6);
         } else if (last_level) {
             // last resort for this wave: scan global memory (list of positions aliases the halo buffer)
             if (!done && wave == w0) {
@@ -920,9 +886,426 @@ __global__ __launch_bounds__(BLOCK, (C <= 16 ? 4 : 3)) void nn_tile_kernel(float
             }
             done_mask |= pass_mask;
             lds_barrier();
-            stamp(7);
         }
       }
+    __syncthreads();  // the LDS buffers are reused by this workgroup's next listed block
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1, FAST flavour (the one every association launches): same algorithm as the general flavour above — spatially
+// compact block of 256 queries, target halo staged once into LDS, per-lane scan of the nine clipped stencil runs
+// into a lane-private u16 list, v_med3 threshold selection — stripped of everything the common case does not need,
+// because the kernel is bound by VALU issue (round-1 counters: 3050 VALU instructions per wave, 45 % of them
+// integer bookkeeping):
+//   * ONE halo per workgroup of at most 128 (y,z) row slots, slot = rz << ys | ry with ys = 3 (up to 8 x 16 rows) or
+//     4 (16 x 8: blocks that straddle two columns of the source order): no division, no subdivision passes, no
+//     per-pass state; a block whose halo does not fit that shape or CAP appends itself to ovf_list and
+//     nn_tile_cleanup_kernel redoes it;
+//   * the nine run windows are computed branch-free in slice units (one v_sqrt_f32 each: a 1-ulp root is inside the
+//     slack the window carries anyway) and their 18 cell_start loads are unconditional (index 0 for a dead run);
+//   * wave reductions / scans on the DPP row_shr / row_bcast network instead of ds_bpermute trees;
+//   * the halo's sorted-target position is ONE table entry per row (gbo[row] = global begin - LDS offset), so a
+//     run's LDS start and a winner's position cost one LDS read each;
+//   * list entries are BYTE offsets into the halo arrays (the selection passes use them as addresses as they are),
+//     pairs are read with 4-byte alignment from the run's true start (no head test, fewer trips), an accepted
+//     candidate costs a store and two VALU instructions;
+//   * a lane whose list overflows takes the m-th smallest of the C candidates it did store as its new threshold and
+//     scans again (no compacting flavour of the scan in the binary); a second overflow (> C exact ties) hands the
+//     block to the cleanup kernel.
+// Every d2 that is computed is computed with the same IEEE operations as dist2_flann, and the final selection is the
+// same code as before, so neighbour sets and cut-off states stay bit-identical to the general flavour and the oracle.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_pull(int identity, int v)
+{
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+// inclusive scan over the 64 lanes (ALL lanes must be active); lane 63 ends up with the reduction
+template <class Op>
+__device__ __forceinline__ int wave_scan(int v, int identity, Op op)
+{
+    v = op(v, dpp_pull<0x111, 0xf>(identity, v));  // row_shr:1
+    v = op(v, dpp_pull<0x112, 0xf>(identity, v));  // row_shr:2
+    v = op(v, dpp_pull<0x114, 0xf>(identity, v));  // row_shr:4
+    v = op(v, dpp_pull<0x118, 0xf>(identity, v));  // row_shr:8   -> inclusive within each row of 16
+    v = op(v, dpp_pull<0x142, 0xa>(identity, v));  // row_bcast:15 into rows 1 and 3
+    v = op(v, dpp_pull<0x143, 0xc>(identity, v));  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+struct OpMin { __device__ __forceinline__ int operator()(int a, int b) const { return a < b ? a : b; } };
+struct OpMax { __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; } };
+struct OpAdd { __device__ __forceinline__ int operator()(int a, int b) const { return a + b; } };
+template <class Op>
+__device__ __forceinline__ int wave_reduce(int v, int identity, Op op)  // wave-uniform result
+{
+    return __builtin_amdgcn_readlane(wave_scan(v, identity, op), 63);
+}
+
+// candidate source of the fast flavour: list entries are byte offsets (4 * LDS index) into the SoA halo
+struct HaloList {
+    const char *hx;                 // s_x as bytes; y and z follow at fixed strides
+    int stride;                     // bytes between the x, y and z arrays
+    const unsigned char *rowid;     // per staged point: its row slot
+    const char *gbo;                // s_gbo as bytes
+    unsigned short *list;           // [slot * 256 + tid]
+    __device__ __forceinline__ float4 get(int a) const
+    {
+        return make_float4(*reinterpret_cast<const float *>(hx + a), *reinterpret_cast<const float *>(hx + stride + a),
+                           *reinterpret_cast<const float *>(hx + 2 * stride + a), 0.f);
+    }
+    __device__ __forceinline__ int load(int t) const { return list[t * 256]; }
+    __device__ __forceinline__ void store(int t, int a) const { list[t * 256] = (unsigned short)a; }
+    __device__ __forceinline__ int pos_of(int a) const
+    {
+        const int e = a >> 2;
+        return e + *reinterpret_cast<const int *>(gbo + 4 * rowid[e]);
+    }
+    __device__ __forceinline__ unsigned orig_of(int a, const float4 *__restrict__ tgt) const
+    {
+        return (unsigned)__float_as_int(tgt[pos_of(a)].w);
+    }
+};
+
+template <int M, int C, int CAP, bool STAMPS>
+__global__ __launch_bounds__(256, (C <= 16 ? 4 : 3)) void nn_fast_kernel(float4 *__restrict__ src, int ns,
+                                                         const float4 *__restrict__ tgt,
+                                                         const int *__restrict__ cell_start, GridDesc g,
+                                                         float r2, int m, int *__restrict__ nbr,
+                                                         int *__restrict__ cnt, PendingMove pm,
+                                                         unsigned *__restrict__ dm2, int dm2_valid,
+                                                         int *__restrict__ ovf_list, unsigned *__restrict__ ovf_count,
+                                                         unsigned *__restrict__ ovf_count_next,
+                                                         unsigned long long *__restrict__ stamps)
+{
+    static_assert(C > M, "a re-scan must leave room in the list");
+    static_assert(CAP % 4 == 0 && CAP * 4 < 65536, "list entries are 16-bit byte offsets into the halo arrays");
+    constexpr int BLOCK = 256, kWaves = 4, kRows = 128, kStageUnroll = 4;
+    __shared__ __attribute__((aligned(16))) float s_halo[3 * CAP + CAP / 4];
+    __shared__ unsigned short s_list[C * BLOCK];
+    __shared__ int s_gbo[kRows];
+    __shared__ int2 s_rowtab[kRows];  // non-empty rows, compacted: {global begin, LDS offset << 19 | length << 7 | slot}
+    __shared__ int s_box[kWaves][6];
+    __shared__ int s_bail;
+    float *const s_x = s_halo, *const s_y = s_halo + CAP, *const s_z = s_halo + 2 * CAP;
+    unsigned char *const s_rowid = reinterpret_cast<unsigned char *>(s_halo + 3 * CAP);
+
+    // diagnostic only (STAMPS instantiation): per-wave, per-phase cycle counts
+    unsigned long long t_prev = 0, t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (STAMPS) t_prev = clock64();
+    auto stamp = [&](int phase) {
+        if constexpr (STAMPS) {
+            const unsigned long long now = clock64();
+#pragma unroll
+            for (int k = 0; k < 8; k++) t_acc[k] += (k == phase) ? now - t_prev : 0ull;
+            t_prev = now;
+        }
+    };
+    auto flush_stamps = [&]() {
+        if constexpr (STAMPS)
+            if (stamps && (threadIdx.x & 63) == 0)
+                for (int k = 0; k < 8; k++) stamps[((size_t)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8 + k] = t_acc[k];
+    };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = blockIdx.x * BLOCK + tid;
+    const bool valid = i < ns;
+    if (tid == 0) {
+        s_bail = 0;
+        if (blockIdx.x == 0) *ovf_count_next = 0;  // the other counter of the ping-pong pair: idle during this launch
+    }
+
+    // ---- prologue: query, pending move, temporal cut-off ---------------------------------------------------------
+    float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float moved = 0.f;  // how far this query travelled since the association that produced dm2
+    if (pm.enabled && valid) {
+        const float4 q0 = q;
+        q = move_point(q, pm.P);
+        src[i] = q;
+        const float ex = q.x - q0.x, ey = q.y - q0.y, ez = q.z - q0.z;
+        moved = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez);  // 1 ulp: far inside the 1e-5 inflation below
+    }
+    // Temporal cut-off.  dm2[i] holds the float d2 of this query's m-th neighbour in the previous association
+    // (all-ones when it had fewer than m).  Those m targets are now at most dm + |move| away, so the new m-th distance
+    // is <= dm + |move|: a candidate farther than that cannot be among the m closest and is never appended.  The
+    // bound is inflated by 1e-5 (float rounding of d2 and of the two roots is ~1e-6 relative); the final selection is
+    // exact — only the amount of list traffic changes.
+    unsigned thr0 = 0xFFFFFFFFu;
+    if (dm2_valid && valid) {
+        const unsigned prev = dm2[i];
+        if (prev != 0xFFFFFFFFu) {
+            const float bound = __builtin_amdgcn_sqrtf(__uint_as_float(prev)) + moved;
+            const float t2 = bound * bound * 1.00001f + 1e-30f;
+            thr0 = (t2 < r2) ? __float_as_uint(t2) : 0xFFFFFFFFu;
+        }
+    }
+    const QueryCells qc = query_cells(q, g);
+
+    // ---- the nine stencil runs [rb, re) in sorted-target positions, clipped in x --------------------------------
+    // A target of row (dy, dz) is at least (gy, gz) away in y and z (gap between the query and that row's slab,
+    // under-estimated by g.eps), so it can only be within the cut-off radius R if |dx| <= sqrt(R^2 - gy^2 - gz^2);
+    // R^2 is the radius or the temporal cut-off, inflated by 4e-6 for the float rounding of d2.  The window is taken
+    // in SLICE units: targets were binned by floor((x - org) * inv_hx), a monotone map, so every in-window target has
+    // its slice in [floor(ux - ws), floor(ux + ws)] up to the rounding of ux, ws and the root (a few ulp of the
+    // largest slice coordinate), which 2 * g.eps (64 ulp of the cloud's extent) covers several times over.
+    // Loads are unconditional: a dead run reads cell_start[0] twice (= 0, 0: empty).
+    const int x0 = max(qc.cx - g.xr, 0), x1 = min(qc.cx + g.xr, g.n[0] - 1);
+    int rb[9], re[9];
+    // the part of the grid this query's LIVE runs touch: rows [ylo, yhi] x [zlo, zhi], slices [xlo, xhi].  The
+    // workgroup's halo is the union of these boxes — tighter than "cell bounding box +- 1": a query that has drifted a
+    // little way into a cell does not need the row beyond it.
+    int xlo = INT_MAX, xhi = INT_MIN, ylo = INT_MAX, yhi = INT_MIN, zlo = INT_MAX, zhi = INT_MIN;
+    {
+        const float R2 = __uint_as_float(min(thr0, __float_as_uint(r2))) * 1.000004f;
+        const float ux = (q.x - g.org[0]) * g.inv_hx;
+        const float fy = q.y - g.org[1], fz = q.z - g.org[2];
+        const float gy0 = fmaxf(fy - (float)qc.cy * g.h - g.eps, 0.f), gy2 = fmaxf((float)(qc.cy + 1) * g.h - fy - g.eps, 0.f);
+        const float gz0 = fmaxf(fz - (float)qc.cz * g.h - g.eps, 0.f), gz2 = fmaxf((float)(qc.cz + 1) * g.h - fz - g.eps, 0.f);
+        const float gy_sq[3] = {gy0 * gy0, 0.f, gy2 * gy2}, gz_sq[3] = {gz0 * gz0, 0.f, gz2 * gz2};
+        const float k_s = g.inv_hx * 1.000001f, eps_s = 2.0f * g.eps * g.inv_hx;
+        const bool x_ok = valid & (x0 <= x1);
+        const bool oky[3] = {bool(x_ok & ((unsigned)(qc.cy - 1) < (unsigned)g.n[1])), bool(x_ok & ((unsigned)qc.cy < (unsigned)g.n[1])),
+                             bool(x_ok & ((unsigned)(qc.cy + 1) < (unsigned)g.n[1]))};
+        const bool okz[3] = {(unsigned)(qc.cz - 1) < (unsigned)g.n[2], (unsigned)qc.cz < (unsigned)g.n[2],
+                             (unsigned)(qc.cz + 1) < (unsigned)g.n[2]};
+        int base_c = (qc.cz * g.n[1] + qc.cy) * g.n[0];
+        asm volatile("" : "+v"(base_c));  // keep the nine row bases as base_c + uniform offset (not nine multiplies)
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int dz = k / 3 - 1, dy = k % 3 - 1;
+            const float w2 = R2 - (gy_sq[k % 3] + gz_sq[k / 3]);
+            const float ws = __builtin_fmaf(__builtin_amdgcn_sqrtf(fmaxf(w2, 0.f)), k_s, eps_s);
+            const int fa = max((int)floorf(ux - ws), x0), fb = min((int)floorf(ux + ws), x1);
+            const bool in = bool(oky[k % 3] & okz[k / 3]) & bool((w2 >= 0.f) & (fa <= fb));  // no short circuit: no branches
+            const int row_base = base_c + (dz * g.n[1] + dy) * g.n[0];  // uniform offset from the centre row
+            rb[k] = cell_start[(unsigned)(in ? row_base + fa : 0)];
+            re[k] = cell_start[(unsigned)(in ? row_base + fb + 1 : 0)];
+            xlo = in ? min(xlo, fa) : xlo;
+            xhi = in ? max(xhi, fb) : xhi;
+            ylo = in ? min(ylo, qc.cy + dy) : ylo;
+            yhi = in ? max(yhi, qc.cy + dy) : yhi;
+            zlo = in ? min(zlo, qc.cz + dz) : zlo;
+            zhi = in ? max(zhi, qc.cz + dz) : zhi;
+        }
+    }
+
+    // ---- per-wave union of the queries' boxes -> LDS ------------------------------------------------------------
+    {
+        const int lx = wave_reduce(xlo, INT_MAX, OpMin()), hx = wave_reduce(xhi, INT_MIN, OpMax());
+        const int ly = wave_reduce(ylo, INT_MAX, OpMin()), hy = wave_reduce(yhi, INT_MIN, OpMax());
+        const int lz = wave_reduce(zlo, INT_MAX, OpMin()), hz = wave_reduce(zhi, INT_MIN, OpMax());
+        if (lane == 0) {
+            s_box[wave][0] = lx, s_box[wave][1] = ly, s_box[wave][2] = lz;
+            s_box[wave][3] = hx, s_box[wave][4] = hy, s_box[wave][5] = hz;
+        }
+    }
+    lds_barrier();
+    stamp(0);
+
+    // ---- halo box and row table (every wave builds it for itself: no barrier before the staging) -----------------
+    int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+#pragma unroll
+    for (int w = 0; w < kWaves; w++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            lo[a] = min(lo[a], s_box[w][a]);
+            hi[a] = max(hi[a], s_box[w][3 + a]);
+        }
+    // live runs only name rows and slices inside the grid; a workgroup without any live run has an empty box
+    const bool any_live = lo[0] <= hi[0];
+    const int hx0 = any_live ? lo[0] : 0, hx1 = any_live ? hi[0] : 0;
+    const int hy0 = any_live ? lo[1] : 0, hy1 = any_live ? hi[1] : 0;
+    const int hz0 = any_live ? lo[2] : 0, hz1 = any_live ? hi[2] : 0;
+    const int ny_h = hy1 - hy0 + 1, nz_h = hz1 - hz0 + 1;
+    // row slot = rz << ys | ry: 8 (y) x 16 (z) slots, or 16 x 8 for the blocks that straddle two columns of the source
+    // order in y (a block that straddles in z as well, one in a few hundred, goes to the cleanup kernel)
+    const int ys = (ny_h <= 8) ? 3 : 4;
+    const bool shape_ok = hx0 <= hx1 && ny_h >= 1 && nz_h >= 1 && ny_h <= 16 && nz_h <= (kRows >> ys);
+    // lane l owns halo row slots l (A) and l + 64 (B): global begin, length; LDS offsets from a scan of A + B
+    int gbA, lenA, gbB, lenB;
+    {
+        const int ymask = (1 << ys) - 1;
+        const int ryA = lane & ymask, rzA = lane >> ys, ryB = (lane + 64) & ymask, rzB = (lane + 64) >> ys;
+        const bool hasA = shape_ok && ryA < ny_h && rzA < nz_h, hasB = shape_ok && ryB < ny_h && rzB < nz_h;
+        const int baseA = ((hz0 + rzA) * g.n[1] + hy0 + ryA) * g.n[0], baseB = ((hz0 + rzB) * g.n[1] + hy0 + ryB) * g.n[0];
+        gbA = cell_start[(unsigned)(hasA ? baseA + hx0 : 0)];
+        lenA = cell_start[(unsigned)(hasA ? baseA + hx1 + 1 : 0)] - gbA;
+        gbB = cell_start[(unsigned)(hasB ? baseB + hx0 : 0)];
+        lenB = cell_start[(unsigned)(hasB ? baseB + hx1 + 1 : 0)] - gbB;
+    }
+    const int incl = wave_scan(lenA + lenB, 0, OpAdd());
+    const int exclA = incl - lenA - lenB, exclB = exclA + lenA;
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    stamp(1);
+    if constexpr (STAMPS) {  // diagnostic: slot 6 = staged candidates, slot 7 = (ny_h << 8) | nz_h of this block's halo
+        t_acc[6] = (unsigned long long)total;
+        t_acc[7] = (unsigned long long)((ny_h << 8) | nz_h);
+    }
+    if (!shape_ok || total > CAP) {  // uniform over the workgroup: derived from the shared boxes and cell_start only
+        if (tid == 0) ovf_list[atomicAdd(ovf_count, 1u)] = blockIdx.x;
+        flush_stamps();
+        return;
+    }
+    // sorted-target position of a staged point = its LDS index + gbo[row slot]
+    if (wave == 0) {
+        s_gbo[lane] = gbA - exclA;
+        s_gbo[lane + 64] = gbB - exclB;
+    }
+
+    // ---- stage the halo: the non-empty rows are dealt round-robin to the four waves, kStageUnroll rows in flight --
+    {
+        // compact the non-empty rows into s_rowtab (every wave writes the same values; each reads back its own writes)
+        const unsigned long long neA = __ballot(lenA > 0), neB = __ballot(lenB > 0);
+        const int nA = __popcll(neA), nrows = nA + __popcll(neB);
+        const int rankA = __builtin_amdgcn_mbcnt_hi((unsigned)(neA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)neA, 0u));
+        const int rankB = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(neB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)neB, 0u));
+        if (lenA > 0) s_rowtab[rankA] = make_int2(gbA, (exclA << 19) | (lenA << 7) | lane);          // 12 + 12 + 7 bits
+        if (lenB > 0) s_rowtab[rankB] = make_int2(gbB, (exclB << 19) | (lenB << 7) | (lane + 64));
+        for (int j0 = 0; wave + kWaves * j0 < nrows; j0 += kStageUnroll) {
+            float4 c[kStageUnroll];
+            int so[kStageUnroll], sl[kStageUnroll], sg[kStageUnroll], sr[kStageUnroll];
+#pragma unroll
+            for (int u = 0; u < kStageUnroll; u++) {
+                const int t = wave + kWaves * (j0 + u);
+                const int2 row = s_rowtab[min(t, kRows - 1)];  // uniform address: one broadcast read
+                const int pk = __builtin_amdgcn_readfirstlane(row.y);
+                sg[u] = __builtin_amdgcn_readfirstlane(row.x);
+                so[u] = (int)((unsigned)pk >> 19);
+                sl[u] = (t < nrows) ? ((pk >> 7) & 0xFFF) : 0;
+                sr[u] = pk & 127;
+                c[u] = tgt[(lane < sl[u]) ? sg[u] + lane : 0];  // unconditional load (slot 0 always exists)
+            }
+#pragma unroll
+            for (int u = 0; u < kStageUnroll; u++) {
+                if (lane < sl[u]) {
+                    const int d = so[u] + lane;
+                    s_x[d] = c[u].x;
+                    s_y[d] = c[u].y;
+                    s_z[d] = c[u].z;
+                    s_rowid[d] = (unsigned char)sr[u];
+                }
+                for (int k = lane + 64; k < sl[u]; k += 64) {  // rows longer than a wave (dense data)
+                    const float4 t = tgt[sg[u] + k];
+                    const int d = so[u] + k;
+                    s_x[d] = t.x;
+                    s_y[d] = t.y;
+                    s_z[d] = t.z;
+                    s_rowid[d] = (unsigned char)sr[u];
+                }
+            }
+        }
+    }
+    lds_barrier();
+    stamp(2);
+
+    int n = 0;
+    unsigned tm = 0xFFFFFFFFu;  // d2 bits of the m-th neighbour (all-ones: fewer than m found)
+    const HaloList L{reinterpret_cast<const char *>(s_x), CAP * 4, s_rowid, reinterpret_cast<const char *>(s_gbo), s_list + tid};
+    if (valid) {
+        // the nine runs as ONE 32-bit key each, (length << 16) | LDS byte offset of the run's first candidate, sorted
+        // by DESCENDING length: every lane of the wave walks its longest run first, ... — a run's trip count is the
+        // maximum over the 64 lanes, and the maxima of order statistics add up to far fewer steps than the maxima of
+        // arbitrary runs.  25-comparator network (0/1 principle), a comparator is a v_max_u32 / v_min_u32 pair.
+        unsigned key[9];
+        {
+            const char *gbo_c = reinterpret_cast<const char *>(s_gbo) + 4 * ((qc.cz - hz0) * (1 << ys) + (qc.cy - hy0));
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int rl = re[k] - rb[k];
+                const int start = rb[k] - *reinterpret_cast<const int *>(gbo_c + 4 * ((k / 3 - 1) * (1 << ys) + (k % 3 - 1)));
+                key[k] = rl > 0 ? ((unsigned)rl << 16) | (unsigned)(start << 2) : 0u;
+            }
+            constexpr int net[25][2] = {{0, 3}, {1, 7}, {2, 5}, {4, 8}, {0, 7}, {2, 4}, {3, 8}, {5, 6}, {0, 2},
+                                        {1, 3}, {4, 5}, {7, 8}, {1, 4}, {3, 6}, {5, 7}, {0, 1}, {2, 4}, {3, 5},
+                                        {6, 8}, {2, 3}, {4, 5}, {6, 7}, {1, 2}, {3, 4}, {5, 6}};
+#pragma unroll
+            for (int c = 0; c < 25; c++) {
+                const int a = net[c][0], b = net[c][1];
+                const unsigned kh = max(key[a], key[b]), kl = min(key[a], key[b]);  // descending
+                key[a] = kh;
+                key[b] = kl;
+            }
+        }
+        // d2 >= +0 and r2 > 0, so "d2 < r2" is "bits(d2) <= bits(r2) - 1" (a NaN d2 has larger bits and fails): the
+        // radius test and the running cut-off are ONE unsigned compare per candidate
+        unsigned thr = min(thr0, __float_as_uint(r2) - 1u);
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f qx2 = {q.x, q.x}, qy2 = {q.y, q.y}, qz2 = {q.z, q.z};
+        // LDS addresses as plain 32-bit integers (address space 3): the write cursor and the candidate cursor are
+        // one VGPR each and an accepted candidate costs v_min + ds_write + v_add
+        typedef __attribute__((address_space(3))) unsigned short *lds_u16p;
+        typedef __attribute__((address_space(3))) const float *lds_f32p;
+        // (the casts go through uintptr_t so that the host pass, where every pointer is 64-bit, parses them too)
+        const unsigned list0 = (unsigned)(__UINTPTR_TYPE__)(lds_u16p)(s_list + tid), list_last = list0 + (C - 1) * 512;
+        const unsigned halo0 = (unsigned)(__UINTPTR_TYPE__)(lds_f32p)s_x;
+        for (int attempt = 0;; attempt++) {
+            // the list's write cursor counts every accepted candidate (so n is exact), the store slot is clamped: an
+            // overflowing lane keeps its first C - 1 entries and scribbles over the last slot
+            unsigned wp = list0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                if (key[k] > 0xFFFFu) {
+                    const unsigned a0 = halo0 + (key[k] & 0xFFFFu), a_end = a0 + 4 * (key[k] >> 16), a_pair = a_end - 4;
+                    // two candidates per trip from the run's true start (4-byte aligned reads), packed f32
+                    // sub / mul / add (no FMA: the same IEEE operations per element as dist2_flann)
+                    for (unsigned a = a0; a < a_end; a += 8) {
+                        const lds_f32p px = (lds_f32p)(__UINTPTR_TYPE__)a, py = (lds_f32p)(__UINTPTR_TYPE__)(a + CAP * 4),
+                                       pz = (lds_f32p)(__UINTPTR_TYPE__)(a + CAP * 8);
+                        const v2f cx = {px[0], px[1]}, cy = {py[0], py[1]}, cz = {pz[0], pz[1]};
+                        const v2f dx = qx2 - cx, dy = qy2 - cy, dz = qz2 - cz;
+                        v2f d = dx * dx;
+                        d = d + dy * dy;
+                        d = d + dz * dz;
+                        const unsigned slot_x = min(wp, list_last);  // outside the branch: the wave pays it either way
+                        if (__float_as_uint(d.x) <= thr) {
+                            *(lds_u16p)(__UINTPTR_TYPE__)slot_x = (unsigned short)(a - halo0);
+                            wp += 512;
+                        }
+                        const unsigned slot_y = min(wp, list_last);
+                        if (a < a_pair && __float_as_uint(d.y) <= thr) {
+                            *(lds_u16p)(__UINTPTR_TYPE__)slot_y = (unsigned short)(a - halo0 + 4);
+                            wp += 512;
+                        }
+                    }
+                }
+            }
+            n = (int)((wp - list0) >> 9);
+            if (n <= C) break;
+            if (attempt == 1) {  // more than C candidates tie at the threshold: leave the block to the general flavour
+                n = -1;
+                break;
+            }
+            // list overflow (dense neighbourhood, or no usable cut-off yet): the C - 1 entries that were kept are
+            // genuine in-radius candidates, so the m-th smallest of them bounds the final m-th distance: scan again
+            (void)select_top_m<M>(L, tgt, q, C - 1, m, thr);
+        }
+        stamp(3);
+        if (n > m) {
+            n = select_top_m<M>(L, tgt, q, n, m, thr);
+            tm = thr;
+        } else if (n == m) {
+            tm = 0;
+            for_each_entry(L, q, n, [&](int, int, unsigned b) { tm = max(tm, b); });
+        }
+        stamp(4);
+    }
+    // a wave with a twice-overflowed lane registers the block (once) for the cleanup kernel; its other results are
+    // simply overwritten there with identical values
+    if (__ballot(n < 0) != 0ull) {
+        if (lane == 0 && atomicExch(&s_bail, 1) == 0) ovf_list[atomicAdd(ovf_count, 1u)] = blockIdx.x;
+        n = max(n, 0);
+    }
+    if (valid) {
+        int *out = nbr + i;
+        for (int j = 0; j < n; j++) {
+            *out = L.pos_of(L.load(j));
+            out += ns;
+        }
+        cnt[i] = n;
+        dm2[i] = tm;
+    }
+    stamp(5);
     flush_stamps();
 }
 

@@ -20,7 +20,23 @@ def show(tag):
     v = np.array(list(out), dtype=np.float64)
     tot = v[:8].sum()
     print(tag, " ".join(f"{names[k]}={v[k]/nw:.0f}" for k in range(8)), f"| ticks per wave: {tot/nw:.0f}")
-c.associate(); c.synchronize(); show("fresh    ")
+def halo_stats(tag):
+    """slots 6 / 7 of every wave's stamp record carry the block's halo size and shape (not cycle counts)"""
+    nst = nw * 8
+    h = np.zeros(nst, dtype=np.uint64)
+    import ctypes
+    L.ppcr_debug_get_stamps_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    assert L.ppcr_debug_get_stamps_raw(c._h, h.ctypes.data, nst) == 0
+    h = h.reshape(-1, 8)[::4]          # one record per block (wave 0)
+    tot, shape = h[:, 6].astype(np.int64), h[:, 7].astype(np.int64)
+    q = np.percentile(tot, [50, 90, 99, 99.9, 100])
+    ny, nz = shape >> 8, shape & 255
+    print(tag, "halo candidates p50/p90/p99/p99.9/max:", " ".join(f"{v:.0f}" for v in q),
+          f"| >1536: {(tot > 1536).mean():.4f} >1664: {(tot > 1664).mean():.4f} >1792: {(tot > 1792).mean():.4f} >2048: {(tot > 2048).mean():.4f} >2240: {(tot > 2240).mean():.5f}",
+          f"| ny max {ny.max()} nz max {nz.max()} ny>8: {(ny > 8).mean():.4f} nz>8: {(nz > 8).mean():.4f} both: {((ny > 8) & (nz > 8)).mean():.5f}")
+c.associate(); c.synchronize(); show("fresh    "); halo_stats("fresh    ")
 for k in range(8):
     c.iterate(); c.synchronize()
-    if k in (0, 3, 7): show(f"iterate {k}")
+    if k in (0, 3, 7):
+        show(f"iterate {k}")
+        halo_stats(f"iterate {k}")
