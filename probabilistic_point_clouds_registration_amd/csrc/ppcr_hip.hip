@@ -57,6 +57,7 @@ const char *const kKernelNames[K_NUM] = {
     "nn_select_kernel", "csr_compact_kernel", "ell_count_sum_kernel", "weights_kernel", "accumulate_kernel",
     "reduce_partials_kernel", "transform_kernel"};
 
+constexpr int kMailboxRing = 4;    // at most two fold-and-solve launches are ever in flight
 constexpr int kEllMaxWidth = 32;   // widest register-list NN variant / widest ELL association
 constexpr int kAccumMaxBlocks = 1024;
 
@@ -130,6 +131,7 @@ struct ppcr_ctx {
     DevBuf<int> ovf_list;        // blocks nn_fast_kernel handed over to nn_tile_cleanup_kernel
     DevBuf<unsigned> ovf_state;  // two list counters used alternately (ovf_parity): the idle one is cleared by the fast kernel
     int ovf_parity = 0;
+    unsigned ovf_last = ~0u;     // blocks handed over by the most recent association whose count reached the host (~0: unknown)
     DevBuf<unsigned> dm2;    // per (sorted) source row: float d2 bits of its m-th neighbour in the last tiled K1
     bool dm2_valid = false;  // dm2 matches the current source order / target / radius / max_neighbours
     int opt_temporal = 1;
@@ -144,9 +146,11 @@ struct ppcr_ctx {
     bool move_pending = false;        // a source move that the next tiled K1 will apply in its prologue
     double pending_T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     double *h_sums = nullptr;          // pinned
-    HostMailbox *h_mbox = nullptr;     // pinned + device-mapped: moments and sequence flag written by the GPU
+    HostMailbox *h_mbox = nullptr;     // pinned + device-mapped ring of kMailboxRing slots written by the GPU
     HostMailbox *d_mbox = nullptr;     // device-side alias of h_mbox
-    unsigned mbox_seq = 0;
+    unsigned mbox_seq = 0;             // sequence number of the last fold-and-solve launch (slot = seq % ring)
+    DevBuf<Pose> d_pose;               // transform solved by the last reduce_solve_kernel (next K1's move)
+    bool move_on_device = false;       // the pending source move is *d_pose (host copy not read back yet)
     int opt_mailbox = 1;               // 1: deliver the moments through the mailbox and spin (default)
     unsigned long long *h_total = nullptr;  // pinned
 
@@ -173,6 +177,7 @@ struct ppcr_ctx {
     bool have_companion = false, have_ground_truth = false, have_previous = false;
     DevBuf<double> mse_part;
     int opt_short_lists = 1;
+    int opt_run_ahead = 1;       // ppcr_align keeps the device one iteration ahead of the host when the rule allows
     int opt_brick_xshift = 0;    // log2 of the source bricks' x extent in cells (0: 4x4 yz columns walked along x)
     int opt_grid_xf = 4;         // x slices per grid cell (GridDesc::xr)
     float tgt_lo[3] = {0, 0, 0}, tgt_hi[3] = {0, 0, 0};
@@ -493,7 +498,10 @@ void launch_tile(ppcr_ctx *c, float r2, int m, const PendingMove &pm)
         }
     }
 #undef PPCR_FAST
-    nn_tile_cleanup_kernel<M, C, 256, CAP><<<std::min(nb, 512), 256, 0, c->stream>>>(
+    // persistent workgroups over the list: few when the last association this handle heard from handed nothing over
+    // (an empty grid of 512 workgroups costs 4 us between K1 and K23, one of 32 about half of that)
+    const int cleanup_grid = (c->ovf_last == 0) ? std::min(nb, 32) : std::min(nb, 512);
+    nn_tile_cleanup_kernel<M, C, 256, CAP><<<cleanup_grid, 256, 0, c->stream>>>(
         c->src.p, (int)c->ns, c->tgt_sorted.p, c->cell_start.p, c->grid, r2, m, c->nbr.p, c->cnt.p, c->dm2.p,
         c->ovf_list.p, ovf_now);
 }
@@ -530,7 +538,12 @@ int associate_impl(ppcr_ctx *c)
     const bool tiled = !unbounded && c->max_nb <= kEllMaxWidth && ns > 0;
     PendingMove pm;
     std::memset(&pm, 0, sizeof(pm));
-    if (c->move_pending && tiled) {
+    if (c->move_on_device && tiled) {
+        // the previous iteration's transform is still on its way to the host: K1 reads it from device memory
+        pm.enabled = 2;
+        pm.dev = c->d_pose.p;
+        c->move_on_device = false;
+    } else if (c->move_pending && tiled) {
         // the deferred source move rides in this kernel's prologue
         pm.enabled = 1;
         for (int a = 0; a < 3; a++) {
@@ -736,61 +749,22 @@ int build_csr_cache(ppcr_ctx *c)
     return PPCR_OK;
 }
 
-// fold partials[19][nb] and deliver the 19 moments to the host (mailbox + spin, or copy + synchronise)
-int fold_and_deliver(ppcr_ctx *c, int nb, double sums[PPCR_NSUMS])
-{
-    if (c->opt_mailbox) {
-        // the fold delivers the moments to the host mailbox; the host spins on its sequence number
-        const unsigned seq = ++c->mbox_seq;
-        const auto tl0 = std::chrono::steady_clock::now();
-        {
-            ProfScope ps(c, K_REDUCE);
-            reduce_partials_mailbox_kernel<<<kNSums, kBlock, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p, c->d_mbox,
-                                                                              c->d_ticket.p, seq);
-        }
-        PPCR_TRY(check_launch(c, "reduce_partials_mailbox_kernel"));
-        volatile unsigned *flag = &c->h_mbox->seq;
-        bool arrived = false;
-        const auto tw0 = std::chrono::steady_clock::now();
-        c->dbg_host[6] = std::max(c->dbg_host[6], std::chrono::duration<double>(tw0 - tl0).count());
-        for (long spin = 0; spin < 200000000L; spin++) {  // ~ seconds; a fault on the device ends up below
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) {
-                arrived = true;
-                break;
-            }
-            if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(c->stream) != hipErrorNotReady) {
-                arrived = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq;
-                break;
-            }
-        }
-        if (!arrived) {
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return fail(c, PPCR_ERR_HIP, "moment mailbox never arrived");
-        }
-        for (int j = 0; j < kNSums; j++) sums[j] = c->h_mbox->sums[j];
-        {
-            const double w = std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
-            c->dbg_host[0] += 1;
-            c->dbg_host[1] += w;
-            c->dbg_host[2] = std::max(c->dbg_host[2], w);
-        }
-        return PPCR_OK;
-    }
-    {
-        ProfScope ps(c, K_REDUCE);
-        reduce_partials_kernel<<<kNSums, kBlock, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p);
-    }
-    PPCR_TRY(check_launch(c, "reduce_partials_kernel"));
-    HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->d_sums.p, sizeof(double) * kNSums, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    std::memcpy(sums, c->h_sums, sizeof(double) * kNSums);
-    return PPCR_OK;
-}
+// One IRLS half-step on the device: K23 (weights + moments at the pose R, t) -> fold -> closed-form solve.
+struct StepResult {
+    double sums[PPCR_NSUMS];
+    double T[12];      // minimiser for these moments
+    double cost;       // 0.5 * sum w |y - R x - t|^2 at T (Ceres' convention)
+    bool degenerate;   // no weight mass: T = identity
+};
+struct StepTicket {
+    unsigned seq = 0;  // mailbox sequence number (mailbox path)
+    int nb = 0;        // partial vectors to fold (copy path)
+};
 
-int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PPCR_NSUMS])
+// enqueue K23 + fold (+ solve); nothing here waits for the device
+int launch_step(ppcr_ctx *c, const Mat3 &R, const double t[3], StepTicket &tk)
 {
     if (c->assoc == ppcr_ctx::ASSOC_NONE) return fail(c, PPCR_ERR_STATE, "no association (call ppcr_associate or ppcr_set_association)");
-    PPCR_TRY(flush_pending_move(c));
     if (!c->origin_valid) {
         // set_association path without a grid: origin = 0 is fine for the exact-association API,
         // but prefer the target bounding-box centre when a grid has been built
@@ -804,6 +778,7 @@ int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PP
     const int nb = ell_rows ? std::max(1, nblocks(ns, kAccumBlock * kAccumRows)) : std::max(1, std::min(kAccumMaxBlocks, nblocks(ns)));
     HIP_TRY(c, c->partials.reserve((size_t)nb * kNSums));
     HIP_TRY(c, c->d_sums.reserve(kNSums));
+    HIP_TRY(c, c->d_pose.reserve(1));
     if (!c->d_ticket.p) {
         HIP_TRY(c, c->d_ticket.reserve(1));
         HIP_TRY(c, hipMemsetAsync(c->d_ticket.p, 0, sizeof(unsigned), c->stream));
@@ -827,7 +802,82 @@ int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PP
         }
     }
     PPCR_TRY(check_launch(c, "accumulate_kernel"));
-    return fold_and_deliver(c, nb, sums);
+    tk.nb = nb;
+    if (c->opt_mailbox) {
+        // fold + solve on the device; moments, transform and cost arrive in the host mailbox ring
+        tk.seq = ++c->mbox_seq;
+        const auto tl0 = std::chrono::steady_clock::now();
+        {
+            ProfScope ps(c, K_REDUCE);
+            reduce_solve_kernel<<<kNSums, kBlock, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p,
+                                                               make_double3(c->origin[0], c->origin[1], c->origin[2]),
+                                                               c->d_pose.p, c->d_mbox + (tk.seq % kMailboxRing), c->d_ticket.p,
+                                                               tk.seq, c->ovf_state.p ? c->ovf_state.p + c->ovf_parity : nullptr);
+        }
+        PPCR_TRY(check_launch(c, "reduce_solve_kernel"));
+        c->dbg_host[6] = std::max(c->dbg_host[6], std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count());
+        return PPCR_OK;
+    }
+    {
+        ProfScope ps(c, K_REDUCE);
+        reduce_partials_kernel<<<kNSums, kBlock, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p);
+    }
+    return check_launch(c, "reduce_partials_kernel");
+}
+
+// wait for that step and fetch its result
+int collect_step(ppcr_ctx *c, const StepTicket &tk, StepResult &out)
+{
+    if (c->opt_mailbox) {
+        const HostMailbox *mb = c->h_mbox + (tk.seq % kMailboxRing);
+        volatile const unsigned *flag = &mb->seq;
+        bool arrived = false;
+        const auto tw0 = std::chrono::steady_clock::now();
+        for (long spin = 0; spin < 200000000L; spin++) {  // ~ seconds; a fault on the device ends up below
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == tk.seq) {
+                arrived = true;
+                break;
+            }
+            if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(c->stream) != hipErrorNotReady) {
+                arrived = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == tk.seq;
+                break;
+            }
+        }
+        if (!arrived) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != tk.seq) return fail(c, PPCR_ERR_HIP, "moment mailbox never arrived");
+        }
+        for (int j = 0; j < kNSums; j++) out.sums[j] = mb->sums[j];
+        for (int j = 0; j < 12; j++) out.T[j] = mb->T[j];
+        out.cost = mb->cost;
+        out.degenerate = mb->degenerate != 0;
+        c->ovf_last = mb->handed_over;
+        const double w = std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+        c->dbg_host[0] += 1;
+        c->dbg_host[1] += w;
+        c->dbg_host[2] = std::max(c->dbg_host[2], w);
+        return PPCR_OK;
+    }
+    // copy path: moments back, solve on the host (same source as the device solve)
+    HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->d_sums.p, sizeof(double) * kNSums, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::memcpy(out.sums, c->h_sums, sizeof(double) * kNSums);
+    const RigidSolve rs = solve_rigid_from_moments(out.sums, c->origin);
+    pack_T(rs.R, rs.t, out.T);
+    out.degenerate = rs.degenerate;
+    out.cost = rs.degenerate ? 0.5 * out.sums[16] : cost_from_moments(out.sums, c->origin, rs.R, rs.t);
+    return PPCR_OK;
+}
+
+int run_accumulate(ppcr_ctx *c, const Mat3 &R, const double t[3], double sums[PPCR_NSUMS])
+{
+    PPCR_TRY(flush_pending_move(c));
+    StepTicket tk;
+    StepResult res;
+    PPCR_TRY(launch_step(c, R, t, tk));
+    PPCR_TRY(collect_step(c, tk, res));
+    std::memcpy(sums, res.sums, sizeof(res.sums));
+    return PPCR_OK;
 }
 
 int apply_transform_now(ppcr_ctx *c, const double T[12]);
@@ -835,6 +885,7 @@ int apply_transform_now(ppcr_ctx *c, const double T[12]);
 // make the device copy of the source current (a move deferred to the next tiled K1 is applied now)
 int flush_pending_move(ppcr_ctx *c)
 {
+    if (c->move_on_device) return fail(c, PPCR_ERR_STATE, "internal: a device-resident move is pending outside the align loop");
     if (!c->move_pending) return PPCR_OK;
     c->move_pending = false;
     return apply_transform_now(c, c->pending_T);
@@ -880,32 +931,38 @@ int apply_transform_now(ppcr_ctx *c, const double T[12])
     return check_launch(c, "transform_kernel");
 }
 
-// IRLS on the current association (see ppcr_solve in ppcr.h)
+// IRLS on the current association (see ppcr_solve in ppcr.h): every half-step is K23 -> fold -> solve on the device;
+// the host only compares costs
 int solve_impl(ppcr_ctx *c, const double q0[4], const double t0[3], int max_steps, double f_tol, double T_out[12],
                double cost_out[2], int *steps_out)
 {
     const double qn = q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3];
     if (!(qn > 0) || !std::isfinite(qn)) return fail(c, PPCR_ERR_INVALID, "initial rotation quaternion has zero or non-finite norm");
+    PPCR_TRY(flush_pending_move(c));
     Mat3 R = quat_to_rot(q0);
     Vec3 t{{t0[0], t0[1], t0[2]}};
-    double sums[PPCR_NSUMS];
-    PPCR_TRY(run_accumulate(c, R, t.v, sums));
-    double cost_old = 0.5 * sums[16];
+    StepTicket tk;
+    StepResult res;
+    PPCR_TRY(launch_step(c, R, t.v, tk));
+    PPCR_TRY(collect_step(c, tk, res));
+    double cost_old = 0.5 * res.sums[16];
     cost_out[0] = cost_out[1] = cost_old;
     int steps = 0;
     if (max_steps < 1) max_steps = 1;
     for (;;) {
-        const RigidSolve rs = solve_rigid_from_moments(sums, c->origin);
-        const double fc = rs.degenerate ? cost_old : cost_from_moments(sums, c->origin, rs.R, rs.t);
+        const double fc = res.degenerate ? cost_old : res.cost;
         steps++;
-        R = rs.R;
-        t = rs.t;
+        for (int a = 0; a < 3; a++) {
+            for (int b = 0; b < 3; b++) R.m[a][b] = res.T[4 * a + b];
+            t[a] = res.T[4 * a + 3];
+        }
         cost_out[1] = fc;
-        if (rs.degenerate || steps >= max_steps) break;
+        if (res.degenerate || steps >= max_steps) break;
         // a decrease below the rounding floor of the moment-based cost (eps * (Sxx + Syy)) is no decrease
-        if ((cost_old - fc) <= std::max(f_tol * cost_old, 1e-14 * 0.5 * (sums[17] + sums[18]))) break;
-        PPCR_TRY(run_accumulate(c, R, t.v, sums));
-        cost_old = 0.5 * sums[16];
+        if ((cost_old - fc) <= std::max(f_tol * cost_old, 1e-14 * 0.5 * (res.sums[17] + res.sums[18]))) break;
+        PPCR_TRY(launch_step(c, R, t.v, tk));
+        PPCR_TRY(collect_step(c, tk, res));
+        cost_old = 0.5 * res.sums[16];
     }
     // transformation(): normalised quaternion -> rotation (..._iteration.hpp:59-67); R is already
     // orthonormal to rounding so the round trip through a quaternion is not needed here
@@ -955,9 +1012,9 @@ int ppcr_create(int device_id, ppcr_ctx **out)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_sums), sizeof(double) * kNSums, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_total), sizeof(unsigned long long), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_mbox), sizeof(HostMailbox), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_mbox), sizeof(HostMailbox) * kMailboxRing, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) {
-        std::memset(c->h_mbox, 0, sizeof(HostMailbox));
+        std::memset(c->h_mbox, 0, sizeof(HostMailbox) * kMailboxRing);
         e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_mbox), c->h_mbox, 0);
     }
     if (e != hipSuccess) {
@@ -1009,6 +1066,7 @@ int ppcr_destroy(ppcr_ctx *c)
     c->partials.release();
     c->d_sums.release();
     c->d_ticket.release();
+    c->d_pose.release();
     c->d_w.release();
     c->d_s.release();
     c->mse_part.release();
@@ -1063,6 +1121,10 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
         c->src_sorted = false;
         return PPCR_OK;
     }
+    if (std::strcmp(key, "run_ahead") == 0) {
+        c->opt_run_ahead = value ? 1 : 0;
+        return PPCR_OK;
+    }
     if (std::strcmp(key, "short_lists") == 0) {
         c->opt_short_lists = value ? 1 : 0;
         return PPCR_OK;
@@ -1100,7 +1162,9 @@ static int set_target_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, in
 
 static int set_source_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, int64_t stride)
 {
+    c->ovf_last = ~0u;
     c->move_pending = false;  // a deferred move of the previous source dies with it
+    c->move_on_device = false;
     c->dm2_valid = false;
     PPCR_TRY(upload_cloud(c, p, dev, n, stride, c->src));
     c->ns = n;
@@ -1428,20 +1492,7 @@ static int align_impl(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n
     ppcr_stop_rule rule = {0, 0, 0.0};  // hasConverged(), shared with the C++ class (ppcr.h)
     double Tcum[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     for (double &v : c->dbg_host) v = 0;
-    const auto ta0 = std::chrono::steady_clock::now();
-    while (ppcr_stop_rule_check(&rule, n_iter, cost_drop_thresh, n_cost_drop_it) == PPCR_CONTINUE) {
-        double Tk[12], cost[2];
-        int st = 0;
-        const auto ti0 = std::chrono::steady_clock::now();
-        const double w_before = c->dbg_host[1];
-        PPCR_TRY(associate_impl(c));
-        const auto ti1 = std::chrono::steady_clock::now();
-        c->dbg_host[5] = std::max(c->dbg_host[5], std::chrono::duration<double>(ti1 - ti0).count());
-        const double fold0 = c->dbg_host[6];
-        PPCR_TRY(solve_impl(c, q0, t0, inner_steps, f_tol, Tk, cost, &st));
-        c->dbg_host[7] = std::max(c->dbg_host[7], std::chrono::duration<double>(std::chrono::steady_clock::now() - ti1).count() -
-                                                      (c->dbg_host[1] - w_before) - std::max(0.0, c->dbg_host[6] - fold0));
-        PPCR_TRY(apply_transform_impl(c, Tk, /*defer=*/true));  // rides in the next iteration's K1 prologue
+    auto record = [&](const double Tk[12], const double cost[2], int st) {
         compose(Tk, Tcum, Tcum);  // T_cum <- T_k * T_cum (cc:101-107)
         const int it = rule.iteration;
         if (history) std::memcpy(history + (size_t)it * 12, Tcum, sizeof(Tcum));
@@ -1452,14 +1503,64 @@ static int align_impl(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n
         if (steps) steps[it] = st;
         rule.cost_drop = (cost[0] - cost[1]) / cost[0];  // cc:119
         rule.iteration++;                                // cc:130
-        {
-            const double it_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - ti0).count();
-            const double busy = it_s - (c->dbg_host[1] - w_before);  // launches + host solve, waits excluded
-            c->dbg_host[3] += busy;
-            c->dbg_host[4] = std::max(c->dbg_host[4], busy);
+    };
+    // One inner step per association (the benchmark schedule) runs with the device one iteration AHEAD of the host:
+    // the solve happens on the GPU and the next K1 takes its move from device memory, so iteration k + 1 can be
+    // enqueued before the host has seen iteration k — but only when hasConverged() cannot stop in between, whatever
+    // the cost of iteration k turns out to be: the cap is not reached and the idle count is within the patience.  The
+    // rule therefore stays exact: nothing speculative is ever enqueued.
+    const bool unbounded = (c->max_nb <= 0 || (int64_t)c->max_nb >= c->nt);
+    const bool pipelined = inner_steps <= 1 && c->opt_mailbox && c->opt_run_ahead && !c->have_companion && !unbounded &&
+                           c->max_nb <= kEllMaxWidth && c->ns > 0;
+    if (pipelined) {
+        const double qn0[4] = {q0[0], q0[1], q0[2], q0[3]};
+        const Mat3 R0 = quat_to_rot(qn0);
+        StepTicket in_flight[2];
+        int enq = 0, done = 0;
+        auto enqueue = [&]() -> int {
+            PPCR_TRY(associate_impl(c));  // moves the source by the previous iteration's transform in its prologue
+            PPCR_TRY(launch_step(c, R0, t0, in_flight[enq & 1]));
+            c->move_on_device = true;     // ... and this iteration's transform is the next pending move
+            enq++;
+            return PPCR_OK;
+        };
+        double T_last[12];
+        auto consume = [&]() -> int {
+            StepResult res;
+            PPCR_TRY(collect_step(c, in_flight[done & 1], res));
+            const double cost[2] = {0.5 * res.sums[16], res.cost};
+            std::memcpy(T_last, res.T, sizeof(T_last));
+            record(res.T, cost, 1);
+            done++;
+            return PPCR_OK;
+        };
+        for (;;) {
+            if (enq == done) {  // nothing in flight: the ordinary check
+                if (ppcr_stop_rule_check(&rule, n_iter, cost_drop_thresh, n_cost_drop_it) != PPCR_CONTINUE) break;
+                PPCR_TRY(enqueue());
+            }
+            // iteration `done` is in flight.  The check before iteration done + 1 cannot stop if the cap is not hit and
+            // the idle count (already updated by the check that let iteration `done` through) is within the patience.
+            const bool sure = (rule.iteration + 1 != n_iter) && !((double)rule.idle > n_cost_drop_it);
+            if (sure) PPCR_TRY(enqueue());
+            PPCR_TRY(consume());
+            if (sure && ppcr_stop_rule_check(&rule, n_iter, cost_drop_thresh, n_cost_drop_it) != PPCR_CONTINUE)
+                return fail(c, PPCR_ERR_STATE, "internal: run-ahead broke the stopping rule");
         }
+        if (done > 0) {  // the last transform becomes an ordinary host-side pending move
+            c->move_on_device = false;
+            PPCR_TRY(apply_transform_impl(c, T_last, /*defer=*/true));
+        }
+    } else {
+    while (ppcr_stop_rule_check(&rule, n_iter, cost_drop_thresh, n_cost_drop_it) == PPCR_CONTINUE) {
+        double Tk[12], cost[2];
+        int st = 0;
+        PPCR_TRY(associate_impl(c));
+        PPCR_TRY(solve_impl(c, q0, t0, inner_steps, f_tol, Tk, cost, &st));
+        PPCR_TRY(apply_transform_impl(c, Tk, /*defer=*/true));  // rides in the next iteration's K1 prologue
+        record(Tk, cost, st);
     }
-    (void)ta0;
+    }
     PPCR_TRY(flush_pending_move(c));  // leave the device copy of the source current
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (T_final) std::memcpy(T_final, Tcum, sizeof(Tcum));  // identity when no iteration ran

@@ -1,33 +1,41 @@
-// Host-side fixed-size math for the registration hot path: quaternion <-> rotation, the 3x3 SVD
+// Fixed-size math for the registration hot path (host and device): quaternion <-> rotation, the 3x3 SVD
 // and the closed-form weighted rigid solve that replaces the Ceres problem of
 // prob_point_cloud_registration_iteration.hpp:36-57 for fixed weights.  Header-only, no deps.
 #pragma once
 #include <cmath>
 #include <cstring>
 
+// the same code serves the host (ppcr_solve_moments, the host-driven inner loop) and the device (the solve that
+// reduce_solve_kernel runs right behind the moment fold, so that the next association need not wait for the host)
+#if defined(__HIPCC__)
+#define PPCR_HD __host__ __device__
+#else
+#define PPCR_HD
+#endif
+
 namespace ppcr {
 
 struct Vec3 {
     double v[3];
-    double &operator[](int i) { return v[i]; }
-    double operator[](int i) const { return v[i]; }
+    PPCR_HD double &operator[](int i) { return v[i]; }
+    PPCR_HD double operator[](int i) const { return v[i]; }
 };
 
 struct Mat3 {
     double m[3][3];
-    static Mat3 identity()
+    PPCR_HD static Mat3 identity()
     {
         Mat3 r;
         for (int i = 0; i < 3; i++)
             for (int j = 0; j < 3; j++) r.m[i][j] = (i == j) ? 1.0 : 0.0;
         return r;
     }
-    Vec3 col(int j) const { return Vec3{{m[0][j], m[1][j], m[2][j]}}; }
-    void set_col(int j, const Vec3 &c)
+    PPCR_HD Vec3 col(int j) const { return Vec3{{m[0][j], m[1][j], m[2][j]}}; }
+    PPCR_HD void set_col(int j, const Vec3 &c)
     {
         for (int i = 0; i < 3; i++) m[i][j] = c[i];
     }
-    double det() const
+    PPCR_HD double det() const
     {
         return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) -
                m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
@@ -35,22 +43,22 @@ struct Mat3 {
     }
 };
 
-inline double dot(const Vec3 &a, const Vec3 &b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-inline Vec3 cross(const Vec3 &a, const Vec3 &b)
+PPCR_HD inline double dot(const Vec3 &a, const Vec3 &b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+PPCR_HD inline Vec3 cross(const Vec3 &a, const Vec3 &b)
 {
     return Vec3{{a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]}};
 }
-inline Vec3 mul(const Mat3 &A, const Vec3 &x)
+PPCR_HD inline Vec3 mul(const Mat3 &A, const Vec3 &x)
 {
     Vec3 r;
     for (int i = 0; i < 3; i++) r[i] = A.m[i][0] * x[0] + A.m[i][1] * x[1] + A.m[i][2] * x[2];
     return r;
 }
-inline double norm(const Vec3 &a) { return std::sqrt(dot(a, a)); }
+PPCR_HD inline double norm(const Vec3 &a) { return std::sqrt(dot(a, a)); }
 
 // q = (w,x,y,z), any non-zero length (normalised here like Eigen's estimated_rot.normalize(),
 // ..._iteration.hpp:62-63)
-inline Mat3 quat_to_rot(const double q[4])
+PPCR_HD inline Mat3 quat_to_rot(const double q[4])
 {
     const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     const double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
@@ -67,7 +75,7 @@ inline Mat3 quat_to_rot(const double q[4])
     return R;
 }
 
-inline void rot_to_quat(const Mat3 &R, double q[4])
+PPCR_HD inline void rot_to_quat(const Mat3 &R, double q[4])
 {
     const double tr = R.m[0][0] + R.m[1][1] + R.m[2][2];
     // pick the largest of (w,x,y,z) to divide by — the numerically stable branch
@@ -96,7 +104,7 @@ inline void rot_to_quat(const Mat3 &R, double q[4])
 // One-sided Jacobi SVD: A = U * diag(s) * V^T, singular values sorted descending.
 // Columns of U belonging to (numerically) zero singular values are left zero; the caller
 // completes them.
-inline void svd3(const Mat3 &A, Mat3 &U, double s[3], Mat3 &V)
+PPCR_HD inline void svd3(const Mat3 &A, Mat3 &U, double s[3], Mat3 &V)
 {
     Mat3 W = A;
     V = Mat3::identity();
@@ -152,7 +160,7 @@ struct RigidSolve {
     bool degenerate;  // no weight mass: R = I, t = 0
 };
 
-inline RigidSolve solve_rigid_from_moments(const double S[19], const double c[3])
+PPCR_HD inline RigidSolve solve_rigid_from_moments(const double S[19], const double c[3])
 {
     RigidSolve out;
     out.R = Mat3::identity();
@@ -205,7 +213,7 @@ inline RigidSolve solve_rigid_from_moments(const double S[19], const double c[3]
 
 // 0.5 * sum w |y - R x - t|^2 from the moments (Ceres cost convention: cc:119 consumes
 // Summary::initial_cost/final_cost which carry the 1/2)
-inline double cost_from_moments(const double S[19], const double c[3], const Mat3 &R, const Vec3 &t)
+PPCR_HD inline double cost_from_moments(const double S[19], const double c[3], const Mat3 &R, const Vec3 &t)
 {
     const double W = S[0];
     const Vec3 cc{{c[0], c[1], c[2]}};
@@ -222,7 +230,7 @@ inline double cost_from_moments(const double S[19], const double c[3], const Mat
 }
 
 // T_out = A * B for [R|t] 3x4 row-major rigid transforms
-inline void compose(const double A[12], const double B[12], double out[12])
+PPCR_HD inline void compose(const double A[12], const double B[12], double out[12])
 {
     double r[12];
     for (int a = 0; a < 3; a++)
@@ -232,10 +240,10 @@ inline void compose(const double A[12], const double B[12], double out[12])
             if (b == 3) acc += A[4 * a + 3];
             r[4 * a + b] = acc;
         }
-    std::memcpy(out, r, sizeof(r));
+    for (int k = 0; k < 12; k++) out[k] = r[k];
 }
 
-inline void pack_T(const Mat3 &R, const Vec3 &t, double T[12])
+PPCR_HD inline void pack_T(const Mat3 &R, const Vec3 &t, double T[12])
 {
     for (int a = 0; a < 3; a++) {
         for (int b = 0; b < 3; b++) T[4 * a + b] = R.m[a][b];

@@ -15,6 +15,8 @@
 #include <limits.h>
 #include <type_traits>
 
+#include "ppcr_host_math.hpp"
+
 namespace ppcr {
 namespace dev {
 
@@ -543,8 +545,9 @@ __device__ __forceinline__ float4 move_point(float4 p, const Pose &P)
 // transform is applied while the query is loaded and the moved point is written back, which saves one
 // kernel launch and one 32 MB read+write pass per iteration.
 struct PendingMove {
-    int enabled;
+    int enabled;      // 0 none, 1 P below, 2 *dev (written by reduce_solve_kernel of the previous iteration)
     Pose P;
+    const Pose *dev;
 };
 
 // GENERAL flavour of K1, run on the workgroups nn_fast_kernel hands over (ovf_list[0 .. *ovf_count)): halos of any
@@ -1021,7 +1024,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? 4 : 3)) void nn_fast_kernel(float4 
     float moved = 0.f;  // how far this query travelled since the association that produced dm2
     if (pm.enabled && valid) {
         const float4 q0 = q;
-        q = move_point(q, pm.P);
+        q = move_point(q, pm.enabled == 2 ? *pm.dev : pm.P);  // uniform choice, scalar loads
         src[i] = q;
         const float ex = q.x - q0.x, ey = q.y - q0.y, ez = q.z - q0.z;
         moved = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez);  // 1 ulp: far inside the 1e-5 inflation below
@@ -1600,19 +1603,252 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double *_
     }
 }
 
-// Host mailbox in pinned, device-mapped memory: the final fold writes the moments there and then the
-// sequence number (system-scope release), and the host spins on `seq` — no copy kernel, no stream
-// synchronisation on the iteration's critical path.
+// ---------------------------------------------------------------------------------------------
+// The closed-form weighted rigid solve for ONE lane (it sits on the iteration's critical path right behind the moment
+// fold, with the whole chip waiting): the algorithm of solve_rigid_from_moments / svd3 / cost_from_moments in
+// ppcr_host_math.hpp — one-sided Jacobi SVD of the 3x3 cross-covariance, rank handling, R = V diag(1,1,d) U^T — written
+// for latency: every index is static (the shared source indexes small arrays dynamically, which lands in scratch
+// memory: ~9 us measured), reciprocals and roots are v_rcp_f64 / v_rsq_f64 seeds with two Newton steps instead of the
+// IEEE sequences (a Jacobi rotation only has to be orthogonal to rounding, and it is: c^2 (1 + t^2) = 1 to ~1 ulp).
+// Agrees with the host solve to a few ulp of the moments; the oracle tolerance on transforms is 1e-5.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double fast_rsqrt(double x)  // x > 0, finite
+{
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r;
+}
+
+struct DeviceSolve {
+    double R[9], t[3], cost;
+    bool degenerate;
+};
+
+__device__ __forceinline__ void jacobi_pair(double (&w)[3][3], double (&v)[3][3], const int p, const int q, bool &rotated)
+{
+    const double alpha = w[0][p] * w[0][p] + w[1][p] * w[1][p] + w[2][p] * w[2][p];
+    const double beta = w[0][q] * w[0][q] + w[1][q] * w[1][q] + w[2][q] * w[2][q];
+    const double gamma = w[0][p] * w[0][q] + w[1][p] * w[1][q] + w[2][p] * w[2][q];
+    if (gamma * gamma <= 1e-32 * (alpha * beta)) return;  // columns orthogonal to rounding (also gamma == 0)
+    rotated = true;
+    const double zeta = (beta - alpha) * fast_rcp(2.0 * fabs(gamma)) * (gamma < 0 ? -1.0 : 1.0);
+    const double az = fabs(zeta), h2 = fma(zeta, zeta, 1.0);
+    const double tn = (zeta < 0 ? -1.0 : 1.0) * fast_rcp(az + h2 * fast_rsqrt(h2));
+    const double c = fast_rsqrt(fma(tn, tn, 1.0)), sn = c * tn;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const double wp = w[r][p], wq = w[r][q];
+        w[r][p] = c * wp - sn * wq;
+        w[r][q] = sn * wp + c * wq;
+        const double vp = v[r][p], vq = v[r][q];
+        v[r][p] = c * vp - sn * vq;
+        v[r][q] = sn * vp + c * vq;
+    }
+}
+
+__device__ __forceinline__ void swap_cols(double (&w)[3][3], double (&v)[3][3], double (&len)[3], const int a, const int b)
+{
+    if (len[b] > len[a]) {
+        double tmp = len[a];
+        len[a] = len[b];
+        len[b] = tmp;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            tmp = w[r][a], w[r][a] = w[r][b], w[r][b] = tmp;
+            tmp = v[r][a], v[r][a] = v[r][b], v[r][b] = tmp;
+        }
+    }
+}
+
+// Rotation of the weighted Kabsch problem by Newton's iteration for the polar decomposition,
+//     X <- (z X + X^-T / z) / 2,   z = sqrt(|X^-1|_F / |X|_F),   X_0 = H^T,
+// which converges quadratically to the orthogonal factor V U^T of H^T = V S U^T: the same R as the SVD route whenever
+// det H > 0 (no reflection to repair) — i.e. for every well-posed registration.  An iteration is a 3x3 adjugate with
+// all nine cofactors independent, so the dependent chain is ~a dozen operations (a Jacobi sweep is three rotations of
+// ~70 dependent operations each).  Returns false (and the caller takes the Jacobi SVD route with its rank handling)
+// when H is singular to working precision, contains a reflection, or the iteration has not settled.
+__device__ __forceinline__ bool polar_rotation(const double (&h)[3][3], double (&R)[9])
+{
+    double x[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) x[a][b] = h[b][a];
+    bool settled = false;
+    for (int it = 0; it < 24; ++it) {
+        double cf[3][3];  // cofactors: X^-T = cf / det
+        cf[0][0] = x[1][1] * x[2][2] - x[1][2] * x[2][1];
+        cf[0][1] = x[1][2] * x[2][0] - x[1][0] * x[2][2];
+        cf[0][2] = x[1][0] * x[2][1] - x[1][1] * x[2][0];
+        cf[1][0] = x[0][2] * x[2][1] - x[0][1] * x[2][2];
+        cf[1][1] = x[0][0] * x[2][2] - x[0][2] * x[2][0];
+        cf[1][2] = x[0][1] * x[2][0] - x[0][0] * x[2][1];
+        cf[2][0] = x[0][1] * x[1][2] - x[0][2] * x[1][1];
+        cf[2][1] = x[0][2] * x[1][0] - x[0][0] * x[1][2];
+        cf[2][2] = x[0][0] * x[1][1] - x[0][1] * x[1][0];
+        const double det = x[0][0] * cf[0][0] + x[0][1] * cf[0][1] + x[0][2] * cf[0][2];
+        double nx = 0, nc = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                nx = fma(x[a][b], x[a][b], nx);
+                nc = fma(cf[a][b], cf[a][b], nc);
+            }
+        // well conditioned and orientation preserving?  (|X|_F^3 bounds |det|; 1e-9 leaves cond(H) up to ~1e4-1e9 here)
+        if (!(det > 1e-9 * nx * sqrt(nx))) return false;
+        const double idet = fast_rcp(det);
+        // z^2 = |X^-T|_F / |X|_F = sqrt(nc) / (det sqrt(nx))
+        const double z2 = sqrt(nc) * idet * fast_rsqrt(nx);
+        const double z = sqrt(z2), a_x = 0.5 * z, a_c = 0.5 * idet * fast_rcp(z);
+        double diff = 0, nn = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                const double nv = a_x * x[a][b] + a_c * cf[a][b];
+                const double d = nv - x[a][b];
+                diff = fma(d, d, diff);
+                nn = fma(nv, nv, nn);
+                x[a][b] = nv;
+            }
+        if (diff <= 1e-30 * nn) {  // |X_{k+1} - X_k| <= 1e-15 |X|: converged to rounding
+            settled = true;
+            break;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) R[3 * a + b] = x[a][b];
+    return settled;
+}
+
+__device__ inline DeviceSolve solve_rigid_device(const double (&S)[kNSums], const double (&c)[3])
+{
+    DeviceSolve out;
+#pragma unroll
+    for (int k = 0; k < 9; k++) out.R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    out.t[0] = out.t[1] = out.t[2] = 0.0;
+    out.cost = 0.5 * S[16];
+    out.degenerate = true;
+    const double W = S[0];
+    if (!(W > 0) || !isfinite(W)) return out;
+    out.degenerate = false;
+    const double iW = 1.0 / W;
+    const double mx[3] = {S[1] * iW, S[2] * iW, S[3] * iW}, my[3] = {S[4] * iW, S[5] * iW, S[6] * iW};
+    double w[3][3], v[3][3];  // w = H = sum w (x - mx)(y - my)^T, columns rotated in place; v accumulates V
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            w[a][b] = S[7 + 3 * a + b] - S[1 + a] * my[b];
+            v[a][b] = (a == b) ? 1.0 : 0.0;
+        }
+    const bool polar_ok = polar_rotation(w, out.R);
+    if (!polar_ok) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) out.R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        bool rotated = false;
+        jacobi_pair(w, v, 0, 1, rotated);
+        jacobi_pair(w, v, 0, 2, rotated);
+        jacobi_pair(w, v, 1, 2, rotated);
+        if (!rotated) break;
+    }
+    double len[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const double n2 = w[0][j] * w[0][j] + w[1][j] * w[1][j] + w[2][j] * w[2][j];
+        len[j] = n2 > 0 ? n2 * fast_rsqrt(n2) : 0.0;
+    }
+    swap_cols(w, v, len, 0, 1);  // singular values descending
+    swap_cols(w, v, len, 0, 2);
+    swap_cols(w, v, len, 1, 2);
+    if (len[0] > 0) {
+        double u[3][3];  // columns of U
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double il = len[j] > 0 ? fast_rcp(len[j]) : 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; r++) u[r][j] = w[r][j] * il;
+        }
+        const double tiny = len[0] * 1e-14;
+        if (len[1] <= tiny) {  // rank 1: any unit vector orthogonal to u0 (cross with the axis u0 is least aligned with)
+            const double a0 = fabs(u[0][0]), a1 = fabs(u[1][0]), a2 = fabs(u[2][0]);
+            const bool pick1 = a1 < a0, pick2 = a2 < (pick1 ? a1 : a0);
+            const double e0 = (!pick1 && !pick2) ? 1.0 : 0.0, e1 = (pick1 && !pick2) ? 1.0 : 0.0, e2 = pick2 ? 1.0 : 0.0;
+            double x0 = u[1][0] * e2 - u[2][0] * e1, x1 = u[2][0] * e0 - u[0][0] * e2, x2 = u[0][0] * e1 - u[1][0] * e0;
+            const double in = fast_rsqrt(x0 * x0 + x1 * x1 + x2 * x2);
+            u[0][1] = x0 * in, u[1][1] = x1 * in, u[2][1] = x2 * in;
+        }
+        if (len[2] <= tiny || len[1] <= tiny) {
+            u[0][2] = u[1][0] * u[2][1] - u[2][0] * u[1][1];
+            u[1][2] = u[2][0] * u[0][1] - u[0][0] * u[2][1];
+            u[2][2] = u[0][0] * u[1][1] - u[1][0] * u[0][1];
+        }
+        auto det3 = [](const double (&m)[3][3]) {
+            return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                   m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+        };
+        // H = U S V^T with H = sum x y^T  =>  R = V diag(1,1,d) U^T maps x onto y
+        const double d = (det3(u) * det3(v) < 0) ? -1.0 : 1.0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) out.R[3 * a + b] = v[a][0] * u[b][0] + v[a][1] * u[b][1] + d * v[a][2] * u[b][2];
+    }
+    }
+    double Rmx[3], Rc[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        Rmx[a] = out.R[3 * a] * mx[0] + out.R[3 * a + 1] * mx[1] + out.R[3 * a + 2] * mx[2];
+        Rc[a] = out.R[3 * a] * c[0] + out.R[3 * a + 1] * c[1] + out.R[3 * a + 2] * c[2];
+        out.t[a] = (my[a] - Rmx[a]) + c[a] - Rc[a];
+    }
+    // 0.5 * sum w |y - R x - t|^2 from the moments (cost_from_moments)
+    double tp[3], RSx[3], yRx = 0, tpRSx = 0, tptp = 0, tpSy = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        tp[a] = out.t[a] + Rc[a] - c[a];
+        RSx[a] = out.R[3 * a] * S[1] + out.R[3 * a + 1] * S[2] + out.R[3 * a + 2] * S[3];
+#pragma unroll
+        for (int b = 0; b < 3; b++) yRx += out.R[3 * a + b] * S[7 + 3 * b + a];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        tpRSx += tp[a] * RSx[a];
+        tptp += tp[a] * tp[a];
+        tpSy += tp[a] * S[4 + a];
+    }
+    out.cost = 0.5 * (S[18] + S[17] + 2 * tpRSx + W * tptp - 2 * yRx - 2 * tpSy);
+    return out;
+}
+
+// Host mailbox in pinned, device-mapped memory: the fold-and-solve kernel writes the moments, the rigid transform it
+// solved from them and its cost there, then the sequence number (system-scope release); the host spins on `seq` — no
+// copy kernel and no stream synchronisation on the iteration's critical path.
 struct HostMailbox {
     double sums[kNSums];
+    double T[12];        // [R|t] minimising sum w |y - R x - t|^2 for these moments (identity when degenerate)
+    double cost;         // 0.5 * sum w |y - R x - t|^2 at that transform
+    unsigned degenerate; // no weight mass
+    unsigned handed_over; // blocks the association's fast kernel left to the cleanup kernel (sizes the next cleanup grid)
     unsigned seq;
 };
 
-// Same fold as reduce_partials_kernel (one block per sum, fixed order) with the result delivered to the host
-// mailbox; the block that draws the last ticket publishes the sequence number.
-__global__ __launch_bounds__(kBlock) void reduce_partials_mailbox_kernel(const double *__restrict__ partials, int nblocks,
-                                                                         double *__restrict__ sums, HostMailbox *mbox,
-                                                                         unsigned *__restrict__ ticket, unsigned seq)
+// Fold of partials[19][nblocks] (one block per sum, fixed order: deterministic, no float atomics) FOLLOWED BY THE SOLVE:
+// the block that draws the last ticket reads the 19 moments back and one lane runs the closed-form weighted rigid
+// solve (solve_rigid_device above) and the cost at the solution.  The
+// transform goes to *pose_out in device memory, where the next association's prologue picks it up as its pending
+// source move (PendingMove::dev): the outer loop no longer waits for the host between iterations.  The host gets
+// everything through the mailbox and only trails behind for hasConverged() and the history.
+__global__ __launch_bounds__(kBlock) void reduce_solve_kernel(const double *__restrict__ partials, int nblocks,
+                                                              double *__restrict__ sums, double3 origin,
+                                                              Pose *__restrict__ pose_out, HostMailbox *mbox,
+                                                              unsigned *__restrict__ ticket, unsigned seq,
+                                                              const unsigned *__restrict__ handed_over)
 {
     __shared__ double sh[kBlock / 64];
     const double *row = partials + (size_t)blockIdx.x * nblocks;
@@ -1630,18 +1866,38 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_mailbox_kernel(const d
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double x = sh[0];
-        for (int w = 1; w < kBlock / 64; w++) x += sh[w];
-        sums[blockIdx.x] = x;
-        __hip_atomic_store(&mbox->sums[blockIdx.x], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __atomic_thread_fence(__ATOMIC_RELEASE);  // system scope: the sum is visible to the host before the ticket
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (t == gridDim.x - 1) {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&mbox->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+    if (threadIdx.x != 0) return;
+    double x = sh[0];
+    for (int w = 1; w < kBlock / 64; w++) x += sh[w];
+    __hip_atomic_store(&sums[blockIdx.x], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk != gridDim.x - 1) return;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double S[kNSums];
+#pragma unroll
+    for (int j = 0; j < kNSums; j++) S[j] = __hip_atomic_load(&sums[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double c[3] = {origin.x, origin.y, origin.z};
+    const DeviceSolve rs = solve_rigid_device(S, c);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int b = 0; b < 3; b++) pose_out->R[3 * a + b] = rs.R[3 * a + b];
+        pose_out->t[a] = rs.t[a];
+        pose_out->c[a] = 0.0;
     }
+#pragma unroll
+    for (int j = 0; j < kNSums; j++) mbox->sums[j] = S[j];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int b = 0; b < 3; b++) mbox->T[4 * a + b] = rs.R[3 * a + b];
+        mbox->T[4 * a + 3] = rs.t[a];
+    }
+    mbox->cost = rs.cost;
+    mbox->degenerate = rs.degenerate ? 1u : 0u;
+    mbox->handed_over = handed_over ? *handed_over : 0u;
+    __hip_atomic_store(&mbox->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ProbabilisticWeights::updateWeights on caller-supplied squared errors (probabilistic_weights.hpp:48-105):

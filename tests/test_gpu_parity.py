@@ -856,7 +856,7 @@ def test_device_pointer_inputs(ctx):
 
 
 @pytest.mark.parametrize("opts", [dict(short_lists=0), dict(mailbox=0), dict(sort_source=0), dict(sort_source=2),
-                                  dict(temporal=0, short_lists=0)])
+                                  dict(temporal=0, short_lists=0), dict(run_ahead=0)])
 def test_every_tuning_option_keeps_the_result(ctx, opts):
     """ppcr_set_option knobs never change results: the association of every iteration is identical and the transforms
     agree to rounding with the default configuration."""
@@ -879,3 +879,84 @@ def test_every_tuning_option_keeps_the_result(ctx, opts):
     finally:
         a.close()
         b.close()
+
+
+def test_align_run_ahead_is_exact():
+    """ppcr_align keeps the device one iteration ahead of the host (solve on the GPU, next K1 takes its move from device
+    memory) whenever hasConverged() cannot stop in between.  Histories, costs, iteration counts and the moved source
+    must be IDENTICAL to the host-paced loop (run_ahead = 0), for the iteration cap, the cost-drop rule with every
+    patience, a NaN cost drop (nothing in radius) and a second align() on the same handle."""
+    src, tgt, _, _ = synth.make_pair(20000, cfg=2, stride=3)
+    cases = [dict(n_iter=7, cost_drop_thresh=0.0, n_cost_drop_it=5),
+             dict(n_iter=1, cost_drop_thresh=0.0, n_cost_drop_it=5),
+             dict(n_iter=0, cost_drop_thresh=0.0, n_cost_drop_it=5),
+             dict(n_iter=60, cost_drop_thresh=0.05, n_cost_drop_it=0),
+             dict(n_iter=60, cost_drop_thresh=0.05, n_cost_drop_it=1),
+             dict(n_iter=60, cost_drop_thresh=0.05, n_cost_drop_it=3),
+             dict(n_iter=60, cost_drop_thresh=2.0, n_cost_drop_it=5),
+             dict(n_iter=9, cost_drop_thresh=0.3, n_cost_drop_it=2.5)]
+    for case in cases:
+        res = []
+        for ahead in (1, 0):
+            with _lib.Context(0) as c:
+                c.set_option("run_ahead", ahead)
+                c.set_params(1.0, 10, 5.0, 3)
+                c.set_target(tgt)
+                c.set_source(src)
+                r1 = c.align(inner_steps=1, **case)
+                moved = c.get_source()
+                r2 = c.align(3, cost_drop_thresh=0.0, inner_steps=1)       # continues from the moved source
+                res.append((r1, moved, r2, c.get_source()))
+        (a1, am, a2, as2), (b1, bm, b2, bs2) = res
+        assert a1["n_iter"] == b1["n_iter"], case
+        for key in ("history", "costs", "inner_steps"):
+            np.testing.assert_array_equal(a1[key], b1[key], err_msg=str(case))
+            np.testing.assert_array_equal(a2[key], b2[key], err_msg=str(case))
+        np.testing.assert_array_equal(am, bm)
+        np.testing.assert_array_equal(as2, bs2)
+    # against the oracle too (the early-stop count and the final transform)
+    ora = po.align(src, tgt, 1.0, 10, 5.0, 60, cost_drop_thresh=0.05, n_cost_drop_it=1, inner_max_steps=1)
+    with _lib.Context(0) as c:
+        c.set_params(1.0, 10, 5.0, 3)
+        c.set_target(tgt)
+        c.set_source(src)
+        r = c.align(60, cost_drop_thresh=0.05, n_cost_drop_it=1, inner_steps=1)
+        assert r["n_iter"] == ora["n_iter"]
+        assert synth.rotation_angle(r["history"][-1][:, :3], ora["history"][-1][:, :3]) < ROT_TOL
+        assert np.linalg.norm(r["history"][-1][:, 3] - ora["history"][-1][:, 3]) < TRANS_TOL
+        # nothing in radius: 0/0 cost drop, the loop runs to the cap with identity transforms
+        c.set_source(src + np.float32(1000.0))
+        r = c.align(6, cost_drop_thresh=0.01, n_cost_drop_it=5, inner_steps=1)
+        assert r["n_iter"] == 6 and np.allclose(r["history"][-1], np.eye(4)[:3])
+
+
+def test_device_solve_handles_rank_deficient_clouds():
+    """The closed-form solve runs on the device (solve_rigid_device behind the moment fold).  Planar clouds (rank-2
+    cross-covariance), collinear clouds (rank 1) and a single pair must give a proper rotation that maps the source onto
+    the target, like the host solver the oracle is compared with (tests/test_capi_host.py)."""
+    rng = np.random.default_rng(11)
+    Rg = synth.rodrigues([0.3, -1.0, 0.5], 0.8)
+    tg = np.array([0.7, -0.2, 1.5])
+    n = 400
+    flat = rng.uniform(-3, 3, size=(n, 3))
+    flat[:, 2] = 1.25                                            # planar: rank 2
+    line = np.outer(rng.uniform(-4, 4, size=n), [0.6, -0.3, 0.74]) + [1.0, 2.0, -0.5]   # collinear: rank 1
+    full = rng.normal(size=(n, 3)) * 2
+    rp = np.arange(n + 1, dtype=np.int32)
+    col = np.arange(n, dtype=np.int32)
+    for name, x in (("full", full), ("planar", flat), ("collinear", line), ("single", full[:1])):
+        y = x @ Rg.T + tg
+        m = x.shape[0]
+        with _lib.Context(0) as c:
+            c.set_params(1.0, 3, float("inf"), 3)
+            c.set_target(y.astype(np.float32))
+            c.set_source(x.astype(np.float32))
+            c.set_association(rp[:m + 1], col[:m])
+            T, cost, steps = c.solve([1, 0, 0, 0], [0, 0, 0], max_steps=3, f_tol=1e-12)
+        R, t = T[:, :3], T[:, 3]
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(R) - 1) < 1e-12, name
+        resid = np.abs(x.astype(np.float32).astype(np.float64) @ R.T + t - y.astype(np.float32).astype(np.float64)).max()
+        assert resid < 5e-6, (name, resid)                        # float32 inputs: ~1e-6 of the coordinates
+        assert cost[1] <= cost[0] * (1 + 1e-12) + 1e-12
+        if name == "full":
+            assert synth.rotation_angle(R, Rg) < 1e-6 and np.linalg.norm(t - tg) < 1e-5
