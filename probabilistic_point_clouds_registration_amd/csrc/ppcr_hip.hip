@@ -514,12 +514,24 @@ void launch_accumulate_ell(ppcr_ctx *c, int nb, const Pose &P, const Model &md)
 {
     // the two models the reference's CLI reaches by default are compiled in (Gaussian -u; t with dof 5, dim 3:
     // v + dim = 8); any other dof takes the run-time form of the same arithmetic
-#define PPCR_K23(TMc)                                                                                              \
-    accumulate_ell_kernel<W, kAccumRows, kAccumBlock, TMc><<<nb, kAccumBlock, 0, c->stream>>>(              \
+#define PPCR_K23(TMc, ONEc)                                                                                        \
+    accumulate_ell_kernel<W, kAccumRows, kAccumBlock, TMc, ONEc><<<nb, kAccumBlock, 0, c->stream>>>(        \
         c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md, c->partials.p, c->ell_width)
-    if (md.is_normal) PPCR_K23(0);
-    else if (md.vpd_int == 8) PPCR_K23(8);
-    else PPCR_K23(-1);
+    // one-pass form (likelihoods relative to s = 0) only while that ratio stays far from underflow for every s the
+    // association can hold (s < radius^2 up to the float rounding of d2 and the f64 re-evaluation at another pose; the
+    // factor 4 on the radius covers residuals at a pose other than the one the association was made at)
+    const double s_max = 16.0 * c->radius * c->radius;
+    const bool one_t = md.vpd_int == 8 && 4.0 * std::log10((md.v + s_max) / md.v) < 250.0;
+    const bool one_g = md.is_normal && 0.5 * s_max < 600.0;
+    if (md.is_normal) {
+        if (one_g) PPCR_K23(0, true);
+        else PPCR_K23(0, false);
+    } else if (md.vpd_int == 8) {
+        if (one_t) PPCR_K23(8, true);
+        else PPCR_K23(8, false);
+    } else {
+        PPCR_K23(-1, false);
+    }
 #undef PPCR_K23
 }
 

@@ -305,10 +305,36 @@ __device__ __forceinline__ double fast_rcp(double x)
 // TM (compile-time model): -1 = read md at run time; 0 = Gaussian; k > 0 = t model with v + dim == k.
 // (The run-time form keeps the odd-power sqrt behind an opaque branch: as a plain ?: the compiler if-converts
 //  it and every pair pays the 20-instruction f64 sqrt expansion — measured: 220 of 970 VALU instructions per row.)
+// exp(x) for x <= 0 (the Gaussian model's likelihood ratios), ~1 ulp: x = k ln2 + r with |r| <= ln2 / 2, a degree-13
+// Taylor polynomial in r (remainder < 4e-18) and v_ldexp_f64; arguments below -745 give 0 like exp().  About 20
+// instructions against ~45 for the library routine, which has to serve the whole real line.
+__device__ __forceinline__ double exp_nonpositive(double x)
+{
+    x = fmax(x, -800.0);
+    const double kf = rint(x * 1.4426950408889634);            // log2(e)
+    double r = fma(kf, -6.93147180369123816490e-01, x);        // ln2 high part (exact product for |k| < 2^11)
+    r = fma(kf, -1.90821492927058770002e-10, r);               // ln2 low part
+    double p = 1.0 / 6227020800.0;                              // 1/13!
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)kf);
+}
+
 template <int TM = -1>
 __device__ __forceinline__ double rel_likelihood(const Model &md, double s, double smin, double lp_max, double inv_vs)
 {
-    if constexpr (TM == 0) return exp(-0.5 * (s - smin));
+    if constexpr (TM == 0) return exp_nonpositive(-0.5 * (s - smin));
     if constexpr (TM > 0) {
         const double rho = (md.v + smin) * inv_vs;
         double r = 1.0, base = rho;  // same multiplication sequence as the run-time loop below (1.0 * x is exact)
@@ -368,29 +394,37 @@ __device__ __forceinline__ void row_finish(RowAcc &acc, const Pose &P, float4 xf
 // part = t / 32) then adds 32 consecutive entries of row j, and 19 threads add the 8 parts: ~90 instructions per
 // wave, fixed summation order, no atomics.  Row stride 257 doubles: lanes j = 0..18 of a half-wave hit
 // consecutive 8-byte bank pairs.
-template <int BLOCK = kBlock>
+// HALVES = true folds ten sums, then nine, through a buffer half the size (20.6 KB instead of 39 KB: six instead of
+// four workgroups per CU for a kernel that is otherwise lean in registers) at the price of two more barriers.
+template <int BLOCK = kBlock, bool HALVES = false>
 __device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__restrict__ partials)
 {
     static_assert(BLOCK == 256, "fold layout assumes 256 lanes (8 parts of 32)");
     constexpr int STRIDE = BLOCK + 1;
-    __shared__ double sh[kNSums * STRIDE];
+    constexpr int ROUND = HALVES ? (kNSums + 1) / 2 : kNSums;  // sums per round
+    __shared__ double sh[ROUND * STRIDE];
     __shared__ double part[kNSums][8];
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < kNSums; j++) sh[j * STRIDE + tid] = acc.a[j];
-    __syncthreads();
     const int j = tid & 31, p = tid >> 5;
-    if (j < kNSums) {
-        const double *row = sh + j * STRIDE + p * 32;
-        double v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
 #pragma unroll
-        for (int k = 4; k < 32; k += 4) {
-            v0 += row[k];
-            v1 += row[k + 1];
-            v2 += row[k + 2];
-            v3 += row[k + 3];
+    for (int j0 = 0; j0 < kNSums; j0 += ROUND) {
+        if (j0 > 0) __syncthreads();  // the buffer is reused
+#pragma unroll
+        for (int q = 0; q < ROUND; q++)
+            if (j0 + q < kNSums) sh[q * STRIDE + tid] = acc.a[j0 + q];
+        __syncthreads();
+        if (j < ROUND && j0 + j < kNSums) {
+            const double *row = sh + j * STRIDE + p * 32;
+            double v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
+#pragma unroll
+            for (int k = 4; k < 32; k += 4) {
+                v0 += row[k];
+                v1 += row[k + 1];
+                v2 += row[k + 2];
+                v3 += row[k + 3];
+            }
+            part[j0 + j][p] = (v0 + v1) + (v2 + v3);
         }
-        part[j][p] = (v0 + v1) + (v2 + v3);
     }
     __syncthreads();
     if (tid < kNSums) {
@@ -1498,7 +1532,12 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(A a, const float4 *_
 // gathers in flight; the rows are then finished from registers in a single sweep (never re-read).  The
 // grid covers every row exactly once (no grid-stride loop).  Measured at 1M rows, W = 10: ROWS = 1
 // (124 VGPRs, 4 waves/SIMD) 58.6 us; ROWS = 2 (168 VGPRs, 3 waves/SIMD) 67 us; forcing 96 VGPRs spills: 74 us.
-template <int W, int ROWS, int BLOCK, int TM = -1>
+// ONEPASS (compile-time models only): likelihoods are taken relative to s = 0 instead of the row's smallest s —
+// (v / (v + s))^((v+d)/2) or exp(-s / 2) — so a pair is finished the moment its point arrives and nothing per pair
+// stays in registers (the two-pass form keeps s[W] and the centred points: 130 VGPRs, three waves per SIMD).  The host
+// picks it only when that ratio cannot underflow for any s below radius^2; the weights w = g / Z are the same numbers
+// up to rounding.
+template <int W, int ROWS, int BLOCK, int TM = -1, bool ONEPASS = false>
 __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__restrict__ nbr,
                                                                 const int *__restrict__ cnt,
                                                                 const float4 *__restrict__ src,
@@ -1534,44 +1573,80 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
                 yz[r][k] = y.z;
             }
     }
+    // Row arithmetic, written for instruction count (the kernel is bound by VALU issue: 599 instructions per wave for
+    // one row per lane at W = 10 before this form, ~57 % VALU busy):
+    //   * explicit FMAs (the translation unit is compiled with contraction off for K1's sake);
+    //   * residual and centred target share their work: yc = y - c, r = yc - (R x + t - c);
+    //   * unused slots are given s = 1e300, for which every model's likelihood ratio underflows to exactly 0: no
+    //     per-pair masks (their y is slot 0 of the target: finite, so 0 * y stays 0);
+    //   * sum g |y - c|^2 is not accumulated: with yc = r + xrc it equals Gs + 2 xrc . Gy - |xrc|^2 G.
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         if (n[r] == 0) continue;
-        double xr[3];
-        rotate_point(P, xf[r], xr);
-        double s[W];
-        double smin = INFINITY;
+        const double px = xf[r].x, py = xf[r].y, pz = xf[r].z;
+        // xrc = R x + t - c
+        const double xrc[3] = {fma(P.R[2], pz, fma(P.R[1], py, fma(P.R[0], px, P.t[0] - P.c[0]))),
+                               fma(P.R[5], pz, fma(P.R[4], py, fma(P.R[3], px, P.t[1] - P.c[1]))),
+                               fma(P.R[8], pz, fma(P.R[7], py, fma(P.R[6], px, P.t[2] - P.c[2])))};
+        if constexpr (ONEPASS && TM >= 0) {
+            double Z = 0, G = 0, Gs = 0, Gy[3] = {0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                const double y0 = (double)yx[r][k] - P.c[0], y1 = (double)yy[r][k] - P.c[1], y2 = (double)yz[r][k] - P.c[2];
+                const double r0 = y0 - xrc[0], r1 = y1 - xrc[1], r2 = y2 - xrc[2];
+                const double sk = fma(r2, r2, fma(r1, r1, r0 * r0));
+                const bool live = k < n[r];
+                const double sv = live ? sk : 1e300;
+                const double inv_vs = (TM == 0) ? 0.0 : fast_rcp(md.v + sv);
+                const double e = rel_likelihood<TM>(md, sv, 0.0, 0.0, inv_vs);
+                Z += e;
+                const double gk = (TM == 0) ? e : e * (md.vpd * inv_vs);
+                G += gk;
+                Gs = fma(gk, live ? sk : 0.0, Gs);
+                Gy[0] = fma(gk, y0, Gy[0]);
+                Gy[1] = fma(gk, y1, Gy[1]);
+                Gy[2] = fma(gk, y2, Gy[2]);
+            }
+            const double x2 = fma(xrc[2], xrc[2], fma(xrc[1], xrc[1], xrc[0] * xrc[0]));
+            const double Gyy = fma(-x2, G, fma(2.0, fma(xrc[2], Gy[2], fma(xrc[1], Gy[1], xrc[0] * Gy[0])), Gs));
+            row_finish(acc, P, xf[r], Z, G, Gs, Gyy, Gy);
+            continue;
+        }
+        double s[W], yc[W][3];
+        double smin = 1e300;
 #pragma unroll
         for (int k = 0; k < W; k++) {
-            const double r0 = (double)yx[r][k] - xr[0], r1 = (double)yy[r][k] - xr[1], r2 = (double)yz[r][k] - xr[2];
-            s[k] = r0 * r0 + r1 * r1 + r2 * r2;
-            smin = (k < n[r] && s[k] < smin) ? s[k] : smin;
+            yc[k][0] = (double)yx[r][k] - P.c[0];
+            yc[k][1] = (double)yy[r][k] - P.c[1];
+            yc[k][2] = (double)yz[r][k] - P.c[2];
+            const double r0 = yc[k][0] - xrc[0], r1 = yc[k][1] - xrc[1], r2 = yc[k][2] - xrc[2];
+            const double sk = fma(r2, r2, fma(r1, r1, r0 * r0));
+            s[k] = (k < n[r]) ? sk : 1e300;
+            smin = fmin(smin, s[k]);
         }
         // model known at compile time (TM >= 0): no run-time model tests inside the pair loop
         const bool normal = (TM >= 0) ? (TM == 0) : (md.is_normal != 0);
         const double lp_max = (TM >= 0 || md.is_normal || md.vpd_int) ? 0.0 : log_prob(md, smin);
-        double Z = 0, G = 0, Gs = 0, Gyy = 0, Gy[3] = {0, 0, 0};
+        double Z = 0, G = 0, Gs = 0, Gy[3] = {0, 0, 0};
 #pragma unroll
         for (int k = 0; k < W; k++) {
-            if (k < n[r]) {
-                const double inv_vs = normal ? 0.0 : fast_rcp(md.v + s[k]);
-                const double e = rel_likelihood<TM>(md, s[k], smin, lp_max, inv_vs);
-                Z += e;
-                const double gk = normal ? e : e * (md.vpd * inv_vs);
-                const double yc0 = (double)yx[r][k] - P.c[0], yc1 = (double)yy[r][k] - P.c[1], yc2 = (double)yz[r][k] - P.c[2];
-                G += gk;
-                Gs = fma(gk, s[k], Gs);
-                Gy[0] = fma(gk, yc0, Gy[0]);
-                Gy[1] = fma(gk, yc1, Gy[1]);
-                Gy[2] = fma(gk, yc2, Gy[2]);
-                Gyy = fma(gk, yc0 * yc0 + yc1 * yc1 + yc2 * yc2, Gyy);
-            }
+            const double inv_vs = normal ? 0.0 : fast_rcp(md.v + s[k]);
+            const double e = rel_likelihood<TM>(md, s[k], smin, lp_max, inv_vs);
+            Z += e;
+            const double gk = normal ? e : e * (md.vpd * inv_vs);
+            G += gk;
+            Gs = fma(gk, (k < n[r]) ? s[k] : 0.0, Gs);  // (0 * 1e300 is 0 already; the select keeps inf/NaN models out)
+            Gy[0] = fma(gk, yc[k][0], Gy[0]);
+            Gy[1] = fma(gk, yc[k][1], Gy[1]);
+            Gy[2] = fma(gk, yc[k][2], Gy[2]);
         }
+        const double x2 = fma(xrc[2], xrc[2], fma(xrc[1], xrc[1], xrc[0] * xrc[0]));
+        const double Gyy = fma(-x2, G, fma(2.0, fma(xrc[2], Gy[2], fma(xrc[1], Gy[1], xrc[0] * Gy[0])), Gs));
         row_finish(acc, P, xf[r], Z, G, Gs, Gyy, Gy);
     }
     // (an in-kernel last-block fold was measured and removed: its register footprint cost this kernel more than
     //  the separate fold kernel does: 101.6 us vs 67.6 + 17.2 us at the time; the fold kernel is 4.4 us now)
-    block_reduce_store<BLOCK>(acc, partials);
+    block_reduce_store<BLOCK, (ONEPASS && TM >= 0)>(acc, partials);  // the lean form is worth six workgroups per CU
 }
 
 // fold partials[19][nblocks] -> sums[19].  One 256-thread block PER SUM (grid = 19): every thread issues its
