@@ -59,8 +59,8 @@ def parse():
                     help="initialise torch.distributed (RCCL) even with one rank, to exercise the collective path")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="ppcr_set_option knob applied to every handle (experiments; the default run sets none)")
-    ap.add_argument("--lanes", type=int, default=4,
-                    help="pairs in flight per GPU when a rank holds several pairs (ppcr_align_many host worker threads)")
+    ap.add_argument("--lanes", type=int, default=8,
+                    help="pairs in flight per GPU when a rank holds several pairs (ppcr_align_many: one host thread polls them all)")
     ap.add_argument("--pairs-per-gpu", type=int, default=0,
                     help="independent pairs per rank (0 = the config's own: 1, or 64 / N for config 5)")
     ap.add_argument("--no-verify", action="store_true", help="config 5: skip the single-rank re-run of every pair")

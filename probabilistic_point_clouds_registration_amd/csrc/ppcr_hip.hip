@@ -837,6 +837,13 @@ int launch_step(ppcr_ctx *c, const Mat3 &R, const double t[3], StepTicket &tk)
     return check_launch(c, "reduce_partials_kernel");
 }
 
+// has that step's result reached the host mailbox yet?  (mailbox path only; never blocks)
+bool step_arrived(const ppcr_ctx *c, const StepTicket &tk)
+{
+    const HostMailbox *mb = c->h_mbox + (tk.seq % kMailboxRing);
+    return __atomic_load_n(&mb->seq, __ATOMIC_ACQUIRE) == tk.seq;
+}
+
 // wait for that step and fetch its result
 int collect_step(ppcr_ctx *c, const StepTicket &tk, StepResult &out)
 {
@@ -850,6 +857,9 @@ int collect_step(ppcr_ctx *c, const StepTicket &tk, StepResult &out)
                 arrived = true;
                 break;
             }
+            // a short wait is spun through (an iteration lasts ~0.1 ms); past that the core is offered to whoever
+            // else wants it, so many handles driven from more threads than cores do not starve each other
+            if (spin > 4096) std::this_thread::yield();
             if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(c->stream) != hipErrorNotReady) {
                 arrived = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == tk.seq;
                 break;
@@ -1483,28 +1493,55 @@ int ppcr_stop_rule_check(ppcr_stop_rule *rule, int n_iter, double cost_drop_thre
     return PPCR_CONTINUE;
 }
 
-// align() with the per-iteration outputs optional and the last cumulative transform returned separately
-static int align_impl(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_drop_it, const double q0[4],
-                      const double t0[3], int inner_steps, double f_tol, double *history, double *costs, int32_t *steps,
-                      double *T_final, int *n_done)
-{
-    CTX_ENTER(c);
-    if (!q0 || !t0) return fail(c, PPCR_ERR_INVALID, "null argument");
-    // n_iter < 0 means "no iteration cap" in the reference (cc:140 never fires): legal, but then the per-iteration
-    // arrays cannot be sized by the caller
-    if (n_iter < 0 && (history || costs || steps))
-        return fail(c, PPCR_ERR_INVALID, "ppcr_align: n_iter < 0 (no iteration cap) needs history, costs and steps to be NULL");
-    if (n_iter < 0 && !(cost_drop_thresh > 0))
-        return fail(c, PPCR_ERR_INVALID, "ppcr_align: n_iter < 0 (no iteration cap) needs cost_drop_thresh > 0, or the loop never ends");
-    if (!c->have_src || !c->have_tgt) return fail(c, PPCR_ERR_STATE, "set source and target before ppcr_align");
-    {
-        const double qn = q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3];
-        if (!(qn > 0) || !std::isfinite(qn)) return fail(c, PPCR_ERR_INVALID, "initial rotation quaternion has zero or non-finite norm");
-    }
+}  // extern "C"
+
+namespace {
+
+// One align() call as a resumable state machine, so that ONE host thread can keep several handles busy (each handle
+// has its own stream; the device paces itself through reduce_solve_kernel and PendingMove::dev).
+//
+// Pipelined mode (one inner step per association, the benchmark schedule): the device runs one iteration AHEAD of
+// the host.  Iteration k + 1 is enqueued before the host has seen iteration k — but only when hasConverged() cannot
+// stop in between whatever the cost of iteration k turns out to be: the cap is not reached and the idle count is
+// within the patience.  The rule therefore stays exact: nothing speculative is ever enqueued.
+struct AlignJob {
+    ppcr_ctx *c = nullptr;
+    int n_iter = 0, inner_steps = 1;
+    double thresh = 0, patience = 0, f_tol = 1e-5;
+    double q0[4] = {1, 0, 0, 0}, t0[3] = {0, 0, 0};
+    double *history = nullptr, *costs = nullptr;
+    int32_t *steps = nullptr;
     ppcr_stop_rule rule = {0, 0, 0.0};  // hasConverged(), shared with the C++ class (ppcr.h)
     double Tcum[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    for (double &v : c->dbg_host) v = 0;
-    auto record = [&](const double Tk[12], const double cost[2], int st) {
+    double T_last[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    Mat3 R0 = Mat3::identity();
+    StepTicket in_flight[2];
+    int enq = 0, done = 0;
+    bool pipelined = false, finished = false;
+
+    int validate()
+    {
+        if (!c) return PPCR_ERR_INVALID;
+        HIP_TRY(c, hipSetDevice(c->device));
+        // n_iter < 0 means "no iteration cap" in the reference (cc:140 never fires): legal, but then the per-iteration
+        // arrays cannot be sized by the caller
+        if (n_iter < 0 && (history || costs || steps))
+            return fail(c, PPCR_ERR_INVALID, "ppcr_align: n_iter < 0 (no iteration cap) needs history, costs and steps to be NULL");
+        if (n_iter < 0 && !(thresh > 0))
+            return fail(c, PPCR_ERR_INVALID, "ppcr_align: n_iter < 0 (no iteration cap) needs cost_drop_thresh > 0, or the loop never ends");
+        if (!c->have_src || !c->have_tgt) return fail(c, PPCR_ERR_STATE, "set source and target before ppcr_align");
+        const double qn = q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3];
+        if (!(qn > 0) || !std::isfinite(qn)) return fail(c, PPCR_ERR_INVALID, "initial rotation quaternion has zero or non-finite norm");
+        R0 = quat_to_rot(q0);
+        for (double &v : c->dbg_host) v = 0;
+        const bool unbounded = (c->max_nb <= 0 || (int64_t)c->max_nb >= c->nt);
+        pipelined = inner_steps <= 1 && c->opt_mailbox && c->opt_run_ahead && !c->have_companion && !unbounded &&
+                    c->max_nb <= kEllMaxWidth && c->ns > 0;
+        return PPCR_OK;
+    }
+
+    void record(const double Tk[12], const double cost[2], int st)
+    {
         compose(Tk, Tcum, Tcum);  // T_cum <- T_k * T_cum (cc:101-107)
         const int it = rule.iteration;
         if (history) std::memcpy(history + (size_t)it * 12, Tcum, sizeof(Tcum));
@@ -1515,70 +1552,129 @@ static int align_impl(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n
         if (steps) steps[it] = st;
         rule.cost_drop = (cost[0] - cost[1]) / cost[0];  // cc:119
         rule.iteration++;                                // cc:130
-    };
-    // One inner step per association (the benchmark schedule) runs with the device one iteration AHEAD of the host:
-    // the solve happens on the GPU and the next K1 takes its move from device memory, so iteration k + 1 can be
-    // enqueued before the host has seen iteration k — but only when hasConverged() cannot stop in between, whatever
-    // the cost of iteration k turns out to be: the cap is not reached and the idle count is within the patience.  The
-    // rule therefore stays exact: nothing speculative is ever enqueued.
-    const bool unbounded = (c->max_nb <= 0 || (int64_t)c->max_nb >= c->nt);
-    const bool pipelined = inner_steps <= 1 && c->opt_mailbox && c->opt_run_ahead && !c->have_companion && !unbounded &&
-                           c->max_nb <= kEllMaxWidth && c->ns > 0;
-    if (pipelined) {
-        const double qn0[4] = {q0[0], q0[1], q0[2], q0[3]};
-        const Mat3 R0 = quat_to_rot(qn0);
-        StepTicket in_flight[2];
-        int enq = 0, done = 0;
-        auto enqueue = [&]() -> int {
-            PPCR_TRY(associate_impl(c));  // moves the source by the previous iteration's transform in its prologue
-            PPCR_TRY(launch_step(c, R0, t0, in_flight[enq & 1]));
-            c->move_on_device = true;     // ... and this iteration's transform is the next pending move
-            enq++;
-            return PPCR_OK;
-        };
-        double T_last[12];
-        auto consume = [&]() -> int {
-            StepResult res;
-            PPCR_TRY(collect_step(c, in_flight[done & 1], res));
-            const double cost[2] = {0.5 * res.sums[16], res.cost};
-            std::memcpy(T_last, res.T, sizeof(T_last));
-            record(res.T, cost, 1);
-            done++;
-            return PPCR_OK;
-        };
-        for (;;) {
-            if (enq == done) {  // nothing in flight: the ordinary check
-                if (ppcr_stop_rule_check(&rule, n_iter, cost_drop_thresh, n_cost_drop_it) != PPCR_CONTINUE) break;
-                PPCR_TRY(enqueue());
+    }
+
+    int enqueue()
+    {
+        PPCR_TRY(associate_impl(c));  // moves the source by the previous iteration's transform in its prologue
+        PPCR_TRY(launch_step(c, R0, t0, in_flight[enq & 1]));
+        c->move_on_device = true;     // ... and this iteration's transform is the next pending move
+        enq++;
+        return PPCR_OK;
+    }
+
+    int consume()
+    {
+        StepResult res;
+        PPCR_TRY(collect_step(c, in_flight[done & 1], res));
+        const double cost[2] = {0.5 * res.sums[16], res.cost};
+        std::memcpy(T_last, res.T, sizeof(T_last));
+        record(res.T, cost, 1);
+        done++;
+        // an iteration enqueued ahead was let through on the strength of the idle count: replay its check now
+        if (enq > done && ppcr_stop_rule_check(&rule, n_iter, thresh, patience) != PPCR_CONTINUE)
+            return fail(c, PPCR_ERR_STATE, "internal: run-ahead broke the stopping rule");
+        return PPCR_OK;
+    }
+
+    // Pipelined mode: do whatever can be done without waiting; with may_block, wait for the oldest iteration in flight
+    // when nothing else is possible.  *progressed tells a scheduler whether to come back soon.
+    int advance(bool may_block, bool *progressed)
+    {
+        if (progressed) *progressed = false;
+        if (finished) return PPCR_OK;
+        HIP_TRY(c, hipSetDevice(c->device));
+        if (enq == done) {  // nothing in flight: the ordinary check
+            if (ppcr_stop_rule_check(&rule, n_iter, thresh, patience) != PPCR_CONTINUE) {
+                finished = true;
+                if (done > 0) {  // the last transform becomes an ordinary host-side pending move
+                    c->move_on_device = false;
+                    PPCR_TRY(apply_transform_impl(c, T_last, /*defer=*/true));
+                }
+                if (progressed) *progressed = true;
+                return PPCR_OK;
             }
-            // iteration `done` is in flight.  The check before iteration done + 1 cannot stop if the cap is not hit and
-            // the idle count (already updated by the check that let iteration `done` through) is within the patience.
-            const bool sure = (rule.iteration + 1 != n_iter) && !((double)rule.idle > n_cost_drop_it);
-            if (sure) PPCR_TRY(enqueue());
+            PPCR_TRY(enqueue());
+            if (progressed) *progressed = true;
+        }
+        // iteration `done` is in flight.  The check before iteration done + 1 cannot stop if the cap is not hit and the
+        // idle count (already updated by the check that let iteration `done` through) is within the patience.
+        if (enq == done + 1 && (rule.iteration + 1 != n_iter) && !((double)rule.idle > patience)) {
+            PPCR_TRY(enqueue());
+            if (progressed) *progressed = true;
+        }
+        if (may_block || step_arrived(c, in_flight[done & 1])) {
             PPCR_TRY(consume());
-            if (sure && ppcr_stop_rule_check(&rule, n_iter, cost_drop_thresh, n_cost_drop_it) != PPCR_CONTINUE)
-                return fail(c, PPCR_ERR_STATE, "internal: run-ahead broke the stopping rule");
+            if (progressed) *progressed = true;
         }
-        if (done > 0) {  // the last transform becomes an ordinary host-side pending move
-            c->move_on_device = false;
-            PPCR_TRY(apply_transform_impl(c, T_last, /*defer=*/true));
+        return PPCR_OK;
+    }
+
+    // the whole call on this thread
+    int run()
+    {
+        if (pipelined) {
+            while (!finished) PPCR_TRY(advance(true, nullptr));
+        } else {
+            while (ppcr_stop_rule_check(&rule, n_iter, thresh, patience) == PPCR_CONTINUE) {
+                double Tk[12], cost[2];
+                int st = 0;
+                PPCR_TRY(associate_impl(c));
+                PPCR_TRY(solve_impl(c, q0, t0, inner_steps, f_tol, Tk, cost, &st));
+                PPCR_TRY(apply_transform_impl(c, Tk, /*defer=*/true));  // rides in the next iteration's K1 prologue
+                record(Tk, cost, st);
+            }
+            finished = true;
         }
-    } else {
-    while (ppcr_stop_rule_check(&rule, n_iter, cost_drop_thresh, n_cost_drop_it) == PPCR_CONTINUE) {
-        double Tk[12], cost[2];
-        int st = 0;
-        PPCR_TRY(associate_impl(c));
-        PPCR_TRY(solve_impl(c, q0, t0, inner_steps, f_tol, Tk, cost, &st));
-        PPCR_TRY(apply_transform_impl(c, Tk, /*defer=*/true));  // rides in the next iteration's K1 prologue
-        record(Tk, cost, st);
+        return PPCR_OK;
     }
+
+    // leave the device copy of the source current and hand the totals over
+    int finish(double *T_final, int *n_done)
+    {
+        HIP_TRY(c, hipSetDevice(c->device));
+        PPCR_TRY(flush_pending_move(c));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (T_final) std::memcpy(T_final, Tcum, sizeof(Tcum));  // identity when no iteration ran
+        if (n_done) *n_done = rule.iteration;
+        return PPCR_OK;
     }
-    PPCR_TRY(flush_pending_move(c));  // leave the device copy of the source current
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (T_final) std::memcpy(T_final, Tcum, sizeof(Tcum));  // identity when no iteration ran
-    if (n_done) *n_done = rule.iteration;
-    return PPCR_OK;
+};
+
+AlignJob make_job(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_drop_it, const double q0[4], const double t0[3],
+                  int inner_steps, double f_tol, double *history, double *costs, int32_t *steps)
+{
+    AlignJob j;
+    j.c = c;
+    j.n_iter = n_iter;
+    j.thresh = cost_drop_thresh;
+    j.patience = n_cost_drop_it;
+    j.inner_steps = inner_steps;
+    j.f_tol = f_tol;
+    std::memcpy(j.q0, q0, sizeof(j.q0));
+    std::memcpy(j.t0, t0, sizeof(j.t0));
+    j.history = history;
+    j.costs = costs;
+    j.steps = steps;
+    return j;
 }
+
+// align() with the per-iteration outputs optional and the last cumulative transform returned separately
+int align_impl(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_drop_it, const double q0[4],
+               const double t0[3], int inner_steps, double f_tol, double *history, double *costs, int32_t *steps,
+               double *T_final, int *n_done)
+{
+    if (!c) return PPCR_ERR_INVALID;
+    if (!q0 || !t0) return fail(c, PPCR_ERR_INVALID, "null argument");
+    AlignJob job = make_job(c, n_iter, cost_drop_thresh, n_cost_drop_it, q0, t0, inner_steps, f_tol, history, costs, steps);
+    PPCR_TRY(job.validate());
+    PPCR_TRY(job.run());
+    return job.finish(T_final, n_done);
+}
+
+}  // namespace
+
+extern "C" {
 
 int ppcr_align(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_drop_it, const double q0[4],
                const double t0[3], int inner_steps, double f_tol, double *history, double *costs, int32_t *steps,
@@ -2020,6 +2116,50 @@ int ppcr_align_many(ppcr_ctx *const *ctxs, int n, int lanes, int n_iter, double 
             if (ctxs[j] == ctxs[k]) return fail(ctxs[k], PPCR_ERR_INVALID, "ppcr_align_many: the same handle appears twice");
     }
     lanes = std::max(1, std::min(lanes, n));
+    // Handles whose loop can run ahead of the host (one inner step per association) are all driven from THIS thread:
+    // up to `lanes` of them are in flight at a time, each on its own stream, and the thread only polls their mailboxes
+    // — no thread per pair, nothing to oversubscribe when many ranks share few cores.
+    {
+        std::vector<AlignJob> jobs;
+        jobs.reserve((size_t)n);
+        bool all_pipelined = true;
+        for (int k = 0; k < n && all_pipelined; k++) {
+            jobs.push_back(make_job(ctxs[k], n_iter, cost_drop_thresh, n_cost_drop_it, q0, t0, inner_steps, f_tol, nullptr, nullptr, nullptr));
+            const int rc = jobs.back().validate();
+            if (rc != PPCR_OK) return rc;
+            all_pipelined = jobs.back().pipelined;
+        }
+        if (all_pipelined) {
+            int next_job = 0, retired = 0;
+            std::vector<int> window;  // indices of the jobs in flight
+            while (retired < n) {
+                while ((int)window.size() < lanes && next_job < n) window.push_back(next_job++);
+                bool any = false;
+                for (size_t w = 0; w < window.size();) {
+                    AlignJob &j = jobs[(size_t)window[w]];
+                    bool progressed = false;
+                    const int rc = j.advance(false, &progressed);
+                    if (rc != PPCR_OK) return rc;
+                    any = any || progressed;
+                    if (j.finished) {
+                        // its last move is queued on its own stream; the synchronising tail runs after the loop
+                        window.erase(window.begin() + (long)w);
+                        retired++;
+                    } else {
+                        w++;
+                    }
+                }
+                if (!any) std::this_thread::yield();
+            }
+            for (int k = 0; k < n; k++) {
+                int done = 0;
+                const int rc = jobs[(size_t)k].finish(T_final + (size_t)k * 12, &done);
+                if (rc != PPCR_OK) return rc;
+                if (n_done) n_done[k] = done;
+            }
+            return PPCR_OK;
+        }
+    }
     std::atomic<int> next{0};
     FirstError first;
     auto worker = [&]() {
