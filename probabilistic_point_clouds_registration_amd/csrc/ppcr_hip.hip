@@ -128,6 +128,10 @@ struct ppcr_ctx {
     enum { ASSOC_NONE, ASSOC_ELL, ASSOC_CSR } assoc = ASSOC_NONE;
     int ell_width = 0;
     DevBuf<int> nbr, cnt, row_ptr;
+    DevBuf<unsigned char> split_flag;  // per 256-query block: scanned in two halves (its halo outgrew the steady-state capacity)
+    DevBuf<int> split_list;            // the split blocks (<= kMaxSplit), in order of registration
+    DevBuf<unsigned> split_state;      // [0] registrations so far, [1] registrations visible to the next launch's extra workgroups
+    bool split_clean = false;          // the three buffers above are zeroed for the current source order
     DevBuf<int> ovf_list;        // blocks nn_fast_kernel handed over to nn_tile_cleanup_kernel
     DevBuf<unsigned> ovf_state;  // two list counters used alternately (ovf_parity): the idle one is cleared by the fast kernel
     int ovf_parity = 0;
@@ -450,6 +454,7 @@ int ensure_source_sorted(ppcr_ctx *c)
     std::swap(c->src, c->src_alt);
     c->src_sorted = true;
     c->dm2_valid = false;  // row order changed
+    c->split_clean = false;
     return PPCR_OK;
 }
 
@@ -459,6 +464,8 @@ int ensure_source_sorted(ppcr_ctx *c)
 // column order of the source typical halos are ~1000-1400 candidates at the benchmark density; the margin keeps
 // denser clouds and drifted sources in the fast flavour (measured when the source was ordered in 4x4x4 bricks, fresh /
 // drifted: CAP 2048: 249/341 us, 2176: 231/246, 2240: 230/246, 2272: 302/318).
+constexpr int kCapSteady = 1728;  // halo capacity of the 16-slot variant: 31.3 KB of LDS, five workgroups per CU (1792: four)
+
 template <int M>
 void launch_tile(ppcr_ctx *c, float r2, int m, const PendingMove &pm)
 {
@@ -467,13 +474,16 @@ void launch_tile(ppcr_ctx *c, float r2, int m, const PendingMove &pm)
     constexpr int C = (M <= 24) ? 32 : 48;
     constexpr int CAP = (M <= 24) ? 2240 : 2048;
     const int nb = nblocks(c->ns, 256);
+    const SplitTable split_on{c->split_flag.p, c->split_list.p, c->split_state.p, c->split_state.p + 1, kMaxSplit};
+    const SplitTable split_off{nullptr, nullptr, nullptr, nullptr, 0};
     c->ovf_parity ^= 1;
     unsigned *const ovf_now = c->ovf_state.p + c->ovf_parity, *const ovf_next = c->ovf_state.p + (c->ovf_parity ^ 1);
+    // the steady-state (16-slot) variant runs with a halo capacity that gives FIVE workgroups per CU (31.3 KB of LDS)
+    // and splits the few blocks that outgrow it; the first association (32 slots, three per CU) keeps the large one
 #define PPCR_FAST(Cc, STAMPc)                                                                                          \
-    nn_fast_kernel<M, Cc, CAP, STAMPc><<<nb, 256, 0, c->stream>>>(c->src.p, (int)c->ns, c->tgt_sorted.p,                \
-                                                                  c->cell_start.p, c->grid, r2, m, c->nbr.p, c->cnt.p, \
-                                                                  pm, c->dm2.p, dm2_in, c->ovf_list.p, ovf_now,         \
-                                                                  ovf_next, st)
+    nn_fast_kernel<M, Cc, (Cc <= 16 ? kCapSteady : CAP), STAMPc><<<nb + (Cc <= 16 ? kMaxSplit : 0), 256, 0, c->stream>>>( \
+        c->src.p, (int)c->ns, c->tgt_sorted.p, c->cell_start.p, c->grid, r2, m, c->nbr.p, c->cnt.p, pm, c->dm2.p, dm2_in, \
+        c->ovf_list.p, ovf_now, ovf_next, (Cc <= 16 ? split_on : split_off), st)
     bool launched = false;
     if constexpr (M <= 12) {
         // steady state: the temporal cut-off keeps every list near m entries, so half the list capacity does (an
@@ -503,7 +513,7 @@ void launch_tile(ppcr_ctx *c, float r2, int m, const PendingMove &pm)
     const int cleanup_grid = (c->ovf_last == 0) ? std::min(nb, 32) : std::min(nb, 512);
     nn_tile_cleanup_kernel<M, C, 256, CAP><<<cleanup_grid, 256, 0, c->stream>>>(
         c->src.p, (int)c->ns, c->tgt_sorted.p, c->cell_start.p, c->grid, r2, m, c->nbr.p, c->cnt.p, c->dm2.p,
-        c->ovf_list.p, ovf_now);
+        c->ovf_list.p, ovf_now, c->split_state.p, c->split_state.p + 1);
 }
 
 constexpr int kAccumRows = 1;     // rows per lane of accumulate_ell_kernel
@@ -572,7 +582,16 @@ int associate_impl(ppcr_ctx *c)
         HIP_TRY(c, c->nbr.reserve((size_t)m * (size_t)std::max(ns, 1)));
         HIP_TRY(c, c->cnt.reserve((size_t)std::max(ns, 1)));
         HIP_TRY(c, c->dm2.reserve((size_t)std::max(ns, 1)));
-        HIP_TRY(c, c->ovf_list.reserve((size_t)nblocks(std::max(ns, 1), 256)));
+        HIP_TRY(c, c->ovf_list.reserve((size_t)nblocks(std::max(ns, 1), 256) + kMaxSplit));
+        if (!c->split_clean) {
+            const size_t nbk = (size_t)nblocks(std::max(ns, 1), 256);
+            HIP_TRY(c, c->split_flag.reserve(nbk));
+            HIP_TRY(c, c->split_list.reserve(kMaxSplit));
+            HIP_TRY(c, c->split_state.reserve(2));
+            HIP_TRY(c, hipMemsetAsync(c->split_flag.p, 0, nbk, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->split_state.p, 0, 2 * sizeof(unsigned), c->stream));
+            c->split_clean = true;
+        }
         if (!c->ovf_state.p) {
             HIP_TRY(c, c->ovf_state.reserve(2));
             HIP_TRY(c, hipMemsetAsync(c->ovf_state.p, 0, 2 * sizeof(unsigned), c->stream));
@@ -1076,6 +1095,9 @@ int ppcr_destroy(ppcr_ctx *c)
     c->nbr.release();
     c->dm2.release();
     c->ovf_list.release();
+    c->split_flag.release();
+    c->split_list.release();
+    c->split_state.release();
     c->ovf_state.release();
     c->cnt.release();
     c->row_ptr.release();
@@ -1160,7 +1182,7 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
         return PPCR_OK;
     }
     if (std::strcmp(key, "stamps") == 0) {  // diagnostic: per-phase cycle totals of nn_tile_kernel
-        const size_t nst = (size_t)(nblocks(std::max<int64_t>(c->ns, 1)) * (kBlock / 64) + 64) * 8;
+        const size_t nst = (size_t)((nblocks(std::max<int64_t>(c->ns, 1)) + kMaxSplit) * (kBlock / 64) + 64) * 8;
         HIP_TRY(c, c->d_stamps.reserve(nst));
         HIP_TRY(c, hipMemsetAsync(c->d_stamps.p, 0, nst * sizeof(unsigned long long), c->stream));
         c->opt_stamps = value;
@@ -1185,6 +1207,7 @@ static int set_target_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, in
 static int set_source_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, int64_t stride)
 {
     c->ovf_last = ~0u;
+    c->split_clean = false;
     c->move_pending = false;  // a deferred move of the previous source dies with it
     c->move_on_device = false;
     c->dm2_valid = false;

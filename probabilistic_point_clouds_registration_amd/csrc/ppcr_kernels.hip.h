@@ -598,8 +598,12 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
                                                          float r2, int m, int *__restrict__ nbr,
                                                          int *__restrict__ cnt, unsigned *__restrict__ dm2,
                                                          const int *__restrict__ ovf_list,
-                                                         const unsigned *__restrict__ ovf_count)
+                                                         const unsigned *__restrict__ ovf_count,
+                                                         const unsigned *__restrict__ split_total,
+                                                         unsigned *__restrict__ split_visible)
 {
+    // blocks registered for splitting by the fast kernel that just ran may be acted on from the next launch on
+    if (blockIdx.x == 0 && threadIdx.x == 0 && split_visible) *split_visible = *split_total;
     const unsigned n_listed = *ovf_count;
     for (unsigned listed = blockIdx.x; listed < n_listed; listed += gridDim.x) {
     const int bid = ovf_list[listed];
@@ -1004,15 +1008,29 @@ struct HaloList {
     }
 };
 
+// Blocks whose halo outgrew CAP once are SPLIT from then on: the block's own workgroup scans waves 0-1's queries, an
+// extra workgroup at the front of the grid scans waves 2-3's (both stage with all four waves; a half-block's halo is
+// ~60 % of the block's).  The split set lives in device memory, is extended by the workgroup that bails and takes
+// effect at the next launch (the bailing block itself goes to the cleanup kernel this once), so a small CAP — five
+// workgroups per CU instead of four — costs one cleanup launch per newly outgrown block, not one per iteration.
+struct SplitTable {
+    unsigned char *flag;      // [nblocks] 1: split
+    int *list;                // [kMaxSplit] block ids, in order of registration
+    unsigned *total;          // registrations so far (may exceed kMaxSplit: the surplus is not split)
+    const unsigned *visible;  // registrations the extra workgroups of THIS launch may act on (set by the cleanup kernel)
+    int n_extra;              // extra workgroups at the front of this launch's grid (0: no splitting in this launch)
+};
+constexpr int kMaxSplit = 64;
+
 template <int M, int C, int CAP, bool STAMPS>
-__global__ __launch_bounds__(256, (C <= 16 ? 4 : 3)) void nn_fast_kernel(float4 *__restrict__ src, int ns,
+__global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 4) : 3)) void nn_fast_kernel(float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt,
                                                          const int *__restrict__ cell_start, GridDesc g,
                                                          float r2, int m, int *__restrict__ nbr,
                                                          int *__restrict__ cnt, PendingMove pm,
                                                          unsigned *__restrict__ dm2, int dm2_valid,
                                                          int *__restrict__ ovf_list, unsigned *__restrict__ ovf_count,
-                                                         unsigned *__restrict__ ovf_count_next,
+                                                         unsigned *__restrict__ ovf_count_next, SplitTable split,
                                                          unsigned long long *__restrict__ stamps)
 {
     static_assert(C > M, "a re-scan must leave room in the list");
@@ -1021,7 +1039,10 @@ __global__ __launch_bounds__(256, (C <= 16 ? 4 : 3)) void nn_fast_kernel(float4 
     __shared__ __attribute__((aligned(16))) float s_halo[3 * CAP + CAP / 4];
     __shared__ unsigned short s_list[C * BLOCK];
     __shared__ int s_gbo[kRows];
-    __shared__ int2 s_rowtab[kRows];  // non-empty rows, compacted: {global begin, LDS offset << 19 | length << 7 | slot}
+    // non-empty rows, compacted: {global begin, LDS offset << 19 | length << 7 | slot}; only alive between the row
+    // table and the staging barrier, so it borrows the (not yet written) list area
+    static_assert(sizeof(int2) * kRows <= sizeof(s_list), "row table aliases the list area");
+    int2 *const s_rowtab = reinterpret_cast<int2 *>(s_list);
     __shared__ int s_box[kWaves][6];
     __shared__ int s_bail;
     float *const s_x = s_halo, *const s_y = s_halo + CAP, *const s_z = s_halo + 2 * CAP;
@@ -1046,12 +1067,20 @@ __global__ __launch_bounds__(256, (C <= 16 ? 4 : 3)) void nn_fast_kernel(float4 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = blockIdx.x * BLOCK + tid;
-    const bool valid = i < ns;
-    if (tid == 0) {
-        s_bail = 0;
-        if (blockIdx.x == 0) *ovf_count_next = 0;  // the other counter of the ping-pong pair: idle during this launch
+    if (tid == 0 && blockIdx.x == 0) *ovf_count_next = 0;  // the other counter of the ping-pong pair: idle during this launch
+    // which block, and which of its waves' queries, this workgroup scans (uniform)
+    int bid, half = 0;  // half: 0 whole block, 1 waves 0-1, 2 waves 2-3
+    if ((int)blockIdx.x < split.n_extra) {
+        if (blockIdx.x >= min(*split.visible, (unsigned)kMaxSplit)) return;
+        bid = split.list[blockIdx.x];
+        half = 2;
+    } else {
+        bid = (int)blockIdx.x - split.n_extra;
+        if (split.n_extra > 0 && split.flag[bid]) half = 1;
     }
+    const int i = bid * BLOCK + tid;
+    const bool valid = i < ns && (half == 0 || (wave >> 1) == half - 1);  // lanes whose query this workgroup owns
+    if (tid == 0) s_bail = 0;
 
     // ---- prologue: query, pending move, temporal cut-off ---------------------------------------------------------
     float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1106,6 +1135,8 @@ __global__ __launch_bounds__(256, (C <= 16 ? 4 : 3)) void nn_fast_kernel(float4 
                              bool(x_ok & ((unsigned)(qc.cy + 1) < (unsigned)g.n[1]))};
         const bool okz[3] = {(unsigned)(qc.cz - 1) < (unsigned)g.n[2], (unsigned)qc.cz < (unsigned)g.n[2],
                              (unsigned)(qc.cz + 1) < (unsigned)g.n[2]};
+        bool live[9];
+        int cfa = 0, cfb = -1;
         int base_c = (qc.cz * g.n[1] + qc.cy) * g.n[0];
         asm volatile("" : "+v"(base_c));  // keep the nine row bases as base_c + uniform offset (not nine multiplies)
 #pragma unroll
@@ -1118,12 +1149,19 @@ __global__ __launch_bounds__(256, (C <= 16 ? 4 : 3)) void nn_fast_kernel(float4 
             const int row_base = base_c + (dz * g.n[1] + dy) * g.n[0];  // uniform offset from the centre row
             rb[k] = cell_start[(unsigned)(in ? row_base + fa : 0)];
             re[k] = cell_start[(unsigned)(in ? row_base + fb + 1 : 0)];
-            xlo = in ? min(xlo, fa) : xlo;
-            xhi = in ? max(xhi, fb) : xhi;
-            ylo = in ? min(ylo, qc.cy + dy) : ylo;
-            yhi = in ? max(yhi, qc.cy + dy) : yhi;
-            zlo = in ? min(zlo, qc.cz + dz) : zlo;
-            zhi = in ? max(zhi, qc.cz + dz) : zhi;
+            live[k] = in;
+            if (k == 4) cfa = fa, cfb = fb;
+        }
+        // box of the live runs.  x: the centre run has the widest window (its w2 is the largest), so [cfa, cfb] covers
+        // every live run's slices (it is computed whether or not the centre row itself is inside the grid).
+        const bool ym = live[0] | live[3] | live[6], y0 = live[1] | live[4] | live[7], yp = live[2] | live[5] | live[8];
+        const bool zm = live[0] | live[1] | live[2], z0 = live[3] | live[4] | live[5], zp = live[6] | live[7] | live[8];
+        if (ym | y0 | yp) {
+            xlo = cfa, xhi = cfb;
+            ylo = qc.cy + (ym ? -1 : (y0 ? 0 : 1));
+            yhi = qc.cy + (yp ? 1 : (y0 ? 0 : -1));
+            zlo = qc.cz + (zm ? -1 : (z0 ? 0 : 1));
+            zhi = qc.cz + (zp ? 1 : (z0 ? 0 : -1));
         }
     }
 
@@ -1180,7 +1218,16 @@ __global__ __launch_bounds__(256, (C <= 16 ? 4 : 3)) void nn_fast_kernel(float4 
         t_acc[7] = (unsigned long long)((ny_h << 8) | nz_h);
     }
     if (!shape_ok || total > CAP) {  // uniform over the workgroup: derived from the shared boxes and cell_start only
-        if (tid == 0) ovf_list[atomicAdd(ovf_count, 1u)] = blockIdx.x;
+        if (tid == 0) {
+            ovf_list[atomicAdd(ovf_count, 1u)] = bid;  // the cleanup kernel redoes the whole block (this launch)
+            if (half == 0 && split.n_extra > 0) {       // ... and from the next launch on it is scanned in two halves
+                const unsigned slot = atomicAdd(split.total, 1u);
+                if (slot < (unsigned)kMaxSplit) {
+                    split.list[slot] = bid;
+                    split.flag[bid] = 1;
+                }
+            }
+        }
         flush_stamps();
         return;
     }
@@ -1330,7 +1377,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? 4 : 3)) void nn_fast_kernel(float4 
     // a wave with a twice-overflowed lane registers the block (once) for the cleanup kernel; its other results are
     // simply overwritten there with identical values
     if (__ballot(n < 0) != 0ull) {
-        if (lane == 0 && atomicExch(&s_bail, 1) == 0) ovf_list[atomicAdd(ovf_count, 1u)] = blockIdx.x;
+        if (lane == 0 && atomicExch(&s_bail, 1) == 0) ovf_list[atomicAdd(ovf_count, 1u)] = bid;
         n = max(n, 0);
     }
     if (valid) {
