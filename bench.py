@@ -321,7 +321,7 @@ def run_rank(a):
             tj = json.load(open(tpath))
             traffic = tj.get("traffic_bytes_per_launch")
             traffic_source = "profiles/k1_traffic.json (%s)" % tj.get("source", "separate rocprofv3 --pmc passes")
-        out["roofline"] = {"bound": "hbm", "kernel": "nn_tile_kernel (K1)", "achieved": ach, "peak": HBM_PEAK_GBS,
+        out["roofline"] = {"bound": "hbm", "kernel": "nn_fast_kernel (K1)", "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": traffic_source,
                            "avg_kernel_ms": avg_ms, "algorithmic_bytes_per_launch": b_nn,

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""profiles/k1_traffic.json from the FETCH_SIZE / WRITE_SIZE summary that tools/profile_round.sh writes
+(pmc_hbm_traffic.txt): HBM bytes per launch of the steady-state K1 kernel, with the gfx950 correction the
+MI355X_MICROARCH.md HBM section prescribes (FETCH_SIZE counts wide coalesced reads at half size)."""
+import json
+import re
+import sys
+
+
+def main(summary, out, tag):
+    txt = open(summary).read()
+    blocks = re.split(r"\n(?=\S)", txt)
+    pick = None
+    for b in blocks:
+        head = b.splitlines()[0]
+        if head.startswith("nn_fast_kernel<10, 16"):
+            pick = b
+    if pick is None:
+        raise SystemExit("no nn_fast_kernel<10, 16, ...> block in " + summary)
+    vals = {m.group(1): (float(m.group(2)), int(m.group(3))) for m in re.finditer(r"(\w+)\s+([0-9.]+)\s+\(n=(\d+)\)", pick)}
+    fetch_kb, n = vals["FETCH_SIZE"]
+    write_kb, _ = vals["WRITE_SIZE"]
+    doc = {
+        "kernel": pick.splitlines()[0].strip() + "> (steady-state K1: nn_fast_kernel, 16-slot lists, deferred source move and "
+                  "temporal cut-off folded in)",
+        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, MI355X, profiles/{tag}_pmc_hbm_traffic.txt; "
+                  f"tools/profile_round.sh), mean over {n} dispatches",
+        "FETCH_SIZE_KB": fetch_kb,
+        "WRITE_SIZE_KB": write_kb,
+        "correction": "gfx950: FETCH_SIZE counts 128-B fabric requests at 64 B for wide coalesced reads -> x2 "
+                      "(MI355X_MICROARCH.md HBM section); WRITE_SIZE taken as is; Infinity-Cache hits are included in both",
+        "traffic_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
+    }
+    json.dump(doc, open(out, "w"), indent=1)
+    print(json.dumps(doc))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "rXX")

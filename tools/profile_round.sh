@@ -12,8 +12,9 @@ for set in "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --kernel-trace --output-format csv --pmc $set -d $OUT/pmc_$set -o pmc -- python3 $R/tools/exp_iter.py 1000000 > $OUT/log_$set.txt 2>&1
 done
 python3 $R/tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/pmc_hbm_traffic.txt 2>&1
+python3 $R/tools/make_k1_traffic.py $OUT/pmc_hbm_traffic.txt $OUT/k1_traffic.json $TAG > /dev/null 2>&1
 python3 $R/tools/summarize_rocprof.py $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_summary.csv
 cd $R && python3 bench.py > $OUT/bench.json 2>$OUT/bench.err
 tail -1 $OUT/bench_under_rocprof.log | cut -c1-160
 head -12 $OUT/kernel_stats_summary.csv
-grep -E "^nn_tile|^accumulate_ell" -A3 $OUT/pmc_hbm_traffic.txt
+grep -E "^nn_fast|^nn_tile|^accumulate_ell" -A3 $OUT/pmc_hbm_traffic.txt
