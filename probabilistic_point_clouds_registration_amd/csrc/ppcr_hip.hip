@@ -181,6 +181,9 @@ struct ppcr_ctx {
     bool have_companion = false, have_ground_truth = false, have_previous = false;
     DevBuf<double> mse_part;
     int opt_short_lists = 1;
+    int opt_fuse_k23 = 1;        // ppcr_align's one-step iterations fold K23 into the steady-state K1
+    bool assoc_fused = false;    // the last association also left the partial moments of the pose it was given
+    int fused_slots = 0;         // ... in this many partial vectors
     int opt_run_ahead = 1;       // ppcr_align keeps the device one iteration ahead of the host when the rule allows
     int opt_brick_xshift = 0;    // log2 of the source bricks' x extent in cells (0: 4x4 yz columns walked along x)
     int opt_grid_xf = 4;         // x slices per grid cell (GridDesc::xr)
@@ -466,8 +469,10 @@ int ensure_source_sorted(ppcr_ctx *c)
 // drifted: CAP 2048: 249/341 us, 2176: 231/246, 2240: 230/246, 2272: 302/318).
 constexpr int kCapSteady = 1728;  // halo capacity of the 16-slot variant: 31.3 KB of LDS, five workgroups per CU (1792: four)
 
+// fuse: when given (and the steady-state variant runs) K23 is folded into K1 for that pose/model; *fused tells whether
+// it was — the partials then have one slot per fast-kernel workgroup (nb + kMaxSplit)
 template <int M>
-void launch_tile(ppcr_ctx *c, float r2, int m, const PendingMove &pm)
+void launch_tile(ppcr_ctx *c, float r2, int m, const PendingMove &pm, const FusedMoments *fuse, bool *fused)
 {
     unsigned long long *st = c->opt_stamps ? c->d_stamps.p : nullptr;
     const int dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
@@ -476,44 +481,58 @@ void launch_tile(ppcr_ctx *c, float r2, int m, const PendingMove &pm)
     const int nb = nblocks(c->ns, 256);
     const SplitTable split_on{c->split_flag.p, c->split_list.p, c->split_state.p, c->split_state.p + 1, kMaxSplit};
     const SplitTable split_off{nullptr, nullptr, nullptr, nullptr, 0};
+    FusedMoments fm_none;
+    std::memset(&fm_none, 0, sizeof(fm_none));
     c->ovf_parity ^= 1;
     unsigned *const ovf_now = c->ovf_state.p + c->ovf_parity, *const ovf_next = c->ovf_state.p + (c->ovf_parity ^ 1);
     // the steady-state (16-slot) variant runs with a halo capacity that gives FIVE workgroups per CU (31.3 KB of LDS)
     // and splits the few blocks that outgrow it; the first association (32 slots, three per CU) keeps the large one
-#define PPCR_FAST(Cc, STAMPc)                                                                                          \
-    nn_fast_kernel<M, Cc, (Cc <= 16 ? kCapSteady : CAP), STAMPc><<<nb + (Cc <= 16 ? kMaxSplit : 0), 256, 0, c->stream>>>( \
+#define PPCR_FAST(Cc, STAMPc, FTMc, FMc)                                                                               \
+    nn_fast_kernel<M, Cc, (Cc <= 16 ? kCapSteady : CAP), STAMPc, FTMc><<<nb + (Cc <= 16 ? kMaxSplit : 0), 256, 0, c->stream>>>( \
         c->src.p, (int)c->ns, c->tgt_sorted.p, c->cell_start.p, c->grid, r2, m, c->nbr.p, c->cnt.p, pm, c->dm2.p, dm2_in, \
-        c->ovf_list.p, ovf_now, ovf_next, (Cc <= 16 ? split_on : split_off), st)
-    bool launched = false;
+        c->ovf_list.p, ovf_now, ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc)
+    *fused = false;
+    int ftm = -2;  // model folded into this launch (-2: none)
+    bool steady = false;
     if constexpr (M <= 12) {
         // steady state: the temporal cut-off keeps every list near m entries, so half the list capacity does (an
-        // overflowing lane tightens its threshold and scans again): under 40 KB of LDS and 128 VGPRs, FOUR
-        // workgroups per CU instead of three
+        // overflowing lane tightens its threshold and scans again)
         if (dm2_in && c->opt_short_lists) {
+            steady = true;
+            if (fuse && !st) ftm = fuse->md.is_normal ? 0 : 8;
             if constexpr (M == 10) {
-                if (st) PPCR_FAST(16, true);
-                else PPCR_FAST(16, false);
+                if (st) PPCR_FAST(16, true, -2, fm_none);
+                else if (ftm == 0) PPCR_FAST(16, false, 0, *fuse);
+                else if (ftm == 8) PPCR_FAST(16, false, 8, *fuse);
+                else PPCR_FAST(16, false, -2, fm_none);
             } else {
-                PPCR_FAST(16, false);
+                if (ftm == 0) PPCR_FAST(16, false, 0, *fuse);
+                else if (ftm == 8) PPCR_FAST(16, false, 8, *fuse);
+                else PPCR_FAST(16, false, -2, fm_none);
             }
-            launched = true;
+            *fused = ftm != -2;
         }
     }
-    if (!launched) {
+    if (!steady) {
         if constexpr (M == 10) {
-            if (st) PPCR_FAST(C, true);
-            else PPCR_FAST(C, false);
+            if (st) PPCR_FAST(C, true, -2, fm_none);
+            else PPCR_FAST(C, false, -2, fm_none);
         } else {
-            PPCR_FAST(C, false);
+            PPCR_FAST(C, false, -2, fm_none);
         }
     }
 #undef PPCR_FAST
     // persistent workgroups over the list: few when the last association this handle heard from handed nothing over
-    // (an empty grid of 512 workgroups costs 4 us between K1 and K23, one of 32 about half of that)
     const int cleanup_grid = (c->ovf_last == 0) ? std::min(nb, 32) : std::min(nb, 512);
-    nn_tile_cleanup_kernel<M, C, 256, CAP><<<cleanup_grid, 256, 0, c->stream>>>(
-        c->src.p, (int)c->ns, c->tgt_sorted.p, c->cell_start.p, c->grid, r2, m, c->nbr.p, c->cnt.p, c->dm2.p,
-        c->ovf_list.p, ovf_now, c->split_state.p, c->split_state.p + 1);
+    const int n_extra = steady ? kMaxSplit : 0;
+#define PPCR_CLEANUP(FTMc, FMc)                                                                                        \
+    nn_tile_cleanup_kernel<M, C, 256, CAP, FTMc><<<cleanup_grid, 256, 0, c->stream>>>(                                 \
+        c->src.p, (int)c->ns, c->tgt_sorted.p, c->cell_start.p, c->grid, r2, m, c->nbr.p, c->cnt.p, c->dm2.p,          \
+        c->ovf_list.p, ovf_now, c->split_state.p, c->split_state.p + 1, c->split_list.p, n_extra, FMc)
+    if (ftm == 0) PPCR_CLEANUP(0, *fuse);
+    else if (ftm == 8) PPCR_CLEANUP(8, *fuse);
+    else PPCR_CLEANUP(-2, fm_none);
+#undef PPCR_CLEANUP
 }
 
 constexpr int kAccumRows = 1;     // rows per lane of accumulate_ell_kernel
@@ -547,8 +566,10 @@ void launch_accumulate_ell(ppcr_ctx *c, int nb, const Pose &P, const Model &md)
 
 int flush_pending_move(ppcr_ctx *c);
 
-// K1 (or the generic count/scan/fill path for unbounded searches and max_neighbours > 32)
-int associate_impl(ppcr_ctx *c)
+// K1 (or the generic count/scan/fill path for unbounded searches and max_neighbours > 32).
+// fuse_R / fuse_t (nullable): the pose the first IRLS half-step will be evaluated at; when given, the steady-state K1
+// also produces that step's partial moments (c->assoc_fused, c->fused_slots) and the caller skips the K23 launch.
+int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse_t = nullptr)
 {
     PPCR_TRY(ensure_grid(c));
     if (!c->src_sorted) PPCR_TRY(flush_pending_move(c));  // the one-time spatial sort reads the source
@@ -599,15 +620,37 @@ int associate_impl(ppcr_ctx *c)
         // dm2 is only trusted when the source moved by nothing but the deferred rigid move applied in this
         // very kernel since the association that wrote it
         if (!tiled) c->dm2_valid = false;
+        c->assoc_fused = false;
         if (ns > 0) {
+            // K23 folded in: only the two compiled-in models in their one-pass form (see launch_accumulate_ell)
+            FusedMoments fm;
+            const FusedMoments *fuse = nullptr;
+            if (fuse_R && c->opt_fuse_k23 && c->nt > 0) {
+                const Model md = make_model(c);
+                const double s_max = 16.0 * c->radius * c->radius;
+                const bool one_t = md.vpd_int == 8 && 4.0 * std::log10((md.v + s_max) / md.v) < 250.0;
+                const bool one_g = md.is_normal && 0.5 * s_max < 600.0;
+                if (one_t || one_g) {
+                    const int slots = nblocks(ns, 256) + kMaxSplit;
+                    HIP_TRY(c, c->partials.reserve((size_t)slots * kNSums));
+                    fm.P = make_pose(c, *fuse_R, fuse_t);
+                    fm.md = md;
+                    fm.partials = c->partials.p;
+                    fm.nslots = slots;
+                    fuse = &fm;
+                }
+            }
+            bool fused = false;
             ProfScope ps(c, K_NN_TOPM);
-            if (m <= 4) launch_tile<4>(c, r2, m, pm);
-            else if (m <= 5) launch_tile<5>(c, r2, m, pm);
-            else if (m <= 8) launch_tile<8>(c, r2, m, pm);
-            else if (m <= 10) launch_tile<10>(c, r2, m, pm);
-            else if (m <= 16) launch_tile<16>(c, r2, m, pm);
-            else if (m <= 20) launch_tile<20>(c, r2, m, pm);
-            else launch_tile<32>(c, r2, m, pm);
+            if (m <= 4) launch_tile<4>(c, r2, m, pm, fuse, &fused);
+            else if (m <= 5) launch_tile<5>(c, r2, m, pm, fuse, &fused);
+            else if (m <= 8) launch_tile<8>(c, r2, m, pm, fuse, &fused);
+            else if (m <= 10) launch_tile<10>(c, r2, m, pm, fuse, &fused);
+            else if (m <= 16) launch_tile<16>(c, r2, m, pm, fuse, &fused);
+            else if (m <= 20) launch_tile<20>(c, r2, m, pm, fuse, &fused);
+            else launch_tile<32>(c, r2, m, pm, fuse, &fused);
+            c->assoc_fused = fused;
+            c->fused_slots = fused ? fm.nslots : 0;
         }
         c->assoc_space = 1;
         PPCR_TRY(check_launch(c, "nn_tile_kernel"));
@@ -792,8 +835,9 @@ struct StepTicket {
     int nb = 0;        // partial vectors to fold (copy path)
 };
 
-// enqueue K23 + fold (+ solve); nothing here waits for the device
-int launch_step(ppcr_ctx *c, const Mat3 &R, const double t[3], StepTicket &tk)
+// enqueue K23 + fold (+ solve); nothing here waits for the device.  use_fused: the association just made already
+// produced the partial moments for this pose (associate_impl with a fuse pose): only the fold and the solve remain.
+int launch_step(ppcr_ctx *c, const Mat3 &R, const double t[3], StepTicket &tk, bool use_fused = false)
 {
     if (c->assoc == ppcr_ctx::ASSOC_NONE) return fail(c, PPCR_ERR_STATE, "no association (call ppcr_associate or ppcr_set_association)");
     if (!c->origin_valid) {
@@ -806,7 +850,8 @@ int launch_step(ppcr_ctx *c, const Mat3 &R, const double t[3], StepTicket &tk)
     const Model md = make_model(c);
     const bool ell_rows = c->assoc == ppcr_ctx::ASSOC_ELL && c->nt > 0;
     // the ELL kernel covers every row exactly once (kAccumRows rows per lane); the generic one grid-strides
-    const int nb = ell_rows ? std::max(1, nblocks(ns, kAccumBlock * kAccumRows)) : std::max(1, std::min(kAccumMaxBlocks, nblocks(ns)));
+    const int nb = use_fused ? c->fused_slots
+                             : (ell_rows ? std::max(1, nblocks(ns, kAccumBlock * kAccumRows)) : std::max(1, std::min(kAccumMaxBlocks, nblocks(ns))));
     HIP_TRY(c, c->partials.reserve((size_t)nb * kNSums));
     HIP_TRY(c, c->d_sums.reserve(kNSums));
     HIP_TRY(c, c->d_pose.reserve(1));
@@ -814,7 +859,7 @@ int launch_step(ppcr_ctx *c, const Mat3 &R, const double t[3], StepTicket &tk)
         HIP_TRY(c, c->d_ticket.reserve(1));
         HIP_TRY(c, hipMemsetAsync(c->d_ticket.p, 0, sizeof(unsigned), c->stream));
     }
-    {
+    if (!use_fused) {
         ProfScope ps(c, K_ACCUMULATE);
         if (c->assoc == ppcr_ctx::ASSOC_ELL && c->nt > 0) {
             const int w = c->ell_width;
@@ -1163,6 +1208,10 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
         if (value != 1 && value != 2 && value != 4) return fail(c, PPCR_ERR_INVALID, "brick_x must be 1, 2 or 4");
         c->opt_brick_xshift = value == 1 ? 0 : (value == 2 ? 1 : 2);
         c->src_sorted = false;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "fuse_k23") == 0) {
+        c->opt_fuse_k23 = value ? 1 : 0;
         return PPCR_OK;
     }
     if (std::strcmp(key, "run_ahead") == 0) {
@@ -1579,8 +1628,10 @@ struct AlignJob {
 
     int enqueue()
     {
-        PPCR_TRY(associate_impl(c));  // moves the source by the previous iteration's transform in its prologue
-        PPCR_TRY(launch_step(c, R0, t0, in_flight[enq & 1]));
+        // moves the source by the previous iteration's transform in its prologue and (steady state) leaves this
+        // iteration's partial moments at (q0, t0) behind: K23 folded in
+        PPCR_TRY(associate_impl(c, &R0, t0));
+        PPCR_TRY(launch_step(c, R0, t0, in_flight[enq & 1], c->assoc_fused));
         c->move_on_device = true;     // ... and this iteration's transform is the next pending move
         enq++;
         return PPCR_OK;

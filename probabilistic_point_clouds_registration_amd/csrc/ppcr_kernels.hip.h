@@ -394,6 +394,88 @@ __device__ __forceinline__ void row_finish(RowAcc &acc, const Pose &P, float4 xf
 // part = t / 32) then adds 32 consecutive entries of row j, and 19 threads add the 8 parts: ~90 instructions per
 // wave, fixed summation order, no atomics.  Row stride 257 doubles: lanes j = 0..18 of a half-wave hit
 // consecutive 8-byte bank pairs.
+// The same two-round fold on scratch memory the caller provides (kernels that fold at their very end lend the buffers
+// they no longer need): sh holds 10 * 257 doubles, part 19 * 8.  All 256 threads must call it.
+__device__ __forceinline__ void block_reduce_scratch(const RowAcc &acc, double *sh, double *part, double *__restrict__ out,
+                                                     size_t out_stride, bool write)
+{
+    constexpr int STRIDE = 257, ROUND = (kNSums + 1) / 2;
+    const int tid = threadIdx.x;
+    const int j = tid & 31, p = tid >> 5;
+#pragma unroll
+    for (int j0 = 0; j0 < kNSums; j0 += ROUND) {
+        if (j0 > 0) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < ROUND; q++)
+            if (j0 + q < kNSums) sh[q * STRIDE + tid] = acc.a[j0 + q];
+        __syncthreads();
+        if (j < ROUND && j0 + j < kNSums) {
+            const double *row = sh + j * STRIDE + p * 32;
+            double v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
+#pragma unroll
+            for (int k = 4; k < 32; k += 4) {
+                v0 += row[k];
+                v1 += row[k + 1];
+                v2 += row[k + 2];
+                v3 += row[k + 3];
+            }
+            part[(j0 + j) * 8 + p] = (v0 + v1) + (v2 + v3);
+        }
+    }
+    __syncthreads();
+    if (write && tid < kNSums) {
+        double v = part[tid * 8];
+#pragma unroll
+        for (int q = 1; q < 8; q++) v += part[tid * 8 + q];
+        out[(size_t)tid * out_stride] = v;
+    }
+}
+constexpr int kFoldScratchBytes = (10 * 257 + kNSums * 8) * 8;  // 21 776
+
+// One row's contribution to the moments for a compiled-in model, pairs handed over one at a time (the one-pass form of
+// accumulate_ell_kernel: likelihoods relative to s = 0).  Used by the kernels that fold K23 into the association.
+template <int TM>
+struct RowMoments {
+    double Z = 0, G = 0, Gs = 0, Gy[3] = {0, 0, 0};
+    __device__ __forceinline__ void add(const Pose &P, const Model &md, const double (&xrc)[3], float yx, float yy, float yz, bool live)
+    {
+        const double y0 = (double)yx - P.c[0], y1 = (double)yy - P.c[1], y2 = (double)yz - P.c[2];
+        const double r0 = y0 - xrc[0], r1 = y1 - xrc[1], r2 = y2 - xrc[2];
+        const double sk = fma(r2, r2, fma(r1, r1, r0 * r0));
+        const double sv = live ? sk : 1e300;
+        const double inv_vs = (TM == 0) ? 0.0 : fast_rcp(md.v + sv);
+        const double e = rel_likelihood<TM>(md, sv, 0.0, 0.0, inv_vs);
+        Z += e;
+        const double gk = (TM == 0) ? e : e * (md.vpd * inv_vs);
+        G += gk;
+        Gs = fma(gk, live ? sk : 0.0, Gs);
+        Gy[0] = fma(gk, y0, Gy[0]);
+        Gy[1] = fma(gk, y1, Gy[1]);
+        Gy[2] = fma(gk, y2, Gy[2]);
+    }
+    __device__ __forceinline__ void finish(RowAcc &acc, const Pose &P, float4 xf, const double (&xrc)[3]) const
+    {
+        const double x2 = fma(xrc[2], xrc[2], fma(xrc[1], xrc[1], xrc[0] * xrc[0]));
+        const double Gyy = fma(-x2, G, fma(2.0, fma(xrc[2], Gy[2], fma(xrc[1], Gy[1], xrc[0] * Gy[0])), Gs));
+        row_finish(acc, P, xf, Z, G, Gs, Gyy, Gy);
+    }
+};
+__device__ __forceinline__ void rotated_centred(const Pose &P, float4 xf, double (&xrc)[3])
+{
+    const double px = xf.x, py = xf.y, pz = xf.z;
+    xrc[0] = fma(P.R[2], pz, fma(P.R[1], py, fma(P.R[0], px, P.t[0] - P.c[0])));
+    xrc[1] = fma(P.R[5], pz, fma(P.R[4], py, fma(P.R[3], px, P.t[1] - P.c[1])));
+    xrc[2] = fma(P.R[8], pz, fma(P.R[7], py, fma(P.R[6], px, P.t[2] - P.c[2])));
+}
+// K23 folded into the association: the pose and model the first IRLS half-step is evaluated at, and where this
+// workgroup's 19 partial sums go (slot = its index in the FAST kernel's grid; stride = number of slots)
+struct FusedMoments {
+    Pose P;
+    Model md;
+    double *partials;
+    int nslots;
+};
+
 // HALVES = true folds ten sums, then nine, through a buffer half the size (20.6 KB instead of 39 KB: six instead of
 // four workgroups per CU for a kernel that is otherwise lean in registers) at the price of two more barriers.
 template <int BLOCK = kBlock, bool HALVES = false>
@@ -591,7 +673,11 @@ struct PendingMove {
 // Persistent workgroups stride over the list.  The list counters ping-pong: launch k counts in ovf_state[k & 1] and the
 // fast kernel of launch k clears ovf_state[(k + 1) & 1] (last used by launch k - 1, whose cleanup has finished by then in
 // stream order), so nobody needs an atomic ticket (1024 same-address atomics cost this kernel 20 us when it was tried).
-template <int M, int C, int BLOCK, int CAP>
+// Entries are (index of the handing-over workgroup in the fast kernel's grid) * 4 + half: half 0 = the whole block,
+// 1 / 2 = only the queries of waves 0-1 / 2-3 (split blocks).  FTM >= 0: the fast kernel also folded K23 in, so this one
+// finishes the rows it redoes the same way (gathering their neighbours from global memory) and fills the slot of the
+// partials the fast workgroup left empty.
+template <int M, int C, int BLOCK, int CAP, int FTM = -2>
 __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt,
                                                          const int *__restrict__ cell_start, GridDesc g,
@@ -600,13 +686,16 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
                                                          const int *__restrict__ ovf_list,
                                                          const unsigned *__restrict__ ovf_count,
                                                          const unsigned *__restrict__ split_total,
-                                                         unsigned *__restrict__ split_visible)
+                                                         unsigned *__restrict__ split_visible,
+                                                         const int *__restrict__ split_list, int n_extra, FusedMoments fm)
 {
     // blocks registered for splitting by the fast kernel that just ran may be acted on from the next launch on
     if (blockIdx.x == 0 && threadIdx.x == 0 && split_visible) *split_visible = *split_total;
     const unsigned n_listed = *ovf_count;
     for (unsigned listed = blockIdx.x; listed < n_listed; listed += gridDim.x) {
-    const int bid = ovf_list[listed];
+    const int entry = ovf_list[listed];
+    const int fast_slot = entry >> 2, half = entry & 3;
+    const int bid = fast_slot < n_extra ? split_list[fast_slot] : fast_slot - n_extra;
     static_assert(C > M, "a compaction must leave room in the list");
     static_assert(CAP % 4 == 0 && CAP <= 65536 && C * 64 <= 3 * CAP && kTileRows <= 256, "the global fallback aliases the candidate buffer");
     static_assert(kTileRows == 128, "row table: two rows per lane of one wave");
@@ -625,7 +714,7 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = bid * BLOCK + tid;
-    const bool valid = i < ns;
+    const bool valid = i < ns && (half == 0 || (wave >> 1) == half - 1);  // lanes whose query the fast workgroup owned
     const float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const unsigned thr0 = 0xFFFFFFFFu;  // no temporal cut-off in this flavour
     const QueryCells qc = query_cells(q, g);
@@ -929,7 +1018,27 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
             lds_barrier();
         }
       }
-    __syncthreads();  // the LDS buffers are reused by this workgroup's next listed block
+    __syncthreads();  // the LDS buffers are reused by this workgroup's next listed block (and by the fold below)
+    if constexpr (FTM != -2) {
+        // K23 for the rows just redone: each lane re-reads its own row (it wrote it itself) and gathers the neighbours
+        RowAcc acc;
+#pragma unroll
+        for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
+        const int nrow = valid ? cnt[i] : 0;
+        if (nrow > 0) {
+            double xrc[3];
+            rotated_centred(fm.P, q, xrc);
+            RowMoments<FTM> row;
+            for (int j = 0; j < nrow; j++) {
+                const float4 y = tgt[nbr[(size_t)j * ns + i]];
+                row.add(fm.P, fm.md, xrc, y.x, y.y, y.z, true);
+            }
+            row.finish(acc, fm.P, q, xrc);
+        }
+        double *const scratch = reinterpret_cast<double *>(s_halo);
+        block_reduce_scratch(acc, scratch, scratch + 10 * 257, fm.partials + fast_slot, (size_t)fm.nslots, true);
+        __syncthreads();
+    }
     }
 }
 
@@ -1022,7 +1131,10 @@ struct SplitTable {
 };
 constexpr int kMaxSplit = 64;
 
-template <int M, int C, int CAP, bool STAMPS>
+// FTM >= 0 (0: Gaussian, k: t model with v + dim = k) folds K23 into this kernel: each lane finishes its row's
+// contribution to the 19 moments from the winners' coordinates while they are still in LDS (no neighbour gathers, no
+// second pass over the source, no K23 launch) and the workgroup folds them into fm.partials.  FTM = -2: plain K1.
+template <int M, int C, int CAP, bool STAMPS, int FTM = -2>
 __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 4) : 3)) void nn_fast_kernel(float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt,
                                                          const int *__restrict__ cell_start, GridDesc g,
@@ -1031,9 +1143,10 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
                                                          unsigned *__restrict__ dm2, int dm2_valid,
                                                          int *__restrict__ ovf_list, unsigned *__restrict__ ovf_count,
                                                          unsigned *__restrict__ ovf_count_next, SplitTable split,
-                                                         unsigned long long *__restrict__ stamps)
+                                                         unsigned long long *__restrict__ stamps, FusedMoments fm)
 {
     static_assert(C > M, "a re-scan must leave room in the list");
+    static_assert(FTM == -2 || (3 * CAP + CAP / 4) * 4 >= kFoldScratchBytes, "the final fold borrows the halo buffer");
     static_assert(CAP % 4 == 0 && CAP * 4 < 65536, "list entries are 16-bit byte offsets into the halo arrays");
     constexpr int BLOCK = 256, kWaves = 4, kRows = 128, kStageUnroll = 4;
     __shared__ __attribute__((aligned(16))) float s_halo[3 * CAP + CAP / 4];
@@ -1071,7 +1184,11 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     // which block, and which of its waves' queries, this workgroup scans (uniform)
     int bid, half = 0;  // half: 0 whole block, 1 waves 0-1, 2 waves 2-3
     if ((int)blockIdx.x < split.n_extra) {
-        if (blockIdx.x >= min(*split.visible, (unsigned)kMaxSplit)) return;
+        if (blockIdx.x >= min(*split.visible, (unsigned)kMaxSplit)) {
+            if constexpr (FTM != -2)  // an idle slot of the partials still has to read as zero
+                if (tid < kNSums) fm.partials[(size_t)tid * fm.nslots + blockIdx.x] = 0.0;
+            return;
+        }
         bid = split.list[blockIdx.x];
         half = 2;
     } else {
@@ -1219,7 +1336,8 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     }
     if (!shape_ok || total > CAP) {  // uniform over the workgroup: derived from the shared boxes and cell_start only
         if (tid == 0) {
-            ovf_list[atomicAdd(ovf_count, 1u)] = bid;  // the cleanup kernel redoes the whole block (this launch)
+            // the cleanup kernel redoes this workgroup's queries (this launch): entry = grid index * 4 + half
+            ovf_list[atomicAdd(ovf_count, 1u)] = (int)blockIdx.x * 4 + half;
             if (half == 0 && split.n_extra > 0) {       // ... and from the next launch on it is scanned in two halves
                 const unsigned slot = atomicAdd(split.total, 1u);
                 if (slot < (unsigned)kMaxSplit) {
@@ -1377,7 +1495,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     // a wave with a twice-overflowed lane registers the block (once) for the cleanup kernel; its other results are
     // simply overwritten there with identical values
     if (__ballot(n < 0) != 0ull) {
-        if (lane == 0 && atomicExch(&s_bail, 1) == 0) ovf_list[atomicAdd(ovf_count, 1u)] = bid;
+        if (lane == 0 && atomicExch(&s_bail, 1) == 0) ovf_list[atomicAdd(ovf_count, 1u)] = (int)blockIdx.x * 4 + half;
         n = max(n, 0);
     }
     if (valid) {
@@ -1390,6 +1508,29 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         dm2[i] = tm;
     }
     stamp(5);
+    if constexpr (FTM != -2) {
+        // ---- K23 for this row, from LDS: weights at fm.P, the row's share of the 19 moments ----------------------
+        RowAcc acc;
+#pragma unroll
+        for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
+        if (valid && n > 0) {
+            double xrc[3];
+            rotated_centred(fm.P, q, xrc);
+            RowMoments<FTM> row;
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                const bool live = j < n;
+                const float4 y = L.get(live ? L.load(j) : 0);  // slot 0 of the halo for the unused pairs: finite, weight 0
+                row.add(fm.P, fm.md, xrc, y.x, y.y, y.z, live);
+            }
+            row.finish(acc, fm.P, q, xrc);
+        }
+        __syncthreads();  // every wave is through with the halo: the fold borrows its memory
+        double *const scratch = reinterpret_cast<double *>(s_halo);
+        // a block that was handed to the cleanup kernel (s_bail) leaves its slot to that kernel
+        block_reduce_scratch(acc, scratch, scratch + 10 * 257, fm.partials + blockIdx.x, (size_t)fm.nslots, s_bail == 0);
+        stamp(6);
+    }
     flush_stamps();
 }
 

@@ -390,9 +390,21 @@ def test_profile_reports_kernels(ctx):
     ctx.align(3, inner_steps=1)
     st = ctx.profile_get()
     ctx.profile_enable(False)
-    assert st["nn_topm_kernel"]["launches"] == 3 and st["accumulate_kernel"]["launches"] == 3, st
+    # K23 is its own launch for the first association only: from the second one on (temporal cut-off valid, steady-state
+    # K1) it is folded into K1; the fold-and-solve kernel runs every iteration
+    assert st["nn_topm_kernel"]["launches"] == 3 and st["accumulate_kernel"]["launches"] == 1, st
+    assert st["reduce_partials_kernel"]["launches"] == 3, st
     # the source move rides in the next K1 prologue; only the last one needs its own launch
     assert st["transform_kernel"]["launches"] == 1 and st["nn_topm_kernel"]["total_ms"] > 0
+    # with the fold switched off every iteration launches K23
+    ctx.set_option("fuse_k23", 0)
+    ctx.set_source(g["src"])
+    ctx.profile_enable(True)
+    ctx.align(3, inner_steps=1)
+    st = ctx.profile_get()
+    ctx.profile_enable(False)
+    ctx.set_option("fuse_k23", 1)
+    assert st["accumulate_kernel"]["launches"] == 3, st
 
 
 # ----------------------------------------------------------------------------- python mirror + batch
@@ -856,7 +868,7 @@ def test_device_pointer_inputs(ctx):
 
 
 @pytest.mark.parametrize("opts", [dict(short_lists=0), dict(mailbox=0), dict(sort_source=0), dict(sort_source=2),
-                                  dict(temporal=0, short_lists=0), dict(run_ahead=0)])
+                                  dict(temporal=0, short_lists=0), dict(run_ahead=0), dict(fuse_k23=0)])
 def test_every_tuning_option_keeps_the_result(ctx, opts):
     """ppcr_set_option knobs never change results: the association of every iteration is identical and the transforms
     agree to rounding with the default configuration."""
@@ -900,6 +912,7 @@ def test_align_run_ahead_is_exact():
         for ahead in (1, 0):
             with _lib.Context(0) as c:
                 c.set_option("run_ahead", ahead)
+                c.set_option("fuse_k23", 0)       # same kernels on both sides: bit-identical results expected
                 c.set_params(1.0, 10, 5.0, 3)
                 c.set_target(tgt)
                 c.set_source(src)
@@ -909,6 +922,14 @@ def test_align_run_ahead_is_exact():
                 res.append((r1, moved, r2, c.get_source()))
         (a1, am, a2, as2), (b1, bm, b2, bs2) = res
         assert a1["n_iter"] == b1["n_iter"], case
+        with _lib.Context(0) as c:   # the default: K23 folded into K1 — same moments in a different summation order
+            c.set_params(1.0, 10, 5.0, 3)
+            c.set_target(tgt)
+            c.set_source(src)
+            u1 = c.align(inner_steps=1, **case)
+        assert u1["n_iter"] == a1["n_iter"], case
+        np.testing.assert_allclose(u1["history"], a1["history"], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(u1["costs"], a1["costs"], rtol=1e-10)
         for key in ("history", "costs", "inner_steps"):
             np.testing.assert_array_equal(a1[key], b1[key], err_msg=str(case))
             np.testing.assert_array_equal(a2[key], b2[key], err_msg=str(case))
