@@ -436,11 +436,11 @@ constexpr int kFoldScratchBytes = (10 * 257 + kNSums * 8) * 8;  // 21 776
 // accumulate_ell_kernel: likelihoods relative to s = 0).  Used by the kernels that fold K23 into the association.
 template <int TM>
 struct RowMoments {
-    double Z = 0, G = 0, Gs = 0, Gy[3] = {0, 0, 0};
-    __device__ __forceinline__ void add(const Pose &P, const Model &md, const double (&xrc)[3], float yx, float yy, float yz, bool live)
+    double Z = 0, G = 0, Gs = 0, Gr[3] = {0, 0, 0};  // sum e, sum g, sum g s, sum g r   (r = y - (R x + t))
+    // xr = R x + t.  The centred target never appears: sum g (y - c) = sum g r + (xr - c) sum g.
+    __device__ __forceinline__ void add(const Model &md, const double (&xr)[3], float yx, float yy, float yz, bool live)
     {
-        const double y0 = (double)yx - P.c[0], y1 = (double)yy - P.c[1], y2 = (double)yz - P.c[2];
-        const double r0 = y0 - xrc[0], r1 = y1 - xrc[1], r2 = y2 - xrc[2];
+        const double r0 = (double)yx - xr[0], r1 = (double)yy - xr[1], r2 = (double)yz - xr[2];
         const double sk = fma(r2, r2, fma(r1, r1, r0 * r0));
         const double sv = live ? sk : 1e300;
         const double inv_vs = (TM == 0) ? 0.0 : fast_rcp(md.v + sv);
@@ -449,23 +449,26 @@ struct RowMoments {
         const double gk = (TM == 0) ? e : e * (md.vpd * inv_vs);
         G += gk;
         Gs = fma(gk, live ? sk : 0.0, Gs);
-        Gy[0] = fma(gk, y0, Gy[0]);
-        Gy[1] = fma(gk, y1, Gy[1]);
-        Gy[2] = fma(gk, y2, Gy[2]);
+        Gr[0] = fma(gk, r0, Gr[0]);
+        Gr[1] = fma(gk, r1, Gr[1]);
+        Gr[2] = fma(gk, r2, Gr[2]);
     }
-    __device__ __forceinline__ void finish(RowAcc &acc, const Pose &P, float4 xf, const double (&xrc)[3]) const
+    __device__ __forceinline__ void finish(RowAcc &acc, const Pose &P, float4 xf, const double (&xr)[3]) const
     {
+        const double xrc[3] = {xr[0] - P.c[0], xr[1] - P.c[1], xr[2] - P.c[2]};
+        const double Gy[3] = {fma(xrc[0], G, Gr[0]), fma(xrc[1], G, Gr[1]), fma(xrc[2], G, Gr[2])};
+        // sum g |y - c|^2 with y - c = r + xrc:  Gs + 2 xrc . Gr + |xrc|^2 G
         const double x2 = fma(xrc[2], xrc[2], fma(xrc[1], xrc[1], xrc[0] * xrc[0]));
-        const double Gyy = fma(-x2, G, fma(2.0, fma(xrc[2], Gy[2], fma(xrc[1], Gy[1], xrc[0] * Gy[0])), Gs));
+        const double Gyy = fma(x2, G, fma(2.0, fma(xrc[2], Gr[2], fma(xrc[1], Gr[1], xrc[0] * Gr[0])), Gs));
         row_finish(acc, P, xf, Z, G, Gs, Gyy, Gy);
     }
 };
-__device__ __forceinline__ void rotated_centred(const Pose &P, float4 xf, double (&xrc)[3])
+__device__ __forceinline__ void rotated_point(const Pose &P, float4 xf, double (&xr)[3])
 {
     const double px = xf.x, py = xf.y, pz = xf.z;
-    xrc[0] = fma(P.R[2], pz, fma(P.R[1], py, fma(P.R[0], px, P.t[0] - P.c[0])));
-    xrc[1] = fma(P.R[5], pz, fma(P.R[4], py, fma(P.R[3], px, P.t[1] - P.c[1])));
-    xrc[2] = fma(P.R[8], pz, fma(P.R[7], py, fma(P.R[6], px, P.t[2] - P.c[2])));
+    xr[0] = fma(P.R[2], pz, fma(P.R[1], py, fma(P.R[0], px, P.t[0])));
+    xr[1] = fma(P.R[5], pz, fma(P.R[4], py, fma(P.R[3], px, P.t[1])));
+    xr[2] = fma(P.R[8], pz, fma(P.R[7], py, fma(P.R[6], px, P.t[2])));
 }
 // K23 folded into the association: the pose and model the first IRLS half-step is evaluated at, and where this
 // workgroup's 19 partial sums go (slot = its index in the FAST kernel's grid; stride = number of slots)
@@ -1026,14 +1029,14 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
         for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
         const int nrow = valid ? cnt[i] : 0;
         if (nrow > 0) {
-            double xrc[3];
-            rotated_centred(fm.P, q, xrc);
+            double xr[3];
+            rotated_point(fm.P, q, xr);
             RowMoments<FTM> row;
             for (int j = 0; j < nrow; j++) {
                 const float4 y = tgt[nbr[(size_t)j * ns + i]];
-                row.add(fm.P, fm.md, xrc, y.x, y.y, y.z, true);
+                row.add(fm.md, xr, y.x, y.y, y.z, true);
             }
-            row.finish(acc, fm.P, q, xrc);
+            row.finish(acc, fm.P, q, xr);
         }
         double *const scratch = reinterpret_cast<double *>(s_halo);
         block_reduce_scratch(acc, scratch, scratch + 10 * 257, fm.partials + fast_slot, (size_t)fm.nslots, true);
@@ -1514,16 +1517,16 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
 #pragma unroll
         for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
         if (valid && n > 0) {
-            double xrc[3];
-            rotated_centred(fm.P, q, xrc);
+            double xr[3];
+            rotated_point(fm.P, q, xr);
             RowMoments<FTM> row;
 #pragma unroll
             for (int j = 0; j < M; j++) {
                 const bool live = j < n;
                 const float4 y = L.get(live ? L.load(j) : 0);  // slot 0 of the halo for the unused pairs: finite, weight 0
-                row.add(fm.P, fm.md, xrc, y.x, y.y, y.z, live);
+                row.add(fm.md, xr, y.x, y.y, y.z, live);
             }
-            row.finish(acc, fm.P, q, xrc);
+            row.finish(acc, fm.P, q, xr);
         }
         __syncthreads();  // every wave is through with the halo: the fold borrows its memory
         double *const scratch = reinterpret_cast<double *>(s_halo);
@@ -1777,27 +1780,12 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
                                fma(P.R[5], pz, fma(P.R[4], py, fma(P.R[3], px, P.t[1] - P.c[1]))),
                                fma(P.R[8], pz, fma(P.R[7], py, fma(P.R[6], px, P.t[2] - P.c[2])))};
         if constexpr (ONEPASS && TM >= 0) {
-            double Z = 0, G = 0, Gs = 0, Gy[3] = {0, 0, 0};
+            double xr[3];
+            rotated_point(P, xf[r], xr);
+            RowMoments<TM> row;
 #pragma unroll
-            for (int k = 0; k < W; k++) {
-                const double y0 = (double)yx[r][k] - P.c[0], y1 = (double)yy[r][k] - P.c[1], y2 = (double)yz[r][k] - P.c[2];
-                const double r0 = y0 - xrc[0], r1 = y1 - xrc[1], r2 = y2 - xrc[2];
-                const double sk = fma(r2, r2, fma(r1, r1, r0 * r0));
-                const bool live = k < n[r];
-                const double sv = live ? sk : 1e300;
-                const double inv_vs = (TM == 0) ? 0.0 : fast_rcp(md.v + sv);
-                const double e = rel_likelihood<TM>(md, sv, 0.0, 0.0, inv_vs);
-                Z += e;
-                const double gk = (TM == 0) ? e : e * (md.vpd * inv_vs);
-                G += gk;
-                Gs = fma(gk, live ? sk : 0.0, Gs);
-                Gy[0] = fma(gk, y0, Gy[0]);
-                Gy[1] = fma(gk, y1, Gy[1]);
-                Gy[2] = fma(gk, y2, Gy[2]);
-            }
-            const double x2 = fma(xrc[2], xrc[2], fma(xrc[1], xrc[1], xrc[0] * xrc[0]));
-            const double Gyy = fma(-x2, G, fma(2.0, fma(xrc[2], Gy[2], fma(xrc[1], Gy[1], xrc[0] * Gy[0])), Gs));
-            row_finish(acc, P, xf[r], Z, G, Gs, Gyy, Gy);
+            for (int k = 0; k < W; k++) row.add(md, xr, yx[r][k], yy[r][k], yz[r][k], k < n[r]);
+            row.finish(acc, P, xf[r], xr);
             continue;
         }
         double s[W], yc[W][3];
