@@ -139,7 +139,13 @@ int ppcr_stop_rule_check(ppcr_stop_rule *rule, int n_iter, double cost_drop_thre
 
 /* The whole align() loop including hasConverged() (cc:63-158).  history (n_iter*12 doubles,
  * cumulative transforms T_cum <- T_k*T_cum), costs (n_iter*2), steps (n_iter ints) may be NULL.
- * n_done receives the number of outer iterations performed. */
+ * n_done receives the number of outer iterations performed.
+ * n_iter < 0 = no iteration cap (the reference's meaning): then history, costs and steps must be NULL and
+ * cost_drop_thresh > 0 (PPCR_ERR_INVALID otherwise: the arrays could not be sized / the loop would never end).
+ * With inner_steps <= 1 the solve runs on the device and the next association takes its source move from device
+ * memory, so the device works one iteration ahead of this thread — but an iteration is only enqueued early when
+ * hasConverged() cannot stop before it whatever the pending cost turns out to be, so the iterations performed, and
+ * every number returned, are those of the one-at-a-time loop. */
 int ppcr_align(ppcr_ctx *ctx, int n_iter, double cost_drop_thresh, double n_cost_drop_it,
                const double q0[4], const double t0[3], int inner_steps, double f_tol, double *history,
                double *costs, int32_t *steps, int *n_done);
@@ -182,7 +188,9 @@ int ppcr_batch_run(const ppcr_pair *pairs, int64_t n_pairs, const ppcr_batch_opt
 
 /* The same loop over handles whose clouds are already resident (set_source/set_target done by the caller):
  * ppcr_align on each of the n handles, `lanes` of them in flight at a time on their own streams.
- * T_final: n*12 doubles; n_done: n ints or NULL.  Handles may live on different devices. */
+ * T_final: n*12 doubles; n_done: n ints or NULL.  Handles may live on different devices.
+ * With inner_steps <= 1 all handles are driven from the CALLING thread (it enqueues and polls their mailboxes; the
+ * devices pace themselves), so `lanes` costs no host threads; otherwise `lanes` worker threads are used. */
 int ppcr_align_many(ppcr_ctx *const *ctxs, int n, int lanes, int n_iter, double cost_drop_thresh,
                     double n_cost_drop_it, const double q0[4], const double t0[3], int inner_steps,
                     double f_tol, double *T_final, int32_t *n_done);
@@ -231,6 +239,10 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
 /* Tuning / debugging knobs (never change results): key is one of
  *   "sort_source"  0 keep caller order, 1 brick order, boustrophedon (default; see "brick_x"), 2 x-fastest cell order;
  *   "temporal"     1 start each query's cut-off from its previous m-th distance (default), 0 off;
+ *   "run_ahead"    1 ppcr_align keeps the device one iteration ahead of the host when the stopping rule allows
+ *                  (default), 0 one iteration at a time;
+ *   "fuse_k23"     1 ppcr_align's one-step iterations compute the weighted moments inside the association kernel
+ *                  (default; a different summation order: results agree to rounding), 0 separate kernel;
  *   "mailbox"      1 deliver the moments through pinned host memory and spin (default), 0 copy + synchronise;
  *   "grid_xf"      x slices per grid cell, 1/2/4/8 (default 4; set before the target): every stencil row is clipped
  *                  to the x window the search sphere needs in that row;
