@@ -479,8 +479,11 @@ void launch_tile(ppcr_ctx *c, float r2, int m, const PendingMove &pm, const Fuse
     constexpr int C = (M <= 24) ? 32 : 48;
     constexpr int CAP = (M <= 24) ? 2240 : 2048;
     const int nb = nblocks(c->ns, 256);
-    const SplitTable split_on{c->split_flag.p, c->split_list.p, c->split_state.p, c->split_state.p + 1, kMaxSplit};
-    const SplitTable split_off{nullptr, nullptr, nullptr, nullptr, 0};
+    // the steady-state variant acts on the split table (extra workgroups) and extends it; the first association only
+    // extends it (blocks whose fresh halo is already close to the steady-state capacity)
+    const SplitTable split_on{c->split_flag.p, c->split_list.p, c->split_state.p, c->split_state.p + 1, kMaxSplit, kCapSteady * 15 / 16};
+    const SplitTable split_off = (M <= 12) ? SplitTable{c->split_flag.p, c->split_list.p, c->split_state.p, c->split_state.p + 1, 0, kCapSteady * 15 / 16}
+                                           : SplitTable{nullptr, nullptr, nullptr, nullptr, 0, INT_MAX};  // no steady-state variant to split for
     FusedMoments fm_none;
     std::memset(&fm_none, 0, sizeof(fm_none));
     c->ovf_parity ^= 1;

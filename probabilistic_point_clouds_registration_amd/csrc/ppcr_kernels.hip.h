@@ -1131,6 +1131,8 @@ struct SplitTable {
     unsigned *total;          // registrations so far (may exceed kMaxSplit: the surplus is not split)
     const unsigned *visible;  // registrations the extra workgroups of THIS launch may act on (set by the cleanup kernel)
     int n_extra;              // extra workgroups at the front of this launch's grid (0: no splitting in this launch)
+    int presplit;             // a whole block whose halo exceeds this is registered for splitting BEFORE it overflows
+                              // (halos grow a few per cent per iteration as the source drifts: 15/16 of the capacity)
 };
 constexpr int kMaxSplit = 64;
 
@@ -1337,18 +1339,19 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         t_acc[6] = (unsigned long long)total;
         t_acc[7] = (unsigned long long)((ny_h << 8) | nz_h);
     }
-    if (!shape_ok || total > CAP) {  // uniform over the workgroup: derived from the shared boxes and cell_start only
-        if (tid == 0) {
-            // the cleanup kernel redoes this workgroup's queries (this launch): entry = grid index * 4 + half
-            ovf_list[atomicAdd(ovf_count, 1u)] = (int)blockIdx.x * 4 + half;
-            if (half == 0 && split.n_extra > 0) {       // ... and from the next launch on it is scanned in two halves
-                const unsigned slot = atomicAdd(split.total, 1u);
-                if (slot < (unsigned)kMaxSplit) {
-                    split.list[slot] = bid;
-                    split.flag[bid] = 1;
-                }
-            }
+    const bool handed_over = !shape_ok || total > CAP;  // uniform: derived from the shared boxes and cell_start only
+    if (tid == 0 && half == 0 && split.flag != nullptr && (handed_over || total > split.presplit) &&
+        (split.n_extra > 0 || !split.flag[bid])) {
+        // from the next launch on this block is scanned in two halves (n_extra > 0: half == 0 says it is not split yet)
+        const unsigned slot = atomicAdd(split.total, 1u);
+        if (slot < (unsigned)kMaxSplit) {
+            split.list[slot] = bid;
+            split.flag[bid] = 1;
         }
+    }
+    if (handed_over) {
+        // the cleanup kernel redoes this workgroup's queries (this launch): entry = grid index * 4 + half
+        if (tid == 0) ovf_list[atomicAdd(ovf_count, 1u)] = (int)blockIdx.x * 4 + half;
         flush_stamps();
         return;
     }
