@@ -182,6 +182,9 @@ struct ppcr_ctx {
     DevBuf<double> mse_part;
     int opt_short_lists = 1;
     int opt_fuse_k23 = 1;        // ppcr_align's one-step iterations fold K23 into the steady-state K1
+    int opt_merge_fold = 1;      // ... and the fold-and-solve step rides in the cleanup launch
+    bool shares_device = false;  // set by ppcr_align_many / ppcr_batch_run while other handles run on the same GPU
+    bool assoc_folded = false;   // the last association's launches included the fold-and-solve step
     bool assoc_fused = false;    // the last association also left the partial moments of the pose it was given
     int fused_slots = 0;         // ... in this many partial vectors
     int opt_run_ahead = 1;       // ppcr_align keeps the device one iteration ahead of the host when the rule allows
@@ -471,8 +474,11 @@ constexpr int kCapSteady = 1728;  // halo capacity of the 16-slot variant: 31.3 
 
 // fuse: when given (and the steady-state variant runs) K23 is folded into K1 for that pose/model; *fused tells whether
 // it was — the partials then have one slot per fast-kernel workgroup (nb + kMaxSplit)
+// fold (with fuse, steady-state variant only): when given, the fold-and-solve step rides in the cleanup launch and
+// *merged tells whether it did
 template <int M>
-void launch_tile(ppcr_ctx *c, float r2, int m, const PendingMove &pm, const FusedMoments *fuse, bool *fused)
+void launch_tile(ppcr_ctx *c, float r2, int m, const PendingMove &pm, const FusedMoments *fuse, bool *fused,
+                 const FoldSolve *fold = nullptr, bool *merged = nullptr)
 {
     unsigned long long *st = c->opt_stamps ? c->d_stamps.p : nullptr;
     const int dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
@@ -528,13 +534,21 @@ void launch_tile(ppcr_ctx *c, float r2, int m, const PendingMove &pm, const Fuse
     // persistent workgroups over the list: few when the last association this handle heard from handed nothing over
     const int cleanup_grid = (c->ovf_last == 0) ? std::min(nb, 32) : std::min(nb, 512);
     const int n_extra = steady ? kMaxSplit : 0;
-#define PPCR_CLEANUP(FTMc, FMc)                                                                                        \
-    nn_tile_cleanup_kernel<M, C, 256, CAP, FTMc><<<cleanup_grid, 256, 0, c->stream>>>(                                 \
+    FoldSolve fs_none;
+    std::memset(&fs_none, 0, sizeof(fs_none));
+    const bool merge = ftm != -2 && fold != nullptr;
+    if (merged) *merged = merge;
+    FoldSolve fold_now = fold ? *fold : fs_none;
+    fold_now.handed_over = ovf_now;  // this launch's counter (the parity was toggled above, after the fold was prepared)
+#define PPCR_CLEANUP(FTMc, FMc, MERGEc, FSc)                                                                           \
+    nn_tile_cleanup_kernel<M, C, 256, CAP, FTMc, MERGEc><<<cleanup_grid + (MERGEc ? kNSums : 0), 256, 0, c->stream>>>( \
         c->src.p, (int)c->ns, c->tgt_sorted.p, c->cell_start.p, c->grid, r2, m, c->nbr.p, c->cnt.p, c->dm2.p,          \
-        c->ovf_list.p, ovf_now, c->split_state.p, c->split_state.p + 1, c->split_list.p, n_extra, FMc)
-    if (ftm == 0) PPCR_CLEANUP(0, *fuse);
-    else if (ftm == 8) PPCR_CLEANUP(8, *fuse);
-    else PPCR_CLEANUP(-2, fm_none);
+        c->ovf_list.p, ovf_now, c->split_list.p, n_extra, FMc, FSc)
+    if (ftm == 0 && merge) PPCR_CLEANUP(0, *fuse, true, fold_now);
+    else if (ftm == 8 && merge) PPCR_CLEANUP(8, *fuse, true, fold_now);
+    else if (ftm == 0) PPCR_CLEANUP(0, *fuse, false, fs_none);
+    else if (ftm == 8) PPCR_CLEANUP(8, *fuse, false, fs_none);
+    else PPCR_CLEANUP(-2, fm_none, false, fs_none);
 #undef PPCR_CLEANUP
 }
 
@@ -572,7 +586,13 @@ int flush_pending_move(ppcr_ctx *c);
 // K1 (or the generic count/scan/fill path for unbounded searches and max_neighbours > 32).
 // fuse_R / fuse_t (nullable): the pose the first IRLS half-step will be evaluated at; when given, the steady-state K1
 // also produces that step's partial moments (c->assoc_fused, c->fused_slots) and the caller skips the K23 launch.
-int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse_t = nullptr)
+struct StepTicket {
+    unsigned seq = 0;  // mailbox sequence number (mailbox path)
+    int nb = 0;        // partial vectors to fold (copy path)
+};
+int prepare_fold(ppcr_ctx *c, int nslots, StepTicket &tk, FoldSolve &fs);
+// merge_tk (with a fuse pose): the fold-and-solve step may ride in the cleanup launch; c->assoc_folded tells whether it did
+int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse_t = nullptr, StepTicket *merge_tk = nullptr)
 {
     PPCR_TRY(ensure_grid(c));
     if (!c->src_sorted) PPCR_TRY(flush_pending_move(c));  // the one-time spatial sort reads the source
@@ -643,17 +663,32 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
                     fuse = &fm;
                 }
             }
-            bool fused = false;
+            bool fused = false, merged = false;
+            // the fold-and-solve step in the same launch as the cleanup: only worth preparing when K23 will be folded
+            // in, i.e. for the steady-state variant (dm2 valid, short lists, m <= 12)
+            FoldSolve fs;
+            const FoldSolve *fold = nullptr;
+            // (not when several handles share the GPU: the merged launch has the cleanup kernel's LDS / register
+            //  footprint, and its fold workgroups then queue behind other pairs' K1 blocks: 64 x 250k, 8 in flight:
+            //  24.0 k it/s merged against 28.2 k with the small fold kernel)
+            const bool steady_next = fuse && c->opt_merge_fold && !c->shares_device && c->opt_mailbox && c->opt_temporal && c->dm2_valid &&
+                                     c->opt_short_lists && m <= 12 && !c->opt_stamps;
+            if (merge_tk && steady_next) {
+                PPCR_TRY(prepare_fold(c, fm.nslots, *merge_tk, fs));
+                fold = &fs;
+            }
             ProfScope ps(c, K_NN_TOPM);
-            if (m <= 4) launch_tile<4>(c, r2, m, pm, fuse, &fused);
-            else if (m <= 5) launch_tile<5>(c, r2, m, pm, fuse, &fused);
-            else if (m <= 8) launch_tile<8>(c, r2, m, pm, fuse, &fused);
-            else if (m <= 10) launch_tile<10>(c, r2, m, pm, fuse, &fused);
-            else if (m <= 16) launch_tile<16>(c, r2, m, pm, fuse, &fused);
-            else if (m <= 20) launch_tile<20>(c, r2, m, pm, fuse, &fused);
-            else launch_tile<32>(c, r2, m, pm, fuse, &fused);
+            if (m <= 4) launch_tile<4>(c, r2, m, pm, fuse, &fused, fold, &merged);
+            else if (m <= 5) launch_tile<5>(c, r2, m, pm, fuse, &fused, fold, &merged);
+            else if (m <= 8) launch_tile<8>(c, r2, m, pm, fuse, &fused, fold, &merged);
+            else if (m <= 10) launch_tile<10>(c, r2, m, pm, fuse, &fused, fold, &merged);
+            else if (m <= 16) launch_tile<16>(c, r2, m, pm, fuse, &fused, fold, &merged);
+            else if (m <= 20) launch_tile<20>(c, r2, m, pm, fuse, &fused, fold, &merged);
+            else launch_tile<32>(c, r2, m, pm, fuse, &fused, fold, &merged);
             c->assoc_fused = fused;
+            c->assoc_folded = merged;
             c->fused_slots = fused ? fm.nslots : 0;
+            if (fold && !merged) return fail(c, PPCR_ERR_STATE, "internal: a fold was prepared but not launched");
         }
         c->assoc_space = 1;
         PPCR_TRY(check_launch(c, "nn_tile_kernel"));
@@ -833,10 +868,32 @@ struct StepResult {
     double cost;       // 0.5 * sum w |y - R x - t|^2 at T (Ceres' convention)
     bool degenerate;   // no weight mass: T = identity
 };
-struct StepTicket {
-    unsigned seq = 0;  // mailbox sequence number (mailbox path)
-    int nb = 0;        // partial vectors to fold (copy path)
-};
+// buffers and arguments of one fold-and-solve step; draws the step's mailbox sequence number
+int prepare_fold(ppcr_ctx *c, int nslots, StepTicket &tk, FoldSolve &fs)
+{
+    HIP_TRY(c, c->d_sums.reserve(kNSums));
+    HIP_TRY(c, c->d_pose.reserve(1));
+    if (!c->d_ticket.p) {
+        HIP_TRY(c, c->d_ticket.reserve(2));
+        HIP_TRY(c, hipMemsetAsync(c->d_ticket.p, 0, 2 * sizeof(unsigned), c->stream));
+    }
+    tk.seq = ++c->mbox_seq;
+    tk.nb = nslots;
+    fs.partials = c->partials.p;
+    fs.nslots = nslots;
+    fs.sums = c->d_sums.p;
+    fs.origin = make_double3(c->origin[0], c->origin[1], c->origin[2]);
+    fs.pose_out = c->d_pose.p;
+    fs.mbox = c->d_mbox + (tk.seq % kMailboxRing);
+    fs.ticket = c->d_ticket.p;
+    fs.seq = tk.seq;
+    fs.handed_over = c->ovf_state.p ? c->ovf_state.p + c->ovf_parity : nullptr;
+    fs.split_list = c->split_clean ? c->split_list.p : nullptr;
+    fs.split_flag = c->split_clean ? c->split_flag.p : nullptr;
+    fs.split_total = c->split_clean ? c->split_state.p : nullptr;
+    fs.split_visible = c->split_clean ? c->split_state.p + 1 : nullptr;
+    return PPCR_OK;
+}
 
 // enqueue K23 + fold (+ solve); nothing here waits for the device.  use_fused: the association just made already
 // produced the partial moments for this pose (associate_impl with a fuse pose): only the fold and the solve remain.
@@ -857,11 +914,6 @@ int launch_step(ppcr_ctx *c, const Mat3 &R, const double t[3], StepTicket &tk, b
                              : (ell_rows ? std::max(1, nblocks(ns, kAccumBlock * kAccumRows)) : std::max(1, std::min(kAccumMaxBlocks, nblocks(ns))));
     HIP_TRY(c, c->partials.reserve((size_t)nb * kNSums));
     HIP_TRY(c, c->d_sums.reserve(kNSums));
-    HIP_TRY(c, c->d_pose.reserve(1));
-    if (!c->d_ticket.p) {
-        HIP_TRY(c, c->d_ticket.reserve(1));
-        HIP_TRY(c, hipMemsetAsync(c->d_ticket.p, 0, sizeof(unsigned), c->stream));
-    }
     if (!use_fused) {
         ProfScope ps(c, K_ACCUMULATE);
         if (c->assoc == ppcr_ctx::ASSOC_ELL && c->nt > 0) {
@@ -884,14 +936,12 @@ int launch_step(ppcr_ctx *c, const Mat3 &R, const double t[3], StepTicket &tk, b
     tk.nb = nb;
     if (c->opt_mailbox) {
         // fold + solve on the device; moments, transform and cost arrive in the host mailbox ring
-        tk.seq = ++c->mbox_seq;
+        FoldSolve fs;
+        PPCR_TRY(prepare_fold(c, nb, tk, fs));
         const auto tl0 = std::chrono::steady_clock::now();
         {
             ProfScope ps(c, K_REDUCE);
-            reduce_solve_kernel<<<kNSums, kBlock, 0, c->stream>>>(c->partials.p, nb, c->d_sums.p,
-                                                               make_double3(c->origin[0], c->origin[1], c->origin[2]),
-                                                               c->d_pose.p, c->d_mbox + (tk.seq % kMailboxRing), c->d_ticket.p,
-                                                               tk.seq, c->ovf_state.p ? c->ovf_state.p + c->ovf_parity : nullptr);
+            reduce_solve_kernel<<<kNSums, kBlock, 0, c->stream>>>(fs);
         }
         PPCR_TRY(check_launch(c, "reduce_solve_kernel"));
         c->dbg_host[6] = std::max(c->dbg_host[6], std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count());
@@ -1211,6 +1261,10 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
         if (value != 1 && value != 2 && value != 4) return fail(c, PPCR_ERR_INVALID, "brick_x must be 1, 2 or 4");
         c->opt_brick_xshift = value == 1 ? 0 : (value == 2 ? 1 : 2);
         c->src_sorted = false;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "merge_fold") == 0) {
+        c->opt_merge_fold = value ? 1 : 0;
         return PPCR_OK;
     }
     if (std::strcmp(key, "fuse_k23") == 0) {
@@ -1633,8 +1687,8 @@ struct AlignJob {
     {
         // moves the source by the previous iteration's transform in its prologue and (steady state) leaves this
         // iteration's partial moments at (q0, t0) behind: K23 folded in
-        PPCR_TRY(associate_impl(c, &R0, t0));
-        PPCR_TRY(launch_step(c, R0, t0, in_flight[enq & 1], c->assoc_fused));
+        PPCR_TRY(associate_impl(c, &R0, t0, &in_flight[enq & 1]));
+        if (!c->assoc_folded) PPCR_TRY(launch_step(c, R0, t0, in_flight[enq & 1], c->assoc_fused));
         c->move_on_device = true;     // ... and this iteration's transform is the next pending move
         enq++;
         return PPCR_OK;
@@ -2207,6 +2261,15 @@ int ppcr_align_many(ppcr_ctx *const *ctxs, int n, int lanes, int n_iter, double 
             all_pipelined = jobs.back().pipelined;
         }
         if (all_pipelined) {
+            for (int k = 0; k < n; k++) ctxs[k]->shares_device = lanes > 1;
+            struct Unshare {  // whatever way this scope is left
+                ppcr_ctx *const *ctxs;
+                int n;
+                ~Unshare()
+                {
+                    for (int k = 0; k < n; k++) ctxs[k]->shares_device = false;
+                }
+            } unshare{ctxs, n};
             int next_job = 0, retired = 0;
             std::vector<int> window;  // indices of the jobs in flight
             while (retired < n) {
@@ -2290,6 +2353,7 @@ int ppcr_batch_run(const ppcr_pair *pairs, int64_t n_pairs, const ppcr_batch_opt
             first.set(rc, ppcr_last_error(nullptr));
             return;
         }
+        c->shares_device = lanes_per_device > 1;
         for (;;) {
             const int64_t k = next[d].fetch_add(1);
             const int64_t p = (int64_t)d + k * n_devices;

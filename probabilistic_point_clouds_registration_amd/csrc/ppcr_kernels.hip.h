@@ -669,6 +669,333 @@ struct PendingMove {
     const Pose *dev;
 };
 
+// ---------------------------------------------------------------------------------------------
+// The closed-form weighted rigid solve for ONE lane (it sits on the iteration's critical path right behind the moment
+// fold, with the whole chip waiting): the algorithm of solve_rigid_from_moments / svd3 / cost_from_moments in
+// ppcr_host_math.hpp — one-sided Jacobi SVD of the 3x3 cross-covariance, rank handling, R = V diag(1,1,d) U^T — written
+// for latency: every index is static (the shared source indexes small arrays dynamically, which lands in scratch
+// memory: ~9 us measured), reciprocals and roots are v_rcp_f64 / v_rsq_f64 seeds with two Newton steps instead of the
+// IEEE sequences (a Jacobi rotation only has to be orthogonal to rounding, and it is: c^2 (1 + t^2) = 1 to ~1 ulp).
+// Agrees with the host solve to a few ulp of the moments; the oracle tolerance on transforms is 1e-5.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double fast_rsqrt(double x)  // x > 0, finite
+{
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r;
+}
+
+struct DeviceSolve {
+    double R[9], t[3], cost;
+    bool degenerate;
+};
+
+__device__ __forceinline__ void jacobi_pair(double (&w)[3][3], double (&v)[3][3], const int p, const int q, bool &rotated)
+{
+    const double alpha = w[0][p] * w[0][p] + w[1][p] * w[1][p] + w[2][p] * w[2][p];
+    const double beta = w[0][q] * w[0][q] + w[1][q] * w[1][q] + w[2][q] * w[2][q];
+    const double gamma = w[0][p] * w[0][q] + w[1][p] * w[1][q] + w[2][p] * w[2][q];
+    if (gamma * gamma <= 1e-32 * (alpha * beta)) return;  // columns orthogonal to rounding (also gamma == 0)
+    rotated = true;
+    const double zeta = (beta - alpha) * fast_rcp(2.0 * fabs(gamma)) * (gamma < 0 ? -1.0 : 1.0);
+    const double az = fabs(zeta), h2 = fma(zeta, zeta, 1.0);
+    const double tn = (zeta < 0 ? -1.0 : 1.0) * fast_rcp(az + h2 * fast_rsqrt(h2));
+    const double c = fast_rsqrt(fma(tn, tn, 1.0)), sn = c * tn;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const double wp = w[r][p], wq = w[r][q];
+        w[r][p] = c * wp - sn * wq;
+        w[r][q] = sn * wp + c * wq;
+        const double vp = v[r][p], vq = v[r][q];
+        v[r][p] = c * vp - sn * vq;
+        v[r][q] = sn * vp + c * vq;
+    }
+}
+
+__device__ __forceinline__ void swap_cols(double (&w)[3][3], double (&v)[3][3], double (&len)[3], const int a, const int b)
+{
+    if (len[b] > len[a]) {
+        double tmp = len[a];
+        len[a] = len[b];
+        len[b] = tmp;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            tmp = w[r][a], w[r][a] = w[r][b], w[r][b] = tmp;
+            tmp = v[r][a], v[r][a] = v[r][b], v[r][b] = tmp;
+        }
+    }
+}
+
+// Rotation of the weighted Kabsch problem by Newton's iteration for the polar decomposition,
+//     X <- (z X + X^-T / z) / 2,   z = sqrt(|X^-1|_F / |X|_F),   X_0 = H^T,
+// which converges quadratically to the orthogonal factor V U^T of H^T = V S U^T: the same R as the SVD route whenever
+// det H > 0 (no reflection to repair) — i.e. for every well-posed registration.  An iteration is a 3x3 adjugate with
+// all nine cofactors independent, so the dependent chain is ~a dozen operations (a Jacobi sweep is three rotations of
+// ~70 dependent operations each).  Returns false (and the caller takes the Jacobi SVD route with its rank handling)
+// when H is singular to working precision, contains a reflection, or the iteration has not settled.
+__device__ __forceinline__ bool polar_rotation(const double (&h)[3][3], double (&R)[9])
+{
+    double x[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) x[a][b] = h[b][a];
+    bool settled = false;
+    for (int it = 0; it < 24; ++it) {
+        double cf[3][3];  // cofactors: X^-T = cf / det
+        cf[0][0] = x[1][1] * x[2][2] - x[1][2] * x[2][1];
+        cf[0][1] = x[1][2] * x[2][0] - x[1][0] * x[2][2];
+        cf[0][2] = x[1][0] * x[2][1] - x[1][1] * x[2][0];
+        cf[1][0] = x[0][2] * x[2][1] - x[0][1] * x[2][2];
+        cf[1][1] = x[0][0] * x[2][2] - x[0][2] * x[2][0];
+        cf[1][2] = x[0][1] * x[2][0] - x[0][0] * x[2][1];
+        cf[2][0] = x[0][1] * x[1][2] - x[0][2] * x[1][1];
+        cf[2][1] = x[0][2] * x[1][0] - x[0][0] * x[1][2];
+        cf[2][2] = x[0][0] * x[1][1] - x[0][1] * x[1][0];
+        const double det = x[0][0] * cf[0][0] + x[0][1] * cf[0][1] + x[0][2] * cf[0][2];
+        double nx = 0, nc = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                nx = fma(x[a][b], x[a][b], nx);
+                nc = fma(cf[a][b], cf[a][b], nc);
+            }
+        // well conditioned and orientation preserving?  (|X|_F^3 bounds |det|; 1e-9 leaves cond(H) up to ~1e4-1e9 here)
+        if (!(det > 1e-9 * nx * sqrt(nx))) return false;
+        const double idet = fast_rcp(det);
+        // z^2 = |X^-T|_F / |X|_F = sqrt(nc) / (det sqrt(nx))
+        const double z2 = sqrt(nc) * idet * fast_rsqrt(nx);
+        const double z = sqrt(z2), a_x = 0.5 * z, a_c = 0.5 * idet * fast_rcp(z);
+        double diff = 0, nn = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                const double nv = a_x * x[a][b] + a_c * cf[a][b];
+                const double d = nv - x[a][b];
+                diff = fma(d, d, diff);
+                nn = fma(nv, nv, nn);
+                x[a][b] = nv;
+            }
+        if (diff <= 1e-30 * nn) {  // |X_{k+1} - X_k| <= 1e-15 |X|: converged to rounding
+            settled = true;
+            break;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) R[3 * a + b] = x[a][b];
+    return settled;
+}
+
+__device__ inline DeviceSolve solve_rigid_device(const double (&S)[kNSums], const double (&c)[3])
+{
+    DeviceSolve out;
+#pragma unroll
+    for (int k = 0; k < 9; k++) out.R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    out.t[0] = out.t[1] = out.t[2] = 0.0;
+    out.cost = 0.5 * S[16];
+    out.degenerate = true;
+    const double W = S[0];
+    if (!(W > 0) || !isfinite(W)) return out;
+    out.degenerate = false;
+    const double iW = 1.0 / W;
+    const double mx[3] = {S[1] * iW, S[2] * iW, S[3] * iW}, my[3] = {S[4] * iW, S[5] * iW, S[6] * iW};
+    double w[3][3], v[3][3];  // w = H = sum w (x - mx)(y - my)^T, columns rotated in place; v accumulates V
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            w[a][b] = S[7 + 3 * a + b] - S[1 + a] * my[b];
+            v[a][b] = (a == b) ? 1.0 : 0.0;
+        }
+    const bool polar_ok = polar_rotation(w, out.R);
+    if (!polar_ok) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) out.R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        bool rotated = false;
+        jacobi_pair(w, v, 0, 1, rotated);
+        jacobi_pair(w, v, 0, 2, rotated);
+        jacobi_pair(w, v, 1, 2, rotated);
+        if (!rotated) break;
+    }
+    double len[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const double n2 = w[0][j] * w[0][j] + w[1][j] * w[1][j] + w[2][j] * w[2][j];
+        len[j] = n2 > 0 ? n2 * fast_rsqrt(n2) : 0.0;
+    }
+    swap_cols(w, v, len, 0, 1);  // singular values descending
+    swap_cols(w, v, len, 0, 2);
+    swap_cols(w, v, len, 1, 2);
+    if (len[0] > 0) {
+        double u[3][3];  // columns of U
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double il = len[j] > 0 ? fast_rcp(len[j]) : 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; r++) u[r][j] = w[r][j] * il;
+        }
+        const double tiny = len[0] * 1e-14;
+        if (len[1] <= tiny) {  // rank 1: any unit vector orthogonal to u0 (cross with the axis u0 is least aligned with)
+            const double a0 = fabs(u[0][0]), a1 = fabs(u[1][0]), a2 = fabs(u[2][0]);
+            const bool pick1 = a1 < a0, pick2 = a2 < (pick1 ? a1 : a0);
+            const double e0 = (!pick1 && !pick2) ? 1.0 : 0.0, e1 = (pick1 && !pick2) ? 1.0 : 0.0, e2 = pick2 ? 1.0 : 0.0;
+            double x0 = u[1][0] * e2 - u[2][0] * e1, x1 = u[2][0] * e0 - u[0][0] * e2, x2 = u[0][0] * e1 - u[1][0] * e0;
+            const double in = fast_rsqrt(x0 * x0 + x1 * x1 + x2 * x2);
+            u[0][1] = x0 * in, u[1][1] = x1 * in, u[2][1] = x2 * in;
+        }
+        if (len[2] <= tiny || len[1] <= tiny) {
+            u[0][2] = u[1][0] * u[2][1] - u[2][0] * u[1][1];
+            u[1][2] = u[2][0] * u[0][1] - u[0][0] * u[2][1];
+            u[2][2] = u[0][0] * u[1][1] - u[1][0] * u[0][1];
+        }
+        auto det3 = [](const double (&m)[3][3]) {
+            return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                   m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+        };
+        // H = U S V^T with H = sum x y^T  =>  R = V diag(1,1,d) U^T maps x onto y
+        const double d = (det3(u) * det3(v) < 0) ? -1.0 : 1.0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) out.R[3 * a + b] = v[a][0] * u[b][0] + v[a][1] * u[b][1] + d * v[a][2] * u[b][2];
+    }
+    }
+    double Rmx[3], Rc[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        Rmx[a] = out.R[3 * a] * mx[0] + out.R[3 * a + 1] * mx[1] + out.R[3 * a + 2] * mx[2];
+        Rc[a] = out.R[3 * a] * c[0] + out.R[3 * a + 1] * c[1] + out.R[3 * a + 2] * c[2];
+        out.t[a] = (my[a] - Rmx[a]) + c[a] - Rc[a];
+    }
+    // 0.5 * sum w |y - R x - t|^2 from the moments (cost_from_moments)
+    double tp[3], RSx[3], yRx = 0, tpRSx = 0, tptp = 0, tpSy = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        tp[a] = out.t[a] + Rc[a] - c[a];
+        RSx[a] = out.R[3 * a] * S[1] + out.R[3 * a + 1] * S[2] + out.R[3 * a + 2] * S[3];
+#pragma unroll
+        for (int b = 0; b < 3; b++) yRx += out.R[3 * a + b] * S[7 + 3 * b + a];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        tpRSx += tp[a] * RSx[a];
+        tptp += tp[a] * tp[a];
+        tpSy += tp[a] * S[4 + a];
+    }
+    out.cost = 0.5 * (S[18] + S[17] + 2 * tpRSx + W * tptp - 2 * yRx - 2 * tpSy);
+    return out;
+}
+
+// Host mailbox in pinned, device-mapped memory: the fold-and-solve kernel writes the moments, the rigid transform it
+// solved from them and its cost there, then the sequence number (system-scope release); the host spins on `seq` — no
+// copy kernel and no stream synchronisation on the iteration's critical path.
+struct HostMailbox {
+    double sums[kNSums];
+    double T[12];        // [R|t] minimising sum w |y - R x - t|^2 for these moments (identity when degenerate)
+    double cost;         // 0.5 * sum w |y - R x - t|^2 at that transform
+    unsigned degenerate; // no weight mass
+    unsigned handed_over; // blocks the association's fast kernel left to the cleanup kernel (sizes the next cleanup grid)
+    unsigned seq;
+};
+
+// Fold of partials[19][nblocks] (one block per sum, fixed order: deterministic, no float atomics) FOLLOWED BY THE SOLVE:
+// the block that draws the last ticket reads the 19 moments back and one lane runs the closed-form weighted rigid
+// solve (solve_rigid_device above) and the cost at the solution.  The
+// transform goes to *pose_out in device memory, where the next association's prologue picks it up as its pending
+// source move (PendingMove::dev): the outer loop no longer waits for the host between iterations.  The host gets
+// everything through the mailbox and only trails behind for hasConverged() and the history.
+struct FoldSolve {  // everything the fold-and-solve step needs
+    const double *partials;
+    int nslots;
+    double *sums;
+    double3 origin;
+    Pose *pose_out;
+    HostMailbox *mbox;
+    unsigned *ticket;   // [0] ticket of the fold blocks, [1] list entries the cleanup role has finished (merged kernel)
+    unsigned seq;
+    const unsigned *handed_over;
+    // the split table of the fast K1 (nullable): registrations made by the association that just ran become visible
+    // to the next launch here, after the list has been put in ascending order of block id — the order in which blocks
+    // register within one launch depends on atomics, the order of the partial slots (and with it every sum) must not
+    int *split_list;
+    unsigned char *split_flag;
+    const unsigned *split_total;
+    unsigned *split_visible;
+};
+
+// one of the kNSums fold blocks (256 threads): fold row `sum_index` of the partials; the last block to finish solves
+__device__ __forceinline__ void fold_and_solve_block(const FoldSolve &fs, int sum_index)
+{
+    __shared__ double sh[kBlock / 64];
+    const double *row = fs.partials + (size_t)sum_index * fs.nslots;
+    double v = 0.0;
+    for (int b0 = 0; b0 < fs.nslots; b0 += 8 * kBlock) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int b = b0 + u * kBlock + threadIdx.x;
+            t[u] = (b < fs.nslots) ? row[b] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) v += t[u];
+    }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double x = sh[0];
+    for (int w = 1; w < kBlock / 64; w++) x += sh[w];
+    __hip_atomic_store(&fs.sums[sum_index], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    const unsigned tk = __hip_atomic_fetch_add(fs.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk != kNSums - 1) return;
+    __hip_atomic_store(fs.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(fs.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every fold block is past its wait
+    double S[kNSums];
+#pragma unroll
+    for (int j = 0; j < kNSums; j++) S[j] = __hip_atomic_load(&fs.sums[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double c[3] = {fs.origin.x, fs.origin.y, fs.origin.z};
+    const DeviceSolve rs = solve_rigid_device(S, c);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int b = 0; b < 3; b++) fs.pose_out->R[3 * a + b] = rs.R[3 * a + b];
+        fs.pose_out->t[a] = rs.t[a];
+        fs.pose_out->c[a] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < kNSums; j++) fs.mbox->sums[j] = S[j];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int b = 0; b < 3; b++) fs.mbox->T[4 * a + b] = rs.R[3 * a + b];
+        fs.mbox->T[4 * a + 3] = rs.t[a];
+    }
+    if (fs.split_visible) {
+        const int n_split = (int)min(*fs.split_total, 64u);
+        for (int a = 1; a < n_split; a++) {  // insertion sort: the list is nearly sorted, at most 64 long
+            const int key = fs.split_list[a];
+            int b = a - 1;
+            for (; b >= 0 && fs.split_list[b] > key; b--) fs.split_list[b + 1] = fs.split_list[b];
+            fs.split_list[b + 1] = key;
+        }
+        for (int a = 0; a < n_split; a++) fs.split_flag[fs.split_list[a]] = 2;  // ... and from now on they ARE split
+        *fs.split_visible = (unsigned)n_split;
+    }
+    fs.mbox->cost = rs.cost;
+    fs.mbox->degenerate = rs.degenerate ? 1u : 0u;
+    fs.mbox->handed_over = fs.handed_over ? *fs.handed_over : 0u;
+    __hip_atomic_store(&fs.mbox->seq, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(kBlock) void reduce_solve_kernel(FoldSolve fs) { fold_and_solve_block(fs, (int)blockIdx.x); }
+
 // GENERAL flavour of K1, run on the workgroups nn_fast_kernel hands over (ovf_list[0 .. *ovf_count)): halos of any
 // shape (up to 128 rows), binary subdivision when a halo does not fit, global-memory scan as the last resort, in-loop
 // list compaction for dense neighbourhoods.  The source has already been moved by the fast kernel and the temporal
@@ -680,7 +1007,10 @@ struct PendingMove {
 // 1 / 2 = only the queries of waves 0-1 / 2-3 (split blocks).  FTM >= 0: the fast kernel also folded K23 in, so this one
 // finishes the rows it redoes the same way (gathering their neighbours from global memory) and fills the slot of the
 // partials the fast workgroup left empty.
-template <int M, int C, int BLOCK, int CAP, int FTM = -2>
+// MERGED (with FTM >= 0): the launch also carries the fold-and-solve step as its last kNSums workgroups — they wait until
+// the cleanup role has finished every listed entry (nothing to wait for in the common case of an empty list) — which
+// saves the ~4 us a dependent launch costs even when it has nothing to do.
+template <int M, int C, int BLOCK, int CAP, int FTM = -2, bool MERGED = false>
 __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt,
                                                          const int *__restrict__ cell_start, GridDesc g,
@@ -688,14 +1018,27 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
                                                          int *__restrict__ cnt, unsigned *__restrict__ dm2,
                                                          const int *__restrict__ ovf_list,
                                                          const unsigned *__restrict__ ovf_count,
-                                                         const unsigned *__restrict__ split_total,
-                                                         unsigned *__restrict__ split_visible,
-                                                         const int *__restrict__ split_list, int n_extra, FusedMoments fm)
+                                                         const int *__restrict__ split_list, int n_extra, FusedMoments fm,
+                                                         FoldSolve fs)
 {
-    // blocks registered for splitting by the fast kernel that just ran may be acted on from the next launch on
-    if (blockIdx.x == 0 && threadIdx.x == 0 && split_visible) *split_visible = *split_total;
+    static_assert(!MERGED || FTM != -2, "the merged launch folds the partials the fused kernels wrote");
     const unsigned n_listed = *ovf_count;
-    for (unsigned listed = blockIdx.x; listed < n_listed; listed += gridDim.x) {
+    const unsigned n_cleanup = MERGED ? gridDim.x - kNSums : gridDim.x;  // workgroups in the cleanup role
+    if constexpr (MERGED) {
+        if (blockIdx.x >= n_cleanup) {
+            // fold role: the partials of the handed-over workgroups must be in place first
+            if (n_listed > 0) {
+                if (threadIdx.x == 0)
+                    while (__hip_atomic_load(fs.ticket + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n_listed)
+                        __builtin_amdgcn_s_sleep(8);
+                __syncthreads();
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            }
+            fold_and_solve_block(fs, (int)(blockIdx.x - n_cleanup));
+            return;
+        }
+    }
+    for (unsigned listed = blockIdx.x; listed < n_listed; listed += n_cleanup) {
     const int entry = ovf_list[listed];
     const int fast_slot = entry >> 2, half = entry & 3;
     const int bid = fast_slot < n_extra ? split_list[fast_slot] : fast_slot - n_extra;
@@ -1041,6 +1384,12 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
         double *const scratch = reinterpret_cast<double *>(s_halo);
         block_reduce_scratch(acc, scratch, scratch + 10 * 257, fm.partials + fast_slot, (size_t)fm.nslots, true);
         __syncthreads();
+        if constexpr (MERGED) {
+            if (threadIdx.x == 0) {  // this entry's partials are written: let the fold role count it
+                __atomic_thread_fence(__ATOMIC_RELEASE);
+                __hip_atomic_fetch_add(fs.ticket + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
     }
 }
@@ -1126,7 +1475,7 @@ struct HaloList {
 // effect at the next launch (the bailing block itself goes to the cleanup kernel this once), so a small CAP — five
 // workgroups per CU instead of four — costs one cleanup launch per newly outgrown block, not one per iteration.
 struct SplitTable {
-    unsigned char *flag;      // [nblocks] 1: split
+    unsigned char *flag;      // [nblocks] 0: whole, 1: registered for splitting, 2: split (an extra workgroup scans waves 2-3)
     int *list;                // [kMaxSplit] block ids, in order of registration
     unsigned *total;          // registrations so far (may exceed kMaxSplit: the surplus is not split)
     const unsigned *visible;  // registrations the extra workgroups of THIS launch may act on (set by the cleanup kernel)
@@ -1198,7 +1547,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         half = 2;
     } else {
         bid = (int)blockIdx.x - split.n_extra;
-        if (split.n_extra > 0 && split.flag[bid]) half = 1;
+        if (split.n_extra > 0 && split.flag[bid] == 2) half = 1;
     }
     const int i = bid * BLOCK + tid;
     const bool valid = i < ns && (half == 0 || (wave >> 1) == half - 1);  // lanes whose query this workgroup owns
@@ -1340,9 +1689,9 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         t_acc[7] = (unsigned long long)((ny_h << 8) | nz_h);
     }
     const bool handed_over = !shape_ok || total > CAP;  // uniform: derived from the shared boxes and cell_start only
-    if (tid == 0 && half == 0 && split.flag != nullptr && (handed_over || total > split.presplit) &&
-        (split.n_extra > 0 || !split.flag[bid])) {
-        // from the next launch on this block is scanned in two halves (n_extra > 0: half == 0 says it is not split yet)
+    if (tid == 0 && half == 0 && split.flag != nullptr && (handed_over || total > split.presplit) && !split.flag[bid]) {
+        // once the fold-and-solve step has published the registration (flag 2, sorted list) this block is scanned in
+        // two halves
         const unsigned slot = atomicAdd(split.total, 1u);
         if (slot < (unsigned)kMaxSplit) {
             split.list[slot] = bid;
@@ -1855,303 +2204,6 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double *_
         for (int w = 1; w < kBlock / 64; w++) x += sh[w];
         sums[blockIdx.x] = x;
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// The closed-form weighted rigid solve for ONE lane (it sits on the iteration's critical path right behind the moment
-// fold, with the whole chip waiting): the algorithm of solve_rigid_from_moments / svd3 / cost_from_moments in
-// ppcr_host_math.hpp — one-sided Jacobi SVD of the 3x3 cross-covariance, rank handling, R = V diag(1,1,d) U^T — written
-// for latency: every index is static (the shared source indexes small arrays dynamically, which lands in scratch
-// memory: ~9 us measured), reciprocals and roots are v_rcp_f64 / v_rsq_f64 seeds with two Newton steps instead of the
-// IEEE sequences (a Jacobi rotation only has to be orthogonal to rounding, and it is: c^2 (1 + t^2) = 1 to ~1 ulp).
-// Agrees with the host solve to a few ulp of the moments; the oracle tolerance on transforms is 1e-5.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double fast_rsqrt(double x)  // x > 0, finite
-{
-    double r = __builtin_amdgcn_rsq(x);
-    r = r * fma(-0.5 * x * r, r, 1.5);
-    r = r * fma(-0.5 * x * r, r, 1.5);
-    return r;
-}
-
-struct DeviceSolve {
-    double R[9], t[3], cost;
-    bool degenerate;
-};
-
-__device__ __forceinline__ void jacobi_pair(double (&w)[3][3], double (&v)[3][3], const int p, const int q, bool &rotated)
-{
-    const double alpha = w[0][p] * w[0][p] + w[1][p] * w[1][p] + w[2][p] * w[2][p];
-    const double beta = w[0][q] * w[0][q] + w[1][q] * w[1][q] + w[2][q] * w[2][q];
-    const double gamma = w[0][p] * w[0][q] + w[1][p] * w[1][q] + w[2][p] * w[2][q];
-    if (gamma * gamma <= 1e-32 * (alpha * beta)) return;  // columns orthogonal to rounding (also gamma == 0)
-    rotated = true;
-    const double zeta = (beta - alpha) * fast_rcp(2.0 * fabs(gamma)) * (gamma < 0 ? -1.0 : 1.0);
-    const double az = fabs(zeta), h2 = fma(zeta, zeta, 1.0);
-    const double tn = (zeta < 0 ? -1.0 : 1.0) * fast_rcp(az + h2 * fast_rsqrt(h2));
-    const double c = fast_rsqrt(fma(tn, tn, 1.0)), sn = c * tn;
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const double wp = w[r][p], wq = w[r][q];
-        w[r][p] = c * wp - sn * wq;
-        w[r][q] = sn * wp + c * wq;
-        const double vp = v[r][p], vq = v[r][q];
-        v[r][p] = c * vp - sn * vq;
-        v[r][q] = sn * vp + c * vq;
-    }
-}
-
-__device__ __forceinline__ void swap_cols(double (&w)[3][3], double (&v)[3][3], double (&len)[3], const int a, const int b)
-{
-    if (len[b] > len[a]) {
-        double tmp = len[a];
-        len[a] = len[b];
-        len[b] = tmp;
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            tmp = w[r][a], w[r][a] = w[r][b], w[r][b] = tmp;
-            tmp = v[r][a], v[r][a] = v[r][b], v[r][b] = tmp;
-        }
-    }
-}
-
-// Rotation of the weighted Kabsch problem by Newton's iteration for the polar decomposition,
-//     X <- (z X + X^-T / z) / 2,   z = sqrt(|X^-1|_F / |X|_F),   X_0 = H^T,
-// which converges quadratically to the orthogonal factor V U^T of H^T = V S U^T: the same R as the SVD route whenever
-// det H > 0 (no reflection to repair) — i.e. for every well-posed registration.  An iteration is a 3x3 adjugate with
-// all nine cofactors independent, so the dependent chain is ~a dozen operations (a Jacobi sweep is three rotations of
-// ~70 dependent operations each).  Returns false (and the caller takes the Jacobi SVD route with its rank handling)
-// when H is singular to working precision, contains a reflection, or the iteration has not settled.
-__device__ __forceinline__ bool polar_rotation(const double (&h)[3][3], double (&R)[9])
-{
-    double x[3][3];
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int b = 0; b < 3; b++) x[a][b] = h[b][a];
-    bool settled = false;
-    for (int it = 0; it < 24; ++it) {
-        double cf[3][3];  // cofactors: X^-T = cf / det
-        cf[0][0] = x[1][1] * x[2][2] - x[1][2] * x[2][1];
-        cf[0][1] = x[1][2] * x[2][0] - x[1][0] * x[2][2];
-        cf[0][2] = x[1][0] * x[2][1] - x[1][1] * x[2][0];
-        cf[1][0] = x[0][2] * x[2][1] - x[0][1] * x[2][2];
-        cf[1][1] = x[0][0] * x[2][2] - x[0][2] * x[2][0];
-        cf[1][2] = x[0][1] * x[2][0] - x[0][0] * x[2][1];
-        cf[2][0] = x[0][1] * x[1][2] - x[0][2] * x[1][1];
-        cf[2][1] = x[0][2] * x[1][0] - x[0][0] * x[1][2];
-        cf[2][2] = x[0][0] * x[1][1] - x[0][1] * x[1][0];
-        const double det = x[0][0] * cf[0][0] + x[0][1] * cf[0][1] + x[0][2] * cf[0][2];
-        double nx = 0, nc = 0;
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) {
-                nx = fma(x[a][b], x[a][b], nx);
-                nc = fma(cf[a][b], cf[a][b], nc);
-            }
-        // well conditioned and orientation preserving?  (|X|_F^3 bounds |det|; 1e-9 leaves cond(H) up to ~1e4-1e9 here)
-        if (!(det > 1e-9 * nx * sqrt(nx))) return false;
-        const double idet = fast_rcp(det);
-        // z^2 = |X^-T|_F / |X|_F = sqrt(nc) / (det sqrt(nx))
-        const double z2 = sqrt(nc) * idet * fast_rsqrt(nx);
-        const double z = sqrt(z2), a_x = 0.5 * z, a_c = 0.5 * idet * fast_rcp(z);
-        double diff = 0, nn = 0;
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) {
-                const double nv = a_x * x[a][b] + a_c * cf[a][b];
-                const double d = nv - x[a][b];
-                diff = fma(d, d, diff);
-                nn = fma(nv, nv, nn);
-                x[a][b] = nv;
-            }
-        if (diff <= 1e-30 * nn) {  // |X_{k+1} - X_k| <= 1e-15 |X|: converged to rounding
-            settled = true;
-            break;
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int b = 0; b < 3; b++) R[3 * a + b] = x[a][b];
-    return settled;
-}
-
-__device__ inline DeviceSolve solve_rigid_device(const double (&S)[kNSums], const double (&c)[3])
-{
-    DeviceSolve out;
-#pragma unroll
-    for (int k = 0; k < 9; k++) out.R[k] = (k % 4 == 0) ? 1.0 : 0.0;
-    out.t[0] = out.t[1] = out.t[2] = 0.0;
-    out.cost = 0.5 * S[16];
-    out.degenerate = true;
-    const double W = S[0];
-    if (!(W > 0) || !isfinite(W)) return out;
-    out.degenerate = false;
-    const double iW = 1.0 / W;
-    const double mx[3] = {S[1] * iW, S[2] * iW, S[3] * iW}, my[3] = {S[4] * iW, S[5] * iW, S[6] * iW};
-    double w[3][3], v[3][3];  // w = H = sum w (x - mx)(y - my)^T, columns rotated in place; v accumulates V
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int b = 0; b < 3; b++) {
-            w[a][b] = S[7 + 3 * a + b] - S[1 + a] * my[b];
-            v[a][b] = (a == b) ? 1.0 : 0.0;
-        }
-    const bool polar_ok = polar_rotation(w, out.R);
-    if (!polar_ok) {
-#pragma unroll
-    for (int k = 0; k < 9; k++) out.R[k] = (k % 4 == 0) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 64; ++sweep) {
-        bool rotated = false;
-        jacobi_pair(w, v, 0, 1, rotated);
-        jacobi_pair(w, v, 0, 2, rotated);
-        jacobi_pair(w, v, 1, 2, rotated);
-        if (!rotated) break;
-    }
-    double len[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        const double n2 = w[0][j] * w[0][j] + w[1][j] * w[1][j] + w[2][j] * w[2][j];
-        len[j] = n2 > 0 ? n2 * fast_rsqrt(n2) : 0.0;
-    }
-    swap_cols(w, v, len, 0, 1);  // singular values descending
-    swap_cols(w, v, len, 0, 2);
-    swap_cols(w, v, len, 1, 2);
-    if (len[0] > 0) {
-        double u[3][3];  // columns of U
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const double il = len[j] > 0 ? fast_rcp(len[j]) : 0.0;
-#pragma unroll
-            for (int r = 0; r < 3; r++) u[r][j] = w[r][j] * il;
-        }
-        const double tiny = len[0] * 1e-14;
-        if (len[1] <= tiny) {  // rank 1: any unit vector orthogonal to u0 (cross with the axis u0 is least aligned with)
-            const double a0 = fabs(u[0][0]), a1 = fabs(u[1][0]), a2 = fabs(u[2][0]);
-            const bool pick1 = a1 < a0, pick2 = a2 < (pick1 ? a1 : a0);
-            const double e0 = (!pick1 && !pick2) ? 1.0 : 0.0, e1 = (pick1 && !pick2) ? 1.0 : 0.0, e2 = pick2 ? 1.0 : 0.0;
-            double x0 = u[1][0] * e2 - u[2][0] * e1, x1 = u[2][0] * e0 - u[0][0] * e2, x2 = u[0][0] * e1 - u[1][0] * e0;
-            const double in = fast_rsqrt(x0 * x0 + x1 * x1 + x2 * x2);
-            u[0][1] = x0 * in, u[1][1] = x1 * in, u[2][1] = x2 * in;
-        }
-        if (len[2] <= tiny || len[1] <= tiny) {
-            u[0][2] = u[1][0] * u[2][1] - u[2][0] * u[1][1];
-            u[1][2] = u[2][0] * u[0][1] - u[0][0] * u[2][1];
-            u[2][2] = u[0][0] * u[1][1] - u[1][0] * u[0][1];
-        }
-        auto det3 = [](const double (&m)[3][3]) {
-            return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
-                   m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
-        };
-        // H = U S V^T with H = sum x y^T  =>  R = V diag(1,1,d) U^T maps x onto y
-        const double d = (det3(u) * det3(v) < 0) ? -1.0 : 1.0;
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) out.R[3 * a + b] = v[a][0] * u[b][0] + v[a][1] * u[b][1] + d * v[a][2] * u[b][2];
-    }
-    }
-    double Rmx[3], Rc[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        Rmx[a] = out.R[3 * a] * mx[0] + out.R[3 * a + 1] * mx[1] + out.R[3 * a + 2] * mx[2];
-        Rc[a] = out.R[3 * a] * c[0] + out.R[3 * a + 1] * c[1] + out.R[3 * a + 2] * c[2];
-        out.t[a] = (my[a] - Rmx[a]) + c[a] - Rc[a];
-    }
-    // 0.5 * sum w |y - R x - t|^2 from the moments (cost_from_moments)
-    double tp[3], RSx[3], yRx = 0, tpRSx = 0, tptp = 0, tpSy = 0;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        tp[a] = out.t[a] + Rc[a] - c[a];
-        RSx[a] = out.R[3 * a] * S[1] + out.R[3 * a + 1] * S[2] + out.R[3 * a + 2] * S[3];
-#pragma unroll
-        for (int b = 0; b < 3; b++) yRx += out.R[3 * a + b] * S[7 + 3 * b + a];
-    }
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        tpRSx += tp[a] * RSx[a];
-        tptp += tp[a] * tp[a];
-        tpSy += tp[a] * S[4 + a];
-    }
-    out.cost = 0.5 * (S[18] + S[17] + 2 * tpRSx + W * tptp - 2 * yRx - 2 * tpSy);
-    return out;
-}
-
-// Host mailbox in pinned, device-mapped memory: the fold-and-solve kernel writes the moments, the rigid transform it
-// solved from them and its cost there, then the sequence number (system-scope release); the host spins on `seq` — no
-// copy kernel and no stream synchronisation on the iteration's critical path.
-struct HostMailbox {
-    double sums[kNSums];
-    double T[12];        // [R|t] minimising sum w |y - R x - t|^2 for these moments (identity when degenerate)
-    double cost;         // 0.5 * sum w |y - R x - t|^2 at that transform
-    unsigned degenerate; // no weight mass
-    unsigned handed_over; // blocks the association's fast kernel left to the cleanup kernel (sizes the next cleanup grid)
-    unsigned seq;
-};
-
-// Fold of partials[19][nblocks] (one block per sum, fixed order: deterministic, no float atomics) FOLLOWED BY THE SOLVE:
-// the block that draws the last ticket reads the 19 moments back and one lane runs the closed-form weighted rigid
-// solve (solve_rigid_device above) and the cost at the solution.  The
-// transform goes to *pose_out in device memory, where the next association's prologue picks it up as its pending
-// source move (PendingMove::dev): the outer loop no longer waits for the host between iterations.  The host gets
-// everything through the mailbox and only trails behind for hasConverged() and the history.
-__global__ __launch_bounds__(kBlock) void reduce_solve_kernel(const double *__restrict__ partials, int nblocks,
-                                                              double *__restrict__ sums, double3 origin,
-                                                              Pose *__restrict__ pose_out, HostMailbox *mbox,
-                                                              unsigned *__restrict__ ticket, unsigned seq,
-                                                              const unsigned *__restrict__ handed_over)
-{
-    __shared__ double sh[kBlock / 64];
-    const double *row = partials + (size_t)blockIdx.x * nblocks;
-    double v = 0.0;
-    for (int b0 = 0; b0 < nblocks; b0 += 8 * kBlock) {
-        double t[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int b = b0 + u * kBlock + threadIdx.x;
-            t[u] = (b < nblocks) ? row[b] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) v += t[u];
-    }
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    double x = sh[0];
-    for (int w = 1; w < kBlock / 64; w++) x += sh[w];
-    __hip_atomic_store(&sums[blockIdx.x], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __atomic_thread_fence(__ATOMIC_RELEASE);
-    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (tk != gridDim.x - 1) return;
-    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    double S[kNSums];
-#pragma unroll
-    for (int j = 0; j < kNSums; j++) S[j] = __hip_atomic_load(&sums[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double c[3] = {origin.x, origin.y, origin.z};
-    const DeviceSolve rs = solve_rigid_device(S, c);
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-#pragma unroll
-        for (int b = 0; b < 3; b++) pose_out->R[3 * a + b] = rs.R[3 * a + b];
-        pose_out->t[a] = rs.t[a];
-        pose_out->c[a] = 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < kNSums; j++) mbox->sums[j] = S[j];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-#pragma unroll
-        for (int b = 0; b < 3; b++) mbox->T[4 * a + b] = rs.R[3 * a + b];
-        mbox->T[4 * a + 3] = rs.t[a];
-    }
-    mbox->cost = rs.cost;
-    mbox->degenerate = rs.degenerate ? 1u : 0u;
-    mbox->handed_over = handed_over ? *handed_over : 0u;
-    __hip_atomic_store(&mbox->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ProbabilisticWeights::updateWeights on caller-supplied squared errors (probabilistic_weights.hpp:48-105):
