@@ -2,7 +2,10 @@
 // are the reference's (src/prob_point_cloud_registration_ex.cc:34-66,93-188, README.md:31-92):
 //   probabilistic_point_cloud_registration [--dump] [-g gt.pcd] [-v] [-u] [-n int] [-c float] [-r float]
 //       [-d float] [-i int] [-m int] [-t float] [-s float] <source.pcd> <target.pcd>
-// Additions (they do not collide with the reference's letters): --device N, --inner-steps K.
+// Additions (they do not collide with the reference's letters): --device N, --inner-steps K, and the batch front end
+//   probabilistic_point_cloud_registration --batch pairs.txt [--lanes L] [-r -m -d -u -i -c -n --inner-steps as above]
+// where every non-empty line of pairs.txt names "<source.pcd> <target.pcd>": the pairs are registered by ppcr_batch_run
+// over every visible GPU (pair p on device p % n, L pairs in flight per device) and one line per pair is printed.
 // The program is organised as a small pipeline of its own: parse -> load -> register -> publish.
 #include <cstdlib>
 #include <filesystem>
@@ -10,6 +13,7 @@
 #include <iostream>
 #include <limits>
 #include <memory>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -26,6 +30,8 @@ using Cloud = pcl::PointCloud<pcl::PointXYZ>;
 struct Job {
     reg::ProbPointCloudRegistrationParams params;
     std::string source_path, target_path, truth_path;  // truth_path empty: no -g
+    std::string batch_path;                            // --batch: a list of pairs instead of one pair
+    int lanes = 2;                                     // --lanes: pairs in flight per device (batch mode)
     bool gaussian = false;
 };
 
@@ -38,7 +44,8 @@ struct BadArgument {
     std::cerr << "error: " << bad.complaint << " for arg " << bad.argument << std::endl;
     std::cerr << "usage: probabilistic_point_cloud_registration [--dump] [-g <string>] [-v] [-u] [-n <int>] [-c <float>]\n"
                  "         [-r <float>] [-d <float>] [-i <int>] [-m <int>] [-t <float>] [-s <float>] [--device <int>]\n"
-                 "         [--inner-steps <int>] <source_file_name> <target_file_name>"
+                 "         [--inner-steps <int>] <source_file_name> <target_file_name>\n"
+                 "   or: probabilistic_point_cloud_registration --batch <pair_list_file> [--lanes <int>] [options as above]"
               << std::endl;
     std::exit(EXIT_FAILURE);
 }
@@ -117,15 +124,22 @@ Job parseCommandLine(int argc, char **argv)
         else if (a == "--dump") job.params.summary = true;
         else if (a == "--device") job.params.device_id = cur.integer(a);
         else if (a == "--inner-steps") job.params.inner_max_steps = cur.integer(a);
+        else if (a == "--batch") job.batch_path = cur.valueOf(a);
+        else if (a == "--lanes") job.lanes = cur.integer(a);
         else if (is("-h", "--help")) throw BadArgument{"help requested", a};
         else if (looksLikeFlag(a)) throw BadArgument{"Couldn't find match for argument", a};
         else files.push_back(a);
     }
     static const char *const kNames[2] = {"source_file_name", "target_file_name"};
-    if (files.size() < 2) throw BadArgument{"Required argument missing", kNames[files.size()]};
-    if (files.size() > 2) throw BadArgument{"Too many positional arguments", files[2]};
-    job.source_path = files[0];
-    job.target_path = files[1];
+    if (!job.batch_path.empty()) {
+        if (!files.empty()) throw BadArgument{"Positional arguments are not used with --batch", files[0]};
+        if (job.lanes < 1) throw BadArgument{"--lanes must be at least 1", "--lanes"};
+    } else {
+        if (files.size() < 2) throw BadArgument{"Required argument missing", kNames[files.size()]};
+        if (files.size() > 2) throw BadArgument{"Too many positional arguments", files[2]};
+        job.source_path = files[0];
+        job.target_path = files[1];
+    }
     if (job.gaussian) job.params.dof = std::numeric_limits<double>::infinity();  // -u: Gaussian weights
     return job;
 }
@@ -193,8 +207,91 @@ void writeSummary(const Job &job, const std::string &table)
     out << table;
 }
 
+// --batch: every pair of the list through ppcr_batch_run on all visible devices
+int runBatch(const Job &job)
+{
+    std::ifstream list(job.batch_path);
+    if (!list) {
+        std::cout << "Could not read the pair list " << job.batch_path << ", closing" << std::endl;
+        return EXIT_FAILURE;
+    }
+    std::vector<Cloud::Ptr> clouds;  // source, target, source, target, ...
+    std::vector<std::string> names;
+    std::string line;
+    while (std::getline(list, line)) {
+        std::istringstream fields(line);
+        std::string src_name, tgt_name;
+        if (!(fields >> src_name)) continue;  // blank line
+        if (src_name[0] == '#') continue;
+        if (!(fields >> tgt_name)) {
+            std::cout << "Pair list line without a target: " << line << std::endl;
+            return EXIT_FAILURE;
+        }
+        for (const std::string *name : {&src_name, &tgt_name}) {
+            Cloud::Ptr cloud = readCloud(*name);
+            if (!cloud) {
+                std::cout << "Could not load " << *name << ", closing" << std::endl;
+                return EXIT_FAILURE;
+            }
+            clouds.push_back(cloud);
+        }
+        names.push_back(src_name + " -> " + tgt_name);
+    }
+    const std::size_t n_pairs = names.size();
+    std::vector<ppcr_pair> pairs(n_pairs);
+    for (std::size_t p = 0; p < n_pairs; p++) {
+        const Cloud &s = *clouds[2 * p], &t = *clouds[2 * p + 1];
+        pairs[p] = ppcr_pair{s.empty() ? nullptr : &s[0].x, static_cast<int64_t>(s.size()), sizeof(pcl::PointXYZ),
+                             t.empty() ? nullptr : &t[0].x, static_cast<int64_t>(t.size()), sizeof(pcl::PointXYZ)};
+    }
+    const auto &p = job.params;
+    ppcr_batch_options opt{};
+    opt.radius = p.radius;
+    opt.dof = p.dof;
+    opt.cost_drop_thresh = p.cost_drop_thresh;
+    opt.n_cost_drop_it = p.n_cost_drop_it;
+    opt.f_tol = 10e-6;  // the reference's function_tolerance
+    for (int k = 0; k < 4; k++) opt.q0[k] = p.initial_rotation[k];
+    for (int k = 0; k < 3; k++) opt.t0[k] = p.initial_translation[k];
+    opt.max_neighbours = p.max_neighbours;
+    opt.dim = 3;
+    opt.n_iter = p.n_iter;
+    opt.inner_steps = p.inner_max_steps;
+    int n_devices = 0;
+    ppcr_device_count(&n_devices);
+    if (n_devices < 1) {
+        std::cerr << "registration failed: no HIP device visible (this library has no CPU fallback)" << std::endl;
+        return EXIT_FAILURE;
+    }
+    std::vector<int> devices(static_cast<std::size_t>(n_devices));
+    for (int d = 0; d < n_devices; d++) devices[static_cast<std::size_t>(d)] = d;
+    std::vector<double> T(12 * n_pairs);
+    std::vector<int32_t> iterations(n_pairs);
+    char err[512] = {0};
+    if (job.params.verbose)
+        std::cout << "Registering " << n_pairs << " pairs on " << n_devices << " device(s), " << job.lanes << " in flight each" << std::endl;
+    const int rc = ppcr_batch_run(pairs.data(), static_cast<int64_t>(n_pairs), &opt, devices.data(), n_devices, job.lanes,
+                                  T.data(), iterations.data(), err, sizeof err);
+    if (rc != PPCR_OK) {
+        std::cerr << "registration failed: " << err << std::endl;
+        return EXIT_FAILURE;
+    }
+    for (std::size_t k = 0; k < n_pairs; k++) {
+        const Eigen::Affine3d A = Eigen::Affine3d::from_rows(&T[12 * k]);
+        const Eigen::Quaterniond q(A.rotation());
+        std::cout << "pair " << k << " (" << names[k] << "), " << iterations[k] << " iterations: T: " << A.translation().x() << ", "
+                  << A.translation().y() << ", " << A.translation().z() << " ||| R: " << q.x() << ", " << q.y() << ", " << q.z() << ", "
+                  << q.w() << std::endl;
+    }
+    return EXIT_SUCCESS;
+}
+
 int run(const Job &job)
 {
+    if (!job.batch_path.empty()) {
+        announce(job);
+        return runBatch(job);
+    }
     announce(job);
     const bool verbose = job.params.verbose;
     const Cloud::Ptr source = readCloudOrExit(job.source_path, "source", verbose);

@@ -107,6 +107,13 @@ def test_cli_argument_errors_exit_like_the_reference(programs):
         assert r.returncode == 1 and "error:" in r.stderr and "for arg" in r.stderr
     r = subprocess.run([cli, "/nonexistent/a.pcd", "/nonexistent/b.pcd"], capture_output=True, text=True)
     assert r.returncode == 1 and "Could not load source cloud, closing" in r.stdout
+    # the batch front end: no positional clouds, a readable list
+    r = subprocess.run([cli, "--batch", "list.txt", "a.pcd"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Positional arguments are not used with --batch" in r.stderr
+    r = subprocess.run([cli, "--batch", "/nonexistent/list.txt"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Could not read the pair list" in r.stdout
+    r = subprocess.run([cli, "--batch", "list.txt", "--lanes", "0"], capture_output=True, text=True)
+    assert r.returncode == 1 and "--lanes must be at least 1" in r.stderr
 
 
 def test_cli_refuses_malformed_pcd_headers(programs, tmp_path):
@@ -271,3 +278,36 @@ def test_cli_with_voxel_filters_ground_truth_and_report(programs, tmp_path):
     aligned = read_pcd_ascii(tmp_path / "aligned_a.pcd")     # the FULL source, moved
     assert aligned.shape[0] == src.shape[0]
     np.testing.assert_allclose(aligned, full, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_cli_batch_front_end_matches_single_runs(programs, tmp_path):
+    """--batch list.txt: every pair of the list through ppcr_batch_run on all visible devices; each printed transform
+    equals the one the ordinary single-pair command line prints for the same pair and options."""
+    cli = programs[0]
+    lines = ["# pairs"]
+    for p in range(3):
+        src, tgt, _, _ = synth.make_pair(3000 + 700 * p, cfg=5, pair=p, stride=3)
+        write_pcd(tmp_path / f"s{p}.pcd", src, binary=True)
+        write_pcd(tmp_path / f"t{p}.pcd", tgt, binary=bool(p % 2))
+        lines.append(f"s{p}.pcd t{p}.pcd")
+    lines.insert(2, "")
+    (tmp_path / "pairs.txt").write_text("\n".join(lines) + "\n")
+    common = ["-r", "1", "-m", "8", "-i", "4", "-c", "0"]
+    r = subprocess.run([cli, "--batch", "pairs.txt", "--lanes", "2", "-v"] + common, capture_output=True, text=True,
+                       cwd=tmp_path, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = re.findall(r"^pair (\d+) \(s\d\.pcd -> t\d\.pcd\), 4 iterations: (T: .*)$", r.stdout, flags=re.M)
+    assert [int(k) for k, _ in got] == [0, 1, 2]
+    for p in range(3):
+        one = subprocess.run([cli, "-v"] + common + [f"s{p}.pcd", f"t{p}.pcd"], capture_output=True, text=True,
+                             cwd=tmp_path, timeout=600)
+        assert one.returncode == 0, one.stdout + one.stderr
+        last = re.findall(r"^T: .*$", one.stdout, flags=re.M)[-1]
+        a = np.array([float(v) for v in re.split(r"[,|R:T ]+", got[p][1]) if v])
+        b = np.array([float(v) for v in re.split(r"[,|R:T ]+", last) if v])
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)      # six significant digits are printed
+    # a list that names a missing cloud fails like the single-pair command
+    (tmp_path / "bad.txt").write_text("s0.pcd nowhere.pcd\n")
+    r = subprocess.run([cli, "--batch", "bad.txt"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 1 and "Could not load nowhere.pcd, closing" in r.stdout
