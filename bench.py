@@ -313,8 +313,8 @@ def run_rank(a):
     #  / average launch duration measured with HIP events above
     b_nn = 16.0 * ns + 12.0 * nt + 4.0 * nnz
     b_iter = 72.0 * ns + 12.0 * nt + 52.0 * nnz + (a.inner_steps - 1) * (32.0 * ns + 48.0 * nnz)
-    if "nn_topm_kernel" in prof:
-        k = prof["nn_topm_kernel"]
+    if "nn_fast_kernel" in prof:
+        k = prof["nn_fast_kernel"]
         avg_ms = k["total_ms"] / max(1, k["launches"])
         ach = b_nn / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch come from PMC counters, which need their own rocprofv3 --pmc passes

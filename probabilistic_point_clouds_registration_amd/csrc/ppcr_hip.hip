@@ -53,7 +53,7 @@ enum KernelId {
 };
 const char *const kKernelNames[K_NUM] = {
     "repack_kernel",   "bbox_kernel",    "cell_key_kernel",   "radix_sort",       "gather_points_kernel",
-    "cell_start_kernel", "nn_topm_kernel", "nn_count_kernel",  "nn_scan",          "nn_fill_kernel",
+    "cell_start_kernel", "nn_fast_kernel", "nn_count_kernel",  "nn_scan",          "nn_fill_kernel",
     "nn_select_kernel", "csr_compact_kernel", "ell_count_sum_kernel", "weights_kernel", "accumulate_kernel",
     "reduce_partials_kernel", "transform_kernel"};
 
@@ -1288,7 +1288,9 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
         return PPCR_OK;
     }
     if (std::strcmp(key, "stamps") == 0) {  // diagnostic: per-phase cycle totals of nn_tile_kernel
-        const size_t nst = (size_t)((nblocks(std::max<int64_t>(c->ns, 1)) + kMaxSplit) * (kBlock / 64) + 64) * 8;
+        // 8 words per wave, then one word per lane (its sorted run lengths)
+        const size_t nwg = (size_t)nblocks(std::max<int64_t>(c->ns, 1)) + kMaxSplit;
+        const size_t nst = (nwg * (kBlock / 64) + 64) * 8 + nwg * 256;
         HIP_TRY(c, c->d_stamps.reserve(nst));
         HIP_TRY(c, hipMemsetAsync(c->d_stamps.p, 0, nst * sizeof(unsigned long long), c->stream));
         c->opt_stamps = value;

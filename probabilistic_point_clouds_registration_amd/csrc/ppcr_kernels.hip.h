@@ -1784,6 +1784,14 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
                 key[b] = kl;
             }
         }
+        if constexpr (STAMPS) {  // diagnostic: this lane's nine sorted run lengths, 7 bits each, behind the wave records
+            if (stamps) {
+                unsigned long long pk = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) pk |= (unsigned long long)min(key[k] >> 16, 127u) << (7 * k);
+                stamps[((size_t)gridDim.x * kWaves + 64) * 8 + (size_t)blockIdx.x * BLOCK + tid] = pk;
+            }
+        }
         // d2 >= +0 and r2 > 0, so "d2 < r2" is "bits(d2) <= bits(r2) - 1" (a NaN d2 has larger bits and fails): the
         // radius test and the running cut-off are ONE unsigned compare per candidate
         unsigned thr = min(thr0, __float_as_uint(r2) - 1u);

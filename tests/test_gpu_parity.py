@@ -392,11 +392,11 @@ def test_profile_reports_kernels(ctx):
     ctx.profile_enable(False)
     # K23 is its own launch for the first association only: from the second one on (temporal cut-off valid, steady-state
     # K1) it is folded into K1; the fold-and-solve kernel runs every iteration
-    assert st["nn_topm_kernel"]["launches"] == 3 and st["accumulate_kernel"]["launches"] == 1, st
+    assert st["nn_fast_kernel"]["launches"] == 3 and st["accumulate_kernel"]["launches"] == 1, st
     # ... and so is the fold-and-solve step (it rides in the cleanup launch, inside the K1 scope of this profile)
     assert st["reduce_partials_kernel"]["launches"] == 1, st
     # the source move rides in the next K1 prologue; only the last one needs its own launch
-    assert st["transform_kernel"]["launches"] == 1 and st["nn_topm_kernel"]["total_ms"] > 0
+    assert st["transform_kernel"]["launches"] == 1 and st["nn_fast_kernel"]["total_ms"] > 0
     # with the fold switched off every iteration launches K23
     ctx.set_option("fuse_k23", 0)
     ctx.set_source(g["src"])
