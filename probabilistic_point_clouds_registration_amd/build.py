@@ -1,8 +1,9 @@
 """Build the HIP C-ABI library (libppcr_hip.so) in-tree for gfx950 with hipcc.
 
 hipcc cross-compiles without a GPU.  -ffp-contract=off is load-bearing: neighbour membership is
-decided by an uncontracted float d^2 (see csrc/ppcr_kernels.hip.h).
+decided by an uncontracted float d^2 (see csrc/ppcr_device.hip.h).
 """
+import concurrent.futures
 import os
 import shutil
 import subprocess
@@ -11,10 +12,15 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "libppcr_hip.so")
-SOURCES = [os.path.join(CSRC, "ppcr_hip.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "ppcr_kernels.hip.h"), os.path.join(CSRC, "ppcr_host_math.hpp"),
-                  os.path.join(ROOT, "include", "ppcr.h")]
+MAIN_TU = os.path.join(CSRC, "ppcr_hip.hip")
+TILE_TU = os.path.join(CSRC, "ppcr_nn_tile.hip")
+TILE_WIDTHS = (10, 4, 5, 8, 16, 20, 32)   # K1's compiled-in list widths, one object each (the default first)
+SOURCES = [MAIN_TU, TILE_TU]
+DEPS = SOURCES + [os.path.join(CSRC, h) for h in ("ppcr_device.hip.h", "ppcr_kernels.hip.h", "ppcr_nn_tile.hip.h",
+                                                  "ppcr_nn_tile_launch.hip.h", "ppcr_host_math.hpp")] + [
+    os.path.join(ROOT, "include", "ppcr.h")]
 
 
 def hipcc():
@@ -25,7 +31,7 @@ def hipcc():
 
 
 def flags():
-    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
             "-Wall", "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 
 
@@ -36,13 +42,35 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
+def _jobs():
+    """(object, compile command) for every translation unit: the C-ABI unit and K1 once per list width."""
+    cc = [hipcc()] + flags() + ["-c"]
+    jobs = [(os.path.join(OBJ, "ppcr_hip.o"), cc + [MAIN_TU])]
+    for m in TILE_WIDTHS:
+        jobs.append((os.path.join(OBJ, "ppcr_nn_tile_m%d.o" % m), cc + ["-DPPCR_TILE_M=%d" % m, TILE_TU]))
+    return [(obj, cmd + ["-o", obj]) for obj, cmd in jobs]
+
+
 def build(force=False, verbose=False):
+    """Compile the translation units in parallel (one hipcc per unit, as many at a time as there are cores) and link."""
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + flags() + ["-o", LIB] + SOURCES
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = _jobs()
+
+    def compile_one(job):
+        if verbose:
+            print(" ".join(job[1]), file=sys.stderr)
+        subprocess.check_call(job[1])
+        return job[0]
+
+    workers = max(1, min(len(jobs), os.cpu_count() or 1))
+    with concurrent.futures.ThreadPoolExecutor(workers) as pool:
+        objects = list(pool.map(compile_one, jobs))
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objects
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+        print(" ".join(link), file=sys.stderr)
+    subprocess.check_call(link)
     return LIB
 
 

@@ -2,7 +2,7 @@
 // r = y - (R(q) x + t), q = (w,x,y,z) normalised before use, templated on the scalar so user code that
 // evaluates residuals (or differentiates them with its own Jet type) keeps working.  In this
 // implementation the registration itself never instantiates ErrorTerms: the same residual is evaluated
-// for every stored pair inside the HIP kernels (sq_residual in ppcr_kernels.hip.h).
+// for every stored pair inside the HIP kernels (sq_residual in ppcr_device.hip.h).
 #pragma once
 #include <cmath>
 

@@ -1,0 +1,759 @@
+// Device-side building blocks shared by every translation unit of the library (structs the kernels take by value,
+// distance / selection / weight / moment helpers, the block folds, the one-lane rigid solve and the fold-and-solve
+// step).  Everything here is a template or __device__ __forceinline__: no kernel is defined in this header, so it can
+// be included from several translation units.
+//
+// Float contraction is OFF for every translation unit (-ffp-contract=off): neighbour membership is decided by a float
+// d^2 accumulated x->y->z (FLANN L2_Simple<float>); f64 code asks for fma() explicitly where wanted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <limits.h>
+#include <type_traits>
+
+#include "ppcr_host_math.hpp"
+
+namespace ppcr {
+namespace dev {
+
+constexpr int kNSums = 19;
+constexpr int kBlock = 256;
+constexpr int kMaxSplit = 64;  // K1: blocks that can be scanned as two half-blocks (SplitTable in ppcr_nn_tile.hip.h)
+
+// Uniform grid over the target's bounding box.  Cells are cubes of edge h >= radius in y and z; in x every cell is
+// split into xr slices (edge h / xr, inv_hx = xr * inv_h): a (dy, dz) row of the stencil is one contiguous run
+// of the cell-sorted target whatever xr is, and a finer x lets every query clip each of its nine runs to the
+// x window the sphere really needs in that row (nn_tile_kernel) instead of three full cells.
+// n[0] counts x SLICES; the stencil reaches xr slices either side of the query's slice.
+struct GridDesc {
+    float org[3];
+    float inv_h;
+    int n[3];
+    int ncells;
+    float inv_hx;  // xr * inv_h
+    float h;       // cell edge in y and z
+    float eps;     // absolute slack that covers the float rounding of cell coordinates and gaps
+    int xr;        // x slices per cell edge (1, 2, 4, 8) = stencil reach in x slices
+    int xr_shift;  // log2(xr)
+};
+
+struct Pose {  // y ~ R x + t ; c = fixed origin of the moments
+    double R[9];
+    double t[3];
+    double c[3];
+};
+
+struct Model {  // ProbabilisticWeights constants (probabilistic_weights.hpp:30-46)
+    int is_normal;
+    int vpd_int;   // v + dim when that is an integer in [1,64], else 0 (hot-path fast power)
+    double v;      // dof
+    double texp;   // -(v + dim)/2
+    double vpd;    // v + dim
+};
+
+// integer cell coordinate clamped to [-1, n]; NaN -> -1.  (v-org)*inv_h is a float sub then a
+// float mul in every kernel that bins points, so targets and queries bin consistently.
+__device__ __forceinline__ int cell_coord(float v, float org, float inv_h, int n)
+{
+    float f = floorf((v - org) * inv_h);
+    f = fminf(fmaxf(f, -1.0f), (float)n);
+    return (int)f;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---------------------------------------------------------------------------------------------
+// K1: radius-NN with top-m cut-off.  One lane per query; the queries were spatially sorted once
+// (x-fastest cell order of the target grid) so the 64 lanes of a wave walk the same few cell
+// rows and their candidate loads hit the same cache lines.  Per (dy,dz) the three x-adjacent
+// cells form ONE contiguous run of the cell-sorted target, so a query scans 9 runs.
+// Candidates are ranked by the packed key (float_bits(d2) << 32 | target_index): d2 >= +0 so
+// float bits order like unsigned ints, and ties fall to the lower target index — the order the
+// oracle defines (FLANN's own tie order is traversal dependent).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dist2_flann(float4 q, float4 t)
+{
+    // L2_Simple<float>: result += diff*diff for x, y, z in turn; no fused multiply-add
+    float dx = __fsub_rn(q.x, t.x), dy = __fsub_rn(q.y, t.y), dz = __fsub_rn(q.z, t.z);
+    float r = __fmul_rn(dx, dx);
+    r = __fadd_rn(r, __fmul_rn(dy, dy));
+    r = __fadd_rn(r, __fmul_rn(dz, dz));
+    return r;
+}
+
+struct QueryCells {
+    int cx, cy, cz;
+};
+
+__device__ __forceinline__ QueryCells query_cells(float4 q, const GridDesc &g)
+{
+    QueryCells c;
+    c.cx = cell_coord(q.x, g.org[0], g.inv_hx, g.n[0]);
+    c.cy = cell_coord(q.y, g.org[1], g.inv_h, g.n[1]);
+    c.cz = cell_coord(q.z, g.org[2], g.inv_h, g.n[2]);
+    return c;
+}
+
+// Visits every candidate of the 27-cell stencil: f(position_in_sorted_target, float4 point)
+template <class F>
+__device__ __forceinline__ void for_each_candidate(float4 q, const GridDesc &g,
+                                                   const int *__restrict__ cell_start,
+                                                   const float4 *__restrict__ tgt, F &&f)
+{
+    const QueryCells c = query_cells(q, g);
+    const int x0 = max(c.cx - g.xr, 0), x1 = min(c.cx + g.xr, g.n[0] - 1);
+    if (x0 > x1) return;
+#pragma unroll 1
+    for (int dz = -1; dz <= 1; dz++) {
+        const int cz = c.cz + dz;
+        if ((unsigned)cz >= (unsigned)g.n[2]) continue;
+#pragma unroll 1
+        for (int dy = -1; dy <= 1; dy++) {
+            const int cy = c.cy + dy;
+            if ((unsigned)cy >= (unsigned)g.n[1]) continue;
+            const int base = (cz * g.n[1] + cy) * g.n[0];
+            const int b = cell_start[base + x0], e = cell_start[base + x1 + 1];
+            for (int p = b; p < e; p++) f(p, tgt[p]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1, list variant (default).  Measured on MI355X: the candidate scan alone costs ~90 us at
+// 1M<->1M while keeping a sorted top-m list inside the scan loop costs another ~320 us (every
+// step some lane of the wave inserts, so the whole wave pays the insertion).  So the scan only
+// APPENDS in-radius candidates to a lane-private list in LDS ([slot][lane]: conflict-free) and
+// the cut-off is applied afterwards:
+//   pass A  threshold T = m-th smallest d2 of the list, by inserting the d2 bit patterns into a
+//           sorted register list with v_med3_u32:  L'_j = med3(L_{j-1}, k, L_j)  — one
+//           instruction per slot and no carry chain (the list stays sorted, duplicates allowed);
+//   pass B  keep the entries with d2 <= T (in place);
+//   ties    only if more entries tie at T than there is room for: keep the tied entries with the
+//           smallest original target index (same med3 trick on the indices) — the oracle's
+//           (d2, index) order, exactly.
+// A list that fills up (C entries) is compacted on the spot and the lane's acceptance
+// threshold drops to T, so dense neighbourhoods cost a few compactions instead of overflowing.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <int M>
+__device__ __forceinline__ void sorted_insert(unsigned (&K)[M], unsigned k)
+{
+#pragma unroll
+    for (int j = M - 1; j >= 1; --j) K[j] = umed3(K[j - 1], k, K[j]);
+    K[0] = min(K[0], k);
+}
+
+template <int M>
+__device__ __forceinline__ unsigned pick(const unsigned (&K)[M], int j)
+{
+    unsigned r = 0;
+#pragma unroll
+    for (int a = 0; a < M; a++) r = (a == j) ? K[a] : r;
+    return r;
+}
+
+__device__ __forceinline__ double log_prob(const Model &md, double s)
+{
+    // additive constants cancel in the row softmax (probabilistic_weights.hpp:39-41,44,69,71-72)
+    return md.is_normal ? -0.5 * s : md.texp * log1p(s / md.v);
+}
+
+__device__ __forceinline__ double sq_residual(const float4 y, const double xr[3])
+{
+    const double r0 = (double)y.x - xr[0], r1 = (double)y.y - xr[1], r2 = (double)y.z - xr[2];
+    return r0 * r0 + r1 * r1 + r2 * r2;
+}
+
+__device__ __forceinline__ void rotate_point(const Pose &P, float4 xf, double xr[3])
+{
+    const double px = xf.x, py = xf.y, pz = xf.z;
+    xr[0] = (P.R[0] * px + P.R[1] * py + P.R[2] * pz) + P.t[0];
+    xr[1] = (P.R[3] * px + P.R[4] * py + P.R[5] * pz) + P.t[1];
+    xr[2] = (P.R[6] * px + P.R[7] * py + P.R[8] * pz) + P.t[2];
+}
+
+// 1/x to ~1 ulp without the IEEE division sequence: v_rcp_f64 seed + two Newton steps (x finite, > 0)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// exp(lp(s) - lp(smin)) for the hot path.  t model: (u_min/u)^((v+d)/2) with u = 1 + s/v; when
+// v + d is an integer (every practical dof) this is an integer power times at most one sqrt — no
+// log1p/exp at all; otherwise the reference's exp(texp * log1p(s/v)) form.  Gaussian: exp(-(s-smin)/2).
+// inv_vs = 1/(v + s) (shared with the expected-weight factor; unused by the Gaussian model)
+// TM (compile-time model): -1 = read md at run time; 0 = Gaussian; k > 0 = t model with v + dim == k.
+// (The run-time form keeps the odd-power sqrt behind an opaque branch: as a plain ?: the compiler if-converts
+//  it and every pair pays the 20-instruction f64 sqrt expansion — measured: 220 of 970 VALU instructions per row.)
+// exp(x) for x <= 0 (the Gaussian model's likelihood ratios), ~1 ulp: x = k ln2 + r with |r| <= ln2 / 2, a degree-13
+// Taylor polynomial in r (remainder < 4e-18) and v_ldexp_f64; arguments below -745 give 0 like exp().  About 20
+// instructions against ~45 for the library routine, which has to serve the whole real line.
+__device__ __forceinline__ double exp_nonpositive(double x)
+{
+    x = fmax(x, -800.0);
+    const double kf = rint(x * 1.4426950408889634);            // log2(e)
+    double r = fma(kf, -6.93147180369123816490e-01, x);        // ln2 high part (exact product for |k| < 2^11)
+    r = fma(kf, -1.90821492927058770002e-10, r);               // ln2 low part
+    double p = 1.0 / 6227020800.0;                              // 1/13!
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)kf);
+}
+
+template <int TM = -1>
+__device__ __forceinline__ double rel_likelihood(const Model &md, double s, double smin, double lp_max, double inv_vs)
+{
+    if constexpr (TM == 0) return exp_nonpositive(-0.5 * (s - smin));
+    if constexpr (TM > 0) {
+        const double rho = (md.v + smin) * inv_vs;
+        double r = 1.0, base = rho;  // same multiplication sequence as the run-time loop below (1.0 * x is exact)
+        if constexpr (TM & 1) r = sqrt(rho);
+#pragma unroll
+        for (int k = TM >> 1; k; k >>= 1) {
+            if (k & 1) r *= base;
+            base *= base;
+        }
+        return r;
+    }
+    if (md.is_normal) return exp(-0.5 * (s - smin));
+    if (md.vpd_int) {
+        const double rho = (md.v + smin) * inv_vs;  // = u_min / u  in (0, 1]
+        double r = 1.0;
+        if (md.vpd_int & 1) {
+            r = sqrt(rho);
+            asm volatile("" : "+v"(r));  // not speculatable: keeps the sqrt out of the even-power path
+        }
+        double base = rho;
+        for (int k = md.vpd_int >> 1; k; k >>= 1) {     // wave-uniform trip count
+            if (k & 1) r *= base;
+            base *= base;
+        }
+        return r;
+    }
+    return exp(md.texp * log1p(s / md.v) - lp_max);
+}
+
+struct RowAcc {  // per-lane running moments
+    double a[kNSums];
+};
+
+__device__ __forceinline__ void row_finish(RowAcc &acc, const Pose &P, float4 xf, double Z, double G, double Gs,
+                                           double Gyy, const double Gy[3])
+{
+    const double iz = fast_rcp(Z);  // w_k = g_k / Z
+    const double Wi = G * iz;
+    const double xc[3] = {(double)xf.x - P.c[0], (double)xf.y - P.c[1], (double)xf.z - P.c[2]};
+    const double wy[3] = {Gy[0] * iz, Gy[1] * iz, Gy[2] * iz};
+    acc.a[0] += Wi;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        acc.a[1 + d] = fma(Wi, xc[d], acc.a[1 + d]);
+        acc.a[4 + d] += wy[d];
+#pragma unroll
+        for (int b = 0; b < 3; b++) acc.a[7 + 3 * d + b] = fma(xc[d], wy[b], acc.a[7 + 3 * d + b]);
+    }
+    acc.a[16] += Gs * iz;
+    acc.a[17] = fma(Wi, xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2], acc.a[17]);
+    acc.a[18] += Gyy * iz;
+}
+
+// Block fold of the 19 per-lane accumulators -> partials[j * nblocks + block], through an LDS transpose.
+// (A shuffle tree costs 19 sums x 6 steps x 2 ds_bpermute + add per WAVE — a third of all instructions of the
+// one-row-per-lane K23 kernel.)  Every lane parks its 19 doubles in sh[j][tid]; thread (j = t % 32 < 19,
+// part = t / 32) then adds 32 consecutive entries of row j, and 19 threads add the 8 parts: ~90 instructions per
+// wave, fixed summation order, no atomics.  Row stride 257 doubles: lanes j = 0..18 of a half-wave hit
+// consecutive 8-byte bank pairs.
+// The same two-round fold on scratch memory the caller provides (kernels that fold at their very end lend the buffers
+// they no longer need): sh holds 10 * 257 doubles, part 19 * 8.  All 256 threads must call it.
+__device__ __forceinline__ void block_reduce_scratch(const RowAcc &acc, double *sh, double *part, double *__restrict__ out,
+                                                     size_t out_stride, bool write)
+{
+    constexpr int STRIDE = 257, ROUND = (kNSums + 1) / 2;
+    const int tid = threadIdx.x;
+    const int j = tid & 31, p = tid >> 5;
+#pragma unroll
+    for (int j0 = 0; j0 < kNSums; j0 += ROUND) {
+        if (j0 > 0) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < ROUND; q++)
+            if (j0 + q < kNSums) sh[q * STRIDE + tid] = acc.a[j0 + q];
+        __syncthreads();
+        if (j < ROUND && j0 + j < kNSums) {
+            const double *row = sh + j * STRIDE + p * 32;
+            double v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
+#pragma unroll
+            for (int k = 4; k < 32; k += 4) {
+                v0 += row[k];
+                v1 += row[k + 1];
+                v2 += row[k + 2];
+                v3 += row[k + 3];
+            }
+            part[(j0 + j) * 8 + p] = (v0 + v1) + (v2 + v3);
+        }
+    }
+    __syncthreads();
+    if (write && tid < kNSums) {
+        double v = part[tid * 8];
+#pragma unroll
+        for (int q = 1; q < 8; q++) v += part[tid * 8 + q];
+        out[(size_t)tid * out_stride] = v;
+    }
+}
+constexpr int kFoldScratchBytes = (10 * 257 + kNSums * 8) * 8;  // 21 776
+
+// One row's contribution to the moments for a compiled-in model, pairs handed over one at a time (the one-pass form of
+// accumulate_ell_kernel: likelihoods relative to s = 0).  Used by the kernels that fold K23 into the association.
+template <int TM>
+struct RowMoments {
+    double Z = 0, G = 0, Gs = 0, Gr[3] = {0, 0, 0};  // sum e, sum g, sum g s, sum g r   (r = y - (R x + t))
+    // xr = R x + t.  The centred target never appears: sum g (y - c) = sum g r + (xr - c) sum g.
+    __device__ __forceinline__ void add(const Model &md, const double (&xr)[3], float yx, float yy, float yz, bool live)
+    {
+        const double r0 = (double)yx - xr[0], r1 = (double)yy - xr[1], r2 = (double)yz - xr[2];
+        const double sk = fma(r2, r2, fma(r1, r1, r0 * r0));
+        const double sv = live ? sk : 1e300;
+        const double inv_vs = (TM == 0) ? 0.0 : fast_rcp(md.v + sv);
+        const double e = rel_likelihood<TM>(md, sv, 0.0, 0.0, inv_vs);
+        Z += e;
+        const double gk = (TM == 0) ? e : e * (md.vpd * inv_vs);
+        G += gk;
+        Gs = fma(gk, live ? sk : 0.0, Gs);
+        Gr[0] = fma(gk, r0, Gr[0]);
+        Gr[1] = fma(gk, r1, Gr[1]);
+        Gr[2] = fma(gk, r2, Gr[2]);
+    }
+    __device__ __forceinline__ void finish(RowAcc &acc, const Pose &P, float4 xf, const double (&xr)[3]) const
+    {
+        const double xrc[3] = {xr[0] - P.c[0], xr[1] - P.c[1], xr[2] - P.c[2]};
+        const double Gy[3] = {fma(xrc[0], G, Gr[0]), fma(xrc[1], G, Gr[1]), fma(xrc[2], G, Gr[2])};
+        // sum g |y - c|^2 with y - c = r + xrc:  Gs + 2 xrc . Gr + |xrc|^2 G
+        const double x2 = fma(xrc[2], xrc[2], fma(xrc[1], xrc[1], xrc[0] * xrc[0]));
+        const double Gyy = fma(x2, G, fma(2.0, fma(xrc[2], Gr[2], fma(xrc[1], Gr[1], xrc[0] * Gr[0])), Gs));
+        row_finish(acc, P, xf, Z, G, Gs, Gyy, Gy);
+    }
+};
+__device__ __forceinline__ void rotated_point(const Pose &P, float4 xf, double (&xr)[3])
+{
+    const double px = xf.x, py = xf.y, pz = xf.z;
+    xr[0] = fma(P.R[2], pz, fma(P.R[1], py, fma(P.R[0], px, P.t[0])));
+    xr[1] = fma(P.R[5], pz, fma(P.R[4], py, fma(P.R[3], px, P.t[1])));
+    xr[2] = fma(P.R[8], pz, fma(P.R[7], py, fma(P.R[6], px, P.t[2])));
+}
+// K23 folded into the association: the pose and model the first IRLS half-step is evaluated at, and where this
+// workgroup's 19 partial sums go (slot = its index in the FAST kernel's grid; stride = number of slots)
+struct FusedMoments {
+    Pose P;
+    Model md;
+    double *partials;
+    int nslots;
+};
+
+// HALVES = true folds ten sums, then nine, through a buffer half the size (20.6 KB instead of 39 KB: six instead of
+// four workgroups per CU for a kernel that is otherwise lean in registers) at the price of two more barriers.
+template <int BLOCK = kBlock, bool HALVES = false>
+__device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__restrict__ partials)
+{
+    static_assert(BLOCK == 256, "fold layout assumes 256 lanes (8 parts of 32)");
+    constexpr int STRIDE = BLOCK + 1;
+    constexpr int ROUND = HALVES ? (kNSums + 1) / 2 : kNSums;  // sums per round
+    __shared__ double sh[ROUND * STRIDE];
+    __shared__ double part[kNSums][8];
+    const int tid = threadIdx.x;
+    const int j = tid & 31, p = tid >> 5;
+#pragma unroll
+    for (int j0 = 0; j0 < kNSums; j0 += ROUND) {
+        if (j0 > 0) __syncthreads();  // the buffer is reused
+#pragma unroll
+        for (int q = 0; q < ROUND; q++)
+            if (j0 + q < kNSums) sh[q * STRIDE + tid] = acc.a[j0 + q];
+        __syncthreads();
+        if (j < ROUND && j0 + j < kNSums) {
+            const double *row = sh + j * STRIDE + p * 32;
+            double v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
+#pragma unroll
+            for (int k = 4; k < 32; k += 4) {
+                v0 += row[k];
+                v1 += row[k + 1];
+                v2 += row[k + 2];
+                v3 += row[k + 3];
+            }
+            part[j0 + j][p] = (v0 + v1) + (v2 + v3);
+        }
+    }
+    __syncthreads();
+    if (tid < kNSums) {
+        double v = part[tid][0];
+#pragma unroll
+        for (int q = 1; q < 8; q++) v += part[tid][q];
+        partials[(size_t)tid * gridDim.x + blockIdx.x] = v;
+    }
+}
+
+
+// rigid move of one point: f64 arithmetic summed left to right, f32 store (pcl::transformPointCloud
+// semantics, src/prob_point_cloud_registration.cc:110-112); the w lane (original index) is preserved
+__device__ __forceinline__ float4 move_point(float4 p, const Pose &P)
+{
+    const double x = p.x, y = p.y, z = p.z;
+    p.x = (float)(((P.R[0] * x + P.R[1] * y) + P.R[2] * z) + P.t[0]);
+    p.y = (float)(((P.R[3] * x + P.R[4] * y) + P.R[5] * z) + P.t[1]);
+    p.z = (float)(((P.R[6] * x + P.R[7] * y) + P.R[8] * z) + P.t[2]);
+    return p;
+}
+
+// Pending in-place move of the source (K4) folded into K1's prologue: the previous iteration's rigid
+// transform is applied while the query is loaded and the moved point is written back, which saves one
+// kernel launch and one 32 MB read+write pass per iteration.
+struct PendingMove {
+    int enabled;      // 0 none, 1 P below, 2 *dev (written by reduce_solve_kernel of the previous iteration)
+    Pose P;
+    const Pose *dev;
+};
+
+// ---------------------------------------------------------------------------------------------
+// The closed-form weighted rigid solve for ONE lane (it sits on the iteration's critical path right behind the moment
+// fold, with the whole chip waiting): the algorithm of solve_rigid_from_moments / svd3 / cost_from_moments in
+// ppcr_host_math.hpp — one-sided Jacobi SVD of the 3x3 cross-covariance, rank handling, R = V diag(1,1,d) U^T — written
+// for latency: every index is static (the shared source indexes small arrays dynamically, which lands in scratch
+// memory: ~9 us measured), reciprocals and roots are v_rcp_f64 / v_rsq_f64 seeds with two Newton steps instead of the
+// IEEE sequences (a Jacobi rotation only has to be orthogonal to rounding, and it is: c^2 (1 + t^2) = 1 to ~1 ulp).
+// Agrees with the host solve to a few ulp of the moments; the oracle tolerance on transforms is 1e-5.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double fast_rsqrt(double x)  // x > 0, finite
+{
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r;
+}
+
+struct DeviceSolve {
+    double R[9], t[3], cost;
+    bool degenerate;
+};
+
+__device__ __forceinline__ void jacobi_pair(double (&w)[3][3], double (&v)[3][3], const int p, const int q, bool &rotated)
+{
+    const double alpha = w[0][p] * w[0][p] + w[1][p] * w[1][p] + w[2][p] * w[2][p];
+    const double beta = w[0][q] * w[0][q] + w[1][q] * w[1][q] + w[2][q] * w[2][q];
+    const double gamma = w[0][p] * w[0][q] + w[1][p] * w[1][q] + w[2][p] * w[2][q];
+    if (gamma * gamma <= 1e-32 * (alpha * beta)) return;  // columns orthogonal to rounding (also gamma == 0)
+    rotated = true;
+    const double zeta = (beta - alpha) * fast_rcp(2.0 * fabs(gamma)) * (gamma < 0 ? -1.0 : 1.0);
+    const double az = fabs(zeta), h2 = fma(zeta, zeta, 1.0);
+    const double tn = (zeta < 0 ? -1.0 : 1.0) * fast_rcp(az + h2 * fast_rsqrt(h2));
+    const double c = fast_rsqrt(fma(tn, tn, 1.0)), sn = c * tn;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const double wp = w[r][p], wq = w[r][q];
+        w[r][p] = c * wp - sn * wq;
+        w[r][q] = sn * wp + c * wq;
+        const double vp = v[r][p], vq = v[r][q];
+        v[r][p] = c * vp - sn * vq;
+        v[r][q] = sn * vp + c * vq;
+    }
+}
+
+__device__ __forceinline__ void swap_cols(double (&w)[3][3], double (&v)[3][3], double (&len)[3], const int a, const int b)
+{
+    if (len[b] > len[a]) {
+        double tmp = len[a];
+        len[a] = len[b];
+        len[b] = tmp;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            tmp = w[r][a], w[r][a] = w[r][b], w[r][b] = tmp;
+            tmp = v[r][a], v[r][a] = v[r][b], v[r][b] = tmp;
+        }
+    }
+}
+
+// Rotation of the weighted Kabsch problem by Newton's iteration for the polar decomposition,
+//     X <- (z X + X^-T / z) / 2,   z = sqrt(|X^-1|_F / |X|_F),   X_0 = H^T,
+// which converges quadratically to the orthogonal factor V U^T of H^T = V S U^T: the same R as the SVD route whenever
+// det H > 0 (no reflection to repair) — i.e. for every well-posed registration.  An iteration is a 3x3 adjugate with
+// all nine cofactors independent, so the dependent chain is ~a dozen operations (a Jacobi sweep is three rotations of
+// ~70 dependent operations each).  Returns false (and the caller takes the Jacobi SVD route with its rank handling)
+// when H is singular to working precision, contains a reflection, or the iteration has not settled.
+__device__ __forceinline__ bool polar_rotation(const double (&h)[3][3], double (&R)[9])
+{
+    double x[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) x[a][b] = h[b][a];
+    bool settled = false;
+    for (int it = 0; it < 24; ++it) {
+        double cf[3][3];  // cofactors: X^-T = cf / det
+        cf[0][0] = x[1][1] * x[2][2] - x[1][2] * x[2][1];
+        cf[0][1] = x[1][2] * x[2][0] - x[1][0] * x[2][2];
+        cf[0][2] = x[1][0] * x[2][1] - x[1][1] * x[2][0];
+        cf[1][0] = x[0][2] * x[2][1] - x[0][1] * x[2][2];
+        cf[1][1] = x[0][0] * x[2][2] - x[0][2] * x[2][0];
+        cf[1][2] = x[0][1] * x[2][0] - x[0][0] * x[2][1];
+        cf[2][0] = x[0][1] * x[1][2] - x[0][2] * x[1][1];
+        cf[2][1] = x[0][2] * x[1][0] - x[0][0] * x[1][2];
+        cf[2][2] = x[0][0] * x[1][1] - x[0][1] * x[1][0];
+        const double det = x[0][0] * cf[0][0] + x[0][1] * cf[0][1] + x[0][2] * cf[0][2];
+        double nx = 0, nc = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                nx = fma(x[a][b], x[a][b], nx);
+                nc = fma(cf[a][b], cf[a][b], nc);
+            }
+        // well conditioned and orientation preserving?  (|X|_F^3 bounds |det|; 1e-9 leaves cond(H) up to ~1e4-1e9 here)
+        if (!(det > 1e-9 * nx * sqrt(nx))) return false;
+        const double idet = fast_rcp(det);
+        // z^2 = |X^-T|_F / |X|_F = sqrt(nc) / (det sqrt(nx))
+        const double z2 = sqrt(nc) * idet * fast_rsqrt(nx);
+        const double z = sqrt(z2), a_x = 0.5 * z, a_c = 0.5 * idet * fast_rcp(z);
+        double diff = 0, nn = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                const double nv = a_x * x[a][b] + a_c * cf[a][b];
+                const double d = nv - x[a][b];
+                diff = fma(d, d, diff);
+                nn = fma(nv, nv, nn);
+                x[a][b] = nv;
+            }
+        if (diff <= 1e-30 * nn) {  // |X_{k+1} - X_k| <= 1e-15 |X|: converged to rounding
+            settled = true;
+            break;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) R[3 * a + b] = x[a][b];
+    return settled;
+}
+
+__device__ inline DeviceSolve solve_rigid_device(const double (&S)[kNSums], const double (&c)[3])
+{
+    DeviceSolve out;
+#pragma unroll
+    for (int k = 0; k < 9; k++) out.R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    out.t[0] = out.t[1] = out.t[2] = 0.0;
+    out.cost = 0.5 * S[16];
+    out.degenerate = true;
+    const double W = S[0];
+    if (!(W > 0) || !isfinite(W)) return out;
+    out.degenerate = false;
+    const double iW = 1.0 / W;
+    const double mx[3] = {S[1] * iW, S[2] * iW, S[3] * iW}, my[3] = {S[4] * iW, S[5] * iW, S[6] * iW};
+    double w[3][3], v[3][3];  // w = H = sum w (x - mx)(y - my)^T, columns rotated in place; v accumulates V
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            w[a][b] = S[7 + 3 * a + b] - S[1 + a] * my[b];
+            v[a][b] = (a == b) ? 1.0 : 0.0;
+        }
+    const bool polar_ok = polar_rotation(w, out.R);
+    if (!polar_ok) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) out.R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        bool rotated = false;
+        jacobi_pair(w, v, 0, 1, rotated);
+        jacobi_pair(w, v, 0, 2, rotated);
+        jacobi_pair(w, v, 1, 2, rotated);
+        if (!rotated) break;
+    }
+    double len[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const double n2 = w[0][j] * w[0][j] + w[1][j] * w[1][j] + w[2][j] * w[2][j];
+        len[j] = n2 > 0 ? n2 * fast_rsqrt(n2) : 0.0;
+    }
+    swap_cols(w, v, len, 0, 1);  // singular values descending
+    swap_cols(w, v, len, 0, 2);
+    swap_cols(w, v, len, 1, 2);
+    if (len[0] > 0) {
+        double u[3][3];  // columns of U
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double il = len[j] > 0 ? fast_rcp(len[j]) : 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; r++) u[r][j] = w[r][j] * il;
+        }
+        const double tiny = len[0] * 1e-14;
+        if (len[1] <= tiny) {  // rank 1: any unit vector orthogonal to u0 (cross with the axis u0 is least aligned with)
+            const double a0 = fabs(u[0][0]), a1 = fabs(u[1][0]), a2 = fabs(u[2][0]);
+            const bool pick1 = a1 < a0, pick2 = a2 < (pick1 ? a1 : a0);
+            const double e0 = (!pick1 && !pick2) ? 1.0 : 0.0, e1 = (pick1 && !pick2) ? 1.0 : 0.0, e2 = pick2 ? 1.0 : 0.0;
+            double x0 = u[1][0] * e2 - u[2][0] * e1, x1 = u[2][0] * e0 - u[0][0] * e2, x2 = u[0][0] * e1 - u[1][0] * e0;
+            const double in = fast_rsqrt(x0 * x0 + x1 * x1 + x2 * x2);
+            u[0][1] = x0 * in, u[1][1] = x1 * in, u[2][1] = x2 * in;
+        }
+        if (len[2] <= tiny || len[1] <= tiny) {
+            u[0][2] = u[1][0] * u[2][1] - u[2][0] * u[1][1];
+            u[1][2] = u[2][0] * u[0][1] - u[0][0] * u[2][1];
+            u[2][2] = u[0][0] * u[1][1] - u[1][0] * u[0][1];
+        }
+        auto det3 = [](const double (&m)[3][3]) {
+            return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                   m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+        };
+        // H = U S V^T with H = sum x y^T  =>  R = V diag(1,1,d) U^T maps x onto y
+        const double d = (det3(u) * det3(v) < 0) ? -1.0 : 1.0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) out.R[3 * a + b] = v[a][0] * u[b][0] + v[a][1] * u[b][1] + d * v[a][2] * u[b][2];
+    }
+    }
+    double Rmx[3], Rc[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        Rmx[a] = out.R[3 * a] * mx[0] + out.R[3 * a + 1] * mx[1] + out.R[3 * a + 2] * mx[2];
+        Rc[a] = out.R[3 * a] * c[0] + out.R[3 * a + 1] * c[1] + out.R[3 * a + 2] * c[2];
+        out.t[a] = (my[a] - Rmx[a]) + c[a] - Rc[a];
+    }
+    // 0.5 * sum w |y - R x - t|^2 from the moments (cost_from_moments)
+    double tp[3], RSx[3], yRx = 0, tpRSx = 0, tptp = 0, tpSy = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        tp[a] = out.t[a] + Rc[a] - c[a];
+        RSx[a] = out.R[3 * a] * S[1] + out.R[3 * a + 1] * S[2] + out.R[3 * a + 2] * S[3];
+#pragma unroll
+        for (int b = 0; b < 3; b++) yRx += out.R[3 * a + b] * S[7 + 3 * b + a];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        tpRSx += tp[a] * RSx[a];
+        tptp += tp[a] * tp[a];
+        tpSy += tp[a] * S[4 + a];
+    }
+    out.cost = 0.5 * (S[18] + S[17] + 2 * tpRSx + W * tptp - 2 * yRx - 2 * tpSy);
+    return out;
+}
+
+// Host mailbox in pinned, device-mapped memory: the fold-and-solve kernel writes the moments, the rigid transform it
+// solved from them and its cost there, then the sequence number (system-scope release); the host spins on `seq` — no
+// copy kernel and no stream synchronisation on the iteration's critical path.
+struct HostMailbox {
+    double sums[kNSums];
+    double T[12];        // [R|t] minimising sum w |y - R x - t|^2 for these moments (identity when degenerate)
+    double cost;         // 0.5 * sum w |y - R x - t|^2 at that transform
+    unsigned degenerate; // no weight mass
+    unsigned handed_over; // blocks the association's fast kernel left to the cleanup kernel (sizes the next cleanup grid)
+    unsigned seq;
+};
+
+// Fold of partials[19][nblocks] (one block per sum, fixed order: deterministic, no float atomics) FOLLOWED BY THE SOLVE:
+// the block that draws the last ticket reads the 19 moments back and one lane runs the closed-form weighted rigid
+// solve (solve_rigid_device above) and the cost at the solution.  The
+// transform goes to *pose_out in device memory, where the next association's prologue picks it up as its pending
+// source move (PendingMove::dev): the outer loop no longer waits for the host between iterations.  The host gets
+// everything through the mailbox and only trails behind for hasConverged() and the history.
+struct FoldSolve {  // everything the fold-and-solve step needs
+    const double *partials;
+    int nslots;
+    double *sums;
+    double3 origin;
+    Pose *pose_out;
+    HostMailbox *mbox;
+    unsigned *ticket;   // [0] ticket of the fold blocks, [1] list entries the cleanup role has finished (merged kernel)
+    unsigned seq;
+    const unsigned *handed_over;
+    // the split table of the fast K1 (nullable): registrations made by the association that just ran become visible
+    // to the next launch here, after the list has been put in ascending order of block id — the order in which blocks
+    // register within one launch depends on atomics, the order of the partial slots (and with it every sum) must not
+    int *split_list;
+    unsigned char *split_flag;
+    const unsigned *split_total;
+    unsigned *split_visible;
+};
+
+// one of the kNSums fold blocks (256 threads): fold row `sum_index` of the partials; the last block to finish solves
+__device__ __forceinline__ void fold_and_solve_block(const FoldSolve &fs, int sum_index)
+{
+    __shared__ double sh[kBlock / 64];
+    const double *row = fs.partials + (size_t)sum_index * fs.nslots;
+    double v = 0.0;
+    for (int b0 = 0; b0 < fs.nslots; b0 += 8 * kBlock) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int b = b0 + u * kBlock + threadIdx.x;
+            t[u] = (b < fs.nslots) ? row[b] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) v += t[u];
+    }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double x = sh[0];
+    for (int w = 1; w < kBlock / 64; w++) x += sh[w];
+    __hip_atomic_store(&fs.sums[sum_index], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    const unsigned tk = __hip_atomic_fetch_add(fs.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk != kNSums - 1) return;
+    __hip_atomic_store(fs.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(fs.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every fold block is past its wait
+    double S[kNSums];
+#pragma unroll
+    for (int j = 0; j < kNSums; j++) S[j] = __hip_atomic_load(&fs.sums[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double c[3] = {fs.origin.x, fs.origin.y, fs.origin.z};
+    const DeviceSolve rs = solve_rigid_device(S, c);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int b = 0; b < 3; b++) fs.pose_out->R[3 * a + b] = rs.R[3 * a + b];
+        fs.pose_out->t[a] = rs.t[a];
+        fs.pose_out->c[a] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < kNSums; j++) fs.mbox->sums[j] = S[j];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int b = 0; b < 3; b++) fs.mbox->T[4 * a + b] = rs.R[3 * a + b];
+        fs.mbox->T[4 * a + 3] = rs.t[a];
+    }
+    if (fs.split_visible) {
+        const int n_split = (int)min(*fs.split_total, 64u);
+        for (int a = 1; a < n_split; a++) {  // insertion sort: the list is nearly sorted, at most 64 long
+            const int key = fs.split_list[a];
+            int b = a - 1;
+            for (; b >= 0 && fs.split_list[b] > key; b--) fs.split_list[b + 1] = fs.split_list[b];
+            fs.split_list[b + 1] = key;
+        }
+        for (int a = 0; a < n_split; a++) fs.split_flag[fs.split_list[a]] = 2;  // ... and from now on they ARE split
+        *fs.split_visible = (unsigned)n_split;
+    }
+    fs.mbox->cost = rs.cost;
+    fs.mbox->degenerate = rs.degenerate ? 1u : 0u;
+    fs.mbox->handed_over = fs.handed_over ? *fs.handed_over : 0u;
+    __hip_atomic_store(&fs.mbox->seq, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+}  // namespace dev
+}  // namespace ppcr

@@ -1,4 +1,4 @@
-// C ABI (include/ppcr.h) over the gfx950 kernels of ppcr_kernels.hip.h.
+// C ABI (include/ppcr.h) over the gfx950 kernels of ppcr_kernels.hip.h and (K1) ppcr_nn_tile.hip.
 // One ppcr_ctx = one device + one HIP stream + the device-resident state of one source/target
 // pair.  There is no CPU fallback anywhere in this file: without a GPU ppcr_create() fails with
 // PPCR_ERR_NODEVICE and nothing else can be called.
@@ -23,6 +23,7 @@
 
 #include "ppcr_host_math.hpp"
 #include "ppcr_kernels.hip.h"
+#include "ppcr_nn_tile_launch.hip.h"
 
 using namespace ppcr;
 using namespace ppcr::dev;
@@ -464,94 +465,6 @@ int ensure_source_sorted(ppcr_ctx *c)
     return PPCR_OK;
 }
 
-// K1 launch: nn_fast_kernel over every block, then nn_tile_cleanup_kernel over the blocks the fast flavour handed over
-// (usually none: the cleanup launch then costs a few microseconds of an empty grid).
-// LDS budget per 256-query block: halo CAP*13 B (x, y, z + a row byte) + list C*512 B (+0.4 KB tables).  With the
-// column order of the source typical halos are ~1000-1400 candidates at the benchmark density; the margin keeps
-// denser clouds and drifted sources in the fast flavour (measured when the source was ordered in 4x4x4 bricks, fresh /
-// drifted: CAP 2048: 249/341 us, 2176: 231/246, 2240: 230/246, 2272: 302/318).
-constexpr int kCapSteady = 1728;  // halo capacity of the 16-slot variant: 31.3 KB of LDS, five workgroups per CU (1792: four)
-
-// fuse: when given (and the steady-state variant runs) K23 is folded into K1 for that pose/model; *fused tells whether
-// it was — the partials then have one slot per fast-kernel workgroup (nb + kMaxSplit)
-// fold (with fuse, steady-state variant only): when given, the fold-and-solve step rides in the cleanup launch and
-// *merged tells whether it did
-template <int M>
-void launch_tile(ppcr_ctx *c, float r2, int m, const PendingMove &pm, const FusedMoments *fuse, bool *fused,
-                 const FoldSolve *fold = nullptr, bool *merged = nullptr)
-{
-    unsigned long long *st = c->opt_stamps ? c->d_stamps.p : nullptr;
-    const int dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
-    constexpr int C = (M <= 24) ? 32 : 48;
-    constexpr int CAP = (M <= 24) ? 2240 : 2048;
-    const int nb = nblocks(c->ns, 256);
-    // the steady-state variant acts on the split table (extra workgroups) and extends it; the first association only
-    // extends it (blocks whose fresh halo is already close to the steady-state capacity)
-    const SplitTable split_on{c->split_flag.p, c->split_list.p, c->split_state.p, c->split_state.p + 1, kMaxSplit, kCapSteady * 15 / 16};
-    const SplitTable split_off = (M <= 12) ? SplitTable{c->split_flag.p, c->split_list.p, c->split_state.p, c->split_state.p + 1, 0, kCapSteady * 15 / 16}
-                                           : SplitTable{nullptr, nullptr, nullptr, nullptr, 0, INT_MAX};  // no steady-state variant to split for
-    FusedMoments fm_none;
-    std::memset(&fm_none, 0, sizeof(fm_none));
-    c->ovf_parity ^= 1;
-    unsigned *const ovf_now = c->ovf_state.p + c->ovf_parity, *const ovf_next = c->ovf_state.p + (c->ovf_parity ^ 1);
-    // the steady-state (16-slot) variant runs with a halo capacity that gives FIVE workgroups per CU (31.3 KB of LDS)
-    // and splits the few blocks that outgrow it; the first association (32 slots, three per CU) keeps the large one
-#define PPCR_FAST(Cc, STAMPc, FTMc, FMc)                                                                               \
-    nn_fast_kernel<M, Cc, (Cc <= 16 ? kCapSteady : CAP), STAMPc, FTMc><<<nb + (Cc <= 16 ? kMaxSplit : 0), 256, 0, c->stream>>>( \
-        c->src.p, (int)c->ns, c->tgt_sorted.p, c->cell_start.p, c->grid, r2, m, c->nbr.p, c->cnt.p, pm, c->dm2.p, dm2_in, \
-        c->ovf_list.p, ovf_now, ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc)
-    *fused = false;
-    int ftm = -2;  // model folded into this launch (-2: none)
-    bool steady = false;
-    if constexpr (M <= 12) {
-        // steady state: the temporal cut-off keeps every list near m entries, so half the list capacity does (an
-        // overflowing lane tightens its threshold and scans again)
-        if (dm2_in && c->opt_short_lists) {
-            steady = true;
-            if (fuse && !st) ftm = fuse->md.is_normal ? 0 : 8;
-            if constexpr (M == 10) {
-                if (st) PPCR_FAST(16, true, -2, fm_none);
-                else if (ftm == 0) PPCR_FAST(16, false, 0, *fuse);
-                else if (ftm == 8) PPCR_FAST(16, false, 8, *fuse);
-                else PPCR_FAST(16, false, -2, fm_none);
-            } else {
-                if (ftm == 0) PPCR_FAST(16, false, 0, *fuse);
-                else if (ftm == 8) PPCR_FAST(16, false, 8, *fuse);
-                else PPCR_FAST(16, false, -2, fm_none);
-            }
-            *fused = ftm != -2;
-        }
-    }
-    if (!steady) {
-        if constexpr (M == 10) {
-            if (st) PPCR_FAST(C, true, -2, fm_none);
-            else PPCR_FAST(C, false, -2, fm_none);
-        } else {
-            PPCR_FAST(C, false, -2, fm_none);
-        }
-    }
-#undef PPCR_FAST
-    // persistent workgroups over the list: few when the last association this handle heard from handed nothing over
-    const int cleanup_grid = (c->ovf_last == 0) ? std::min(nb, 32) : std::min(nb, 512);
-    const int n_extra = steady ? kMaxSplit : 0;
-    FoldSolve fs_none;
-    std::memset(&fs_none, 0, sizeof(fs_none));
-    const bool merge = ftm != -2 && fold != nullptr;
-    if (merged) *merged = merge;
-    FoldSolve fold_now = fold ? *fold : fs_none;
-    fold_now.handed_over = ovf_now;  // this launch's counter (the parity was toggled above, after the fold was prepared)
-#define PPCR_CLEANUP(FTMc, FMc, MERGEc, FSc)                                                                           \
-    nn_tile_cleanup_kernel<M, C, 256, CAP, FTMc, MERGEc><<<cleanup_grid + (MERGEc ? kNSums : 0), 256, 0, c->stream>>>( \
-        c->src.p, (int)c->ns, c->tgt_sorted.p, c->cell_start.p, c->grid, r2, m, c->nbr.p, c->cnt.p, c->dm2.p,          \
-        c->ovf_list.p, ovf_now, c->split_list.p, n_extra, FMc, FSc)
-    if (ftm == 0 && merge) PPCR_CLEANUP(0, *fuse, true, fold_now);
-    else if (ftm == 8 && merge) PPCR_CLEANUP(8, *fuse, true, fold_now);
-    else if (ftm == 0) PPCR_CLEANUP(0, *fuse, false, fs_none);
-    else if (ftm == 8) PPCR_CLEANUP(8, *fuse, false, fs_none);
-    else PPCR_CLEANUP(-2, fm_none, false, fs_none);
-#undef PPCR_CLEANUP
-}
-
 constexpr int kAccumRows = 1;     // rows per lane of accumulate_ell_kernel
 constexpr int kAccumBlock = 256;  // threads per block of accumulate_ell_kernel (fewer partial vectors to fold)
 
@@ -678,13 +591,28 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
                 fold = &fs;
             }
             ProfScope ps(c, K_NN_TOPM);
-            if (m <= 4) launch_tile<4>(c, r2, m, pm, fuse, &fused, fold, &merged);
-            else if (m <= 5) launch_tile<5>(c, r2, m, pm, fuse, &fused, fold, &merged);
-            else if (m <= 8) launch_tile<8>(c, r2, m, pm, fuse, &fused, fold, &merged);
-            else if (m <= 10) launch_tile<10>(c, r2, m, pm, fuse, &fused, fold, &merged);
-            else if (m <= 16) launch_tile<16>(c, r2, m, pm, fuse, &fused, fold, &merged);
-            else if (m <= 20) launch_tile<20>(c, r2, m, pm, fuse, &fused, fold, &merged);
-            else launch_tile<32>(c, r2, m, pm, fuse, &fused, fold, &merged);
+            c->ovf_parity ^= 1;
+            TileLaunch tl{};
+            tl.stream = c->stream;
+            tl.src = c->src.p, tl.ns = (int)c->ns, tl.tgt = c->tgt_sorted.p, tl.cell_start = c->cell_start.p, tl.grid = c->grid;
+            tl.r2 = r2, tl.m = m;
+            tl.nbr = c->nbr.p, tl.cnt = c->cnt.p, tl.dm2 = c->dm2.p;
+            tl.dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
+            tl.short_lists = c->opt_short_lists;
+            tl.stamps = c->opt_stamps ? c->d_stamps.p : nullptr;
+            tl.ovf_list = c->ovf_list.p;
+            tl.ovf_now = c->ovf_state.p + c->ovf_parity, tl.ovf_next = c->ovf_state.p + (c->ovf_parity ^ 1);
+            tl.quiet = c->ovf_last == 0;
+            tl.split_flag = c->split_flag.p, tl.split_list = c->split_list.p, tl.split_state = c->split_state.p;
+            tl.pm = pm, tl.fuse = fuse, tl.fold = fold;
+            if (m <= 4) launch_tile_m4(tl);
+            else if (m <= 5) launch_tile_m5(tl);
+            else if (m <= 8) launch_tile_m8(tl);
+            else if (m <= 10) launch_tile_m10(tl);
+            else if (m <= 16) launch_tile_m16(tl);
+            else if (m <= 20) launch_tile_m20(tl);
+            else launch_tile_m32(tl);
+            fused = tl.fused, merged = tl.merged;
             c->assoc_fused = fused;
             c->assoc_folded = merged;
             c->fused_slots = fused ? fm.nslots : 0;

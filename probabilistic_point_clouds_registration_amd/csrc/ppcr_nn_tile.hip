@@ -1,0 +1,112 @@
+// K1 launches for ONE compiled-in list width M (-DPPCR_TILE_M=<4|5|8|10|16|20|32>): the build compiles this file once
+// per width, in parallel — the instantiations of nn_fast_kernel / nn_tile_cleanup_kernel are most of the library's
+// compile time.  Host code here only picks the variant and launches; the C-ABI translation unit (ppcr_hip.hip) fills
+// the TileLaunch and owns every buffer it names.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstring>
+
+#include "ppcr_nn_tile.hip.h"
+#include "ppcr_nn_tile_launch.hip.h"
+
+#ifndef PPCR_TILE_M
+#error "compile with -DPPCR_TILE_M=<list width>"
+#endif
+
+namespace ppcr {
+namespace {
+
+using namespace ppcr::dev;
+
+// nn_fast_kernel over every block, then nn_tile_cleanup_kernel over the blocks the fast flavour handed over (usually
+// none: the cleanup launch then costs a few microseconds of an empty grid).
+// LDS budget per 256-query block: halo CAP*13 B (x, y, z + a row byte) + list C*512 B (+0.4 KB tables).  With the
+// column order of the source typical halos are ~1000-1400 candidates at the benchmark density; the margin keeps
+// denser clouds and drifted sources in the fast flavour (measured when the source was ordered in 4x4x4 bricks, fresh /
+// drifted: CAP 2048: 249/341 us, 2176: 231/246, 2240: 230/246, 2272: 302/318).
+//
+// t.fuse: when given (and the steady-state variant runs) K23 is folded into K1 for that pose/model; t.fused tells
+// whether it was — the partials then have one slot per fast-kernel workgroup (nb + kMaxSplit).
+// t.fold (with fuse, steady-state variant only): when given, the fold-and-solve step rides in the cleanup launch and
+// t.merged tells whether it did.
+template <int M>
+void launch_tile(TileLaunch &t)
+{
+    unsigned long long *const st = t.stamps;
+    constexpr int C = (M <= 24) ? 32 : 48;
+    constexpr int CAP = (M <= 24) ? 2240 : 2048;
+    const int nb = (t.ns + 255) / 256;
+    // the steady-state variant acts on the split table (extra workgroups) and extends it; the first association only
+    // extends it (blocks whose fresh halo is already close to the steady-state capacity)
+    const SplitTable split_on{t.split_flag, t.split_list, t.split_state, t.split_state + 1, kMaxSplit, kCapSteady * 15 / 16};
+    const SplitTable split_off = (M <= 12) ? SplitTable{t.split_flag, t.split_list, t.split_state, t.split_state + 1, 0, kCapSteady * 15 / 16}
+                                           : SplitTable{nullptr, nullptr, nullptr, nullptr, 0, INT_MAX};  // no steady-state variant to split for
+    FusedMoments fm_none;
+    std::memset(&fm_none, 0, sizeof(fm_none));
+    // the steady-state (16-slot) variant runs with a halo capacity that gives FIVE workgroups per CU (31.3 KB of LDS)
+    // and splits the few blocks that outgrow it; the first association (32 slots, three per CU) keeps the large one
+#define PPCR_FAST(Cc, STAMPc, FTMc, FMc)                                                                               \
+    nn_fast_kernel<M, Cc, (Cc <= 16 ? kCapSteady : CAP), STAMPc, FTMc><<<nb + (Cc <= 16 ? kMaxSplit : 0), 256, 0, t.stream>>>( \
+        t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,  \
+        t.ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc)
+    t.fused = false;
+    int ftm = -2;  // model folded into this launch (-2: none)
+    bool steady = false;
+    if constexpr (M <= 12) {
+        // steady state: the temporal cut-off keeps every list near m entries, so half the list capacity does (an
+        // overflowing lane tightens its threshold and scans again)
+        if (t.dm2_in && t.short_lists) {
+            steady = true;
+            if (t.fuse && !st) ftm = t.fuse->md.is_normal ? 0 : 8;
+            if constexpr (M == 10) {
+                if (st) PPCR_FAST(16, true, -2, fm_none);
+                else if (ftm == 0) PPCR_FAST(16, false, 0, *t.fuse);
+                else if (ftm == 8) PPCR_FAST(16, false, 8, *t.fuse);
+                else PPCR_FAST(16, false, -2, fm_none);
+            } else {
+                if (ftm == 0) PPCR_FAST(16, false, 0, *t.fuse);
+                else if (ftm == 8) PPCR_FAST(16, false, 8, *t.fuse);
+                else PPCR_FAST(16, false, -2, fm_none);
+            }
+            t.fused = ftm != -2;
+        }
+    }
+    if (!steady) {
+        if constexpr (M == 10) {
+            if (st) PPCR_FAST(C, true, -2, fm_none);
+            else PPCR_FAST(C, false, -2, fm_none);
+        } else {
+            PPCR_FAST(C, false, -2, fm_none);
+        }
+    }
+#undef PPCR_FAST
+    // persistent workgroups over the list: few when the last association this handle heard from handed nothing over
+    const int cleanup_grid = t.quiet ? std::min(nb, 32) : std::min(nb, 512);
+    const int n_extra = steady ? kMaxSplit : 0;
+    FoldSolve fs_none;
+    std::memset(&fs_none, 0, sizeof(fs_none));
+    const bool merge = ftm != -2 && t.fold != nullptr;
+    t.merged = merge;
+    FoldSolve fold_now = t.fold ? *t.fold : fs_none;
+    fold_now.handed_over = t.ovf_now;  // this launch's counter (the caller toggled the pair after the fold was prepared)
+#define PPCR_CLEANUP(FTMc, FMc, MERGEc, FSc)                                                                           \
+    nn_tile_cleanup_kernel<M, C, 256, CAP, FTMc, MERGEc><<<cleanup_grid + (MERGEc ? kNSums : 0), 256, 0, t.stream>>>(  \
+        t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.dm2, t.ovf_list, t.ovf_now, t.split_list,  \
+        n_extra, FMc, FSc)
+    if (ftm == 0 && merge) PPCR_CLEANUP(0, *t.fuse, true, fold_now);
+    else if (ftm == 8 && merge) PPCR_CLEANUP(8, *t.fuse, true, fold_now);
+    else if (ftm == 0) PPCR_CLEANUP(0, *t.fuse, false, fs_none);
+    else if (ftm == 8) PPCR_CLEANUP(8, *t.fuse, false, fs_none);
+    else PPCR_CLEANUP(-2, fm_none, false, fs_none);
+#undef PPCR_CLEANUP
+}
+
+}  // namespace
+
+#define PPCR_CAT2(a, b) a##b
+#define PPCR_CAT(a, b) PPCR_CAT2(a, b)
+void PPCR_CAT(launch_tile_m, PPCR_TILE_M)(TileLaunch &t) { launch_tile<PPCR_TILE_M>(t); }
+
+}  // namespace ppcr

@@ -1,0 +1,1039 @@
+// K1, the LDS-tiled radius search with max_neighbours cut-off: nn_fast_kernel (steady state and first association) and
+// nn_tile_cleanup_kernel (the general flavour, run on what the fast kernel hands over).  Templates only; instantiated by
+// ppcr_nn_tile.hip, one translation unit per compiled-in list width M.
+#pragma once
+#include "ppcr_device.hip.h"
+
+namespace ppcr {
+namespace dev {
+
+// ---------------------------------------------------------------------------------------------
+// K1, tiled variant (default).  rocprofv3 on the list variant: the scan is bound by the texture
+// address path (TA busy 79 %, 16 cycles per 64-lane dwordx4 load: every distance test pulls 16 B
+// per lane through L1) and its selection passes re-gather lines L1 has already evicted.  So the
+// candidates are staged in LDS instead:
+//   1. the workgroup's 256 (spatially compact) queries -> bounding box in cells, +-1 cell halo;
+//   2. every halo row (fixed y,z; contiguous in the cell-sorted target) is copied into LDS with
+//      lane-contiguous 16-byte loads — each target point is fetched once per workgroup;
+//   3. each lane walks ITS OWN 27-cell stencil (9 runs) out of LDS (ds_read_b128) — the exact
+//      candidate set, no extra distance tests;
+//   4. in-radius candidates are appended to a lane-private u16 list of LDS indices; the top-m
+//      cut-off is applied afterwards with the v_med3 threshold selection (see nn_list_kernel),
+//      now reading LDS only.
+// A halo that does not fit (sparse or unsorted source) is retried per wave, and as a last resort
+// the wave falls back to scanning global memory with the same selection code.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTileRows = 128;   // halo rows per staging
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL load
+// (s_waitcnt vmcnt(0)): in nn_tile_kernel that serialises the run-bound loads issued in the prologue with the
+// row-table and staging loads behind the barrier; with the LDS-only fences they stay in flight across it.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int BLOCK>
+struct LdsCands {  // candidate source = staged halo (SoA in LDS); list entries are LDS indices
+    const float *sx, *sy, *sz;
+    const unsigned char *srow;  // halo row of every staged candidate: its sorted-target position is
+    const int *row_gb, *row_off;  //   row_gb[row] + (LDS index - row_off[row])  (one byte instead of four per candidate)
+    unsigned short *list;  // [slot * BLOCK + tid]
+    int tid;
+    __device__ __forceinline__ float4 get(int e) const { return make_float4(sx[e], sy[e], sz[e], 0.f); }
+    __device__ __forceinline__ int load(int t) const { return list[t * BLOCK + tid]; }
+    __device__ __forceinline__ void store(int t, int e) const { list[t * BLOCK + tid] = (unsigned short)e; }
+    __device__ __forceinline__ int pos_of(int e) const
+    {
+        const int r = srow[e];
+        return row_gb[r] + (e - row_off[r]);
+    }
+    __device__ __forceinline__ unsigned orig_of(int e, const float4 *__restrict__ tgt) const
+    {
+        return (unsigned)__float_as_int(tgt[pos_of(e)].w);
+    }
+};
+template <int STRIDE = 64>
+struct GlobalCands {  // candidate source = global memory; list entries are sorted-target positions
+    const float4 *tgt;
+    int *list;  // [slot * STRIDE + lane]
+    int lane;
+    __device__ __forceinline__ float4 get(int e) const { return tgt[e]; }
+    __device__ __forceinline__ int load(int t) const { return list[t * STRIDE + lane]; }
+    __device__ __forceinline__ void store(int t, int e) const { list[t * STRIDE + lane] = e; }
+    __device__ __forceinline__ int pos_of(int e) const { return e; }
+    __device__ __forceinline__ unsigned orig_of(int e, const float4 *__restrict__) const
+    {
+        return (unsigned)__float_as_int(tgt[e].w);
+    }
+};
+
+// Visit the lane's list entries [0, n) as f(slot, entry, d2 bits), FOUR entries per trip: their index loads, then
+// their coordinate loads, are issued together, so a trip costs two LDS round trips instead of eight (selection
+// phase -10 % while the source moves; it is mostly instruction-bound: ~36 instructions per entry over two passes).
+// f may store to slots <= the one it is called with (in-place compaction): a trip reads before it writes.
+template <class S, class F>
+__device__ __forceinline__ void for_each_entry(const S &src, float4 q, int n, F &&f)
+{
+    for (int t = 0; t < n; t += 4) {
+        int e[4];
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = src.load(min(t + u, n - 1));
+#pragma unroll
+        for (int u = 0; u < 4; u++) p[u] = src.get(e[u]);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (t + u < n) f(t + u, e[u], __float_as_uint(dist2_flann(q, p[u])));
+    }
+}
+
+// reduce a lane's list (n > m entries) to its top-m by (d2, original index); returns the new n and
+// the threshold T (bit pattern of the m-th smallest d2)
+// (Keeping the first 16 entries' d2 bits in registers between the two passes was measured too: selection
+//  -20 %, but 176 VGPRs -> 2 waves/SIMD (190 us), or 168 with spills for a net 1 %: not kept.)
+template <int M, class S>
+__device__ __forceinline__ int select_top_m(const S &src, const float4 *__restrict__ tgt, float4 q, int n, int m,
+                                            unsigned &thr)
+{
+    unsigned K[M];
+#pragma unroll
+    for (int j = 0; j < M; j++) K[j] = 0xFFFFFFFFu;
+    for_each_entry(src, q, n, [&](int, int, unsigned b) { sorted_insert<M>(K, b); });
+    const unsigned T = pick<M>(K, m - 1);
+    int w = 0, c_eq = 0;
+    for_each_entry(src, q, n, [&](int, int e, unsigned b) {
+        if (b <= T) {
+            src.store(w, e);
+            w++;
+            c_eq += (b == T) ? 1 : 0;
+        }
+    });
+    if (w > m) {  // more ties at the cut-off than room: lowest original target indices win
+        const int need = m - (w - c_eq);
+#pragma unroll
+        for (int j = 0; j < M; j++) K[j] = 0xFFFFFFFFu;
+        for (int t = 0; t < w; t++) {
+            const int e = src.load(t);
+            if (__float_as_uint(dist2_flann(q, src.get(e))) == T) sorted_insert<M>(K, src.orig_of(e, tgt));
+        }
+        const unsigned T2 = pick<M>(K, need - 1);
+        int w2 = 0;
+        for (int t = 0; t < w; t++) {
+            const int e = src.load(t);
+            const unsigned b = __float_as_uint(dist2_flann(q, src.get(e)));
+            if (b < T || src.orig_of(e, tgt) <= T2) {
+                src.store(w2, e);
+                w2++;
+            }
+        }
+        w = w2;
+    }
+    thr = T;
+    return w;
+}
+
+// GENERAL flavour of K1, run on the workgroups nn_fast_kernel hands over (ovf_list[0 .. *ovf_count)): halos of any
+// shape (up to 128 rows), binary subdivision when a halo does not fit, global-memory scan as the last resort, in-loop
+// list compaction for dense neighbourhoods.  The source has already been moved by the fast kernel and the temporal
+// cut-off is not used here (the fast kernel may have overwritten some of this block's dm2 entries already).
+// Persistent workgroups stride over the list.  The list counters ping-pong: launch k counts in ovf_state[k & 1] and the
+// fast kernel of launch k clears ovf_state[(k + 1) & 1] (last used by launch k - 1, whose cleanup has finished by then in
+// stream order), so nobody needs an atomic ticket (1024 same-address atomics cost this kernel 20 us when it was tried).
+// Entries are (index of the handing-over workgroup in the fast kernel's grid) * 4 + half: half 0 = the whole block,
+// 1 / 2 = only the queries of waves 0-1 / 2-3 (split blocks).  FTM >= 0: the fast kernel also folded K23 in, so this one
+// finishes the rows it redoes the same way (gathering their neighbours from global memory) and fills the slot of the
+// partials the fast workgroup left empty.
+// MERGED (with FTM >= 0): the launch also carries the fold-and-solve step as its last kNSums workgroups — they wait until
+// the cleanup role has finished every listed entry (nothing to wait for in the common case of an empty list) — which
+// saves the ~4 us a dependent launch costs even when it has nothing to do.
+template <int M, int C, int BLOCK, int CAP, int FTM = -2, bool MERGED = false>
+__global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 *__restrict__ src, int ns,
+                                                         const float4 *__restrict__ tgt,
+                                                         const int *__restrict__ cell_start, GridDesc g,
+                                                         float r2, int m, int *__restrict__ nbr,
+                                                         int *__restrict__ cnt, unsigned *__restrict__ dm2,
+                                                         const int *__restrict__ ovf_list,
+                                                         const unsigned *__restrict__ ovf_count,
+                                                         const int *__restrict__ split_list, int n_extra, FusedMoments fm,
+                                                         FoldSolve fs)
+{
+    static_assert(!MERGED || FTM != -2, "the merged launch folds the partials the fused kernels wrote");
+    const unsigned n_listed = *ovf_count;
+    const unsigned n_cleanup = MERGED ? gridDim.x - kNSums : gridDim.x;  // workgroups in the cleanup role
+    if constexpr (MERGED) {
+        if (blockIdx.x >= n_cleanup) {
+            // fold role: the partials of the handed-over workgroups must be in place first
+            if (n_listed > 0) {
+                if (threadIdx.x == 0)
+                    while (__hip_atomic_load(fs.ticket + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n_listed)
+                        __builtin_amdgcn_s_sleep(8);
+                __syncthreads();
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            }
+            fold_and_solve_block(fs, (int)(blockIdx.x - n_cleanup));
+            return;
+        }
+    }
+    for (unsigned listed = blockIdx.x; listed < n_listed; listed += n_cleanup) {
+    const int entry = ovf_list[listed];
+    const int fast_slot = entry >> 2, half = entry & 3;
+    const int bid = fast_slot < n_extra ? split_list[fast_slot] : fast_slot - n_extra;
+    static_assert(C > M, "a compaction must leave room in the list");
+    static_assert(CAP % 4 == 0 && CAP <= 65536 && C * 64 <= 3 * CAP && kTileRows <= 256, "the global fallback aliases the candidate buffer");
+    static_assert(kTileRows == 128, "row table: two rows per lane of one wave");
+    constexpr int kWaves = BLOCK / 64;
+    constexpr int kStageUnroll = 8;  // halo rows in flight per wave
+    // staged halo, structure-of-arrays: two candidates per ds_read_b64 and per packed-f32 instruction
+    __shared__ __attribute__((aligned(16))) float s_halo[3 * CAP + CAP / 4];
+    float *const s_x = s_halo, *const s_y = s_halo + CAP, *const s_z = s_halo + 2 * CAP;
+    unsigned char *const s_rowid = reinterpret_cast<unsigned char *>(s_halo + 3 * CAP);
+    int *const s_glist = reinterpret_cast<int *>(s_halo);  // global-fallback list aliases the halo buffer
+    __shared__ unsigned short s_list[C * BLOCK];
+    __shared__ int s_row_gb[kTileRows];
+    __shared__ int s_row_off[kTileRows + 1];
+    __shared__ int s_wlo[kWaves][3], s_whi[kWaves][3];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = bid * BLOCK + tid;
+    const bool valid = i < ns && (half == 0 || (wave >> 1) == half - 1);  // lanes whose query the fast workgroup owned
+    const float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned thr0 = 0xFFFFFFFFu;  // no temporal cut-off in this flavour
+    const QueryCells qc = query_cells(q, g);
+
+    // this lane's 9 stencil runs [rb, re) in sorted-target positions: issued now, consumed after the
+    // halo has been staged, so their latency hides behind the staging phase.
+    // Each run is clipped in x: a target of row (dy, dz) is at least (gy, gz) away in y and z (the gap between the
+    // query and that row's slab, under-estimated by g.eps), so it can only be within the cut-off radius R if
+    // |dx| <= sqrt(R^2 - gy^2 - gz^2); R^2 is the radius or the temporal cut-off, inflated by 4e-6 for the float
+    // rounding of d2.  The x slices that window touches are the run; a row with no window is skipped.
+    const int x0 = max(qc.cx - g.xr, 0), x1 = min(qc.cx + g.xr, g.n[0] - 1);
+    int rb[9], re[9];
+    {
+        const float R2 = __uint_as_float(min(thr0, __float_as_uint(r2))) * 1.000004f;
+        const float fy = q.y - g.org[1], fz = q.z - g.org[2];
+        const float gy[3] = {fmaxf(fy - (float)qc.cy * g.h - g.eps, 0.f), 0.f,
+                             fmaxf((float)(qc.cy + 1) * g.h - fy - g.eps, 0.f)};
+        const float gz[3] = {fmaxf(fz - (float)qc.cz * g.h - g.eps, 0.f), 0.f,
+                             fmaxf((float)(qc.cz + 1) * g.h - fz - g.eps, 0.f)};
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int cz = qc.cz + (k / 3 - 1), cy = qc.cy + (k % 3 - 1);
+            const float w2 = R2 - (gy[k % 3] * gy[k % 3] + gz[k / 3] * gz[k / 3]);
+            const float w = sqrtf(fmaxf(w2, 0.f)) * 1.000001f + g.eps;
+            const int fa = max(cell_coord(q.x - w, g.org[0], g.inv_hx, g.n[0]), x0);
+            const int fb = min(cell_coord(q.x + w, g.org[0], g.inv_hx, g.n[0]), x1);
+            const bool in = valid && w2 >= 0.f && fa <= fb && (unsigned)cz < (unsigned)g.n[2] &&
+                            (unsigned)cy < (unsigned)g.n[1];
+            const int base = in ? (cz * g.n[1] + cy) * g.n[0] : 0;
+            rb[k] = in ? cell_start[base + fa] : 0;
+            re[k] = in ? cell_start[base + fb + 1] : 0;
+        }
+    }
+
+    // per-wave bounding box of the query cells
+    {
+        int lo[3] = {valid ? qc.cx : INT_MAX, valid ? qc.cy : INT_MAX, valid ? qc.cz : INT_MAX};
+        int hi[3] = {valid ? qc.cx : INT_MIN, valid ? qc.cy : INT_MIN, valid ? qc.cz : INT_MIN};
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+            for (int off = 32; off > 0; off >>= 1) {
+                lo[a] = min(lo[a], __shfl_xor(lo[a], off));
+                hi[a] = max(hi[a], __shfl_xor(hi[a], off));
+            }
+        if (lane == 0)
+            for (int a = 0; a < 3; a++) {
+                s_wlo[wave][a] = lo[a];
+                s_whi[wave][a] = hi[a];
+            }
+    }
+    lds_barrier();
+
+    int n = 0;
+    bool done = !valid;
+    // Halo passes, coarse to fine: all waves together; if that halo does not fit, halves, then single
+    // waves (binary subdivision of the wave range).  done_mask (uniform over the block) has a bit per
+    // finished wave; a pass whose waves are all finished is skipped.
+    unsigned done_mask = 0;
+    for (int span = kWaves; span >= 1; span >>= 1)
+      for (int w0 = 0; w0 < kWaves; w0 += span) {
+        const int w1 = w0 + span;
+        const unsigned pass_mask = ((1u << span) - 1u) << w0;
+        if ((done_mask & pass_mask) == pass_mask) continue;
+        const bool last_level = span == 1;
+        int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+        for (int w = w0; w < w1; w++)
+            for (int a = 0; a < 3; a++) {
+                lo[a] = min(lo[a], s_wlo[w][a]);
+                hi[a] = max(hi[a], s_whi[w][a]);
+            }
+        const bool any = lo[0] <= hi[0];  // at least one valid query among these waves
+        const int hx0 = max(lo[0] - g.xr, 0), hx1 = min(hi[0] + g.xr, g.n[0] - 1);
+        const int hy0 = max(lo[1] - 1, 0), hy1 = min(hi[1] + 1, g.n[1] - 1);
+        const int hz0 = max(lo[2] - 1, 0), hz1 = min(hi[2] + 1, g.n[2] - 1);
+        const int ny_h = hy1 - hy0 + 1, nz_h = hz1 - hz0 + 1;
+        const bool empty = !any || hx0 > hx1 || ny_h <= 0 || nz_h <= 0;
+        const long long nrows_ll = empty ? 0 : (long long)ny_h * nz_h;
+        const bool rows_ok = nrows_ll <= kTileRows;
+        const int nrows = rows_ok ? (int)nrows_ll : 0;
+
+        // Row table, built redundantly by every wave in registers (no barrier before the staging):
+        // lane l owns halo rows 2l and 2l+1: global begin, length, exclusive prefix of the lengths.
+        int gbA = 0, gbB = 0, lenA = 0, lenB = 0;
+        {
+            const int rA = 2 * lane, rB = 2 * lane + 1;
+            if (rA < nrows) {
+                const int base = ((hz0 + rA / ny_h) * g.n[1] + hy0 + rA % ny_h) * g.n[0];
+                gbA = cell_start[base + hx0];
+                lenA = cell_start[base + hx1 + 1] - gbA;
+            }
+            if (rB < nrows) {
+                const int base = ((hz0 + rB / ny_h) * g.n[1] + hy0 + rB % ny_h) * g.n[0];
+                gbB = cell_start[base + hx0];
+                lenB = cell_start[base + hx1 + 1] - gbB;
+            }
+        }
+        int incl = lenA + lenB;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        const int offA = incl - lenA - lenB, offB = offA + lenA;
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        const bool ok = rows_ok && total <= CAP;
+        if (ok) {
+            if (wave == w0) {  // one wave publishes the table for the scan phase
+                s_row_gb[2 * lane] = gbA;
+                s_row_gb[2 * lane + 1] = gbB;
+                s_row_off[2 * lane] = offA;
+                s_row_off[2 * lane + 1] = offB;
+                if (lane == 63) s_row_off[kTileRows] = incl;
+            }
+            // stage the halo: one wave per row, lane-contiguous 16-byte loads, kStageUnroll rows in flight
+            for (int k0 = 0; wave + kWaves * k0 < nrows; k0 += kStageUnroll) {
+                float4 c[kStageUnroll];
+                int so[kStageUnroll], sl[kStageUnroll], sg[kStageUnroll];
+#pragma unroll
+                for (int u = 0; u < kStageUnroll; u++) {
+                    const int r = wave + kWaves * (k0 + u);
+                    const int rr = min(r, kTileRows - 1);
+                    const int gA = __builtin_amdgcn_readlane(gbA, rr >> 1), gB = __builtin_amdgcn_readlane(gbB, rr >> 1);
+                    const int oA = __builtin_amdgcn_readlane(offA, rr >> 1), oB = __builtin_amdgcn_readlane(offB, rr >> 1);
+                    const int lA = __builtin_amdgcn_readlane(lenA, rr >> 1), lB = __builtin_amdgcn_readlane(lenB, rr >> 1);
+                    sg[u] = (rr & 1) ? gB : gA;
+                    so[u] = (rr & 1) ? oB : oA;
+                    sl[u] = (r < nrows) ? ((rr & 1) ? lB : lA) : 0;
+                    c[u] = tgt[(lane < sl[u]) ? sg[u] + lane : 0];  // unconditional load (slot 0 always exists)
+                }
+#pragma unroll
+                for (int u = 0; u < kStageUnroll; u++) {
+                    if (lane < sl[u]) {
+                        const int d = so[u] + lane;
+                        s_x[d] = c[u].x;
+                        s_y[d] = c[u].y;
+                        s_z[d] = c[u].z;
+                        s_rowid[d] = (unsigned char)(wave + kWaves * (k0 + u));
+                    }
+                    for (int k = lane + 64; k < sl[u]; k += 64) {  // rows longer than a wave (dense data)
+                        const float4 t = tgt[sg[u] + k];
+                        const int d = so[u] + k;
+                        s_x[d] = t.x;
+                        s_y[d] = t.y;
+                        s_z[d] = t.z;
+                        s_rowid[d] = (unsigned char)(wave + kWaves * (k0 + u));
+                    }
+                }
+            }
+            lds_barrier();
+            if (!done && wave >= w0 && wave < w1) {
+                const LdsCands<BLOCK> L{s_x, s_y, s_z, s_rowid, s_row_gb, s_row_off, s_list, tid};
+                // d2 >= +0 and r2 > 0, so "d2 < r2" is "bits(d2) <= bits(r2) - 1" (a NaN d2 has larger bits and
+                // fails): the radius test and the running cut-off become ONE unsigned compare per candidate
+                const unsigned lim0 = min(thr0, __float_as_uint(r2) - 1u);
+                unsigned thr = lim0;
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                const v2f qx2 = {q.x, q.x}, qy2 = {q.y, q.y}, qz2 = {q.z, q.z};
+                // The 9-run scan.  Fast flavour (COMPACT = false): an accepted candidate is stored at slot
+                // min(n, C-1) and counted, nothing else — the list-full test stays out of the per-candidate path.
+                // A lane that ends with n > C overflowed its list (dense neighbourhood and no usable cut-off);
+                // only those lanes re-run the scan in the compacting flavour, which reduces a full list to its
+                // top-m on the spot and tightens the lane's threshold.
+                // The nine runs as (LDS start, length), ordered by DESCENDING length: every lane of the wave then
+                // walks its longest run first, its second longest next, ... — a run's trip count is the maximum
+                // over the 64 lanes, and the maxima of order statistics add up to far fewer steps than the maxima
+                // of arbitrary runs (simulated for this density: 130 steps instead of 161; 121 would be perfect).
+                // 25-comparator sorting network (verified with the 0/1 principle).
+                // Sorted as ONE 32-bit key per run, (length << 16) | LDS start (both < 65536: list entries are
+                // 16-bit LDS indices): a comparator is a v_max_u32 / v_min_u32 pair instead of a compare and four
+                // selects on a (length, start) pair (~50 instead of ~200 instructions for the 25 comparators).
+                int rf[9], rl[9];
+                {
+                    unsigned key[9];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) {
+                        const int len = re[k] - rb[k];
+                        const int r = (qc.cz + (k / 3 - 1) - hz0) * ny_h + (qc.cy + (k % 3 - 1) - hy0);
+                        const int rr = (len > 0) ? r : 0;
+                        const int start = s_row_off[rr] + (rb[k] - s_row_gb[rr]);
+                        key[k] = len > 0 ? ((unsigned)len << 16) | (unsigned)start : 0u;
+                    }
+                    constexpr int net[25][2] = {{0, 3}, {1, 7}, {2, 5}, {4, 8}, {0, 7}, {2, 4}, {3, 8}, {5, 6}, {0, 2},
+                                                {1, 3}, {4, 5}, {7, 8}, {1, 4}, {3, 6}, {5, 7}, {0, 1}, {2, 4}, {3, 5},
+                                                {6, 8}, {2, 3}, {4, 5}, {6, 7}, {1, 2}, {3, 4}, {5, 6}};
+#pragma unroll
+                    for (int c = 0; c < 25; c++) {
+                        const int a = net[c][0], b = net[c][1];
+                        const unsigned hi = max(key[a], key[b]), lo = min(key[a], key[b]);  // descending
+                        key[a] = hi;
+                        key[b] = lo;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 9; k++) {
+                        rf[k] = (int)(key[k] & 0xFFFFu);
+                        rl[k] = (int)(key[k] >> 16);
+                    }
+                }
+                auto scan_runs = [&](auto compact_tag) {
+                    constexpr bool COMPACT = decltype(compact_tag)::value;
+                    auto accept = [&](int f, float d2) {
+                        if (__float_as_uint(d2) <= thr) {
+                            if constexpr (COMPACT) {
+                                L.store(n, f);
+                                n++;
+                                if (n == C) n = select_top_m<M>(L, tgt, q, n, m, thr);
+                            } else {
+                                L.store(min(n, C - 1), f);
+                                n++;
+                            }
+                        }
+                    };
+                    // One run: ALIGNED pairs from (fb & ~1) while p < fe.  The element below fb (first trip of an
+                    // odd start) and the element at fe (last trip of an odd end) belong to other runs: they are
+                    // kept out by the two index tests, which replace the odd head / tail singles of the previous
+                    // version (two compares per trip instead of ~34 instructions per run, and one code path).
+                    // Two candidates per trip: ds_read_b64 x3, packed f32 sub/mul/add (no FMA: the same IEEE
+                    // operations per element as dist2_flann, so d2 is bit-identical).
+                    auto scan_run = [&](int fb, int len) {
+                        if (len <= 0) return;
+                        const int fe = fb + len;
+                        for (int p = fb & ~1; p < fe; p += 2) {
+                            const v2f cx = *reinterpret_cast<const v2f *>(&s_x[p]);
+                            const v2f cy = *reinterpret_cast<const v2f *>(&s_y[p]);
+                            const v2f cz = *reinterpret_cast<const v2f *>(&s_z[p]);
+                            const v2f dx = qx2 - cx, dy = qy2 - cy, dz = qz2 - cz;
+                            v2f d = dx * dx;
+                            d = d + dy * dy;
+                            d = d + dz * dz;
+                            if (p >= fb) accept(p, d.x);
+                            if (p + 1 < fe) accept(p + 1, d.y);
+                        }
+                    };
+                    if constexpr (COMPACT) {
+                        // rare flavour: keep the code small — one loop body, the runs rotated through rf[0] / rl[0]
+                        // (after nine rotations they are back in place)
+#pragma unroll 1
+                        for (int k = 0; k < 9; k++) {
+                            const int fb = rf[0], len = rl[0];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) {
+                                rf[u] = rf[u + 1];
+                                rl[u] = rl[u + 1];
+                            }
+                            rf[8] = fb;
+                            rl[8] = len;
+                            scan_run(fb, len);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 9; k++) scan_run(rf[k], rl[k]);
+                    }
+                };
+                scan_runs(std::false_type{});
+                if (n > C) {  // list overflow (slot C-1 was overwritten): redo this lane with in-loop compaction
+                    n = 0;
+                    thr = lim0;
+                    scan_runs(std::true_type{});
+                }
+                unsigned tm = 0xFFFFFFFFu;  // d2 bits of the m-th neighbour (all-ones: fewer than m found)
+                if (n > m) {
+                    n = select_top_m<M>(L, tgt, q, n, m, thr);
+                    tm = thr;
+                } else if (n == m) {
+                    tm = 0;
+                    for_each_entry(L, q, n, [&](int, int, unsigned b) { tm = max(tm, b); });
+                }
+                for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = L.pos_of(L.load(j));
+                cnt[i] = n;
+                if (dm2) dm2[i] = tm;
+                done = true;
+            }
+            done_mask |= pass_mask;
+            if (done_mask == (1u << kWaves) - 1u) break;  // common case: nothing left, no trailing barrier
+            lds_barrier();                              // the halo buffer is reused by the next pass
+        } else if (last_level) {
+            // last resort for this wave: scan global memory (list of positions aliases the halo buffer)
+            if (!done && wave == w0) {
+                const GlobalCands<64> G{tgt, s_glist, lane};
+                unsigned thr = thr0;
+                for_each_candidate(q, g, cell_start, tgt, [&](int p, float4 t) {
+                    const float d2 = dist2_flann(q, t);
+                    if (d2 < r2 && __float_as_uint(d2) <= thr) {
+                        G.store(n, p);
+                        n++;
+                        if (n == C) n = select_top_m<M>(G, tgt, q, n, m, thr);
+                    }
+                });
+                unsigned tm = 0xFFFFFFFFu;
+                if (n > m) {
+                    n = select_top_m<M>(G, tgt, q, n, m, thr);
+                    tm = thr;
+                } else if (n == m) {
+                    tm = 0;
+                    for_each_entry(G, q, n, [&](int, int, unsigned b) { tm = max(tm, b); });
+                }
+                for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = G.load(j);
+                cnt[i] = n;
+                if (dm2) dm2[i] = tm;
+                done = true;
+            }
+            done_mask |= pass_mask;
+            lds_barrier();
+        }
+      }
+    __syncthreads();  // the LDS buffers are reused by this workgroup's next listed block (and by the fold below)
+    if constexpr (FTM != -2) {
+        // K23 for the rows just redone: each lane re-reads its own row (it wrote it itself) and gathers the neighbours
+        RowAcc acc;
+#pragma unroll
+        for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
+        const int nrow = valid ? cnt[i] : 0;
+        if (nrow > 0) {
+            double xr[3];
+            rotated_point(fm.P, q, xr);
+            RowMoments<FTM> row;
+            for (int j = 0; j < nrow; j++) {
+                const float4 y = tgt[nbr[(size_t)j * ns + i]];
+                row.add(fm.md, xr, y.x, y.y, y.z, true);
+            }
+            row.finish(acc, fm.P, q, xr);
+        }
+        double *const scratch = reinterpret_cast<double *>(s_halo);
+        block_reduce_scratch(acc, scratch, scratch + 10 * 257, fm.partials + fast_slot, (size_t)fm.nslots, true);
+        __syncthreads();
+        if constexpr (MERGED) {
+            if (threadIdx.x == 0) {  // this entry's partials are written: let the fold role count it
+                __atomic_thread_fence(__ATOMIC_RELEASE);
+                __hip_atomic_fetch_add(fs.ticket + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1, FAST flavour (the one every association launches): same algorithm as the general flavour above — spatially
+// compact block of 256 queries, target halo staged once into LDS, per-lane scan of the nine clipped stencil runs
+// into a lane-private u16 list, v_med3 threshold selection — stripped of everything the common case does not need,
+// because the kernel is bound by VALU issue (round-1 counters: 3050 VALU instructions per wave, 45 % of them
+// integer bookkeeping):
+//   * ONE halo per workgroup of at most 128 (y,z) row slots, slot = rz << ys | ry with ys = 3 (up to 8 x 16 rows) or
+//     4 (16 x 8: blocks that straddle two columns of the source order): no division, no subdivision passes, no
+//     per-pass state; a block whose halo does not fit that shape or CAP appends itself to ovf_list and
+//     nn_tile_cleanup_kernel redoes it;
+//   * the nine run windows are computed branch-free in slice units (one v_sqrt_f32 each: a 1-ulp root is inside the
+//     slack the window carries anyway) and their 18 cell_start loads are unconditional (index 0 for a dead run);
+//   * wave reductions / scans on the DPP row_shr / row_bcast network instead of ds_bpermute trees;
+//   * the halo's sorted-target position is ONE table entry per row (gbo[row] = global begin - LDS offset), so a
+//     run's LDS start and a winner's position cost one LDS read each;
+//   * list entries are BYTE offsets into the halo arrays (the selection passes use them as addresses as they are),
+//     pairs are read with 4-byte alignment from the run's true start (no head test, fewer trips), an accepted
+//     candidate costs a store and two VALU instructions;
+//   * a lane whose list overflows takes the m-th smallest of the C candidates it did store as its new threshold and
+//     scans again (no compacting flavour of the scan in the binary); a second overflow (> C exact ties) hands the
+//     block to the cleanup kernel.
+// Every d2 that is computed is computed with the same IEEE operations as dist2_flann, and the final selection is the
+// same code as before, so neighbour sets and cut-off states stay bit-identical to the general flavour and the oracle.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_pull(int identity, int v)
+{
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+// inclusive scan over the 64 lanes (ALL lanes must be active); lane 63 ends up with the reduction
+template <class Op>
+__device__ __forceinline__ int wave_scan(int v, int identity, Op op)
+{
+    v = op(v, dpp_pull<0x111, 0xf>(identity, v));  // row_shr:1
+    v = op(v, dpp_pull<0x112, 0xf>(identity, v));  // row_shr:2
+    v = op(v, dpp_pull<0x114, 0xf>(identity, v));  // row_shr:4
+    v = op(v, dpp_pull<0x118, 0xf>(identity, v));  // row_shr:8   -> inclusive within each row of 16
+    v = op(v, dpp_pull<0x142, 0xa>(identity, v));  // row_bcast:15 into rows 1 and 3
+    v = op(v, dpp_pull<0x143, 0xc>(identity, v));  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+struct OpMin { __device__ __forceinline__ int operator()(int a, int b) const { return a < b ? a : b; } };
+struct OpMax { __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; } };
+struct OpAdd { __device__ __forceinline__ int operator()(int a, int b) const { return a + b; } };
+template <class Op>
+__device__ __forceinline__ int wave_reduce(int v, int identity, Op op)  // wave-uniform result
+{
+    return __builtin_amdgcn_readlane(wave_scan(v, identity, op), 63);
+}
+
+// candidate source of the fast flavour: list entries are byte offsets (4 * LDS index) into the SoA halo
+struct HaloList {
+    const char *hx;                 // s_x as bytes; y and z follow at fixed strides
+    int stride;                     // bytes between the x, y and z arrays
+    const unsigned char *rowid;     // per staged point: its row slot
+    const char *gbo;                // s_gbo as bytes
+    unsigned short *list;           // [slot * 256 + tid]
+    __device__ __forceinline__ float4 get(int a) const
+    {
+        return make_float4(*reinterpret_cast<const float *>(hx + a), *reinterpret_cast<const float *>(hx + stride + a),
+                           *reinterpret_cast<const float *>(hx + 2 * stride + a), 0.f);
+    }
+    __device__ __forceinline__ int load(int t) const { return list[t * 256]; }
+    __device__ __forceinline__ void store(int t, int a) const { list[t * 256] = (unsigned short)a; }
+    __device__ __forceinline__ int pos_of(int a) const
+    {
+        const int e = a >> 2;
+        return e + *reinterpret_cast<const int *>(gbo + 4 * rowid[e]);
+    }
+    __device__ __forceinline__ unsigned orig_of(int a, const float4 *__restrict__ tgt) const
+    {
+        return (unsigned)__float_as_int(tgt[pos_of(a)].w);
+    }
+};
+
+// Blocks whose halo outgrew CAP once are SPLIT from then on: the block's own workgroup scans waves 0-1's queries, an
+// extra workgroup at the front of the grid scans waves 2-3's (both stage with all four waves; a half-block's halo is
+// ~60 % of the block's).  The split set lives in device memory, is extended by the workgroup that bails and takes
+// effect at the next launch (the bailing block itself goes to the cleanup kernel this once), so a small CAP — five
+// workgroups per CU instead of four — costs one cleanup launch per newly outgrown block, not one per iteration.
+struct SplitTable {
+    unsigned char *flag;      // [nblocks] 0: whole, 1: registered for splitting, 2: split (an extra workgroup scans waves 2-3)
+    int *list;                // [kMaxSplit] block ids, in order of registration
+    unsigned *total;          // registrations so far (may exceed kMaxSplit: the surplus is not split)
+    const unsigned *visible;  // registrations the extra workgroups of THIS launch may act on (set by the cleanup kernel)
+    int n_extra;              // extra workgroups at the front of this launch's grid (0: no splitting in this launch)
+    int presplit;             // a whole block whose halo exceeds this is registered for splitting BEFORE it overflows
+                              // (halos grow a few per cent per iteration as the source drifts: 15/16 of the capacity)
+};
+
+// FTM >= 0 (0: Gaussian, k: t model with v + dim = k) folds K23 into this kernel: each lane finishes its row's
+// contribution to the 19 moments from the winners' coordinates while they are still in LDS (no neighbour gathers, no
+// second pass over the source, no K23 launch) and the workgroup folds them into fm.partials.  FTM = -2: plain K1.
+template <int M, int C, int CAP, bool STAMPS, int FTM = -2>
+__global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 4) : 3)) void nn_fast_kernel(float4 *__restrict__ src, int ns,
+                                                         const float4 *__restrict__ tgt,
+                                                         const int *__restrict__ cell_start, GridDesc g,
+                                                         float r2, int m, int *__restrict__ nbr,
+                                                         int *__restrict__ cnt, PendingMove pm,
+                                                         unsigned *__restrict__ dm2, int dm2_valid,
+                                                         int *__restrict__ ovf_list, unsigned *__restrict__ ovf_count,
+                                                         unsigned *__restrict__ ovf_count_next, SplitTable split,
+                                                         unsigned long long *__restrict__ stamps, FusedMoments fm)
+{
+    static_assert(C > M, "a re-scan must leave room in the list");
+    static_assert(FTM == -2 || (3 * CAP + CAP / 4) * 4 >= kFoldScratchBytes, "the final fold borrows the halo buffer");
+    static_assert(CAP % 4 == 0 && CAP * 4 < 65536, "list entries are 16-bit byte offsets into the halo arrays");
+    constexpr int BLOCK = 256, kWaves = 4, kRows = 128, kStageUnroll = 4;
+    __shared__ __attribute__((aligned(16))) float s_halo[3 * CAP + CAP / 4];
+    __shared__ unsigned short s_list[C * BLOCK];
+    __shared__ int s_gbo[kRows];
+    // non-empty rows, compacted: {global begin, LDS offset << 19 | length << 7 | slot}; only alive between the row
+    // table and the staging barrier, so it borrows the (not yet written) list area
+    static_assert(sizeof(int2) * kRows <= sizeof(s_list), "row table aliases the list area");
+    int2 *const s_rowtab = reinterpret_cast<int2 *>(s_list);
+    __shared__ int s_box[kWaves][6];
+    __shared__ int s_bail;
+    float *const s_x = s_halo, *const s_y = s_halo + CAP, *const s_z = s_halo + 2 * CAP;
+    unsigned char *const s_rowid = reinterpret_cast<unsigned char *>(s_halo + 3 * CAP);
+
+    // diagnostic only (STAMPS instantiation): per-wave, per-phase cycle counts
+    unsigned long long t_prev = 0, t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (STAMPS) t_prev = clock64();
+    auto stamp = [&](int phase) {
+        if constexpr (STAMPS) {
+            const unsigned long long now = clock64();
+#pragma unroll
+            for (int k = 0; k < 8; k++) t_acc[k] += (k == phase) ? now - t_prev : 0ull;
+            t_prev = now;
+        }
+    };
+    auto flush_stamps = [&]() {
+        if constexpr (STAMPS)
+            if (stamps && (threadIdx.x & 63) == 0)
+                for (int k = 0; k < 8; k++) stamps[((size_t)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8 + k] = t_acc[k];
+    };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0 && blockIdx.x == 0) *ovf_count_next = 0;  // the other counter of the ping-pong pair: idle during this launch
+    // which block, and which of its waves' queries, this workgroup scans (uniform)
+    int bid, half = 0;  // half: 0 whole block, 1 waves 0-1, 2 waves 2-3
+    if ((int)blockIdx.x < split.n_extra) {
+        if (blockIdx.x >= min(*split.visible, (unsigned)kMaxSplit)) {
+            if constexpr (FTM != -2)  // an idle slot of the partials still has to read as zero
+                if (tid < kNSums) fm.partials[(size_t)tid * fm.nslots + blockIdx.x] = 0.0;
+            return;
+        }
+        bid = split.list[blockIdx.x];
+        half = 2;
+    } else {
+        bid = (int)blockIdx.x - split.n_extra;
+        if (split.n_extra > 0 && split.flag[bid] == 2) half = 1;
+    }
+    const int i = bid * BLOCK + tid;
+    const bool valid = i < ns && (half == 0 || (wave >> 1) == half - 1);  // lanes whose query this workgroup owns
+    if (tid == 0) s_bail = 0;
+
+    // ---- prologue: query, pending move, temporal cut-off ---------------------------------------------------------
+    float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float moved = 0.f;  // how far this query travelled since the association that produced dm2
+    if (pm.enabled && valid) {
+        const float4 q0 = q;
+        q = move_point(q, pm.enabled == 2 ? *pm.dev : pm.P);  // uniform choice, scalar loads
+        src[i] = q;
+        const float ex = q.x - q0.x, ey = q.y - q0.y, ez = q.z - q0.z;
+        moved = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez);  // 1 ulp: far inside the 1e-5 inflation below
+    }
+    // Temporal cut-off.  dm2[i] holds the float d2 of this query's m-th neighbour in the previous association
+    // (all-ones when it had fewer than m).  Those m targets are now at most dm + |move| away, so the new m-th distance
+    // is <= dm + |move|: a candidate farther than that cannot be among the m closest and is never appended.  The
+    // bound is inflated by 1e-5 (float rounding of d2 and of the two roots is ~1e-6 relative); the final selection is
+    // exact — only the amount of list traffic changes.
+    unsigned thr0 = 0xFFFFFFFFu;
+    if (dm2_valid && valid) {
+        const unsigned prev = dm2[i];
+        if (prev != 0xFFFFFFFFu) {
+            const float bound = __builtin_amdgcn_sqrtf(__uint_as_float(prev)) + moved;
+            const float t2 = bound * bound * 1.00001f + 1e-30f;
+            thr0 = (t2 < r2) ? __float_as_uint(t2) : 0xFFFFFFFFu;
+        }
+    }
+    const QueryCells qc = query_cells(q, g);
+
+    // ---- the nine stencil runs [rb, re) in sorted-target positions, clipped in x --------------------------------
+    // A target of row (dy, dz) is at least (gy, gz) away in y and z (gap between the query and that row's slab,
+    // under-estimated by g.eps), so it can only be within the cut-off radius R if |dx| <= sqrt(R^2 - gy^2 - gz^2);
+    // R^2 is the radius or the temporal cut-off, inflated by 4e-6 for the float rounding of d2.  The window is taken
+    // in SLICE units: targets were binned by floor((x - org) * inv_hx), a monotone map, so every in-window target has
+    // its slice in [floor(ux - ws), floor(ux + ws)] up to the rounding of ux, ws and the root (a few ulp of the
+    // largest slice coordinate), which 2 * g.eps (64 ulp of the cloud's extent) covers several times over.
+    // Loads are unconditional: a dead run reads cell_start[0] twice (= 0, 0: empty).
+    const int x0 = max(qc.cx - g.xr, 0), x1 = min(qc.cx + g.xr, g.n[0] - 1);
+    int rb[9], re[9];
+    // the part of the grid this query's LIVE runs touch: rows [ylo, yhi] x [zlo, zhi], slices [xlo, xhi].  The
+    // workgroup's halo is the union of these boxes — tighter than "cell bounding box +- 1": a query that has drifted a
+    // little way into a cell does not need the row beyond it.
+    int xlo = INT_MAX, xhi = INT_MIN, ylo = INT_MAX, yhi = INT_MIN, zlo = INT_MAX, zhi = INT_MIN;
+    {
+        const float R2 = __uint_as_float(min(thr0, __float_as_uint(r2))) * 1.000004f;
+        const float ux = (q.x - g.org[0]) * g.inv_hx;
+        const float fy = q.y - g.org[1], fz = q.z - g.org[2];
+        const float gy0 = fmaxf(fy - (float)qc.cy * g.h - g.eps, 0.f), gy2 = fmaxf((float)(qc.cy + 1) * g.h - fy - g.eps, 0.f);
+        const float gz0 = fmaxf(fz - (float)qc.cz * g.h - g.eps, 0.f), gz2 = fmaxf((float)(qc.cz + 1) * g.h - fz - g.eps, 0.f);
+        const float gy_sq[3] = {gy0 * gy0, 0.f, gy2 * gy2}, gz_sq[3] = {gz0 * gz0, 0.f, gz2 * gz2};
+        const float k_s = g.inv_hx * 1.000001f, eps_s = 2.0f * g.eps * g.inv_hx;
+        const bool x_ok = valid & (x0 <= x1);
+        const bool oky[3] = {bool(x_ok & ((unsigned)(qc.cy - 1) < (unsigned)g.n[1])), bool(x_ok & ((unsigned)qc.cy < (unsigned)g.n[1])),
+                             bool(x_ok & ((unsigned)(qc.cy + 1) < (unsigned)g.n[1]))};
+        const bool okz[3] = {(unsigned)(qc.cz - 1) < (unsigned)g.n[2], (unsigned)qc.cz < (unsigned)g.n[2],
+                             (unsigned)(qc.cz + 1) < (unsigned)g.n[2]};
+        bool live[9];
+        int cfa = 0, cfb = -1;
+        int base_c = (qc.cz * g.n[1] + qc.cy) * g.n[0];
+        asm volatile("" : "+v"(base_c));  // keep the nine row bases as base_c + uniform offset (not nine multiplies)
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int dz = k / 3 - 1, dy = k % 3 - 1;
+            const float w2 = R2 - (gy_sq[k % 3] + gz_sq[k / 3]);
+            const float ws = __builtin_fmaf(__builtin_amdgcn_sqrtf(fmaxf(w2, 0.f)), k_s, eps_s);
+            const int fa = max((int)floorf(ux - ws), x0), fb = min((int)floorf(ux + ws), x1);
+            const bool in = bool(oky[k % 3] & okz[k / 3]) & bool((w2 >= 0.f) & (fa <= fb));  // no short circuit: no branches
+            const int row_base = base_c + (dz * g.n[1] + dy) * g.n[0];  // uniform offset from the centre row
+            rb[k] = cell_start[(unsigned)(in ? row_base + fa : 0)];
+            re[k] = cell_start[(unsigned)(in ? row_base + fb + 1 : 0)];
+            live[k] = in;
+            if (k == 4) cfa = fa, cfb = fb;
+        }
+        // box of the live runs.  x: the centre run has the widest window (its w2 is the largest), so [cfa, cfb] covers
+        // every live run's slices (it is computed whether or not the centre row itself is inside the grid).
+        const bool ym = live[0] | live[3] | live[6], y0 = live[1] | live[4] | live[7], yp = live[2] | live[5] | live[8];
+        const bool zm = live[0] | live[1] | live[2], z0 = live[3] | live[4] | live[5], zp = live[6] | live[7] | live[8];
+        if (ym | y0 | yp) {
+            xlo = cfa, xhi = cfb;
+            ylo = qc.cy + (ym ? -1 : (y0 ? 0 : 1));
+            yhi = qc.cy + (yp ? 1 : (y0 ? 0 : -1));
+            zlo = qc.cz + (zm ? -1 : (z0 ? 0 : 1));
+            zhi = qc.cz + (zp ? 1 : (z0 ? 0 : -1));
+        }
+    }
+
+    // ---- per-wave union of the queries' boxes -> LDS ------------------------------------------------------------
+    {
+        const int lx = wave_reduce(xlo, INT_MAX, OpMin()), hx = wave_reduce(xhi, INT_MIN, OpMax());
+        const int ly = wave_reduce(ylo, INT_MAX, OpMin()), hy = wave_reduce(yhi, INT_MIN, OpMax());
+        const int lz = wave_reduce(zlo, INT_MAX, OpMin()), hz = wave_reduce(zhi, INT_MIN, OpMax());
+        if (lane == 0) {
+            s_box[wave][0] = lx, s_box[wave][1] = ly, s_box[wave][2] = lz;
+            s_box[wave][3] = hx, s_box[wave][4] = hy, s_box[wave][5] = hz;
+        }
+    }
+    lds_barrier();
+    stamp(0);
+
+    // ---- halo box and row table (every wave builds it for itself: no barrier before the staging) -----------------
+    int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+#pragma unroll
+    for (int w = 0; w < kWaves; w++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            lo[a] = min(lo[a], s_box[w][a]);
+            hi[a] = max(hi[a], s_box[w][3 + a]);
+        }
+    // live runs only name rows and slices inside the grid; a workgroup without any live run has an empty box
+    const bool any_live = lo[0] <= hi[0];
+    const int hx0 = any_live ? lo[0] : 0, hx1 = any_live ? hi[0] : 0;
+    const int hy0 = any_live ? lo[1] : 0, hy1 = any_live ? hi[1] : 0;
+    const int hz0 = any_live ? lo[2] : 0, hz1 = any_live ? hi[2] : 0;
+    const int ny_h = hy1 - hy0 + 1, nz_h = hz1 - hz0 + 1;
+    // row slot = rz << ys | ry: 8 (y) x 16 (z) slots, or 16 x 8 for the blocks that straddle two columns of the source
+    // order in y (a block that straddles in z as well, one in a few hundred, goes to the cleanup kernel)
+    const int ys = (ny_h <= 8) ? 3 : 4;
+    const bool shape_ok = hx0 <= hx1 && ny_h >= 1 && nz_h >= 1 && ny_h <= 16 && nz_h <= (kRows >> ys);
+    // lane l owns halo row slots l (A) and l + 64 (B): global begin, length; LDS offsets from a scan of A + B
+    int gbA, lenA, gbB, lenB;
+    {
+        const int ymask = (1 << ys) - 1;
+        const int ryA = lane & ymask, rzA = lane >> ys, ryB = (lane + 64) & ymask, rzB = (lane + 64) >> ys;
+        const bool hasA = shape_ok && ryA < ny_h && rzA < nz_h, hasB = shape_ok && ryB < ny_h && rzB < nz_h;
+        const int baseA = ((hz0 + rzA) * g.n[1] + hy0 + ryA) * g.n[0], baseB = ((hz0 + rzB) * g.n[1] + hy0 + ryB) * g.n[0];
+        gbA = cell_start[(unsigned)(hasA ? baseA + hx0 : 0)];
+        lenA = cell_start[(unsigned)(hasA ? baseA + hx1 + 1 : 0)] - gbA;
+        gbB = cell_start[(unsigned)(hasB ? baseB + hx0 : 0)];
+        lenB = cell_start[(unsigned)(hasB ? baseB + hx1 + 1 : 0)] - gbB;
+    }
+    const int incl = wave_scan(lenA + lenB, 0, OpAdd());
+    const int exclA = incl - lenA - lenB, exclB = exclA + lenA;
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    stamp(1);
+    if constexpr (STAMPS) {  // diagnostic: slot 6 = staged candidates, slot 7 = (ny_h << 8) | nz_h of this block's halo
+        t_acc[6] = (unsigned long long)total;
+        t_acc[7] = (unsigned long long)((ny_h << 8) | nz_h);
+    }
+    const bool handed_over = !shape_ok || total > CAP;  // uniform: derived from the shared boxes and cell_start only
+    if (tid == 0 && half == 0 && split.flag != nullptr && (handed_over || total > split.presplit) && !split.flag[bid]) {
+        // once the fold-and-solve step has published the registration (flag 2, sorted list) this block is scanned in
+        // two halves
+        const unsigned slot = atomicAdd(split.total, 1u);
+        if (slot < (unsigned)kMaxSplit) {
+            split.list[slot] = bid;
+            split.flag[bid] = 1;
+        }
+    }
+    if (handed_over) {
+        // the cleanup kernel redoes this workgroup's queries (this launch): entry = grid index * 4 + half
+        if (tid == 0) ovf_list[atomicAdd(ovf_count, 1u)] = (int)blockIdx.x * 4 + half;
+        flush_stamps();
+        return;
+    }
+    // sorted-target position of a staged point = its LDS index + gbo[row slot]
+    if (wave == 0) {
+        s_gbo[lane] = gbA - exclA;
+        s_gbo[lane + 64] = gbB - exclB;
+    }
+
+    // ---- stage the halo: the non-empty rows are dealt round-robin to the four waves, kStageUnroll rows in flight --
+    {
+        // compact the non-empty rows into s_rowtab (every wave writes the same values; each reads back its own writes)
+        const unsigned long long neA = __ballot(lenA > 0), neB = __ballot(lenB > 0);
+        const int nA = __popcll(neA), nrows = nA + __popcll(neB);
+        const int rankA = __builtin_amdgcn_mbcnt_hi((unsigned)(neA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)neA, 0u));
+        const int rankB = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(neB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)neB, 0u));
+        if (lenA > 0) s_rowtab[rankA] = make_int2(gbA, (exclA << 19) | (lenA << 7) | lane);          // 12 + 12 + 7 bits
+        if (lenB > 0) s_rowtab[rankB] = make_int2(gbB, (exclB << 19) | (lenB << 7) | (lane + 64));
+        for (int j0 = 0; wave + kWaves * j0 < nrows; j0 += kStageUnroll) {
+            float4 c[kStageUnroll];
+            int so[kStageUnroll], sl[kStageUnroll], sg[kStageUnroll], sr[kStageUnroll];
+#pragma unroll
+            for (int u = 0; u < kStageUnroll; u++) {
+                const int t = wave + kWaves * (j0 + u);
+                const int2 row = s_rowtab[min(t, kRows - 1)];  // uniform address: one broadcast read
+                const int pk = __builtin_amdgcn_readfirstlane(row.y);
+                sg[u] = __builtin_amdgcn_readfirstlane(row.x);
+                so[u] = (int)((unsigned)pk >> 19);
+                sl[u] = (t < nrows) ? ((pk >> 7) & 0xFFF) : 0;
+                sr[u] = pk & 127;
+                c[u] = tgt[(lane < sl[u]) ? sg[u] + lane : 0];  // unconditional load (slot 0 always exists)
+            }
+#pragma unroll
+            for (int u = 0; u < kStageUnroll; u++) {
+                if (lane < sl[u]) {
+                    const int d = so[u] + lane;
+                    s_x[d] = c[u].x;
+                    s_y[d] = c[u].y;
+                    s_z[d] = c[u].z;
+                    s_rowid[d] = (unsigned char)sr[u];
+                }
+                for (int k = lane + 64; k < sl[u]; k += 64) {  // rows longer than a wave (dense data)
+                    const float4 t = tgt[sg[u] + k];
+                    const int d = so[u] + k;
+                    s_x[d] = t.x;
+                    s_y[d] = t.y;
+                    s_z[d] = t.z;
+                    s_rowid[d] = (unsigned char)sr[u];
+                }
+            }
+        }
+    }
+    lds_barrier();
+    stamp(2);
+
+    int n = 0;
+    unsigned tm = 0xFFFFFFFFu;  // d2 bits of the m-th neighbour (all-ones: fewer than m found)
+    const HaloList L{reinterpret_cast<const char *>(s_x), CAP * 4, s_rowid, reinterpret_cast<const char *>(s_gbo), s_list + tid};
+    if (valid) {
+        // the nine runs as ONE 32-bit key each, (length << 16) | LDS byte offset of the run's first candidate, sorted
+        // by DESCENDING length: every lane of the wave walks its longest run first, ... — a run's trip count is the
+        // maximum over the 64 lanes, and the maxima of order statistics add up to far fewer steps than the maxima of
+        // arbitrary runs.  25-comparator network (0/1 principle), a comparator is a v_max_u32 / v_min_u32 pair.
+        unsigned key[9];
+        {
+            const char *gbo_c = reinterpret_cast<const char *>(s_gbo) + 4 * ((qc.cz - hz0) * (1 << ys) + (qc.cy - hy0));
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int rl = re[k] - rb[k];
+                const int start = rb[k] - *reinterpret_cast<const int *>(gbo_c + 4 * ((k / 3 - 1) * (1 << ys) + (k % 3 - 1)));
+                key[k] = rl > 0 ? ((unsigned)rl << 16) | (unsigned)(start << 2) : 0u;
+            }
+            constexpr int net[25][2] = {{0, 3}, {1, 7}, {2, 5}, {4, 8}, {0, 7}, {2, 4}, {3, 8}, {5, 6}, {0, 2},
+                                        {1, 3}, {4, 5}, {7, 8}, {1, 4}, {3, 6}, {5, 7}, {0, 1}, {2, 4}, {3, 5},
+                                        {6, 8}, {2, 3}, {4, 5}, {6, 7}, {1, 2}, {3, 4}, {5, 6}};
+#pragma unroll
+            for (int c = 0; c < 25; c++) {
+                const int a = net[c][0], b = net[c][1];
+                const unsigned kh = max(key[a], key[b]), kl = min(key[a], key[b]);  // descending
+                key[a] = kh;
+                key[b] = kl;
+            }
+        }
+        if constexpr (STAMPS) {  // diagnostic: this lane's nine sorted run lengths, 7 bits each, behind the wave records
+            if (stamps) {
+                unsigned long long pk = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) pk |= (unsigned long long)min(key[k] >> 16, 127u) << (7 * k);
+                stamps[((size_t)gridDim.x * kWaves + 64) * 8 + (size_t)blockIdx.x * BLOCK + tid] = pk;
+            }
+        }
+        // d2 >= +0 and r2 > 0, so "d2 < r2" is "bits(d2) <= bits(r2) - 1" (a NaN d2 has larger bits and fails): the
+        // radius test and the running cut-off are ONE unsigned compare per candidate
+        unsigned thr = min(thr0, __float_as_uint(r2) - 1u);
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f qx2 = {q.x, q.x}, qy2 = {q.y, q.y}, qz2 = {q.z, q.z};
+        // LDS addresses as plain 32-bit integers (address space 3): the write cursor and the candidate cursor are
+        // one VGPR each and an accepted candidate costs v_min + ds_write + v_add
+        typedef __attribute__((address_space(3))) unsigned short *lds_u16p;
+        typedef __attribute__((address_space(3))) const float *lds_f32p;
+        // (the casts go through uintptr_t so that the host pass, where every pointer is 64-bit, parses them too)
+        const unsigned list0 = (unsigned)(__UINTPTR_TYPE__)(lds_u16p)(s_list + tid), list_last = list0 + (C - 1) * 512;
+        const unsigned halo0 = (unsigned)(__UINTPTR_TYPE__)(lds_f32p)s_x;
+        for (int attempt = 0;; attempt++) {
+            // the list's write cursor counts every accepted candidate (so n is exact), the store slot is clamped: an
+            // overflowing lane keeps its first C - 1 entries and scribbles over the last slot
+            unsigned wp = list0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                if (key[k] > 0xFFFFu) {
+                    const unsigned a0 = halo0 + (key[k] & 0xFFFFu), a_end = a0 + 4 * (key[k] >> 16), a_pair = a_end - 4;
+                    // two candidates per trip from the run's true start (4-byte aligned reads), packed f32
+                    // sub / mul / add (no FMA: the same IEEE operations per element as dist2_flann)
+                    for (unsigned a = a0; a < a_end; a += 8) {
+                        const lds_f32p px = (lds_f32p)(__UINTPTR_TYPE__)a, py = (lds_f32p)(__UINTPTR_TYPE__)(a + CAP * 4),
+                                       pz = (lds_f32p)(__UINTPTR_TYPE__)(a + CAP * 8);
+                        const v2f cx = {px[0], px[1]}, cy = {py[0], py[1]}, cz = {pz[0], pz[1]};
+                        const v2f dx = qx2 - cx, dy = qy2 - cy, dz = qz2 - cz;
+                        v2f d = dx * dx;
+                        d = d + dy * dy;
+                        d = d + dz * dz;
+                        const unsigned slot_x = min(wp, list_last);  // outside the branch: the wave pays it either way
+                        if (__float_as_uint(d.x) <= thr) {
+                            *(lds_u16p)(__UINTPTR_TYPE__)slot_x = (unsigned short)(a - halo0);
+                            wp += 512;
+                        }
+                        const unsigned slot_y = min(wp, list_last);
+                        if (a < a_pair && __float_as_uint(d.y) <= thr) {
+                            *(lds_u16p)(__UINTPTR_TYPE__)slot_y = (unsigned short)(a - halo0 + 4);
+                            wp += 512;
+                        }
+                    }
+                }
+            }
+            n = (int)((wp - list0) >> 9);
+            if (n <= C) break;
+            if (attempt == 1) {  // more than C candidates tie at the threshold: leave the block to the general flavour
+                n = -1;
+                break;
+            }
+            // list overflow (dense neighbourhood, or no usable cut-off yet): the C - 1 entries that were kept are
+            // genuine in-radius candidates, so the m-th smallest of them bounds the final m-th distance: scan again
+            (void)select_top_m<M>(L, tgt, q, C - 1, m, thr);
+        }
+        stamp(3);
+        if (n > m) {
+            n = select_top_m<M>(L, tgt, q, n, m, thr);
+            tm = thr;
+        } else if (n == m) {
+            tm = 0;
+            for_each_entry(L, q, n, [&](int, int, unsigned b) { tm = max(tm, b); });
+        }
+        stamp(4);
+    }
+    // a wave with a twice-overflowed lane registers the block (once) for the cleanup kernel; its other results are
+    // simply overwritten there with identical values
+    if (__ballot(n < 0) != 0ull) {
+        if (lane == 0 && atomicExch(&s_bail, 1) == 0) ovf_list[atomicAdd(ovf_count, 1u)] = (int)blockIdx.x * 4 + half;
+        n = max(n, 0);
+    }
+    if (valid) {
+        int *out = nbr + i;
+        for (int j = 0; j < n; j++) {
+            *out = L.pos_of(L.load(j));
+            out += ns;
+        }
+        cnt[i] = n;
+        dm2[i] = tm;
+    }
+    stamp(5);
+    if constexpr (FTM != -2) {
+        // ---- K23 for this row, from LDS: weights at fm.P, the row's share of the 19 moments ----------------------
+        RowAcc acc;
+#pragma unroll
+        for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
+        if (valid && n > 0) {
+            double xr[3];
+            rotated_point(fm.P, q, xr);
+            RowMoments<FTM> row;
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                const bool live = j < n;
+                const float4 y = L.get(live ? L.load(j) : 0);  // slot 0 of the halo for the unused pairs: finite, weight 0
+                row.add(fm.md, xr, y.x, y.y, y.z, live);
+            }
+            row.finish(acc, fm.P, q, xr);
+        }
+        __syncthreads();  // every wave is through with the halo: the fold borrows its memory
+        double *const scratch = reinterpret_cast<double *>(s_halo);
+        // a block that was handed to the cleanup kernel (s_bail) leaves its slot to that kernel
+        block_reduce_scratch(acc, scratch, scratch + 10 * 257, fm.partials + blockIdx.x, (size_t)fm.nslots, s_bail == 0);
+        stamp(6);
+    }
+    flush_stamps();
+}
+
+}  // namespace dev
+}  // namespace ppcr

@@ -1,0 +1,47 @@
+// Host-side handshake between the C-ABI translation unit (ppcr_hip.hip) and the K1 translation units
+// (ppcr_nn_tile.hip, compiled once per list width M): everything one K1 launch needs, by value.
+#pragma once
+#include "ppcr_device.hip.h"
+
+namespace ppcr {
+
+// Halo capacity of the steady-state (16-slot) variant: 31.3 KB of LDS, five workgroups per CU (1792: four).
+constexpr int kCapSteady = 1728;
+
+struct TileLaunch {
+    hipStream_t stream;
+    float4 *src;                  // the (sorted) source; moved in place when pm.enabled
+    int ns;
+    const float4 *tgt;            // the cell-sorted target
+    const int *cell_start;
+    dev::GridDesc grid;
+    float r2;
+    int m;                        // max_neighbours (<= the M of the variant that is called)
+    int *nbr, *cnt;               // the ELL association [m][ns], [ns]
+    unsigned *dm2;                // per query: float bits of its m-th neighbour's d2 (the temporal cut-off)
+    int dm2_in;                   // dm2 of the previous association is usable
+    int short_lists;              // option short_lists
+    unsigned long long *stamps;   // diagnostic build only (nullptr otherwise)
+    int *ovf_list;                // workgroups handed to the cleanup kernel by this launch ...
+    unsigned *ovf_now, *ovf_next; // ... counted here; the other counter of the ping-pong pair
+    bool quiet;                   // the last association this handle heard from handed nothing over
+    unsigned char *split_flag;    // the split table (see SplitTable)
+    int *split_list;
+    unsigned *split_state;        // {registrations, registrations visible to extra workgroups}
+    dev::PendingMove pm;
+    const dev::FusedMoments *fuse;  // fold K23 into K1 at this pose / model when the steady-state variant runs
+    const dev::FoldSolve *fold;     // ... and the fold-and-solve step into the cleanup launch
+    // out
+    bool fused, merged;
+};
+
+// One entry per compiled-in list width (register list of the selection); defined in ppcr_nn_tile.hip.
+__attribute__((visibility("hidden"))) void launch_tile_m4(TileLaunch &t);
+__attribute__((visibility("hidden"))) void launch_tile_m5(TileLaunch &t);
+__attribute__((visibility("hidden"))) void launch_tile_m8(TileLaunch &t);
+__attribute__((visibility("hidden"))) void launch_tile_m10(TileLaunch &t);
+__attribute__((visibility("hidden"))) void launch_tile_m16(TileLaunch &t);
+__attribute__((visibility("hidden"))) void launch_tile_m20(TileLaunch &t);
+__attribute__((visibility("hidden"))) void launch_tile_m32(TileLaunch &t);
+
+}  // namespace ppcr

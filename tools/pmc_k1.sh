@@ -13,4 +13,4 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ
   rocprofv3 --kernel-trace --output-format csv --pmc $set -d $OUT/p$i -o p$i -- python3 $R/tools/exp_iter.py 1000000 > $OUT/log$i.txt 2>&1
 done
 python3 $R/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
-grep -E "^nn_tile|^accumulate_ell" -A28 $OUT/summary.txt | head -90
+grep -E "^nn_fast|^nn_tile|^accumulate_ell" -A28 $OUT/summary.txt | head -90
