@@ -40,6 +40,7 @@ enum KernelId {
     K_GATHER,
     K_CELL_START,
     K_NN_TOPM,
+    K_NN_CLEANUP,
     K_NN_COUNT,
     K_NN_SCAN,
     K_NN_FILL,
@@ -54,7 +55,7 @@ enum KernelId {
 };
 const char *const kKernelNames[K_NUM] = {
     "repack_kernel",   "bbox_kernel",    "cell_key_kernel",   "radix_sort",       "gather_points_kernel",
-    "cell_start_kernel", "nn_fast_kernel", "nn_count_kernel",  "nn_scan",          "nn_fill_kernel",
+    "cell_start_kernel", "nn_fast_kernel", "nn_tile_cleanup_kernel", "nn_count_kernel",  "nn_scan",          "nn_fill_kernel",
     "nn_select_kernel", "csr_compact_kernel", "ell_count_sum_kernel", "weights_kernel", "accumulate_kernel",
     "reduce_partials_kernel", "transform_kernel"};
 
@@ -227,7 +228,9 @@ struct ProfScope {
     ppcr_ctx *c;
     ProfRec r{};
     bool active = false;
-    ProfScope(ppcr_ctx *ctx, int id) : c(ctx)
+    ProfScope(ppcr_ctx *ctx, int id) : c(ctx) { begin(id); }
+    ~ProfScope() { end(); }
+    void begin(int id)
     {
         if (!c->prof_on) return;
         for (int k = 0; k < 2; k++) {
@@ -244,11 +247,19 @@ struct ProfScope {
         active = true;
         (void)hipEventRecord(r.start, c->stream);
     }
-    ~ProfScope()
+    void end()
     {
         if (!active) return;
         (void)hipEventRecord(r.stop, c->stream);
         c->prof_recs.push_back(r);
+        active = false;
+    }
+    // close the running record here and time what follows under another id (two launches inside one call)
+    void split(int id)
+    {
+        if (!active) return;
+        end();
+        begin(id);
     }
 };
 
@@ -605,6 +616,8 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             tl.quiet = c->ovf_last == 0;
             tl.split_flag = c->split_flag.p, tl.split_list = c->split_list.p, tl.split_state = c->split_state.p;
             tl.pm = pm, tl.fuse = fuse, tl.fold = fold;
+            tl.between = [](void *scope) { static_cast<ProfScope *>(scope)->split(K_NN_CLEANUP); };
+            tl.between_arg = &ps;
             if (m <= 4) launch_tile_m4(tl);
             else if (m <= 5) launch_tile_m5(tl);
             else if (m <= 8) launch_tile_m8(tl);

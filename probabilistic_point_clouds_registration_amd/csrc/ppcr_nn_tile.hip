@@ -82,6 +82,7 @@ void launch_tile(TileLaunch &t)
         }
     }
 #undef PPCR_FAST
+    if (t.between) t.between(t.between_arg);
     // persistent workgroups over the list: few when the last association this handle heard from handed nothing over
     const int cleanup_grid = t.quiet ? std::min(nb, 32) : std::min(nb, 512);
     const int n_extra = steady ? kMaxSplit : 0;

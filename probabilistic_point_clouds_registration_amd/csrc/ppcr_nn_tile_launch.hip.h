@@ -31,6 +31,8 @@ struct TileLaunch {
     dev::PendingMove pm;
     const dev::FusedMoments *fuse;  // fold K23 into K1 at this pose / model when the steady-state variant runs
     const dev::FoldSolve *fold;     // ... and the fold-and-solve step into the cleanup launch
+    void (*between)(void *);        // called between the two launches (profiling scopes), may be null
+    void *between_arg;
     // out
     bool fused, merged;
 };

@@ -21,7 +21,7 @@ def main(summary, out, tag):
     fetch_kb, n = vals["FETCH_SIZE"]
     write_kb, _ = vals["WRITE_SIZE"]
     doc = {
-        "kernel": pick.splitlines()[0].strip() + "> (steady-state K1: nn_fast_kernel, 16-slot lists, deferred source move and "
+        "kernel": pick.splitlines()[0].strip() + " (steady-state K1: nn_fast_kernel, 16-slot lists, deferred source move and "
                   "temporal cut-off folded in)",
         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, MI355X, profiles/{tag}_pmc_hbm_traffic.txt; "
                   f"tools/profile_round.sh), mean over {n} dispatches",
