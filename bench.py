@@ -309,7 +309,7 @@ def run_rank(a):
                     "window_ms": 1e3 * dt},
         "nnz": int(nnz),
     }
-    # roofline of the dominant kernel (K1, nn_tile_kernel): algorithmic bytes B_nn = 16*Ns + 12*Nt + 4*nnz
+    # roofline of the dominant kernel (K1, nn_fast_kernel): algorithmic bytes B_nn = 16*Ns + 12*Nt + 4*nnz
     #  / average launch duration measured with HIP events above
     b_nn = 16.0 * ns + 12.0 * nt + 4.0 * nnz
     b_iter = 72.0 * ns + 12.0 * nt + 52.0 * nnz + (a.inner_steps - 1) * (32.0 * ns + 48.0 * nnz)

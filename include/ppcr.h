@@ -249,9 +249,9 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *   "grid_xf"      x slices per grid cell, 1/2/4/8 (default 4; set before the target): every stencil row is clipped
  *                  to the x window the search sphere needs in that row;
  *   "brick_x"      x extent in cells of the 4x4 (y,z) bricks the source is ordered by: 1 (default), 2 or 4;
- *   "short_lists"  1 once the temporal cut-off is valid K1 runs with 16-slot lists and four workgroups per CU
- *                  (default), 0 always 32 slots / three workgroups;
- *   "stamps"       1 collect per-phase cycle counts of the tiled kernel (diagnostic). */
+ *   "short_lists"  1 once the temporal cut-off is valid K1 runs with 16-slot lists, a 1728-candidate halo and five
+ *                  workgroups per CU (default), 0 always 32 slots / three workgroups;
+ *   "stamps"       1 collect per-phase cycle counts and per-lane run lengths of K1 (diagnostic build of the kernel). */
 int ppcr_set_option(ppcr_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus

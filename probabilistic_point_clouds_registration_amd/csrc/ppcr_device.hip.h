@@ -23,7 +23,7 @@ constexpr int kMaxSplit = 64;  // K1: blocks that can be scanned as two half-blo
 // Uniform grid over the target's bounding box.  Cells are cubes of edge h >= radius in y and z; in x every cell is
 // split into xr slices (edge h / xr, inv_hx = xr * inv_h): a (dy, dz) row of the stencil is one contiguous run
 // of the cell-sorted target whatever xr is, and a finer x lets every query clip each of its nine runs to the
-// x window the sphere really needs in that row (nn_tile_kernel) instead of three full cells.
+// x window the sphere really needs in that row (nn_fast_kernel) instead of three full cells.
 // n[0] counts x SLICES; the stencil reaches xr slices either side of the query's slice.
 struct GridDesc {
     float org[3];

@@ -632,7 +632,7 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             if (fold && !merged) return fail(c, PPCR_ERR_STATE, "internal: a fold was prepared but not launched");
         }
         c->assoc_space = 1;
-        PPCR_TRY(check_launch(c, "nn_tile_kernel"));
+        PPCR_TRY(check_launch(c, "nn_fast_kernel"));
         c->dm2_valid = tiled;
         c->assoc = ppcr_ctx::ASSOC_ELL;
         c->ell_width = m;
@@ -1228,7 +1228,7 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
         c->opt_temporal = value ? 1 : 0;
         return PPCR_OK;
     }
-    if (std::strcmp(key, "stamps") == 0) {  // diagnostic: per-phase cycle totals of nn_tile_kernel
+    if (std::strcmp(key, "stamps") == 0) {  // diagnostic: per-phase cycle totals of nn_fast_kernel
         // 8 words per wave, then one word per lane (its sorted run lengths)
         const size_t nwg = (size_t)nblocks(std::max<int64_t>(c->ns, 1)) + kMaxSplit;
         const size_t nst = (nwg * (kBlock / 64) + 64) * 8 + nwg * 256;
@@ -1781,7 +1781,7 @@ int ppcr_get_source(ppcr_ctx *c, float *xyz, int64_t stride_bytes)
     return PPCR_OK;
 }
 
-// diagnostic (tools/exp_stamps.py): out[8] = per-phase cycle totals over all waves of nn_tile_kernel
+// diagnostic (tools/exp_stamps.py): out[8] = per-phase cycle totals over all waves of nn_fast_kernel
 int ppcr_debug_get_stamps(ppcr_ctx *c, unsigned long long out[8])
 {
     CTX_ENTER(c);

@@ -80,7 +80,7 @@ __global__ void cell_key_kernel(const float4 *__restrict__ pts, int n, GridDesc 
 // Source ordering: (2^bxs)x4x4-cell bricks visited boustrophedon (x snakes per brick row, y snakes per
 // brick plane), cells x-fastest inside a brick.  Default bxs = 0: 4x4 columns of cells in (y,z) walked along x.  Any 256 consecutive queries then sit in one or two
 // ADJACENT bricks, so the cell bounding box of a workgroup — and with it the target halo it stages
-// into LDS (nn_tile_kernel) — stays small.  Only the order of the source changes, never a result.
+// into LDS (nn_fast_kernel) — stays small.  Only the order of the source changes, never a result.
 __global__ void brick_key_kernel(const float4 *__restrict__ pts, int n, GridDesc g,
                                  unsigned *__restrict__ keys, int *__restrict__ vals, int bxs)
 {

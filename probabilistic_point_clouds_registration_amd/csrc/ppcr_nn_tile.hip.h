@@ -18,7 +18,7 @@ namespace dev {
 //   3. each lane walks ITS OWN 27-cell stencil (9 runs) out of LDS (ds_read_b128) — the exact
 //      candidate set, no extra distance tests;
 //   4. in-radius candidates are appended to a lane-private u16 list of LDS indices; the top-m
-//      cut-off is applied afterwards with the v_med3 threshold selection (see nn_list_kernel),
+//      cut-off is applied afterwards with the v_med3 threshold selection (select_top_m below),
 //      now reading LDS only.
 // A halo that does not fit (sparse or unsorted source) is retried per wave, and as a last resort
 // the wave falls back to scanning global memory with the same selection code.
@@ -26,7 +26,7 @@ namespace dev {
 constexpr int kTileRows = 128;   // halo rows per staging
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL load
-// (s_waitcnt vmcnt(0)): in nn_tile_kernel that serialises the run-bound loads issued in the prologue with the
+// (s_waitcnt vmcnt(0)): in the K1 kernels that serialises the run-bound loads issued in the prologue with the
 // row-table and staging loads behind the barrier; with the LDS-only fences they stay in flight across it.
 __device__ __forceinline__ void lds_barrier()
 {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-phase cycle shares of nn_tile_kernel (s_memtime stamps; never used in timed runs)."""
+"""Diagnostic: per-phase cycle shares of nn_fast_kernel (s_memtime stamps; never used in timed runs)."""
 import ctypes as C, sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
