@@ -984,12 +984,60 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
             (void)select_top_m<M>(L, tgt, q, C - 1, m, thr);
         }
         stamp(3);
-        if (n > m) {
+        // ---- selection: the list -> its m smallest by (d2, original index); tm = d2 bits of the m-th -----------------
+        // With a valid cut-off nearly every list holds m or a few more candidates (the cut-off is the previous m-th
+        // distance plus the query's own displacement).  Such a list does not need the two-pass threshold selection: ONE
+        // pass finds its three largest d2 and the slots of the first two; a list of m takes the largest as its new
+        // cut-off state, a list of m + 1 drops the slot of the largest (the last entry moves into it) and takes the
+        // second, a list of m + 2 drops two and takes the third, a list of m + 3 goes round once more.  Candidates tying
+        // at a dropped distance (the rule then asks for their original indices), or any lane of the wave with m + 4 or
+        // more, take the general selection.
+        const int surplus = n - m;  // < 0: the list is the answer, no cut-off state
+        bool general = surplus >= 4;
+        if (__ballot(general) == 0ull) {
+            int left = surplus;
+            for (bool first_pass = true;; first_pass = false) {
+                const bool active = !general && (first_pass ? left >= 0 : left > 0);
+                if (__ballot(active) == 0ull) break;
+                if (active) {
+                    unsigned f1 = 0, f2 = 0, f3 = 0;  // the three largest, descending
+                    int s1 = 0, s2 = 0;               // slots of the first two
+                    for_each_entry(L, q, n, [&](int t, int, unsigned b) {
+                        const bool gt1 = b > f1, gt2 = b > f2;
+                        s2 = gt1 ? s1 : (gt2 ? t : s2);
+                        s1 = gt1 ? t : s1;
+                        f3 = umed3(f2, f3, b);  // f2 >= f3: max(f3, min(f2, b))
+                        f2 = umed3(f1, f2, b);  // f1 >= f2: max(f2, min(f1, b))
+                        f1 = max(f1, b);
+                    });
+                    if (left == 0) {
+                        tm = f1;
+                    } else if (f1 == f2 || (left >= 2 && f2 == f3)) {
+                        general = true;
+                    } else {
+                        L.store(s1, L.load(n - 1));
+                        n -= 1;
+                        tm = f2;
+                        if (left >= 2) {
+                            s2 = (s2 == n) ? s1 : s2;  // the second largest was the last entry: it has just moved
+                            L.store(s2, L.load(n - 1));
+                            n -= 1;
+                            tm = f3;
+                        }
+                    }
+                }
+                left -= 2;
+            }
+        } else {
+            general = surplus > 0;
+            if (surplus == 0) {
+                tm = 0;
+                for_each_entry(L, q, n, [&](int, int, unsigned b) { tm = max(tm, b); });
+            }
+        }
+        if (general) {
             n = select_top_m<M>(L, tgt, q, n, m, thr);
             tm = thr;
-        } else if (n == m) {
-            tm = 0;
-            for_each_entry(L, q, n, [&](int, int, unsigned b) { tm = max(tm, b); });
         }
         stamp(4);
     }

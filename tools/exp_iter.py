@@ -19,5 +19,5 @@ for k in range(1):
     c.associate(); show(f"assoc-only {k}:")
 for k in range(12):
     T, cost, st = c.iterate()
-    if k in (0, 3, 7, 11): show(f"iterate {k} (|t|={np.linalg.norm(T[:,3]):.4f}):")
+    if k < 8 or k == 11: show(f"iterate {k} (|t|={np.linalg.norm(T[:,3]):.4f}):")
     else: c.profile_get(); c.profile_enable(True)
