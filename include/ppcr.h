@@ -245,6 +245,8 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *                  (default; a different summation order: results agree to rounding), 0 separate kernel;
  *   "merge_fold"   1 with "fuse_k23": the fold-and-solve step rides in the cleanup launch when the handle has the GPU
  *                  to itself (default), 0 always its own launch;
+ *   "defer_moves"  1 ppcr_apply_transform leaves the move to the prologue of the next association (what ppcr_iterate
+ *                  and ppcr_align always do; the temporal cut-off then survives the move), 0 moves at once (default);
  *   "mailbox"      1 deliver the moments through pinned host memory and spin (default), 0 copy + synchronise;
  *   "grid_xf"      x slices per grid cell, 1/2/4/8 (default 4; set before the target): every stencil row is clipped
  *                  to the x window the search sphere needs in that row;

@@ -190,6 +190,7 @@ struct ppcr_ctx {
     bool assoc_fused = false;    // the last association also left the partial moments of the pose it was given
     int fused_slots = 0;         // ... in this many partial vectors
     int opt_run_ahead = 1;       // ppcr_align keeps the device one iteration ahead of the host when the rule allows
+    int opt_defer_moves = 0;     // ppcr_apply_transform leaves the move to the next association's prologue (as ppcr_iterate does)
     int opt_brick_xshift = 0;    // log2 of the source bricks' x extent in cells (0: 4x4 yz columns walked along x)
     int opt_grid_xf = 4;         // x slices per grid cell (GridDesc::xr)
     float tgt_lo[3] = {0, 0, 0}, tgt_hi[3] = {0, 0, 0};
@@ -1220,6 +1221,10 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
         c->opt_short_lists = value ? 1 : 0;
         return PPCR_OK;
     }
+    if (std::strcmp(key, "defer_moves") == 0) {
+        c->opt_defer_moves = value ? 1 : 0;
+        return PPCR_OK;
+    }
     if (std::strcmp(key, "mailbox") == 0) {
         c->opt_mailbox = value ? 1 : 0;
         return PPCR_OK;
@@ -1534,7 +1539,7 @@ int ppcr_apply_transform(ppcr_ctx *c, const double T[12])
 {
     CTX_ENTER(c);
     if (!T) return fail(c, PPCR_ERR_INVALID, "null transform");
-    return apply_transform_impl(c, T);
+    return apply_transform_impl(c, T, c->opt_defer_moves != 0);
 }
 
 int ppcr_iterate(ppcr_ctx *c, const double q0[4], const double t0[3], int inner_steps, double f_tol, double T_out[12],

@@ -584,11 +584,31 @@ def test_temporal_cutoff_and_deferred_move_change_nothing(ctx):
             np.testing.assert_array_equal(ra[1], ocol)
             po.transform_cloud(cur, np.vstack([Ta, [0, 0, 0, 1]]))
             np.testing.assert_array_equal(a.get_source(), cur)
+        # uninterrupted iterations: every K1 but the first applies the previous move in its prologue and starts from the
+        # cut-off of the previous association (reading the association, as above, flushes the move and resets it)
+        for n_it in (2, 3, 6):
+            a.set_source(src)
+            cur, steps = src.copy(), []
+            for it in range(n_it):
+                steps.append(a.iterate(inner_steps=1)[0])
+            for T in steps[:-1]:
+                po.transform_cloud(cur, np.vstack([T, [0, 0, 0, 1]]))
+            rp, col, _ = a.get_association()       # the last K1's, made before the last move (d2 is re-evaluated after it)
+            orp, ocol, _ = po.radius_search(cur, tgt, 1.0, 10, method=1)
+            np.testing.assert_array_equal(rp, orp)
+            np.testing.assert_array_equal(col, ocol)
+            po.transform_cloud(cur, np.vstack([steps[-1], [0, 0, 0, 1]]))
+            np.testing.assert_array_equal(a.get_source(), cur)
+        for c in (a, b):
+            c.set_source(src)
+            c.associate()
+        cur = src.copy()
         # a big jump (cut-off bound = previous distance + displacement must still hold)
         jump = np.eye(4)
         jump[:3, :3] = synth.rodrigues([0.2, 1.0, -0.3], 0.4)
         jump[:3, 3] = [0.7, -0.4, 0.3]
         for c in (a, b):
+            c.set_option("defer_moves", 1)     # the jump rides in the next K1's prologue, the cut-off stays in force
             c.apply_transform(jump)
             c.associate()
         po.transform_cloud(cur, jump)
@@ -725,11 +745,14 @@ def test_randomised_association_soak(ctx):
         xf = int(rng.choice([1, 2, 4, 8]))
         with _lib.Context(0) as c:
             c.set_option("grid_xf", xf)
+            # every other trial leaves the moves to the next association's prologue, as the align loop does: the
+            # steady-state kernel then runs with the cut-off of the previous association and the query's displacement
+            c.set_option("defer_moves", trial % 2)
             c.set_params(radius, m, 5.0, 3)
             c.set_target(tgt)
             c.set_source(src)
             cur = src.copy()
-            for step in range(4):
+            for step in range(4 + 2 * (trial % 2)):
                 c.associate()
                 rp, col, d2 = c.get_association()
                 orp, ocol, od2 = po.radius_search(cur, tgt, radius, m, method=1)
