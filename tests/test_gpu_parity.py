@@ -355,6 +355,20 @@ def test_headline_1m_properties_and_sampled_parity(ctx):
     assert np.linalg.norm(res["history"][-1][:, 3] - ora["history"][-1][:, 3]) < TRANS_TOL
     # it moves toward the generator's ground truth
     assert np.linalg.norm(res["history"][-1][:, 3] - tgt_t) < np.linalg.norm(tgt_t)
+    # the steady-state kernel at full size: five uninterrupted iterations (each K1 applies the previous move in its
+    # prologue and starts from the previous cut-off; blocks whose halo outgrows the capacity are split or handed over),
+    # then the last association against brute force on the same sample of queries
+    ctx.set_source(src)
+    cur, steps = src.copy(), [ctx.iterate(inner_steps=1)[0] for _ in range(5)]
+    for T in steps[:-1]:
+        po.transform_cloud(cur, np.vstack([T, [0, 0, 0, 1]]))
+    rp, col, _ = ctx.get_association()
+    assert abs(col.size / n - 9.92) < 0.05
+    orp, ocol, _ = po.radius_search(cur[pick], tgt, 1.0, 10, method=0)
+    for j, i in enumerate(pick):
+        np.testing.assert_array_equal(col[rp[i]:rp[i + 1]], ocol[orp[j]:orp[j + 1]])
+    po.transform_cloud(cur, np.vstack([steps[-1], [0, 0, 0, 1]]))
+    np.testing.assert_array_equal(ctx.get_source(), cur[:, :3])
 
 
 # ----------------------------------------------------------------------------- errors
