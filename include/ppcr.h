@@ -145,7 +145,10 @@ int ppcr_stop_rule_check(ppcr_stop_rule *rule, int n_iter, double cost_drop_thre
  * With inner_steps <= 1 the solve runs on the device and the next association takes its source move from device
  * memory, so the device works one iteration ahead of this thread — but an iteration is only enqueued early when
  * hasConverged() cannot stop before it whatever the pending cost turns out to be, so the iterations performed, and
- * every number returned, are those of the one-at-a-time loop. */
+ * every number returned, are those of the one-at-a-time loop.
+ * Like ppcr_iterate, the call leaves its last move pending: it is applied by whatever reads the source next
+ * (ppcr_get_source, ppcr_get_association, the reports ...), or carried in the first association of a following
+ * ppcr_align / ppcr_iterate, which then continues the loop exactly where this call stopped (same cut-off state). */
 int ppcr_align(ppcr_ctx *ctx, int n_iter, double cost_drop_thresh, double n_cost_drop_it,
                const double q0[4], const double t0[3], int inner_steps, double f_tol, double *history,
                double *costs, int32_t *steps, int *n_done);

@@ -1708,11 +1708,13 @@ struct AlignJob {
         return PPCR_OK;
     }
 
-    // leave the device copy of the source current and hand the totals over
+    // Hand the totals over.  The last move stays pending, as after ppcr_iterate: whoever reads the source next (or the
+    // association's distances, weights, reports ...) applies it first; a following ppcr_align / ppcr_iterate takes it
+    // along in its first K1 and keeps the temporal cut-off — two calls of n and m iterations cost what one call of
+    // n + m does.
     int finish(double *T_final, int *n_done)
     {
         HIP_TRY(c, hipSetDevice(c->device));
-        PPCR_TRY(flush_pending_move(c));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (T_final) std::memcpy(T_final, Tcum, sizeof(Tcum));  // identity when no iteration ran
         if (n_done) *n_done = rule.iteration;

@@ -395,6 +395,32 @@ def test_error_behaviour(ctx):
         c.close()
 
 
+def test_chained_aligns_continue_the_loop(ctx):
+    """align(a) followed by align(b) is align(a + b): the last move of a call stays pending and the next call's first
+    association takes it along (and keeps the cut-off) — same histories, same costs, same source, bit for bit."""
+    src, tgt, _, _ = synth.make_pair(20000, cfg=2, stride=5)
+    with _lib.Context(0) as one, _lib.Context(0) as two:
+        for c in (one, two):
+            c.set_params(1.0, 10, 5.0, 3)
+            c.set_target(tgt)
+            c.set_source(src)
+        whole = one.align(7, cost_drop_thresh=0.0, inner_steps=1)
+        first = two.align(3, cost_drop_thresh=0.0, inner_steps=1)
+        second = two.align(4, cost_drop_thresh=0.0, inner_steps=1)
+        np.testing.assert_array_equal(first["history"], whole["history"][:3])
+        np.testing.assert_array_equal(first["costs"], whole["costs"][:3])
+        np.testing.assert_array_equal(second["costs"], whole["costs"][3:])
+        T3 = np.vstack([whole["history"][2], [0, 0, 0, 1]])
+        for k in range(4):      # the second call's history starts from the identity again
+            np.testing.assert_allclose(np.vstack([second["history"][k], [0, 0, 0, 1]]) @ T3,
+                                       np.vstack([whole["history"][3 + k], [0, 0, 0, 1]]), rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(one.get_source(), two.get_source())
+        # reading the association between two calls flushes the move and restarts the cut-off: still the same neighbours
+        a, b = one.get_association(), two.get_association()
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+
+
 def test_profile_reports_kernels(ctx):
     g = load("nn_weights_2k.npz")
     ctx.set_params(1.0, 10, 5.0, 3)
@@ -402,6 +428,8 @@ def test_profile_reports_kernels(ctx):
     ctx.set_source(g["src"])
     ctx.profile_enable(True)
     ctx.align(3, inner_steps=1)
+    assert "transform_kernel" not in ctx.profile_get()   # the last move stays pending until somebody reads the source
+    moved = ctx.get_source()
     st = ctx.profile_get()
     ctx.profile_enable(False)
     # K23 is its own launch for the first association only: from the second one on (temporal cut-off valid, steady-state
@@ -409,8 +437,8 @@ def test_profile_reports_kernels(ctx):
     assert st["nn_fast_kernel"]["launches"] == 3 and st["accumulate_kernel"]["launches"] == 1, st
     # ... and so is the fold-and-solve step (it rides in the cleanup launch, inside the K1 scope of this profile)
     assert st["reduce_partials_kernel"]["launches"] == 1, st
-    # the source move rides in the next K1 prologue; only the last one needs its own launch
-    assert st["transform_kernel"]["launches"] == 1 and st["nn_fast_kernel"]["total_ms"] > 0
+    # the source move rides in the next K1 prologue; only the last one needs its own launch (when the source is read)
+    assert st["transform_kernel"]["launches"] == 1 and st["nn_fast_kernel"]["total_ms"] > 0 and moved.shape[0] == g["src"].shape[0]
     # with the fold switched off every iteration launches K23
     ctx.set_option("fuse_k23", 0)
     ctx.set_source(g["src"])
