@@ -321,35 +321,68 @@ __device__ __forceinline__ void block_reduce_scratch(const RowAcc &acc, double *
 }
 constexpr int kFoldScratchBytes = (10 * 257 + kNSums * 8) * 8;  // 21 776
 
+// 1/x to ~2e-15 (v_rcp_f64 seed, 4.5e-8 measured on gfx950, + ONE Newton step): the per-pair reciprocal of the folded
+// K23, whose results are held to 1e-10
+__device__ __forceinline__ double rcp_1step(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
 // One row's contribution to the moments for a compiled-in model, pairs handed over one at a time (the one-pass form of
 // accumulate_ell_kernel: likelihoods relative to s = 0).  Used by the kernels that fold K23 into the association.
+// t model with v + dim = 8 (the reference's defaults): e = (v / (v + s))^4 and g = e (v + dim) / (v + s); the constant
+// factors v^4 and (v + dim) v^4 are left out of the per-pair sums and applied once per row in finish().
 template <int TM>
 struct RowMoments {
     double Z = 0, G = 0, Gs = 0, Gr[3] = {0, 0, 0};  // sum e, sum g, sum g s, sum g r   (r = y - (R x + t))
     // xr = R x + t.  The centred target never appears: sum g (y - c) = sum g r + (xr - c) sum g.
-    __device__ __forceinline__ void add(const Model &md, const double (&xr)[3], float yx, float yy, float yz, bool live)
+    // One stored pair (callers skip the unused slots of a row by control flow: no selects in here).
+    __device__ __forceinline__ void add_pair(const Model &md, const double (&xr)[3], float yx, float yy, float yz)
     {
         const double r0 = (double)yx - xr[0], r1 = (double)yy - xr[1], r2 = (double)yz - xr[2];
         const double sk = fma(r2, r2, fma(r1, r1, r0 * r0));
-        const double sv = live ? sk : 1e300;
-        const double inv_vs = (TM == 0) ? 0.0 : fast_rcp(md.v + sv);
-        const double e = rel_likelihood<TM>(md, sv, 0.0, 0.0, inv_vs);
-        Z += e;
-        const double gk = (TM == 0) ? e : e * (md.vpd * inv_vs);
+        double gk;
+        if constexpr (TM == 8) {
+            const double inv = rcp_1step(md.v + sk);
+            const double c = inv * inv, p = c * c;
+            Z += p;
+            gk = p * inv;
+        } else {
+            const double inv_vs = (TM == 0) ? 0.0 : rcp_1step(md.v + sk);
+            const double e = rel_likelihood<TM>(md, sk, 0.0, 0.0, inv_vs);
+            Z += e;
+            gk = (TM == 0) ? e : e * (md.vpd * inv_vs);
+        }
         G += gk;
-        Gs = fma(gk, live ? sk : 0.0, Gs);
+        Gs = fma(gk, sk, Gs);
         Gr[0] = fma(gk, r0, Gr[0]);
         Gr[1] = fma(gk, r1, Gr[1]);
         Gr[2] = fma(gk, r2, Gr[2]);
     }
+    __device__ __forceinline__ void add(const Model &md, const double (&xr)[3], float yx, float yy, float yz, bool live)
+    {
+        if (live) add_pair(md, xr, yx, yy, yz);
+    }
     __device__ __forceinline__ void finish(RowAcc &acc, const Pose &P, float4 xf, const double (&xr)[3]) const
     {
+        double Zs = Z, Gk = G, Gsk = Gs, Grk[3] = {Gr[0], Gr[1], Gr[2]};
+        if constexpr (TM == 8) {
+            const double v2 = md_v2, v4 = v2 * v2, k = md_vpd * v4;
+            Zs *= v4, Gk *= k, Gsk *= k, Grk[0] *= k, Grk[1] *= k, Grk[2] *= k;
+        }
         const double xrc[3] = {xr[0] - P.c[0], xr[1] - P.c[1], xr[2] - P.c[2]};
-        const double Gy[3] = {fma(xrc[0], G, Gr[0]), fma(xrc[1], G, Gr[1]), fma(xrc[2], G, Gr[2])};
+        const double Gy[3] = {fma(xrc[0], Gk, Grk[0]), fma(xrc[1], Gk, Grk[1]), fma(xrc[2], Gk, Grk[2])};
         // sum g |y - c|^2 with y - c = r + xrc:  Gs + 2 xrc . Gr + |xrc|^2 G
         const double x2 = fma(xrc[2], xrc[2], fma(xrc[1], xrc[1], xrc[0] * xrc[0]));
-        const double Gyy = fma(x2, G, fma(2.0, fma(xrc[2], Gr[2], fma(xrc[1], Gr[1], xrc[0] * Gr[0])), Gs));
-        row_finish(acc, P, xf, Z, G, Gs, Gyy, Gy);
+        const double Gyy = fma(x2, Gk, fma(2.0, fma(xrc[2], Grk[2], fma(xrc[1], Grk[1], xrc[0] * Grk[0])), Gsk));
+        row_finish(acc, P, xf, Zs, Gk, Gsk, Gyy, Gy);
+    }
+    double md_v2 = 0, md_vpd = 0;  // set by begin() for TM == 8
+    __device__ __forceinline__ void begin(const Model &md)
+    {
+        md_v2 = md.v * md.v;
+        md_vpd = md.vpd;
     }
 };
 __device__ __forceinline__ void rotated_point(const Pose &P, float4 xf, double (&xr)[3])

@@ -371,6 +371,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
             double xr[3];
             rotated_point(P, xf[r], xr);
             RowMoments<TM> row;
+            row.begin(md);
 #pragma unroll
             for (int k = 0; k < W; k++) row.add(md, xr, yx[r][k], yy[r][k], yz[r][k], k < n[r]);
             row.finish(acc, P, xf[r], xr);

@@ -514,9 +514,10 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
             double xr[3];
             rotated_point(fm.P, q, xr);
             RowMoments<FTM> row;
+            row.begin(fm.md);
             for (int j = 0; j < nrow; j++) {
                 const float4 y = tgt[nbr[(size_t)j * ns + i]];
-                row.add(fm.md, xr, y.x, y.y, y.z, true);
+                row.add_pair(fm.md, xr, y.x, y.y, y.z);
             }
             row.finish(acc, fm.P, q, xr);
         }
@@ -1066,11 +1067,13 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
             double xr[3];
             rotated_point(fm.P, q, xr);
             RowMoments<FTM> row;
+            row.begin(fm.md);
 #pragma unroll
             for (int j = 0; j < M; j++) {
-                const bool live = j < n;
-                const float4 y = L.get(live ? L.load(j) : 0);  // slot 0 of the halo for the unused pairs: finite, weight 0
-                row.add(fm.md, xr, y.x, y.y, y.z, live);
+                if (j < n) {  // nearly every row is full: the branch is uniform for most waves
+                    const float4 y = L.get(L.load(j));
+                    row.add_pair(fm.md, xr, y.x, y.y, y.z);
+                }
             }
             row.finish(acc, fm.P, q, xr);
         }
