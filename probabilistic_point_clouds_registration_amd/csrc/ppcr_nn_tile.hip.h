@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     static_assert(CAP % 4 == 0 && CAP * 4 < 65536, "list entries are 16-bit byte offsets into the halo arrays");
     constexpr int BLOCK = 256, kWaves = 4, kRows = 128, kStageUnroll = 4;
     __shared__ __attribute__((aligned(16))) float s_halo[3 * CAP + CAP / 4];
-    __shared__ unsigned short s_list[C * BLOCK];
+    __shared__ unsigned short s_list[(C + 1) * BLOCK];  // C slots per lane + one that rejected candidates land in
     __shared__ int s_gbo[kRows];
     // non-empty rows, compacted: {global begin, LDS offset << 19 | length << 7 | slot}; only alive between the row
     // table and the staging barrier, so it borrows the (not yet written) list area
@@ -937,15 +937,15 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         typedef float v2f __attribute__((ext_vector_type(2)));
         const v2f qx2 = {q.x, q.x}, qy2 = {q.y, q.y}, qz2 = {q.z, q.z};
         // LDS addresses as plain 32-bit integers (address space 3): the write cursor and the candidate cursor are
-        // one VGPR each and an accepted candidate costs v_min + ds_write + v_add
+        // one VGPR each and a candidate costs v_min + ds_write + v_cndmask + v_add, accepted or not
         typedef __attribute__((address_space(3))) unsigned short *lds_u16p;
         typedef __attribute__((address_space(3))) const float *lds_f32p;
         // (the casts go through uintptr_t so that the host pass, where every pointer is 64-bit, parses them too)
-        const unsigned list0 = (unsigned)(__UINTPTR_TYPE__)(lds_u16p)(s_list + tid), list_last = list0 + (C - 1) * 512;
+        const unsigned list0 = (unsigned)(__UINTPTR_TYPE__)(lds_u16p)(s_list + tid), list_last = list0 + C * 512;
         const unsigned halo0 = (unsigned)(__UINTPTR_TYPE__)(lds_f32p)s_x;
         for (int attempt = 0;; attempt++) {
-            // the list's write cursor counts every accepted candidate (so n is exact), the store slot is clamped: an
-            // overflowing lane keeps its first C - 1 entries and scribbles over the last slot
+            // the list's write cursor counts every accepted candidate (so n is exact), the store slot is clamped to
+            // the spare slot C: an overflowing lane keeps its first C entries
             unsigned wp = list0;
 #pragma unroll
             for (int k = 0; k < 9; k++) {
@@ -961,16 +961,14 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
                         v2f d = dx * dx;
                         d = d + dy * dy;
                         d = d + dz * dz;
-                        const unsigned slot_x = min(wp, list_last);  // outside the branch: the wave pays it either way
-                        if (__float_as_uint(d.x) <= thr) {
-                            *(lds_u16p)(__UINTPTR_TYPE__)slot_x = (unsigned short)(a - halo0);
-                            wp += 512;
-                        }
+                        // every candidate is written to the list's next free slot; only an accepted one moves the cursor
+                        // (a rejected one is overwritten by whatever comes next): no branch, no exec juggling
+                        const unsigned slot_x = min(wp, list_last);
+                        *(lds_u16p)(__UINTPTR_TYPE__)slot_x = (unsigned short)(a - halo0);
+                        wp += (__float_as_uint(d.x) <= thr) ? 512u : 0u;
                         const unsigned slot_y = min(wp, list_last);
-                        if (a < a_pair && __float_as_uint(d.y) <= thr) {
-                            *(lds_u16p)(__UINTPTR_TYPE__)slot_y = (unsigned short)(a - halo0 + 4);
-                            wp += 512;
-                        }
+                        *(lds_u16p)(__UINTPTR_TYPE__)slot_y = (unsigned short)(a - halo0 + 4);
+                        wp += (bool(a < a_pair) & bool(__float_as_uint(d.y) <= thr)) ? 512u : 0u;
                     }
                 }
             }
@@ -980,9 +978,9 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
                 n = -1;
                 break;
             }
-            // list overflow (dense neighbourhood, or no usable cut-off yet): the C - 1 entries that were kept are
-            // genuine in-radius candidates, so the m-th smallest of them bounds the final m-th distance: scan again
-            (void)select_top_m<M>(L, tgt, q, C - 1, m, thr);
+            // list overflow (dense neighbourhood, or no usable cut-off yet): the C entries that were kept are genuine
+            // in-radius candidates, so the m-th smallest of them bounds the final m-th distance: scan again
+            (void)select_top_m<M>(L, tgt, q, C, m, thr);
         }
         stamp(3);
         // ---- selection: the list -> its m smallest by (d2, original index); tm = d2 bits of the m-th -----------------
