@@ -135,6 +135,17 @@ __device__ __forceinline__ int select_top_m(const S &src, const float4 *__restri
     return w;
 }
 
+// Which block of 256 queries the g-th workgroup of a launch takes.  The dispatcher deals consecutive workgroups to the
+// eight XCDs in turn; blocks are spatially coherent in their index, and neighbouring blocks stage largely the same
+// target rows.  Giving XCD x the x-th eighth of the blocks (instead of every eighth block) lets those rows hit in that
+// XCD's L2 instead of being fetched once per XCD.  A bijection on [0, nb): the first 8 * (nb / 8) ids are permuted,
+// the remainder keeps its place.
+__device__ __forceinline__ int xcd_block(int g, int nb)
+{
+    const int per = nb >> 3;
+    return g < 8 * per ? (g & 7) * per + (g >> 3) : g;
+}
+
 // GENERAL flavour of K1, run on the workgroups nn_fast_kernel hands over (ovf_list[0 .. *ovf_count)): halos of any
 // shape (up to 128 rows), binary subdivision when a halo does not fit, global-memory scan as the last resort, in-loop
 // list compaction for dense neighbourhoods.  The source has already been moved by the fast kernel and the temporal
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
     for (unsigned listed = blockIdx.x; listed < n_listed; listed += n_cleanup) {
     const int entry = ovf_list[listed];
     const int fast_slot = entry >> 2, half = entry & 3;
-    const int bid = fast_slot < n_extra ? split_list[fast_slot] : fast_slot - n_extra;
+    const int bid = fast_slot < n_extra ? split_list[fast_slot] : xcd_block(fast_slot - n_extra, (ns + BLOCK - 1) / BLOCK);
     static_assert(C > M, "a compaction must leave room in the list");
     static_assert(CAP % 4 == 0 && CAP <= 65536 && C * 64 <= 3 * CAP && kTileRows <= 256, "the global fallback aliases the candidate buffer");
     static_assert(kTileRows == 128, "row table: two rows per lane of one wave");
@@ -685,7 +696,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         bid = split.list[blockIdx.x];
         half = 2;
     } else {
-        bid = (int)blockIdx.x - split.n_extra;
+        bid = xcd_block((int)blockIdx.x - split.n_extra, (ns + BLOCK - 1) / BLOCK);
         if (split.n_extra > 0 && split.flag[bid] == 2) half = 1;
     }
     const int i = bid * BLOCK + tid;
