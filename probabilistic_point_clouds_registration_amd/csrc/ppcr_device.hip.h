@@ -557,11 +557,15 @@ __device__ __forceinline__ bool polar_rotation(const double (&h)[3][3], double (
                 nc = fma(cf[a][b], cf[a][b], nc);
             }
         // well conditioned and orientation preserving?  (|X|_F^3 bounds |det|; 1e-9 leaves cond(H) up to ~1e4-1e9 here)
-        if (!(det > 1e-9 * nx * sqrt(nx))) return false;
+        // Roots by the v_rsq_f64 seed alone (~1e-8): a threshold and a scaling factor do not need more — the scaling
+        // only steers the convergence, the fixed point X = X^-T does not depend on it as long as z and 1/z agree —
+        // and an IEEE f64 sqrt is ~25 dependent instructions on the one lane everybody is waiting for.
+        const double rs_nx = __builtin_amdgcn_rsq(nx);
+        if (!(det * (rs_nx * rs_nx * rs_nx) > 1e-9)) return false;
         const double idet = fast_rcp(det);
         // z^2 = |X^-T|_F / |X|_F = sqrt(nc) / (det sqrt(nx))
-        const double z2 = sqrt(nc) * idet * fast_rsqrt(nx);
-        const double z = sqrt(z2), a_x = 0.5 * z, a_c = 0.5 * idet * fast_rcp(z);
+        const double z2 = (nc * __builtin_amdgcn_rsq(nc)) * idet * rs_nx;
+        const double z = z2 * __builtin_amdgcn_rsq(z2), a_x = 0.5 * z, a_c = 0.5 * idet * fast_rcp(z);
         double diff = 0, nn = 0;
 #pragma unroll
         for (int a = 0; a < 3; a++)
