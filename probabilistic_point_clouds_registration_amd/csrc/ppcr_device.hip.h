@@ -600,7 +600,7 @@ __device__ inline DeviceSolve solve_rigid_device(const double (&S)[kNSums], cons
     const double W = S[0];
     if (!(W > 0) || !isfinite(W)) return out;
     out.degenerate = false;
-    const double iW = 1.0 / W;
+    const double iW = fast_rcp(W);
     const double mx[3] = {S[1] * iW, S[2] * iW, S[3] * iW}, my[3] = {S[4] * iW, S[5] * iW, S[6] * iW};
     double w[3][3], v[3][3];  // w = H = sum w (x - mx)(y - my)^T, columns rotated in place; v accumulates V
 #pragma unroll
@@ -775,7 +775,9 @@ __device__ __forceinline__ void fold_and_solve_block(const FoldSolve &fs, int su
         for (int b = 0; b < 3; b++) fs.mbox->T[4 * a + b] = rs.R[3 * a + b];
         fs.mbox->T[4 * a + 3] = rs.t[a];
     }
-    if (fs.split_visible) {
+    // new registrations only (most launches bring none: then the list is sorted and published already, and walking it
+    // would be a chain of dependent loads on the lane the next launch is waiting for)
+    if (fs.split_visible && min(*fs.split_total, 64u) != *fs.split_visible) {
         const int n_split = (int)min(*fs.split_total, 64u);
         for (int a = 1; a < n_split; a++) {  // insertion sort: the list is nearly sorted, at most 64 long
             const int key = fs.split_list[a];
