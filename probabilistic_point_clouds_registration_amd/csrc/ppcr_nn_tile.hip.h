@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     static_assert(C > M, "a re-scan must leave room in the list");
     static_assert(FTM == -2 || (3 * CAP + CAP / 4) * 4 >= kFoldScratchBytes, "the final fold borrows the halo buffer");
     static_assert(CAP % 4 == 0 && CAP * 4 < 65536, "list entries are 16-bit byte offsets into the halo arrays");
-    constexpr int BLOCK = 256, kWaves = 4, kRows = 128, kStageUnroll = 4;
+    constexpr int BLOCK = 256, kWaves = 4, kRows = 128, kStageUnroll = 6;
     __shared__ __attribute__((aligned(16))) float s_halo[3 * CAP + CAP / 4];
     __shared__ unsigned short s_list[(C + 1) * BLOCK];  // C slots per lane + one that rejected candidates land in
     __shared__ int s_gbo[kRows];
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         if (lenA > 0) s_rowtab[rankA] = make_int2(gbA, (exclA << 19) | (lenA << 7) | lane);          // 12 + 12 + 7 bits
         if (lenB > 0) s_rowtab[rankB] = make_int2(gbB, (exclB << 19) | (lenB << 7) | (lane + 64));
         for (int j0 = 0; wave + kWaves * j0 < nrows; j0 += kStageUnroll) {
-            float4 c[kStageUnroll];
+            float cx[kStageUnroll], cy[kStageUnroll], cz[kStageUnroll];  // 12 of a record's 16 bytes: six rows in flight (four: one more round trip; eight: no better)
             int so[kStageUnroll], sl[kStageUnroll], sg[kStageUnroll], sr[kStageUnroll];
 #pragma unroll
             for (int u = 0; u < kStageUnroll; u++) {
@@ -881,15 +881,16 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
                 so[u] = (int)((unsigned)pk >> 19);
                 sl[u] = (t < nrows) ? ((pk >> 7) & 0xFFF) : 0;
                 sr[u] = pk & 127;
-                c[u] = tgt[(lane < sl[u]) ? sg[u] + lane : 0];  // unconditional load (slot 0 always exists)
+                const float *g = reinterpret_cast<const float *>(tgt + ((lane < sl[u]) ? sg[u] + lane : 0));  // slot 0 always exists
+                cx[u] = g[0], cy[u] = g[1], cz[u] = g[2];
             }
 #pragma unroll
             for (int u = 0; u < kStageUnroll; u++) {
                 if (lane < sl[u]) {
                     const int d = so[u] + lane;
-                    s_x[d] = c[u].x;
-                    s_y[d] = c[u].y;
-                    s_z[d] = c[u].z;
+                    s_x[d] = cx[u];
+                    s_y[d] = cy[u];
+                    s_z[d] = cz[u];
                     s_rowid[d] = (unsigned char)sr[u];
                 }
                 for (int k = lane + 64; k < sl[u]; k += 64) {  // rows longer than a wave (dense data)
