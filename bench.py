@@ -412,12 +412,19 @@ def run_rank(a):
                          "rot_err_rad": synth.rotation_angle(g["history"][-1][:, :3], ora["history"][-1][:, :3]),
                          "trans_err_m": float(np.linalg.norm(g["history"][-1][:, 3] - ora["history"][-1][:, 3])),
                          "vs": "oracle (CPU restatement); the reference itself cannot be built (PCL/Ceres absent)"}
-    print(json.dumps(out))
-    sys.stdout.flush()
+    # the JSON line is the LAST line of stdout: everything that may still print (RCCL's version banner sits in the C
+    # library's stdout buffer until exit) is shut down and flushed first
     for c in ctxs:
         c.close()
     if dist is not None:
         dist.destroy_process_group()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out))
+    sys.stdout.flush()
     return 0
 
 
