@@ -45,11 +45,17 @@ def report(tag, runs):
     dealt = np.take_along_axis(trips, order[:, :, None], axis=1).reshape(-1, 4, 64, 9)
     bywork = dealt.max(axis=2).sum(axis=-1)
     # by-work, and the lanes of each wave keep their ranks but the wave walks ranks of equal index together (same as now)
+    # ranks walked in pairs (longest with shortest) as ONE loop each, a branch-free switch in the body
+    pairs = [(0, 8), (1, 7), (2, 6), (3, 5)]
+    paired = sum((w[..., a] + w[..., b]).max(axis=2) for a, b in pairs) + w[..., 4].max(axis=2)
+    halves = (w[..., 0:9:2].sum(axis=-1)).max(axis=2) + (w[..., 1:9:2].sum(axis=-1)).max(axis=2)   # two flattened loops
     busy = now.sum()
     cand = runs.sum() / max((runs.sum(axis=-1) > 0).sum(), 1)
     print(f"{tag}: candidates/query {cand:.1f} | trips per wave: now {now.mean():.1f}  per-lane {flat.mean():.1f}  "
           f"by-work {bywork.mean():.1f}  ideal {ideal.mean():.1f} | lane utilisation of the scan now {ideal.sum() / busy:.3f}, "
           f"per-lane {ideal.sum() / flat.sum():.3f}, by-work {ideal.sum() / bywork.sum():.3f}")
+    print(f"{tag}: paired ranks (0+8, 1+7, 2+6, 3+5, 4) {paired.mean():.1f} trips, utilisation {ideal.sum() / paired.sum():.3f}; "
+          f"even / odd ranks as two loops {halves.mean():.1f} trips")
     live = (runs > 0).sum(axis=-1)
     print(f"{tag}: live runs per query {live[live > 0].mean():.2f}; rank maxima per wave "
           + " ".join(f"{v:.1f}" for v in w.max(axis=2).mean(axis=(0, 1))) + " | rank means "
