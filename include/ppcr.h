@@ -142,7 +142,8 @@ int ppcr_stop_rule_check(ppcr_stop_rule *rule, int n_iter, double cost_drop_thre
  * n_done receives the number of outer iterations performed.
  * n_iter < 0 = no iteration cap (the reference's meaning): then history, costs and steps must be NULL and
  * cost_drop_thresh > 0 (PPCR_ERR_INVALID otherwise: the arrays could not be sized / the loop would never end).
- * With inner_steps <= 1 the solve runs on the device and the next association takes its source move from device
+ * For every bounded search (0 < max_neighbours <= 32) the whole iteration runs on the device — association, the IRLS
+ * inner loop with its function_tolerance test, the solve — and the next association takes its source move from device
  * memory, so the device works one iteration ahead of this thread — but an iteration is only enqueued early when
  * hasConverged() cannot stop before it whatever the pending cost turns out to be, so the iterations performed, and
  * every number returned, are those of the one-at-a-time loop.
@@ -152,6 +153,36 @@ int ppcr_stop_rule_check(ppcr_stop_rule *rule, int n_iter, double cost_drop_thre
 int ppcr_align(ppcr_ctx *ctx, int n_iter, double cost_drop_thresh, double n_cost_drop_it,
                const double q0[4], const double t0[3], int inner_steps, double f_tol, double *history,
                double *costs, int32_t *steps, int *n_done);
+
+/* The same loop with what ProbPointCloudRegistration::align() does BETWEEN iterations delivered through a callback
+ * (cc:114-129: the verbose log line, the mean distance to the ground-truth cloud, the --dump row with the mean
+ * distance every point moved) — so that the C++ class and the CLI run the device-paced loop instead of one blocking
+ * call per iteration.  on_iteration (nullable) is called on the calling thread, once per outer iteration and in order,
+ * when that iteration's numbers reach the host: the device may already be working on the next one, so the call comes
+ * "one iteration late"; what it is given is exactly what the one-at-a-time loop would have computed.
+ *   report_flags  PPCR_REPORT_TRUTH: mse_truth = calculateMSE(tracked cloud after the move, ground truth) (cc:115;
+ *                 needs ppcr_set_ground_truth), PPCR_REPORT_MOVED: moved = calculateMSE(tracked cloud after the move,
+ *                 the same cloud before it) (cc:121); the tracked cloud is the companion when one is set, else the
+ *                 source.  Unrequested values are NaN.  Ignored without a callback.
+ *   rule_io       (nullable) in: the hasConverged() state to continue from, out: the state the loop stopped in — so a
+ *                 front end that owns a ppcr_stop_rule (the C++ class) sees what it would have seen driving
+ *                 ppcr_stop_rule_check + ppcr_iterate itself.
+ *   T_final       (nullable) the cumulative transform of the iterations of THIS call (identity when none ran).
+ * n_iter < 0 (no cap) is allowed with cost_drop_thresh > 0. */
+typedef struct ppcr_iteration_info {
+    int32_t iteration;    /* index of the outer iteration (ppcr_stop_rule.iteration before it was counted) */
+    int32_t inner_steps;  /* Summary::num_successful_steps analogue: IRLS steps of this iteration */
+    double cost[2];       /* initial_cost, final_cost */
+    double T_step[12];    /* this iteration's increment */
+    double T_cum[12];     /* T_k * ... * T_1 of this call */
+    double mse_truth;     /* PPCR_REPORT_TRUTH, else NaN */
+    double moved;         /* PPCR_REPORT_MOVED, else NaN */
+} ppcr_iteration_info;
+typedef void (*ppcr_iteration_fn)(void *user, const ppcr_iteration_info *info);
+enum { PPCR_REPORT_TRUTH = 1, PPCR_REPORT_MOVED = 2 };
+int ppcr_align_report(ppcr_ctx *ctx, int n_iter, double cost_drop_thresh, double n_cost_drop_it, const double q0[4],
+                      const double t0[3], int inner_steps, double f_tol, ppcr_stop_rule *rule_io, int report_flags,
+                      ppcr_iteration_fn on_iteration, void *user, double T_final[12], int *n_done);
 
 /* ---- multi-pair batches (BASELINE configs[4]; the reference registers one pair per process run) ----
  * Independent pairs never exchange data, so a batch is a work list: pair p is registered on
@@ -192,8 +223,8 @@ int ppcr_batch_run(const ppcr_pair *pairs, int64_t n_pairs, const ppcr_batch_opt
 /* The same loop over handles whose clouds are already resident (set_source/set_target done by the caller):
  * ppcr_align on each of the n handles, `lanes` of them in flight at a time on their own streams.
  * T_final: n*12 doubles; n_done: n ints or NULL.  Handles may live on different devices.
- * With inner_steps <= 1 all handles are driven from the CALLING thread (it enqueues and polls their mailboxes; the
- * devices pace themselves), so `lanes` costs no host threads; otherwise `lanes` worker threads are used. */
+ * Handles whose loop the device paces (bounded searches: see ppcr_align) are all driven from the CALLING thread (it
+ * enqueues and polls their mailboxes), so `lanes` costs no host threads; otherwise `lanes` worker threads are used. */
 int ppcr_align_many(ppcr_ctx *const *ctxs, int n, int lanes, int n_iter, double cost_drop_thresh,
                     double n_cost_drop_it, const double q0[4], const double t0[3], int inner_steps,
                     double f_tol, double *T_final, int32_t *n_done);
@@ -251,6 +282,8 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *   "defer_moves"  1 ppcr_apply_transform leaves the move to the prologue of the next association (what ppcr_iterate
  *                  and ppcr_align always do; the temporal cut-off then survives the move), 0 moves at once (default);
  *   "mailbox"      1 deliver the moments through pinned host memory and spin (default), 0 copy + synchronise;
+ *   "inner_dev_steps"  IRLS steps beyond the first that ppcr_align enqueues for the device per outer iteration
+ *                  (default 3, 0..8); an inner loop that needs more is finished by the host, one step at a time;
  *   "grid_xf"      x slices per grid cell, 1/2/4/8 (default 4; set before the target): every stencil row is clipped
  *                  to the x window the search sphere needs in that row;
  *   "brick_x"      x extent in cells of the 4x4 (y,z) bricks the source is ordered by: 1 (default), 2 or 4;

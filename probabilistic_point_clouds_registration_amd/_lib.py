@@ -22,7 +22,7 @@ SYMBOLS = [
     "ppcr_iterate", "ppcr_align", "ppcr_get_source", "ppcr_synchronize", "ppcr_profile_enable",
     "ppcr_profile_get", "ppcr_set_option", "ppcr_batch_run", "ppcr_align_many", "ppcr_set_companion",
     "ppcr_get_companion", "ppcr_set_ground_truth", "ppcr_mse_ground_truth", "ppcr_mse_previous", "ppcr_voxel_filter",
-    "ppcr_nearest_sq_distances", "ppcr_stop_rule_check",
+    "ppcr_nearest_sq_distances", "ppcr_stop_rule_check", "ppcr_align_report",
 ]
 
 
@@ -35,6 +35,17 @@ class StopRule(C.Structure):
         L = load()
         L.ppcr_stop_rule_check.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
         return int(L.ppcr_stop_rule_check(C.byref(self), int(n_iter), float(cost_drop_thresh), float(n_cost_drop_it)))
+
+
+class IterationInfo(C.Structure):
+    """ppcr_iteration_info: what ppcr_align_report hands its callback once per outer iteration."""
+    _fields_ = [("iteration", C.c_int32), ("inner_steps", C.c_int32), ("cost", C.c_double * 2),
+                ("T_step", C.c_double * 12), ("T_cum", C.c_double * 12), ("mse_truth", C.c_double),
+                ("moved", C.c_double)]
+
+
+ITERATION_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(IterationInfo))
+REPORT_TRUTH, REPORT_MOVED = 1, 2
 
 
 class KernelStat(C.Structure):
@@ -96,6 +107,7 @@ def load():
     L.ppcr_apply_transform.argtypes = [vp, vp]
     L.ppcr_iterate.argtypes = [vp, vp, vp, i32, dbl, vp, vp, C.POINTER(i32)]
     L.ppcr_align.argtypes = [vp, i32, dbl, dbl, vp, vp, i32, dbl, vp, vp, vp, C.POINTER(i32)]
+    L.ppcr_align_report.argtypes = [vp, i32, dbl, dbl, vp, vp, i32, dbl, vp, i32, ITERATION_FN, vp, vp, C.POINTER(i32)]
     L.ppcr_get_source.argtypes = [vp, vp, i64]
     L.ppcr_synchronize.argtypes = [vp]
     L.ppcr_profile_enable.argtypes = [vp, i32]
@@ -281,6 +293,32 @@ class Context:
             return dict(n_iter=n)
         return dict(n_iter=n, history=hist[:12 * n].reshape(n, 3, 4).copy(), costs=costs[:2 * n].reshape(n, 2).copy(),
                     inner_steps=steps[:n].copy())
+
+    def align_report(self, n_iter, cost_drop_thresh=0.0, n_cost_drop_it=5, q0=(1, 0, 0, 0), t0=(0, 0, 0),
+                     inner_steps=1, f_tol=1e-5, report_truth=False, report_moved=False, rule=None, on_iteration=None):
+        """ppcr_align_report: the device-paced loop with the per-iteration reports of the reference's align()
+        (cc:114-129) delivered through a callback.  Returns the iterations as a list of dicts (+ the final cumulative
+        transform and the stop rule's state); on_iteration(dict), when given, is also called as they arrive."""
+        rows = []
+
+        def _cb(_user, info_p):
+            i = info_p.contents
+            row = dict(iteration=i.iteration, inner_steps=i.inner_steps, cost=(i.cost[0], i.cost[1]),
+                       T_step=np.array(i.T_step[:]).reshape(3, 4), T_cum=np.array(i.T_cum[:]).reshape(3, 4),
+                       mse_truth=i.mse_truth, moved=i.moved)
+            rows.append(row)
+            if on_iteration is not None:
+                on_iteration(row)
+
+        cb = ITERATION_FN(_cb)
+        rule = rule if rule is not None else StopRule(0, 0, 0.0)
+        flags = (REPORT_TRUTH if report_truth else 0) | (REPORT_MOVED if report_moved else 0)
+        T, done = np.zeros(12), C.c_int(0)
+        q0, t0 = _f64(q0, 4), _f64(t0, 3)
+        self._ck(self._L.ppcr_align_report(self._h, int(n_iter), float(cost_drop_thresh), float(n_cost_drop_it),
+                                           q0.ctypes.data, t0.ctypes.data, int(inner_steps), float(f_tol),
+                                           C.byref(rule), flags, cb, None, T.ctypes.data, C.byref(done)))
+        return dict(n_iter=done.value, iterations=rows, T_final=T.reshape(3, 4), rule=rule)
 
     def get_source(self, stride=3):
         out = np.zeros((self.ns, stride), dtype=np.float32)

@@ -2,7 +2,7 @@
 // (prob_point_cloud_registration.h:18-45 there): two constructors, align(), hasConverged(), transformation(),
 // transformation_history(), report().  Everything behind it is this library's own: the state lives in a
 // private implementation object (src/prob_point_cloud_registration.cc) that owns one device handle of the C ABI;
-// the loop body of align() runs on the GPU (ppcr_iterate) and the stopping rule is ppcr_stop_rule (ppcr.h).
+// align() is one call into the device-paced loop (ppcr_align_report) and the stopping rule is ppcr_stop_rule (ppcr.h).
 #pragma once
 #include <memory>
 #include <string>

@@ -55,7 +55,7 @@ struct ProbPointCloudRegistration::State {
     DeviceContext gpu;           // one C-ABI handle: device + stream + resident clouds
     ppcr_stop_rule stop{0, 0, 0.0};
     Cloud::Ptr target;           // the caller's cloud (shared; filtered in place when asked)
-    Cloud full_source;           // private copy of the caller's source, refreshed from the device after align()
+    Cloud full_source;           // private copy of the caller's source (what was uploaded; the moved clouds stay on the device)
     bool has_companion = false;  // the device also carries the unfiltered source next to the filtered one
     bool has_truth = false;
     double truth_distance = 0;   // mean distance to the ground truth after the last iteration
@@ -101,11 +101,7 @@ struct ProbPointCloudRegistration::State {
         if (has_companion)
             gpu.check(ppcr_set_companion(handle(), xyz_of(full_source), count_of(full_source), sizeof(pcl::PointXYZ)),
                       "ppcr_set_companion");
-        if (params.summary) {
-            table << kReportColumns << std::endl;
-            // the "previous iteration" snapshot starts as the untouched source
-            gpu.check(ppcr_mse_previous(handle(), nullptr), "ppcr_mse_previous");
-        }
+        if (params.summary) table << kReportColumns << std::endl;
     }
 
     void attachGroundTruth(const Cloud &truth)
@@ -119,47 +115,42 @@ struct ProbPointCloudRegistration::State {
 
     void measureTruthDistance() { gpu.check(ppcr_mse_ground_truth(handle(), &truth_distance), "ppcr_mse_ground_truth"); }
 
-    // one outer iteration on the device: associate, solve, move both copies of the source
-    void iterate()
+    // The whole loop of align() as ONE call: the device paces itself (association, inner loop to function_tolerance,
+    // solve, both source moves, the two mean distances) and runs an iteration ahead of this thread; what the reference
+    // prints and tabulates between two iterations (cc:114-129 there) arrives through absorb(), in order, when that
+    // iteration's numbers reach the host.
+    void runLoop()
     {
-        double step[12], cost[2];
-        int inner = 0;
-        gpu.check(ppcr_iterate(handle(), params.initial_rotation, params.initial_translation, params.inner_max_steps,
-                               kFunctionTolerance, step, cost, &inner),
-                  "ppcr_iterate");
-        const Eigen::Affine3d delta = Eigen::Affine3d::from_rows(step);
+        const int reports = (has_truth ? PPCR_REPORT_TRUTH : 0) | (params.summary ? PPCR_REPORT_MOVED : 0);
+        gpu.check(ppcr_align_report(handle(), params.n_iter, params.cost_drop_thresh, params.n_cost_drop_it,
+                                    params.initial_rotation, params.initial_translation, params.inner_max_steps,
+                                    kFunctionTolerance, &stop, reports, &State::onIteration, this, nullptr, nullptr),
+                  "ppcr_align_report");
+    }
+
+    static void onIteration(void *self, const ppcr_iteration_info *info) { static_cast<State *>(self)->absorb(*info); }
+
+    void absorb(const ppcr_iteration_info &it)
+    {
+        const Eigen::Affine3d delta = Eigen::Affine3d::from_rows(it.T_step);
         cumulative.push_back(cumulative.empty() ? delta : delta * cumulative.back());
-        log << "iteration " << stop.iteration << ": initial_cost " << cost[0] << " final_cost " << cost[1] << " inner steps "
-            << inner << "\n";
+        log << "iteration " << it.iteration << ": initial_cost " << it.cost[0] << " final_cost " << it.cost[1] << " inner steps "
+            << it.inner_steps << "\n";
         if (has_truth) {
-            measureTruthDistance();
+            truth_distance = it.mse_truth;
             log << "MSE w.r.t. ground truth: " << truth_distance << "\n";
         }
-        if (params.summary) appendRow(inner, cost);
-        stop.cost_drop = (cost[0] - cost[1]) / cost[0];
-        stop.iteration += 1;
+        if (params.summary) appendRow(it);
     }
 
-    void appendRow(int inner, const double cost[2])
+    void appendRow(const ppcr_iteration_info &it)
     {
-        double moved = 0;  // mean distance each point travelled in this iteration
-        gpu.check(ppcr_mse_previous(handle(), &moved), "ppcr_mse_previous");
         const Eigen::Affine3d &T = cumulative.back();
         const Eigen::Vector3d angles = T.rotation().eulerAngles(0, 1, 2);
-        table << stop.iteration << ", " << inner << ", " << cost[0] << ", " << cost[1];
+        table << it.iteration << ", " << it.inner_steps << ", " << it.cost[0] << ", " << it.cost[1];
         for (int a = 0; a < 3; a++) table << ", " << T.translation()(a);
         for (int a = 0; a < 3; a++) table << ", " << pcl::rad2deg(angles(a));
-        table << ", " << moved << ", " << truth_distance << std::endl;
-    }
-
-    // bring the caller-visible full-resolution source back from the device
-    void downloadSource()
-    {
-        if (full_source.empty()) return;
-        if (has_companion)
-            gpu.check(ppcr_get_companion(handle(), xyz_of(full_source), sizeof(pcl::PointXYZ)), "ppcr_get_companion");
-        else
-            gpu.check(ppcr_get_source(handle(), xyz_of(full_source), sizeof(pcl::PointXYZ)), "ppcr_get_source");
+        table << ", " << it.moved << ", " << truth_distance << std::endl;  // it.moved: mean distance each point travelled
     }
 };
 
@@ -182,8 +173,8 @@ ProbPointCloudRegistration::~ProbPointCloudRegistration() = default;
 
 void ProbPointCloudRegistration::align()
 {
-    while (!hasConverged()) state_->iterate();
-    state_->downloadSource();
+    state_->runLoop();    // while (!hasConverged()) { one outer iteration }, on the device
+    (void)hasConverged();  // the loop's last look at the rule: prints why it stopped (verbose)
     if (state_->has_truth) {
         state_->measureTruthDistance();
         std::cout << "MSE w.r.t. ground truth: " << state_->truth_distance << std::endl;

@@ -352,7 +352,7 @@ struct RowMoments {
             const double inv_vs = (TM == 0) ? 0.0 : rcp_1step(md.v + sk);
             const double e = rel_likelihood<TM>(md, sk, 0.0, 0.0, inv_vs);
             Z += e;
-            gk = (TM == 0) ? e : e * (md.vpd * inv_vs);
+            gk = (TM == 0 || (TM < 0 && md.is_normal)) ? e : e * (md.vpd * inv_vs);
         }
         G += gk;
         Gs = fma(gk, sk, Gs);
@@ -403,8 +403,9 @@ struct FusedMoments {
 
 // HALVES = true folds ten sums, then nine, through a buffer half the size (20.6 KB instead of 39 KB: six instead of
 // four workgroups per CU for a kernel that is otherwise lean in registers) at the price of two more barriers.
+// The block's sums go to partials[j * stride + slot].
 template <int BLOCK = kBlock, bool HALVES = false>
-__device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__restrict__ partials)
+__device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__restrict__ partials, int stride, int slot)
 {
     static_assert(BLOCK == 256, "fold layout assumes 256 lanes (8 parts of 32)");
     constexpr int STRIDE = BLOCK + 1;
@@ -438,7 +439,7 @@ __device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__
         double v = part[tid][0];
 #pragma unroll
         for (int q = 1; q < 8; q++) v += part[tid][q];
-        partials[(size_t)tid * gridDim.x + blockIdx.x] = v;
+        partials[(size_t)tid * stride + slot] = v;
     }
 }
 
@@ -695,14 +696,50 @@ __device__ inline DeviceSolve solve_rigid_device(const double (&S)[kNSums], cons
 // Host mailbox in pinned, device-mapped memory: the fold-and-solve kernel writes the moments, the rigid transform it
 // solved from them and its cost there, then the sequence number (system-scope release); the host spins on `seq` — no
 // copy kernel and no stream synchronisation on the iteration's critical path.
+enum MailboxStatus : unsigned {
+    kStepResult = 0,   // one IRLS half-step, the host decides what comes next (host-paced paths)
+    kIterationDone = 1,  // the device finished the outer iteration's inner loop: T, cost_init, cost, steps are final
+    kIterationPending = 2,  // the inner loop ran out of device steps before it converged: the host carries on from T
+    kLaunchSkipped = 3,  // this launch stepped aside because an earlier one raised LoopState::abort
+};
 struct HostMailbox {
     double sums[kNSums];
     double T[12];        // [R|t] minimising sum w |y - R x - t|^2 for these moments (identity when degenerate)
     double cost;         // 0.5 * sum w |y - R x - t|^2 at that transform
+    double cost_init;    // device-paced inner loop: 0.5 * sum w s at the pose the outer iteration started from
+    int steps;           // device-paced inner loop: IRLS steps done in this outer iteration
+    unsigned status;     // MailboxStatus
     unsigned degenerate; // no weight mass
     unsigned handed_over; // blocks the association's fast kernel left to the cleanup kernel (sizes the next cleanup grid)
     unsigned seq;
 };
+
+// Inner loop of one outer iteration run by the DEVICE (ProbPointCloudRegistrationIteration::solve iterated to Ceres'
+// function_tolerance, ..._iteration.hpp:52-57 with cc:96-100): the lane that solves a step also decides whether the
+// loop is over — the same test the host loop makes (solve_impl) on the same numbers — and says so in device memory,
+// where the launches already enqueued behind it look before they do anything:
+//   finished  the inner loop is over: the remaining speculative step launches of this iteration return at once;
+//   abort     the device cannot finish this iteration on its own (kIterationPending): EVERY later launch of the
+//             stream steps aside untouched (K1, cleanup, fold, inner steps, companion move) until the host, which has
+//             taken the iteration over, clears the flag in stream order.
+struct LoopState {
+    unsigned abort;
+    unsigned finished;
+    int steps;
+    int pad;
+    double cost_init;
+};
+struct LoopCtl {  // by value with every fold-and-solve launch
+    LoopState *st;    // nullptr: host-paced (every step is published as kStepResult, nothing is decided here)
+    double f_tol;
+    int max_steps;
+    int first;        // this step is the first of its outer iteration
+    int last_dev;     // no further device step is enqueued behind this one: unfinished here means kIterationPending
+};
+__device__ __forceinline__ bool loop_aborted(const LoopState *st)
+{
+    return st != nullptr && __hip_atomic_load(&st->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
 
 // Fold of partials[19][nblocks] (one block per sum, fixed order: deterministic, no float atomics) FOLLOWED BY THE SOLVE:
 // the block that draws the last ticket reads the 19 moments back and one lane runs the closed-form weighted rigid
@@ -727,10 +764,19 @@ struct FoldSolve {  // everything the fold-and-solve step needs
     unsigned char *split_flag;
     const unsigned *split_total;
     unsigned *split_visible;
+    LoopCtl loop;
 };
 
-// one of the kNSums fold blocks (256 threads): fold row `sum_index` of the partials; the last block to finish solves
-__device__ __forceinline__ void fold_and_solve_block(const FoldSolve &fs, int sum_index)
+// a launch that steps aside still owes the host its mailbox slot (the host counts sequence numbers)
+__device__ __forceinline__ void publish_skipped(const FoldSolve &fs)
+{
+    fs.mbox->status = kLaunchSkipped;
+    __hip_atomic_store(&fs.mbox->seq, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// one of the kNSums fold blocks (256 threads): fold row `sum_index` of the partials; the last block to finish solves.
+// Returns true on the ONE lane that solved (after everything it had to write is written).
+__device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int sum_index)
 {
     __shared__ double sh[kBlock / 64];
     const double *row = fs.partials + (size_t)sum_index * fs.nslots;
@@ -748,13 +794,13 @@ __device__ __forceinline__ void fold_and_solve_block(const FoldSolve &fs, int su
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x != 0) return false;
     double x = sh[0];
     for (int w = 1; w < kBlock / 64; w++) x += sh[w];
     __hip_atomic_store(&fs.sums[sum_index], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __atomic_thread_fence(__ATOMIC_RELEASE);
     const unsigned tk = __hip_atomic_fetch_add(fs.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (tk != kNSums - 1) return;
+    if (tk != kNSums - 1) return false;
     __hip_atomic_store(fs.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(fs.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every fold block is past its wait
     double S[kNSums];
@@ -790,10 +836,38 @@ __device__ __forceinline__ void fold_and_solve_block(const FoldSolve &fs, int su
         for (int a = 0; a < n_split; a++) fs.split_flag[fs.split_list[a]] = 2;  // ... and from now on they ARE split
         *fs.split_visible = (unsigned)n_split;
     }
+    // device-paced inner loop: the test of solve_impl / the oracle's po_solve, on the same numbers
+    unsigned status = kStepResult;
+    bool publish = true;
+    if (fs.loop.st != nullptr) {
+        LoopState *st = fs.loop.st;
+        const double cost_old = 0.5 * S[16];
+        const double fc = rs.degenerate ? cost_old : rs.cost;
+        const int steps = fs.loop.first ? 1 : st->steps + 1;
+        const double c0 = fs.loop.first ? cost_old : st->cost_init;
+        const bool fin = rs.degenerate || steps >= fs.loop.max_steps ||
+                         (cost_old - fc) <= fmax(fs.loop.f_tol * cost_old, 1e-14 * 0.5 * (S[17] + S[18]));
+        st->steps = steps;
+        st->cost_init = c0;
+        fs.mbox->cost_init = c0;
+        fs.mbox->steps = steps;
+        if (fin) {
+            status = kIterationDone;
+            __hip_atomic_store(&st->finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (fs.loop.last_dev) {
+            status = kIterationPending;
+            __hip_atomic_store(&st->abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            publish = false;  // an intermediate step: the next device step takes the pose from *pose_out
+        }
+    }
+    if (!publish) return true;
     fs.mbox->cost = rs.cost;
+    fs.mbox->status = status;
     fs.mbox->degenerate = rs.degenerate ? 1u : 0u;
     fs.mbox->handed_over = fs.handed_over ? *fs.handed_over : 0u;
     __hip_atomic_store(&fs.mbox->seq, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    return true;
 }
 
 }  // namespace dev

@@ -51,13 +51,15 @@ enum KernelId {
     K_ACCUMULATE,
     K_REDUCE,
     K_TRANSFORM,
+    K_INNER,
+    K_TRACK,
     K_NUM
 };
 const char *const kKernelNames[K_NUM] = {
     "repack_kernel",   "bbox_kernel",    "cell_key_kernel",   "radix_sort",       "gather_points_kernel",
     "cell_start_kernel", "nn_fast_kernel", "nn_tile_cleanup_kernel", "nn_count_kernel",  "nn_scan",          "nn_fill_kernel",
     "nn_select_kernel", "csr_compact_kernel", "ell_count_sum_kernel", "weights_kernel", "accumulate_kernel",
-    "reduce_partials_kernel", "transform_kernel"};
+    "reduce_partials_kernel", "transform_kernel", "inner_steps_kernel", "track_kernel"};
 
 constexpr int kMailboxRing = 4;    // at most two fold-and-solve launches are ever in flight
 constexpr int kEllMaxWidth = 32;   // widest register-list NN variant / widest ELL association
@@ -158,6 +160,15 @@ struct ppcr_ctx {
     DevBuf<Pose> d_pose;               // transform solved by the last reduce_solve_kernel (next K1's move)
     bool move_on_device = false;       // the pending source move is *d_pose (host copy not read back yet)
     int opt_mailbox = 1;               // 1: deliver the moments through the mailbox and spin (default)
+    // device-paced inner loop (ppcr_align with inner_steps > 1): see LoopState / inner_steps_kernel
+    DevBuf<LoopState> d_loop;
+    DevBuf<unsigned> d_inner_ctl;      // InnerCtl as words
+    int opt_inner_dev_steps = 3;       // IRLS steps 2.. the device may take on its own per outer iteration (<= kMaxDevSteps)
+    // per-iteration reports of the device-paced loop (track_kernel)
+    HostReport *h_report = nullptr;    // pinned + device-mapped ring of kMailboxRing slots
+    HostReport *d_report = nullptr;
+    DevBuf<double> track_part;
+    DevBuf<unsigned> track_ticket;
     unsigned long long *h_total = nullptr;  // pinned
 
     // weights export scratch
@@ -480,28 +491,41 @@ int ensure_source_sorted(ppcr_ctx *c)
 constexpr int kAccumRows = 1;     // rows per lane of accumulate_ell_kernel
 constexpr int kAccumBlock = 256;  // threads per block of accumulate_ell_kernel (fewer partial vectors to fold)
 
-template <int W>
-void launch_accumulate_ell(ppcr_ctx *c, int nb, const Pose &P, const Model &md)
+// which form of K23 serves a model: the two models the reference's CLI reaches by default are compiled in (Gaussian -u;
+// t with dof 5, dim 3: v + dim = 8), any other dof takes the run-time form of the same arithmetic.  The one-pass form
+// (likelihoods relative to s = 0 instead of the row's smallest s) only while that ratio stays far from underflow for
+// every s the association can hold (s < radius^2 up to the float rounding of d2 and the f64 re-evaluation at another
+// pose; the factor 4 on the radius covers residuals at a pose other than the one the association was made at).
+struct K23Form {
+    int tm;        // 0 Gaussian, 8 t with v + dim = 8, -1 run-time t model
+    bool onepass;
+};
+K23Form k23_form(const ppcr_ctx *c, const Model &md)
 {
-    // the two models the reference's CLI reaches by default are compiled in (Gaussian -u; t with dof 5, dim 3:
-    // v + dim = 8); any other dof takes the run-time form of the same arithmetic
+    const double s_max = 16.0 * c->radius * c->radius;
+    if (md.is_normal) return K23Form{0, 0.5 * s_max < 600.0};
+    // (v / (v + s))^((v + d) / 2) > 1e-250
+    const bool safe = 0.5 * md.vpd * std::log10((md.v + s_max) / md.v) < 250.0;
+    if (md.vpd_int == 8) return K23Form{8, safe};
+    return K23Form{-1, safe};
+}
+
+template <int W>
+void launch_accumulate_ell(ppcr_ctx *c, int nb, const Pose &P, const Model &md, const LoopState *loop_st)
+{
 #define PPCR_K23(TMc, ONEc)                                                                                        \
     accumulate_ell_kernel<W, kAccumRows, kAccumBlock, TMc, ONEc><<<nb, kAccumBlock, 0, c->stream>>>(        \
-        c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md, c->partials.p, c->ell_width)
-    // one-pass form (likelihoods relative to s = 0) only while that ratio stays far from underflow for every s the
-    // association can hold (s < radius^2 up to the float rounding of d2 and the f64 re-evaluation at another pose; the
-    // factor 4 on the radius covers residuals at a pose other than the one the association was made at)
-    const double s_max = 16.0 * c->radius * c->radius;
-    const bool one_t = md.vpd_int == 8 && 4.0 * std::log10((md.v + s_max) / md.v) < 250.0;
-    const bool one_g = md.is_normal && 0.5 * s_max < 600.0;
-    if (md.is_normal) {
-        if (one_g) PPCR_K23(0, true);
+        c->nbr.p, c->cnt.p, c->src.p, c->tgt_cur(), (int)c->ns, P, md, c->partials.p, c->ell_width, loop_st)
+    const K23Form f = k23_form(c, md);
+    if (f.tm == 0) {
+        if (f.onepass) PPCR_K23(0, true);
         else PPCR_K23(0, false);
-    } else if (md.vpd_int == 8) {
-        if (one_t) PPCR_K23(8, true);
+    } else if (f.tm == 8) {
+        if (f.onepass) PPCR_K23(8, true);
         else PPCR_K23(8, false);
     } else {
-        PPCR_K23(-1, false);
+        if (f.onepass) PPCR_K23(-1, true);
+        else PPCR_K23(-1, false);
     }
 #undef PPCR_K23
 }
@@ -515,9 +539,12 @@ struct StepTicket {
     unsigned seq = 0;  // mailbox sequence number (mailbox path)
     int nb = 0;        // partial vectors to fold (copy path)
 };
-int prepare_fold(ppcr_ctx *c, int nslots, StepTicket &tk, FoldSolve &fs);
+int prepare_fold(ppcr_ctx *c, int nslots, StepTicket &tk, FoldSolve &fs, const LoopCtl *loop);
 // merge_tk (with a fuse pose): the fold-and-solve step may ride in the cleanup launch; c->assoc_folded tells whether it did
-int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse_t = nullptr, StepTicket *merge_tk = nullptr)
+// loop (device-paced align loop only): the launches step aside while LoopState::abort is up, the fast kernel opens a new
+// outer iteration in the loop state, a merged fold decides about the inner loop
+int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse_t = nullptr, StepTicket *merge_tk = nullptr,
+                   const LoopCtl *loop = nullptr)
 {
     PPCR_TRY(ensure_grid(c));
     if (!c->src_sorted) PPCR_TRY(flush_pending_move(c));  // the one-time spatial sort reads the source
@@ -575,10 +602,8 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             const FusedMoments *fuse = nullptr;
             if (fuse_R && c->opt_fuse_k23 && c->nt > 0) {
                 const Model md = make_model(c);
-                const double s_max = 16.0 * c->radius * c->radius;
-                const bool one_t = md.vpd_int == 8 && 4.0 * std::log10((md.v + s_max) / md.v) < 250.0;
-                const bool one_g = md.is_normal && 0.5 * s_max < 600.0;
-                if (one_t || one_g) {
+                const K23Form form = k23_form(c, md);
+                if (form.onepass && form.tm >= 0) {
                     const int slots = nblocks(ns, 256) + kMaxSplit;
                     HIP_TRY(c, c->partials.reserve((size_t)slots * kNSums));
                     fm.P = make_pose(c, *fuse_R, fuse_t);
@@ -596,10 +621,11 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             // (not when several handles share the GPU: the merged launch has the cleanup kernel's LDS / register
             //  footprint, and its fold workgroups then queue behind other pairs' K1 blocks: 64 x 250k, 8 in flight:
             //  24.0 k it/s merged against 28.2 k with the small fold kernel)
+            // (m <= 10: the widths that HAVE a steady-state variant are 4, 5, 8 and 10 — launch_tile<M> with M <= 12)
             const bool steady_next = fuse && c->opt_merge_fold && !c->shares_device && c->opt_mailbox && c->opt_temporal && c->dm2_valid &&
-                                     c->opt_short_lists && m <= 12 && !c->opt_stamps;
+                                     c->opt_short_lists && m <= 10 && !c->opt_stamps;
             if (merge_tk && steady_next) {
-                PPCR_TRY(prepare_fold(c, fm.nslots, *merge_tk, fs));
+                PPCR_TRY(prepare_fold(c, fm.nslots, *merge_tk, fs, loop));
                 fold = &fs;
             }
             ProfScope ps(c, K_NN_TOPM);
@@ -617,6 +643,9 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             tl.quiet = c->ovf_last == 0;
             tl.split_flag = c->split_flag.p, tl.split_list = c->split_list.p, tl.split_state = c->split_state.p;
             tl.pm = pm, tl.fuse = fuse, tl.fold = fold;
+            tl.loop_st = loop ? loop->st : nullptr;
+            tl.inner_ctl = (loop && loop->max_steps > 1) ? c->d_inner_ctl.p : nullptr;
+            tl.inner_ctl_words = (int)(sizeof(InnerCtl) / sizeof(unsigned));
             tl.between = [](void *scope) { static_cast<ProfScope *>(scope)->split(K_NN_CLEANUP); };
             tl.between_arg = &ps;
             if (m <= 4) launch_tile_m4(tl);
@@ -630,7 +659,11 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             c->assoc_fused = fused;
             c->assoc_folded = merged;
             c->fused_slots = fused ? fm.nslots : 0;
-            if (fold && !merged) return fail(c, PPCR_ERR_STATE, "internal: a fold was prepared but not launched");
+            if (fold && !merged) {
+                // (cannot happen while steady_next mirrors launch_tile's dispatch; were it to, the sequence number
+                //  drawn for the fold is handed back and the caller launches the fold on its own)
+                c->mbox_seq--;
+            }
         }
         c->assoc_space = 1;
         PPCR_TRY(check_launch(c, "nn_fast_kernel"));
@@ -809,9 +842,13 @@ struct StepResult {
     double T[12];      // minimiser for these moments
     double cost;       // 0.5 * sum w |y - R x - t|^2 at T (Ceres' convention)
     bool degenerate;   // no weight mass: T = identity
+    // device-paced inner loop (MailboxStatus other than kStepResult)
+    unsigned status = kStepResult;
+    int steps = 0;          // IRLS steps the device took in this outer iteration
+    double cost_init = 0;   // 0.5 * sum w s at the pose the outer iteration started from
 };
 // buffers and arguments of one fold-and-solve step; draws the step's mailbox sequence number
-int prepare_fold(ppcr_ctx *c, int nslots, StepTicket &tk, FoldSolve &fs)
+int prepare_fold(ppcr_ctx *c, int nslots, StepTicket &tk, FoldSolve &fs, const LoopCtl *loop)
 {
     HIP_TRY(c, c->d_sums.reserve(kNSums));
     HIP_TRY(c, c->d_pose.reserve(1));
@@ -834,12 +871,21 @@ int prepare_fold(ppcr_ctx *c, int nslots, StepTicket &tk, FoldSolve &fs)
     fs.split_flag = c->split_clean ? c->split_flag.p : nullptr;
     fs.split_total = c->split_clean ? c->split_state.p : nullptr;
     fs.split_visible = c->split_clean ? c->split_state.p + 1 : nullptr;
+    if (loop) {
+        fs.loop = *loop;
+    } else {
+        fs.loop.st = nullptr;  // host-paced: every step is published, the host decides
+        fs.loop.f_tol = 0.0;
+        fs.loop.max_steps = 0;
+        fs.loop.first = fs.loop.last_dev = 0;
+    }
     return PPCR_OK;
 }
 
 // enqueue K23 + fold (+ solve); nothing here waits for the device.  use_fused: the association just made already
 // produced the partial moments for this pose (associate_impl with a fuse pose): only the fold and the solve remain.
-int launch_step(ppcr_ctx *c, const Mat3 &R, const double t[3], StepTicket &tk, bool use_fused = false)
+int launch_step(ppcr_ctx *c, const Mat3 &R, const double t[3], StepTicket &tk, bool use_fused = false,
+                const LoopCtl *loop = nullptr)
 {
     if (c->assoc == ppcr_ctx::ASSOC_NONE) return fail(c, PPCR_ERR_STATE, "no association (call ppcr_associate or ppcr_set_association)");
     if (!c->origin_valid) {
@@ -856,16 +902,17 @@ int launch_step(ppcr_ctx *c, const Mat3 &R, const double t[3], StepTicket &tk, b
                              : (ell_rows ? std::max(1, nblocks(ns, kAccumBlock * kAccumRows)) : std::max(1, std::min(kAccumMaxBlocks, nblocks(ns))));
     HIP_TRY(c, c->partials.reserve((size_t)nb * kNSums));
     HIP_TRY(c, c->d_sums.reserve(kNSums));
+    const LoopState *loop_st = loop ? loop->st : nullptr;
     if (!use_fused) {
         ProfScope ps(c, K_ACCUMULATE);
         if (c->assoc == ppcr_ctx::ASSOC_ELL && c->nt > 0) {
             const int w = c->ell_width;
-            if (w <= 4) launch_accumulate_ell<4>(c, nb, P, md);
-            else if (w <= 8) launch_accumulate_ell<8>(c, nb, P, md);
-            else if (w <= 10) launch_accumulate_ell<10>(c, nb, P, md);
-            else if (w <= 16) launch_accumulate_ell<16>(c, nb, P, md);
-            else if (w <= 20) launch_accumulate_ell<20>(c, nb, P, md);
-            else launch_accumulate_ell<32>(c, nb, P, md);
+            if (w <= 4) launch_accumulate_ell<4>(c, nb, P, md, loop_st);
+            else if (w <= 8) launch_accumulate_ell<8>(c, nb, P, md, loop_st);
+            else if (w <= 10) launch_accumulate_ell<10>(c, nb, P, md, loop_st);
+            else if (w <= 16) launch_accumulate_ell<16>(c, nb, P, md, loop_st);
+            else if (w <= 20) launch_accumulate_ell<20>(c, nb, P, md, loop_st);
+            else launch_accumulate_ell<32>(c, nb, P, md, loop_st);
         } else if (c->assoc == ppcr_ctx::ASSOC_ELL) {
             EllAssoc a{c->nbr.p, c->cnt.p, ns};
             accumulate_kernel<EllAssoc><<<nb, kBlock, 0, c->stream>>>(a, c->src.p, c->tgt_cur(), ns, P, md, c->partials.p);
@@ -879,7 +926,7 @@ int launch_step(ppcr_ctx *c, const Mat3 &R, const double t[3], StepTicket &tk, b
     if (c->opt_mailbox) {
         // fold + solve on the device; moments, transform and cost arrive in the host mailbox ring
         FoldSolve fs;
-        PPCR_TRY(prepare_fold(c, nb, tk, fs));
+        PPCR_TRY(prepare_fold(c, nb, tk, fs, loop));
         const auto tl0 = std::chrono::steady_clock::now();
         {
             ProfScope ps(c, K_REDUCE);
@@ -932,7 +979,10 @@ int collect_step(ppcr_ctx *c, const StepTicket &tk, StepResult &out)
         for (int j = 0; j < 12; j++) out.T[j] = mb->T[j];
         out.cost = mb->cost;
         out.degenerate = mb->degenerate != 0;
-        c->ovf_last = mb->handed_over;
+        out.status = mb->status;
+        out.steps = mb->steps;
+        out.cost_init = mb->cost_init;
+        if (out.status != kLaunchSkipped) c->ovf_last = mb->handed_over;
         const double w = std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
         c->dbg_host[0] += 1;
         c->dbg_host[1] += w;
@@ -947,6 +997,142 @@ int collect_step(ppcr_ctx *c, const StepTicket &tk, StepResult &out)
     pack_T(rs.R, rs.t, out.T);
     out.degenerate = rs.degenerate;
     out.cost = rs.degenerate ? 0.5 * out.sums[16] : cost_from_moments(out.sums, c->origin, rs.R, rs.t);
+    return PPCR_OK;
+}
+
+// buffers of the device-paced loop (once per handle)
+int ensure_loop_state(ppcr_ctx *c)
+{
+    if (!c->d_loop.p) {
+        HIP_TRY(c, c->d_loop.reserve(1));
+        HIP_TRY(c, hipMemsetAsync(c->d_loop.p, 0, sizeof(LoopState), c->stream));
+    }
+    if (!c->d_inner_ctl.p) {
+        HIP_TRY(c, c->d_inner_ctl.reserve(sizeof(InnerCtl) / sizeof(unsigned)));
+        HIP_TRY(c, hipMemsetAsync(c->d_inner_ctl.p, 0, sizeof(InnerCtl), c->stream));
+    }
+    if (!c->d_ticket.p) {
+        HIP_TRY(c, c->d_ticket.reserve(2));
+        HIP_TRY(c, hipMemsetAsync(c->d_ticket.p, 0, 2 * sizeof(unsigned), c->stream));
+    }
+    HIP_TRY(c, c->d_pose.reserve(1));
+    return PPCR_OK;
+}
+
+// The later IRLS steps of the current outer iteration as ONE launch the device walks through on its own
+// (inner_steps_kernel): step 1 was enqueued with loop control by the caller; its mailbox slot (tk.seq) is the one the
+// iteration's last step publishes in.
+template <int W>
+void launch_inner_w(ppcr_ctx *c, const InnerArgs &a, const K23Form &f, int grid)
+{
+#define PPCR_INNER(TMc, ONEc) inner_steps_kernel<W, TMc, ONEc><<<grid, kBlock, 0, c->stream>>>(a)
+    if (f.tm == 0) {
+        if (f.onepass) PPCR_INNER(0, true);
+        else PPCR_INNER(0, false);
+    } else if (f.tm == 8) {
+        if (f.onepass) PPCR_INNER(8, true);
+        else PPCR_INNER(8, false);
+    } else {
+        if (f.onepass) PPCR_INNER(-1, true);
+        else PPCR_INNER(-1, false);
+    }
+#undef PPCR_INNER
+}
+int launch_inner(ppcr_ctx *c, const StepTicket &tk, const LoopCtl &loop, int n_dev_steps)
+{
+    if (n_dev_steps <= 0) return PPCR_OK;
+    if (c->assoc != ppcr_ctx::ASSOC_ELL || c->nt <= 0) return fail(c, PPCR_ERR_STATE, "internal: device-paced inner steps need an ELL association");
+    const int ns = (int)c->ns;
+    const int ntiles = nblocks(ns, kBlock);
+    const int G = std::max(1, std::min(ntiles, 1024));
+    HIP_TRY(c, c->partials.reserve((size_t)std::max(G, nblocks(ns, 256) + kMaxSplit) * kNSums));
+    InnerArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.nbr = c->nbr.p, a.cnt = c->cnt.p, a.src = c->src.p, a.tgt = c->tgt_cur();
+    a.ns = ns, a.width = c->ell_width;
+    a.md = make_model(c);
+    StepTicket same = tk;
+    const unsigned seq_keep = c->mbox_seq;
+    PPCR_TRY(prepare_fold(c, G, same, a.fs, &loop));  // (draws a sequence number: handed back below — the steps share tk.seq)
+    c->mbox_seq = seq_keep;
+    a.fs.seq = tk.seq;
+    a.fs.mbox = c->d_mbox + (tk.seq % kMailboxRing);
+    a.fs.loop.first = 0;
+    a.ctl = reinterpret_cast<InnerCtl *>(c->d_inner_ctl.p);
+    a.G = G, a.n_steps = n_dev_steps;
+    const K23Form f = k23_form(c, a.md);
+    const int grid = n_dev_steps * (G + kNSums);
+    {
+        ProfScope ps(c, K_INNER);
+        const int w = c->ell_width;
+        if (w <= 10) launch_inner_w<10>(c, a, f, grid);
+        else if (w <= 16) launch_inner_w<16>(c, a, f, grid);
+        else launch_inner_w<32>(c, a, f, grid);
+    }
+    return check_launch(c, "inner_steps_kernel");
+}
+
+// What follows an outer iteration inside the device-paced loop: the companion cloud moves (in place) by the transform in
+// *d_pose, and the per-iteration reports are formed (track_kernel).  report_flags: PPCR_REPORT_*; the means arrive in
+// the report ring under sequence number `seq`.
+int launch_track(ppcr_ctx *c, unsigned seq, int report_flags)
+{
+    const bool want_truth = (report_flags & PPCR_REPORT_TRUTH) != 0, want_moved = (report_flags & PPCR_REPORT_MOVED) != 0;
+    if (!c->have_companion && !want_truth && !want_moved) return PPCR_OK;
+    TrackArgs a;
+    std::memset(&a, 0, sizeof(a));
+    if (c->have_companion) {
+        a.cloud = c->companion.p, a.n = (int)c->n_companion, a.sorted_source = 0, a.write_back = 1;
+    } else {
+        a.cloud = c->src.p, a.n = (int)c->ns, a.sorted_source = 1, a.write_back = 0;
+    }
+    if (want_truth) {
+        if (!c->have_ground_truth) return fail(c, PPCR_ERR_STATE, "ground truth cloud not set");
+        if ((int64_t)a.n != c->n_ground_truth) return fail(c, PPCR_ERR_INVALID, "ground truth and source clouds differ in size");
+        a.truth = c->ground_truth.p;
+    }
+    a.want_moved = want_moved ? 1 : 0;
+    a.pose = c->d_pose.p;
+    const int nb = std::max(1, std::min(1024, nblocks(a.n)));  // the grid of mean_distance(): same block sums
+    HIP_TRY(c, c->track_part.reserve((size_t)2 * nb));
+    if (!c->track_ticket.p) {
+        HIP_TRY(c, c->track_ticket.reserve(1));
+        HIP_TRY(c, hipMemsetAsync(c->track_ticket.p, 0, sizeof(unsigned), c->stream));
+    }
+    a.part = c->track_part.p;
+    a.ticket = c->track_ticket.p;
+    a.out = (want_truth || want_moved) ? c->d_report + (seq % kMailboxRing) : nullptr;
+    a.seq = seq;
+    a.st = c->d_loop.p;
+    {
+        ProfScope ps(c, K_TRACK);
+        track_kernel<<<nb, kBlock, 0, c->stream>>>(a);
+    }
+    return check_launch(c, "track_kernel");
+}
+
+// wait for the report of iteration `seq` (it trails the iteration's mailbox slot by one small kernel)
+int collect_report(ppcr_ctx *c, unsigned seq, double *mse_truth, double *moved)
+{
+    const HostReport *r = c->h_report + (seq % kMailboxRing);
+    bool arrived = false;
+    for (long spin = 0; spin < 200000000L; spin++) {
+        if (__atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) == seq) {
+            arrived = true;
+            break;
+        }
+        if (spin > 4096) std::this_thread::yield();
+        if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(c->stream) != hipErrorNotReady) {
+            arrived = __atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) == seq;
+            break;
+        }
+    }
+    if (!arrived) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (__atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) != seq) return fail(c, PPCR_ERR_HIP, "iteration report never arrived");
+    }
+    *mse_truth = r->mse_truth;
+    *moved = r->moved;
     return PPCR_OK;
 }
 
@@ -973,11 +1159,11 @@ int flush_pending_move(ppcr_ctx *c)
 }
 
 // move the source; when `defer` the move rides along with the next tiled association instead of its own launch
-int apply_transform_impl(ppcr_ctx *c, const double T[12], bool defer = false)
+int apply_transform_impl(ppcr_ctx *c, const double T[12], bool defer = false, bool move_companion = true)
 {
     if (!c->have_src) return fail(c, PPCR_ERR_STATE, "source cloud not set");
     PPCR_TRY(flush_pending_move(c));
-    if (c->have_companion && c->n_companion > 0) {
+    if (move_companion && c->have_companion && c->n_companion > 0) {
         // the full-resolution copy moves with the same f64 -> f32 arithmetic, at once (it is off the hot path)
         Pose P;
         for (int a = 0; a < 3; a++) {
@@ -1098,6 +1284,11 @@ int ppcr_create(int device_id, ppcr_ctx **out)
         std::memset(c->h_mbox, 0, sizeof(HostMailbox) * kMailboxRing);
         e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_mbox), c->h_mbox, 0);
     }
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_report), sizeof(HostReport) * kMailboxRing, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) {
+        std::memset(c->h_report, 0, sizeof(HostReport) * kMailboxRing);
+        e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_report), c->h_report, 0);
+    }
     if (e != hipSuccess) {
         std::string msg = std::string("context setup: ") + hipGetErrorString(e);
         ppcr_destroy(c);
@@ -1154,9 +1345,14 @@ int ppcr_destroy(ppcr_ctx *c)
     c->d_w.release();
     c->d_s.release();
     c->mse_part.release();
+    c->d_loop.release();
+    c->d_inner_ctl.release();
+    c->track_part.release();
+    c->track_ticket.release();
     if (c->h_sums) (void)hipHostFree(c->h_sums);
     if (c->h_total) (void)hipHostFree(c->h_total);
     if (c->h_mbox) (void)hipHostFree(c->h_mbox);
+    if (c->h_report) (void)hipHostFree(c->h_report);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PPCR_OK;
@@ -1223,6 +1419,11 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
     }
     if (std::strcmp(key, "defer_moves") == 0) {
         c->opt_defer_moves = value ? 1 : 0;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "inner_dev_steps") == 0) {
+        if (value < 0 || value > kMaxDevSteps) return fail(c, PPCR_ERR_INVALID, "inner_dev_steps must be in [0, 8]");
+        c->opt_inner_dev_steps = value;
         return PPCR_OK;
     }
     if (std::strcmp(key, "mailbox") == 0) {
@@ -1572,15 +1773,74 @@ int ppcr_stop_rule_check(ppcr_stop_rule *rule, int n_iter, double cost_drop_thre
 
 }  // extern "C"
 
+// ---- reporting clouds: helpers shared by the align loop and the report entry points ----------------------------------------------------
+namespace {
+
+// the cloud the reference reports on: the full-resolution companion when one is set, else the source itself
+struct Tracked {
+    const float4 *p;
+    int64_t n;
+    int sorted;  // 1: the handle's sorted source (w lane = caller's index)
+};
+int tracked_cloud(ppcr_ctx *c, Tracked &t)
+{
+    if (c->have_companion) {
+        t = Tracked{c->companion.p, c->n_companion, 0};
+        return PPCR_OK;
+    }
+    if (!c->have_src) return fail(c, PPCR_ERR_STATE, "source cloud not set");
+    PPCR_TRY(flush_pending_move(c));
+    t = Tracked{c->src.p, c->ns, 1};
+    return PPCR_OK;
+}
+
+int mean_distance(ppcr_ctx *c, const Tracked &t, const float4 *other, double *out)
+{
+    if (t.n == 0) {
+        *out = std::numeric_limits<double>::quiet_NaN();  // 0 / 0, as the reference's loop would produce
+        return PPCR_OK;
+    }
+    const int nb = std::min(1024, nblocks(t.n));
+    HIP_TRY(c, c->mse_part.reserve((size_t)nb));
+    mean_distance_kernel<<<nb, kBlock, 0, c->stream>>>(t.p, (int)t.n, other, t.sorted, c->mse_part.p);
+    PPCR_TRY(check_launch(c, "mean_distance_kernel"));
+    std::vector<double> h((size_t)nb);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->mse_part.p, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double sum = 0;
+    for (double v : h) sum += v;
+    *out = sum / (double)t.n;
+    return PPCR_OK;
+}
+
+int snapshot_tracked(ppcr_ctx *c, const Tracked &t)
+{
+    HIP_TRY(c, c->previous.reserve((size_t)std::max<int64_t>(t.n, 1)));
+    if (t.n > 0) snapshot_kernel<<<nblocks(t.n), kBlock, 0, c->stream>>>(t.p, (int)t.n, t.sorted, c->previous.p);
+    PPCR_TRY(check_launch(c, "snapshot_kernel"));
+    c->n_previous = t.n;
+    c->have_previous = true;
+    return PPCR_OK;
+}
+
+}  // namespace
+
 namespace {
 
 // One align() call as a resumable state machine, so that ONE host thread can keep several handles busy (each handle
-// has its own stream; the device paces itself through reduce_solve_kernel and PendingMove::dev).
+// has its own stream; the device paces itself through the fold-and-solve lanes and PendingMove::dev).
 //
-// Pipelined mode (one inner step per association, the benchmark schedule): the device runs one iteration AHEAD of
-// the host.  Iteration k + 1 is enqueued before the host has seen iteration k — but only when hasConverged() cannot
-// stop in between whatever the cost of iteration k turns out to be: the cap is not reached and the idle count is
-// within the patience.  The rule therefore stays exact: nothing speculative is ever enqueued.
+// Pipelined mode (every bounded search on the tiled kernels): the device runs one iteration AHEAD of the host.  An
+// outer iteration is a fixed train of launches — association (K23 of the first IRLS step folded in), fold-and-solve,
+// the later IRLS steps of the inner loop as one device-walked launch (inner_steps_kernel; only when inner_steps > 1),
+// the companion move / per-iteration reports (track_kernel; only when there is something to move or report) — and
+// the lane that solves a step decides on the device whether the inner loop is over (LoopCtl: the test of solve_impl).
+// Iteration k + 1 is enqueued before the host has seen iteration k — but only when hasConverged() cannot stop in
+// between whatever the cost of iteration k turns out to be: the cap is not reached and the idle count is within the
+// patience.  The rule therefore stays exact: nothing speculative is ever enqueued.
+// Should an inner loop need more steps than were enqueued for the device (option inner_dev_steps), the device raises
+// LoopState::abort, everything enqueued behind steps aside untouched, and the host finishes that iteration one step
+// at a time (take_over) before the train continues.
 struct AlignJob {
     ppcr_ctx *c = nullptr;
     int n_iter = 0, inner_steps = 1;
@@ -1588,6 +1848,9 @@ struct AlignJob {
     double q0[4] = {1, 0, 0, 0}, t0[3] = {0, 0, 0};
     double *history = nullptr, *costs = nullptr;
     int32_t *steps = nullptr;
+    int report_flags = 0;                   // PPCR_REPORT_*
+    ppcr_iteration_fn on_iteration = nullptr;
+    void *user = nullptr;
     ppcr_stop_rule rule = {0, 0, 0.0};  // hasConverged(), shared with the C++ class (ppcr.h)
     double Tcum[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     double T_last[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
@@ -1595,6 +1858,9 @@ struct AlignJob {
     StepTicket in_flight[2];
     int enq = 0, done = 0;
     bool pipelined = false, finished = false;
+    int max_steps = 1, n_dev_steps = 0;
+    LoopCtl loop{};
+    Pose handback{};  // take_over: the pose the host solved, on its way back to the device
 
     int validate()
     {
@@ -1609,15 +1875,30 @@ struct AlignJob {
         if (!c->have_src || !c->have_tgt) return fail(c, PPCR_ERR_STATE, "set source and target before ppcr_align");
         const double qn = q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3];
         if (!(qn > 0) || !std::isfinite(qn)) return fail(c, PPCR_ERR_INVALID, "initial rotation quaternion has zero or non-finite norm");
+        if ((report_flags & PPCR_REPORT_TRUTH) && !c->have_ground_truth) return fail(c, PPCR_ERR_STATE, "ground truth cloud not set");
+        if (report_flags & PPCR_REPORT_TRUTH) {
+            const int64_t n_tracked = c->have_companion ? c->n_companion : c->ns;
+            if (n_tracked != c->n_ground_truth) return fail(c, PPCR_ERR_INVALID, "ground truth and source clouds differ in size");
+        }
         R0 = quat_to_rot(q0);
         for (double &v : c->dbg_host) v = 0;
         const bool unbounded = (c->max_nb <= 0 || (int64_t)c->max_nb >= c->nt);
-        pipelined = inner_steps <= 1 && c->opt_mailbox && c->opt_run_ahead && !c->have_companion && !unbounded &&
-                    c->max_nb <= kEllMaxWidth && c->ns > 0;
+        pipelined = c->opt_mailbox && c->opt_run_ahead && !unbounded && c->max_nb <= kEllMaxWidth && c->ns > 0;
+        max_steps = std::max(inner_steps, 1);
+        n_dev_steps = (pipelined && c->nt > 0) ? std::min(max_steps - 1, c->opt_inner_dev_steps) : 0;
+        if (pipelined) {
+            PPCR_TRY(ensure_loop_state(c));
+            loop.st = c->d_loop.p;
+            loop.f_tol = f_tol;
+            loop.max_steps = max_steps;
+            loop.first = 1;
+            loop.last_dev = n_dev_steps == 0 ? 1 : 0;
+        }
         return PPCR_OK;
     }
 
-    void record(const double Tk[12], const double cost[2], int st)
+    // book one finished outer iteration; mse_truth / moved: NaN unless asked for
+    void record(const double Tk[12], const double cost[2], int st, double mse_truth, double moved)
     {
         compose(Tk, Tcum, Tcum);  // T_cum <- T_k * T_cum (cc:101-107)
         const int it = rule.iteration;
@@ -1627,28 +1908,93 @@ struct AlignJob {
             costs[2 * it + 1] = cost[1];
         }
         if (steps) steps[it] = st;
+        if (on_iteration) {
+            ppcr_iteration_info info;
+            info.iteration = it;
+            info.inner_steps = st;
+            info.cost[0] = cost[0], info.cost[1] = cost[1];
+            std::memcpy(info.T_step, Tk, sizeof(info.T_step));
+            std::memcpy(info.T_cum, Tcum, sizeof(info.T_cum));
+            info.mse_truth = mse_truth;
+            info.moved = moved;
+            on_iteration(user, &info);
+        }
         rule.cost_drop = (cost[0] - cost[1]) / cost[0];  // cc:119
         rule.iteration++;                                // cc:130
     }
 
     int enqueue()
     {
+        StepTicket &tk = in_flight[enq & 1];
         // moves the source by the previous iteration's transform in its prologue and (steady state) leaves this
         // iteration's partial moments at (q0, t0) behind: K23 folded in
-        PPCR_TRY(associate_impl(c, &R0, t0, &in_flight[enq & 1]));
-        if (!c->assoc_folded) PPCR_TRY(launch_step(c, R0, t0, in_flight[enq & 1], c->assoc_fused));
+        PPCR_TRY(associate_impl(c, &R0, t0, &tk, &loop));
+        if (!c->assoc_folded) PPCR_TRY(launch_step(c, R0, t0, tk, c->assoc_fused, &loop));
+        PPCR_TRY(launch_inner(c, tk, loop, n_dev_steps));
         c->move_on_device = true;     // ... and this iteration's transform is the next pending move
+        PPCR_TRY(launch_track(c, tk.seq, report_flags));
         enq++;
         return PPCR_OK;
+    }
+
+    // The device could not finish iteration `done` by itself (kIterationPending): finish its inner loop one IRLS step at
+    // a time, as solve_impl does, hand the pose back to the device and redo what follows an iteration.
+    int take_over(StepResult &res)
+    {
+        const unsigned seq = in_flight[done & 1].seq;
+        if (enq > done + 1) {
+            // the train of iteration done + 1 stepped aside: wait for its (empty) mailbox slot and take it back
+            StepResult skipped;
+            PPCR_TRY(collect_step(c, in_flight[(done + 1) & 1], skipped));
+            if (skipped.status != kLaunchSkipped) return fail(c, PPCR_ERR_STATE, "internal: a launch ran past an aborted iteration");
+            enq--;
+            c->ovf_parity ^= 1;  // its association had claimed the other counter of the pair
+        }
+        HIP_TRY(c, hipMemsetAsync(&c->d_loop.p->abort, 0, sizeof(unsigned), c->stream));
+        c->move_on_device = false;
+        Mat3 R;
+        Vec3 t;
+        int st = res.steps;
+        for (;;) {
+            for (int a = 0; a < 3; a++) {
+                for (int b = 0; b < 3; b++) R.m[a][b] = res.T[4 * a + b];
+                t[a] = res.T[4 * a + 3];
+            }
+            StepTicket tk;
+            const double c_init = res.cost_init;
+            PPCR_TRY(launch_step(c, R, t.v, tk));
+            PPCR_TRY(collect_step(c, tk, res));
+            res.cost_init = c_init;
+            st++;
+            const double cost_old = 0.5 * res.sums[16];
+            if (res.degenerate) res.cost = cost_old;
+            if (res.degenerate || st >= max_steps) break;
+            if ((cost_old - res.cost) <= std::max(f_tol * cost_old, 1e-14 * 0.5 * (res.sums[17] + res.sums[18]))) break;
+        }
+        res.steps = st;
+        res.status = kIterationDone;
+        for (int a = 0; a < 3; a++) {
+            for (int b = 0; b < 3; b++) handback.R[3 * a + b] = res.T[4 * a + b];
+            handback.t[a] = res.T[4 * a + 3];
+            handback.c[a] = 0.0;
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_pose.p, &handback, sizeof(Pose), hipMemcpyHostToDevice, c->stream));
+        c->move_on_device = true;
+        return launch_track(c, seq, report_flags);
     }
 
     int consume()
     {
         StepResult res;
+        const unsigned seq = in_flight[done & 1].seq;
         PPCR_TRY(collect_step(c, in_flight[done & 1], res));
-        const double cost[2] = {0.5 * res.sums[16], res.cost};
+        if (res.status == kIterationPending) PPCR_TRY(take_over(res));
+        if (res.status != kIterationDone) return fail(c, PPCR_ERR_STATE, "internal: unexpected mailbox status in the align loop");
+        const double cost[2] = {res.cost_init, res.cost};
+        double mse_truth = std::numeric_limits<double>::quiet_NaN(), moved = mse_truth;
+        if (report_flags) PPCR_TRY(collect_report(c, seq, &mse_truth, &moved));
         std::memcpy(T_last, res.T, sizeof(T_last));
-        record(res.T, cost, 1);
+        record(res.T, cost, res.steps, mse_truth, moved);
         done++;
         // an iteration enqueued ahead was let through on the strength of the idle count: replay its check now
         if (enq > done && ppcr_stop_rule_check(&rule, n_iter, thresh, patience) != PPCR_CONTINUE)
@@ -1668,7 +2014,8 @@ struct AlignJob {
                 finished = true;
                 if (done > 0) {  // the last transform becomes an ordinary host-side pending move
                     c->move_on_device = false;
-                    PPCR_TRY(apply_transform_impl(c, T_last, /*defer=*/true));
+                    // (the companion has followed every iteration already: track_kernel)
+                    PPCR_TRY(apply_transform_impl(c, T_last, /*defer=*/true, /*move_companion=*/false));
                 }
                 if (progressed) *progressed = true;
                 return PPCR_OK;
@@ -1689,23 +2036,66 @@ struct AlignJob {
         return PPCR_OK;
     }
 
+    // host-paced loop (unbounded or very wide searches, options mailbox = 0 / run_ahead = 0): one blocking step at a time
+    int run_host_paced()
+    {
+        const double nan = std::numeric_limits<double>::quiet_NaN();
+        Tracked tr{nullptr, 0, 0};
+        if (report_flags & PPCR_REPORT_MOVED) {
+            PPCR_TRY(tracked_cloud(c, tr));
+            PPCR_TRY(snapshot_tracked(c, tr));
+        }
+        while (ppcr_stop_rule_check(&rule, n_iter, thresh, patience) == PPCR_CONTINUE) {
+            double Tk[12], cost[2];
+            int st = 0;
+            PPCR_TRY(associate_impl(c));
+            PPCR_TRY(solve_impl(c, q0, t0, inner_steps, f_tol, Tk, cost, &st));
+            PPCR_TRY(apply_transform_impl(c, Tk, /*defer=*/true));  // rides in the next iteration's K1 prologue
+            double mse_truth = nan, moved = nan;
+            if (report_flags) {
+                PPCR_TRY(tracked_cloud(c, tr));
+                if (report_flags & PPCR_REPORT_TRUTH) PPCR_TRY(mean_distance(c, tr, c->ground_truth.p, &mse_truth));
+                if (report_flags & PPCR_REPORT_MOVED) {
+                    PPCR_TRY(mean_distance(c, tr, c->previous.p, &moved));
+                    PPCR_TRY(snapshot_tracked(c, tr));
+                }
+            }
+            record(Tk, cost, st, mse_truth, moved);
+        }
+        finished = true;
+        return PPCR_OK;
+    }
+
     // the whole call on this thread
     int run()
     {
-        if (pipelined) {
-            while (!finished) PPCR_TRY(advance(true, nullptr));
-        } else {
-            while (ppcr_stop_rule_check(&rule, n_iter, thresh, patience) == PPCR_CONTINUE) {
-                double Tk[12], cost[2];
-                int st = 0;
-                PPCR_TRY(associate_impl(c));
-                PPCR_TRY(solve_impl(c, q0, t0, inner_steps, f_tol, Tk, cost, &st));
-                PPCR_TRY(apply_transform_impl(c, Tk, /*defer=*/true));  // rides in the next iteration's K1 prologue
-                record(Tk, cost, st);
-            }
-            finished = true;
-        }
+        if (!pipelined) return run_host_paced();
+        while (!finished) PPCR_TRY(advance(true, nullptr));
         return PPCR_OK;
+    }
+
+    // After a failure: leave the handle in a defined state (nothing in flight, no device-resident move, no abort flag).
+    void abandon()
+    {
+        if (!c) return;
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        if (c->d_loop.p) (void)hipMemsetAsync(c->d_loop.p, 0, sizeof(LoopState), c->stream);
+        if (c->move_on_device) {
+            // the transform the device solved last moves the source the ordinary way at its next use
+            Pose P;
+            if (hipMemcpy(&P, c->d_pose.p, sizeof(Pose), hipMemcpyDeviceToHost) == hipSuccess) {
+                for (int a = 0; a < 3; a++) {
+                    for (int b = 0; b < 3; b++) c->pending_T[4 * a + b] = P.R[3 * a + b];
+                    c->pending_T[4 * a + 3] = P.t[a];
+                }
+                c->move_pending = true;
+            }
+            c->move_on_device = false;
+        }
+        c->dm2_valid = false;
+        (void)hipStreamSynchronize(c->stream);
+        finished = true;
     }
 
     // Hand the totals over.  The last move stays pending, as after ppcr_iterate: whoever reads the source next (or the
@@ -1716,6 +2106,7 @@ struct AlignJob {
     {
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (report_flags & PPCR_REPORT_MOVED) c->have_previous = false;  // the loop kept no snapshot of its own
         if (T_final) std::memcpy(T_final, Tcum, sizeof(Tcum));  // identity when no iteration ran
         if (n_done) *n_done = rule.iteration;
         return PPCR_OK;
@@ -1743,13 +2134,26 @@ AlignJob make_job(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cos
 // align() with the per-iteration outputs optional and the last cumulative transform returned separately
 int align_impl(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_drop_it, const double q0[4],
                const double t0[3], int inner_steps, double f_tol, double *history, double *costs, int32_t *steps,
-               double *T_final, int *n_done)
+               double *T_final, int *n_done, ppcr_stop_rule *rule_io = nullptr, int report_flags = 0,
+               ppcr_iteration_fn fn = nullptr, void *user = nullptr)
 {
     if (!c) return PPCR_ERR_INVALID;
     if (!q0 || !t0) return fail(c, PPCR_ERR_INVALID, "null argument");
+    if (report_flags & ~(PPCR_REPORT_TRUTH | PPCR_REPORT_MOVED)) return fail(c, PPCR_ERR_INVALID, "unknown report flag");
     AlignJob job = make_job(c, n_iter, cost_drop_thresh, n_cost_drop_it, q0, t0, inner_steps, f_tol, history, costs, steps);
+    job.report_flags = fn ? report_flags : 0;
+    job.on_iteration = fn;
+    job.user = user;
+    if (rule_io) job.rule = *rule_io;
     PPCR_TRY(job.validate());
-    PPCR_TRY(job.run());
+    const int rc = job.run();
+    if (rc != PPCR_OK) {
+        const std::string msg = c->err;
+        job.abandon();
+        c->err = msg;
+        return rc;
+    }
+    if (rule_io) *rule_io = job.rule;
     return job.finish(T_final, n_done);
 }
 
@@ -1763,6 +2167,16 @@ int ppcr_align(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_d
 {
     return align_impl(c, n_iter, cost_drop_thresh, n_cost_drop_it, q0, t0, inner_steps, f_tol, history, costs, steps,
                       nullptr, n_done);
+}
+
+int ppcr_align_report(ppcr_ctx *c, int n_iter, double cost_drop_thresh, double n_cost_drop_it, const double q0[4],
+                      const double t0[3], int inner_steps, double f_tol, ppcr_stop_rule *rule_io, int report_flags,
+                      ppcr_iteration_fn on_iteration, void *user, double T_final[12], int *n_done)
+{
+    if (c && n_iter < 0 && !(cost_drop_thresh > 0))
+        return fail(c, PPCR_ERR_INVALID, "ppcr_align_report: n_iter < 0 (no iteration cap) needs cost_drop_thresh > 0, or the loop never ends");
+    return align_impl(c, n_iter, cost_drop_thresh, n_cost_drop_it, q0, t0, inner_steps, f_tol, nullptr, nullptr, nullptr,
+                      T_final, n_done, rule_io, report_flags, on_iteration, user);
 }
 
 int ppcr_get_source(ppcr_ctx *c, float *xyz, int64_t stride_bytes)
@@ -1877,58 +2291,7 @@ int ppcr_profile_get(ppcr_ctx *c, ppcr_kernel_stat *out, int capacity, int *n_ou
 
 }  // extern "C"
 
-// ---- reporting clouds, voxel filter ----------------------------------------------------
-namespace {
-
-// the cloud the reference reports on: the full-resolution companion when one is set, else the source itself
-struct Tracked {
-    const float4 *p;
-    int64_t n;
-    int sorted;  // 1: the handle's sorted source (w lane = caller's index)
-};
-int tracked_cloud(ppcr_ctx *c, Tracked &t)
-{
-    if (c->have_companion) {
-        t = Tracked{c->companion.p, c->n_companion, 0};
-        return PPCR_OK;
-    }
-    if (!c->have_src) return fail(c, PPCR_ERR_STATE, "source cloud not set");
-    PPCR_TRY(flush_pending_move(c));
-    t = Tracked{c->src.p, c->ns, 1};
-    return PPCR_OK;
-}
-
-int mean_distance(ppcr_ctx *c, const Tracked &t, const float4 *other, double *out)
-{
-    if (t.n == 0) {
-        *out = std::numeric_limits<double>::quiet_NaN();  // 0 / 0, as the reference's loop would produce
-        return PPCR_OK;
-    }
-    const int nb = std::min(1024, nblocks(t.n));
-    HIP_TRY(c, c->mse_part.reserve((size_t)nb));
-    mean_distance_kernel<<<nb, kBlock, 0, c->stream>>>(t.p, (int)t.n, other, t.sorted, c->mse_part.p);
-    PPCR_TRY(check_launch(c, "mean_distance_kernel"));
-    std::vector<double> h((size_t)nb);
-    HIP_TRY(c, hipMemcpyAsync(h.data(), c->mse_part.p, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    double sum = 0;
-    for (double v : h) sum += v;
-    *out = sum / (double)t.n;
-    return PPCR_OK;
-}
-
-int snapshot_tracked(ppcr_ctx *c, const Tracked &t)
-{
-    HIP_TRY(c, c->previous.reserve((size_t)std::max<int64_t>(t.n, 1)));
-    if (t.n > 0) snapshot_kernel<<<nblocks(t.n), kBlock, 0, c->stream>>>(t.p, (int)t.n, t.sorted, c->previous.p);
-    PPCR_TRY(check_launch(c, "snapshot_kernel"));
-    c->n_previous = t.n;
-    c->have_previous = true;
-    return PPCR_OK;
-}
-
-}  // namespace
-
+// ---- reporting clouds, voxel filter: entry points ----------------------------------------
 extern "C" {
 
 int ppcr_set_companion(ppcr_ctx *c, const float *xyz, int64_t n, int64_t stride_bytes)
@@ -2229,7 +2592,13 @@ int ppcr_align_many(ppcr_ctx *const *ctxs, int n, int lanes, int n_iter, double 
                     AlignJob &j = jobs[(size_t)window[w]];
                     bool progressed = false;
                     const int rc = j.advance(false, &progressed);
-                    if (rc != PPCR_OK) return rc;
+                    if (rc != PPCR_OK) {
+                        // leave every handle of the batch in a defined state (nothing in flight, no device-resident move)
+                        const std::string msg = j.c->err;
+                        for (AlignJob &other : jobs) other.abandon();
+                        j.c->err = msg;
+                        return rc;
+                    }
                     any = any || progressed;
                     if (j.finished) {
                         // its last move is queued on its own stream; the synchronising tail runs after the loop

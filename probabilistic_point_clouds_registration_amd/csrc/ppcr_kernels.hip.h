@@ -123,7 +123,14 @@ __global__ void cell_start_kernel(const unsigned *__restrict__ keys_sorted, int 
     for (int c = prev + 1; c <= cur; c++) cell_start[c] = i;
 }
 
-__global__ __launch_bounds__(kBlock) void reduce_solve_kernel(FoldSolve fs) { fold_and_solve_block(fs, (int)blockIdx.x); }
+__global__ __launch_bounds__(kBlock) void reduce_solve_kernel(FoldSolve fs)
+{
+    if (loop_aborted(fs.loop.st)) {  // an earlier launch handed the iteration to the host: step aside
+        if (blockIdx.x == 0 && threadIdx.x == 0) publish_skipped(fs);
+        return;
+    }
+    (void)fold_and_solve_block(fs, (int)blockIdx.x);
+}
 
 // Generic path (unbounded, or max_neighbours above the register-list variants):
 //   count -> exclusive scan -> fill (keys + positions) [-> per-row select of the m smallest]
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(A a, const float4 *_
         }
         row_finish(acc, P, xf, Z, G, Gs, Gyy, Gy);
     }
-    block_reduce_store(acc, partials);
+    block_reduce_store(acc, partials, gridDim.x, blockIdx.x);
 }
 
 // K23 (hot path), ELL rows of width <= W.  Latency, not arithmetic, bounds this kernel (three dependent
@@ -316,18 +323,14 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(A a, const float4 *_
 // stays in registers (the two-pass form keeps s[W] and the centred points: 130 VGPRs, three waves per SIMD).  The host
 // picks it only when that ratio cannot underflow for any s below radius^2; the weights w = g / Z are the same numbers
 // up to rounding.
-template <int W, int ROWS, int BLOCK, int TM = -1, bool ONEPASS = false>
-__global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__restrict__ nbr,
-                                                                const int *__restrict__ cnt,
-                                                                const float4 *__restrict__ src,
-                                                                const float4 *__restrict__ tgt, int ns, Pose P,
-                                                                Model md, double *__restrict__ partials, int width)
+// the rows [base + r * BLOCK | r < ROWS] of one lane, added to acc
+template <int W, int ROWS, int BLOCK, int TM, bool ONEPASS>
+__device__ __forceinline__ void accumulate_ell_rows(RowAcc &acc, int base, const int *__restrict__ nbr,
+                                                    const int *__restrict__ cnt, const float4 *__restrict__ src,
+                                                    const float4 *__restrict__ tgt, int ns, const Pose &P,
+                                                    const Model &md, int width)
 {
     // width = slots the association really has per row (<= W): slots beyond it do not exist in nbr
-    RowAcc acc;
-#pragma unroll
-    for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
-    const int base = blockIdx.x * (BLOCK * ROWS) + threadIdx.x;
     int n[ROWS];
     float4 xf[ROWS];
     float yx[ROWS][W], yy[ROWS][W], yz[ROWS][W];
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
         const double xrc[3] = {fma(P.R[2], pz, fma(P.R[1], py, fma(P.R[0], px, P.t[0] - P.c[0]))),
                                fma(P.R[5], pz, fma(P.R[4], py, fma(P.R[3], px, P.t[1] - P.c[1]))),
                                fma(P.R[8], pz, fma(P.R[7], py, fma(P.R[6], px, P.t[2] - P.c[2])))};
-        if constexpr (ONEPASS && TM >= 0) {
+        if constexpr (ONEPASS) {
             double xr[3];
             rotated_point(P, xf[r], xr);
             RowMoments<TM> row;
@@ -409,9 +412,108 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
         const double Gyy = fma(-x2, G, fma(2.0, fma(xrc[2], Gy[2], fma(xrc[1], Gy[1], xrc[0] * Gy[0])), Gs));
         row_finish(acc, P, xf[r], Z, G, Gs, Gyy, Gy);
     }
+}
+
+template <int W, int ROWS, int BLOCK, int TM = -1, bool ONEPASS = false>
+__global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__restrict__ nbr,
+                                                                const int *__restrict__ cnt,
+                                                                const float4 *__restrict__ src,
+                                                                const float4 *__restrict__ tgt, int ns, Pose P,
+                                                                Model md, double *__restrict__ partials, int width,
+                                                                const LoopState *loop_st)
+{
+    if (loop_aborted(loop_st)) return;
+    RowAcc acc;
+#pragma unroll
+    for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
+    accumulate_ell_rows<W, ROWS, BLOCK, TM, ONEPASS>(acc, blockIdx.x * (BLOCK * ROWS) + threadIdx.x, nbr, cnt, src, tgt, ns, P,
+                                                     md, width);
     // (an in-kernel last-block fold was measured and removed: its register footprint cost this kernel more than
     //  the separate fold kernel does: 101.6 us vs 67.6 + 17.2 us at the time; the fold kernel is 4.4 us now)
-    block_reduce_store<BLOCK, (ONEPASS && TM >= 0)>(acc, partials);  // the lean form is worth six workgroups per CU
+    block_reduce_store<BLOCK, ONEPASS>(acc, partials, gridDim.x, blockIdx.x);  // the lean form is worth six workgroups per CU
+}
+
+// ---------------------------------------------------------------------------------------------
+// The inner loop's later steps, paced by the device (ProbPointCloudRegistrationIteration::solve iterated to
+// function_tolerance, cc:96-100).  Step 1 of an outer iteration rides in the association (K23 folded into K1, or
+// accumulate_ell_kernel) and its fold-and-solve lane decides whether the loop is over (LoopCtl).  This ONE launch,
+// enqueued behind it, holds the next `n_steps` IRLS steps: per step G workgroups redo K23 at the pose the previous step
+// solved (rows dealt G-strided in tiles of 256) and kNSums workgroups fold and solve.  Workgroups take their role from
+// a ticket drawn at entry, so a workgroup only ever waits for workgroups that drew smaller tickets — which are running
+// or done: no co-residency is assumed and several such kernels (other handles) can share the chip.  When the loop
+// is over (the common case at its very first look) every remaining workgroup returns at once.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxDevSteps = 8;
+struct InnerCtl {  // device memory, zeroed by the association kernel that precedes the launch
+    unsigned ticket;
+    unsigned step_done;             // device steps of this launch that have been solved
+    unsigned k23_done[kMaxDevSteps];  // workgroups of step u whose partial sums are in place
+};
+struct InnerArgs {
+    const int *nbr, *cnt;
+    const float4 *src, *tgt;
+    int ns, width;
+    Model md;
+    FoldSolve fs;     // partials = [kNSums][G], nslots = G; loop.first = 0; loop.last_dev is set per step here
+    InnerCtl *ctl;
+    int G, n_steps;
+};
+template <int W, int TM, bool ONEPASS>
+__global__ __launch_bounds__(kBlock) void inner_steps_kernel(InnerArgs a)
+{
+    __shared__ unsigned s_ticket;
+    LoopState *const st = a.fs.loop.st;
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&a.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int per_step = a.G + kNSums;
+    const int u = (int)s_ticket / per_step, r = (int)s_ticket % per_step;
+    if (u > 0) {  // the previous device step must have been solved (step 1 was: it ran in an earlier launch)
+        // (or the loop ended at an earlier step: then step u - 1 never runs and `finished` / `abort` is the news)
+        if (threadIdx.x == 0)
+            while (__hip_atomic_load(&a.ctl->step_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)u &&
+                   __hip_atomic_load(&st->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && !loop_aborted(st))
+                __builtin_amdgcn_s_sleep(16);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    if (__hip_atomic_load(&st->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || loop_aborted(st)) return;
+    if (r < a.G) {
+        // K23 at the pose the previous step solved (written by another workgroup, possibly of this launch: no
+        // scalar-cache / read-only path for it)
+        Pose P;
+#pragma unroll
+        for (int k = 0; k < 9; k++) P.R[k] = __hip_atomic_load(&a.fs.pose_out->R[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < 3; k++) P.t[k] = __hip_atomic_load(&a.fs.pose_out->t[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        P.c[0] = a.fs.origin.x, P.c[1] = a.fs.origin.y, P.c[2] = a.fs.origin.z;
+        RowAcc acc;
+#pragma unroll
+        for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
+        const int ntiles = (a.ns + kBlock - 1) / kBlock;
+        for (int tile = r; tile < ntiles; tile += a.G)
+            accumulate_ell_rows<W, 1, kBlock, TM, ONEPASS>(acc, tile * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.tgt, a.ns, P,
+                                                           a.md, a.width);
+        block_reduce_store<kBlock, true>(acc, const_cast<double *>(a.fs.partials), a.G, r);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(&a.ctl->k23_done[u], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    // fold role: every partial of this step must be in place
+    if (threadIdx.x == 0)
+        while (__hip_atomic_load(&a.ctl->k23_done[u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.G)
+            __builtin_amdgcn_s_sleep(8);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    FoldSolve fs = a.fs;
+    fs.loop.first = 0;
+    fs.loop.last_dev = (u == a.n_steps - 1) ? 1 : 0;
+    if (fold_and_solve_block(fs, r - a.G)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&a.ctl->step_done, (unsigned)(u + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // fold partials[19][nblocks] -> sums[19].  One 256-thread block PER SUM (grid = 19): every thread issues its
@@ -570,6 +672,88 @@ __global__ __launch_bounds__(kBlock) void mean_distance_kernel(const float4 *__r
         for (int w = 1; w < kBlock / 64; w++) v += sh[w];
         partials[blockIdx.x] = v;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The step AFTER each outer iteration inside the device-paced loop (cc:110-122): the cloud the reference reports on —
+// the full-resolution companion (moved here, in place, by the transform the iteration just solved: the second
+// pcl::transformPointCloud of cc:110-112) or the source itself (its move rides in the next association's prologue, so
+// here the moved point is only formed, not stored) — and the two mean distances the reference prints per iteration:
+// calculateMSE(cloud, ground truth) (cc:114-117) and calculateMSE(cloud, cloud before the move) (cc:121).
+// Same per-point float arithmetic, block sums and summation order as mean_distance_kernel + the host sum of
+// ppcr_mse_ground_truth / ppcr_mse_previous, so the numbers are those of the one-call-at-a-time path.  The last
+// workgroup (ticket) adds the block sums in ascending order and hands the means to the host in pinned memory.
+// ---------------------------------------------------------------------------------------------
+struct HostReport {
+    double mse_truth, moved;
+    unsigned seq, pad;
+};
+struct TrackArgs {
+    float4 *cloud;
+    int n;
+    int sorted_source;   // 1: the handle's sorted source (w lane = caller's index; never written here)
+    int write_back;      // 1: store the moved points (companion)
+    const Pose *pose;    // device memory: written by the iteration's last solve
+    const float4 *truth; // caller's index order; nullptr: no ground-truth distance
+    int want_moved;
+    double *part;        // [2][gridDim.x]
+    unsigned *ticket;
+    HostReport *out;     // pinned, device-mapped; nullptr: nothing to report (the companion is only moved)
+    unsigned seq;
+    const LoopState *st;
+};
+__global__ __launch_bounds__(kBlock) void track_kernel(TrackArgs a)
+{
+    if (loop_aborted(a.st)) return;
+    __shared__ double sh[2][kBlock / 64];
+    const Pose P = *a.pose;
+    double acc_t = 0.0, acc_m = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n; i += gridDim.x * kBlock) {
+        const float4 p = a.cloud[i];
+        const float4 p2 = move_point(p, P);
+        if (a.write_back) a.cloud[i] = p2;
+        if (a.truth) {
+            const float4 q = a.truth[a.sorted_source ? __float_as_int(p.w) : i];
+            const float dx = __fsub_rn(p2.x, q.x), dy = __fsub_rn(p2.y, q.y), dz = __fsub_rn(p2.z, q.z);
+            acc_t += (double)sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+        }
+        if (a.want_moved) {
+            const float dx = __fsub_rn(p2.x, p.x), dy = __fsub_rn(p2.y, p.y), dz = __fsub_rn(p2.z, p.z);
+            acc_m += (double)sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+        }
+    }
+    if (!a.out) return;
+    for (int off = 32; off > 0; off >>= 1) {
+        acc_t += __shfl_down(acc_t, off);
+        acc_m += __shfl_down(acc_m, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sh[0][threadIdx.x >> 6] = acc_t;
+        sh[1][threadIdx.x >> 6] = acc_m;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double vt = sh[0][0], vm = sh[1][0];
+    for (int w = 1; w < kBlock / 64; w++) {
+        vt += sh[0][w];
+        vm += sh[1][w];
+    }
+    __hip_atomic_store(&a.part[blockIdx.x], vt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&a.part[gridDim.x + blockIdx.x], vm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk != gridDim.x - 1) return;
+    __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double st = 0.0, sm = 0.0;
+    for (unsigned b = 0; b < gridDim.x; b++) {
+        st += __hip_atomic_load(&a.part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sm += __hip_atomic_load(&a.part[gridDim.x + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    a.out->mse_truth = a.truth ? st / (double)a.n : nan;
+    a.out->moved = a.want_moved ? sm / (double)a.n : nan;
+    __hip_atomic_store(&a.out->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // snapshot of the tracked cloud in the caller's index order: dst[w(r)] = a[r] (sorted source) or dst[i] = a[i]

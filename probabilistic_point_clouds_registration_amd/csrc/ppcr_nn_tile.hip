@@ -45,12 +45,13 @@ void launch_tile(TileLaunch &t)
                                            : SplitTable{nullptr, nullptr, nullptr, nullptr, 0, INT_MAX};  // no steady-state variant to split for
     FusedMoments fm_none;
     std::memset(&fm_none, 0, sizeof(fm_none));
+    const LoopReset lr{t.loop_st, t.inner_ctl, t.inner_ctl_words};
     // the steady-state (16-slot) variant runs with a halo capacity that gives FIVE workgroups per CU (31.3 KB of LDS)
     // and splits the few blocks that outgrow it; the first association (32 slots, three per CU) keeps the large one
 #define PPCR_FAST(Cc, STAMPc, FTMc, FMc)                                                                               \
     nn_fast_kernel<M, Cc, (Cc <= 16 ? kCapSteady : CAP), STAMPc, FTMc><<<nb + (Cc <= 16 ? kMaxSplit : 0), 256, 0, t.stream>>>( \
         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,  \
-        t.ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc)
+        t.ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc, lr)
     t.fused = false;
     int ftm = -2;  // model folded into this launch (-2: none)
     bool steady = false;
@@ -88,6 +89,7 @@ void launch_tile(TileLaunch &t)
     const int n_extra = steady ? kMaxSplit : 0;
     FoldSolve fs_none;
     std::memset(&fs_none, 0, sizeof(fs_none));
+    fs_none.loop.st = t.loop_st;  // the cleanup role steps aside with everybody else
     const bool merge = ftm != -2 && t.fold != nullptr;
     t.merged = merge;
     FoldSolve fold_now = t.fold ? *t.fold : fs_none;

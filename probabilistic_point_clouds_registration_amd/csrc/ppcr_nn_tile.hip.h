@@ -172,6 +172,11 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
                                                          FoldSolve fs)
 {
     static_assert(!MERGED || FTM != -2, "the merged launch folds the partials the fused kernels wrote");
+    if (loop_aborted(fs.loop.st)) {  // an earlier launch handed the iteration to the host: step aside (see LoopState)
+        if constexpr (MERGED)
+            if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) publish_skipped(fs);
+        return;
+    }
     const unsigned n_listed = *ovf_count;
     const unsigned n_cleanup = MERGED ? gridDim.x - kNSums : gridDim.x;  // workgroups in the cleanup role
     if constexpr (MERGED) {
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
                 __syncthreads();
                 __atomic_thread_fence(__ATOMIC_ACQUIRE);
             }
-            fold_and_solve_block(fs, (int)(blockIdx.x - n_cleanup));
+            (void)fold_and_solve_block(fs, (int)(blockIdx.x - n_cleanup));
             return;
         }
     }
@@ -635,6 +640,13 @@ struct SplitTable {
                               // (halos grow a few per cent per iteration as the source drifts: 15/16 of the capacity)
 };
 
+// what the first kernel of an outer iteration resets for the device-paced inner loop (all nullable)
+struct LoopReset {
+    LoopState *st;
+    unsigned *ctl;   // InnerCtl of the inner-step launch that follows, as words
+    int ctl_words;
+};
+
 // FTM >= 0 (0: Gaussian, k: t model with v + dim = k) folds K23 into this kernel: each lane finishes its row's
 // contribution to the 19 moments from the winners' coordinates while they are still in LDS (no neighbour gathers, no
 // second pass over the source, no K23 launch) and the workgroup folds them into fm.partials.  FTM = -2: plain K1.
@@ -647,8 +659,12 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
                                                          unsigned *__restrict__ dm2, int dm2_valid,
                                                          int *__restrict__ ovf_list, unsigned *__restrict__ ovf_count,
                                                          unsigned *__restrict__ ovf_count_next, SplitTable split,
-                                                         unsigned long long *__restrict__ stamps, FusedMoments fm)
+                                                         unsigned long long *__restrict__ stamps, FusedMoments fm,
+                                                         LoopReset lr)
 {
+    // an earlier launch may have handed the iteration to the host (LoopState::abort, set before this kernel started):
+    // then this one must touch nothing.  A uniform scalar load, tested below once the query load is in flight.
+    const unsigned aborted = lr.st ? lr.st->abort : 0u;
     static_assert(C > M, "a re-scan must leave room in the list");
     static_assert(FTM == -2 || (3 * CAP + CAP / 4) * 4 >= kFoldScratchBytes, "the final fold borrows the halo buffer");
     static_assert(CAP % 4 == 0 && CAP * 4 < 65536, "list entries are 16-bit byte offsets into the halo arrays");
@@ -684,7 +700,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0 && blockIdx.x == 0) *ovf_count_next = 0;  // the other counter of the ping-pong pair: idle during this launch
+
     // which block, and which of its waves' queries, this workgroup scans (uniform)
     int bid, half = 0;  // half: 0 whole block, 1 waves 0-1, 2 waves 2-3
     if ((int)blockIdx.x < split.n_extra) {
@@ -705,6 +721,14 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
 
     // ---- prologue: query, pending move, temporal cut-off ---------------------------------------------------------
     float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (aborted) return;
+    if (tid == 0 && blockIdx.x == gridDim.x - 1) {  // (the last workgroup is never an idle split slot)
+        *ovf_count_next = 0;  // the other counter of the ping-pong pair: idle during this launch
+        // a new outer iteration of the device-paced loop: its inner loop has not finished, its step launch starts over
+        if (lr.st) lr.st->finished = 0u;
+        if (lr.ctl)
+            for (int k = 0; k < lr.ctl_words; k++) lr.ctl[k] = 0u;
+    }
     float moved = 0.f;  // how far this query travelled since the association that produced dm2
     if (pm.enabled && valid) {
         const float4 q0 = q;

@@ -266,6 +266,65 @@ static void hostUtilitiesTest()
     EXPECT_NEAR(qz.z(), std::sqrt(0.5), 1e-15);
 }
 
+// The class's align() is ONE call into the device-paced loop (ppcr_align_report): its history must be, bit for bit, the
+// history ppcr_align returns for the same clouds and parameters — for one inner step per association and for the
+// reference's schedule (inner loop to function_tolerance), with and without the reports that -g / --dump ask for.
+static void alignIsTheDevicePacedLoop()
+{
+    auto target = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>(generateCloud());
+    auto source = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+    Eigen::Affine3d Ti;
+    const double a = -0.015;
+    Ti.R.m[0][0] = std::cos(a), Ti.R.m[0][1] = -std::sin(a), Ti.R.m[1][0] = std::sin(a), Ti.R.m[1][1] = std::cos(a);
+    Ti.t = Eigen::Vector3d(-0.04, 0.02, -0.03);
+    pcl::transformPointCloud(*target, *source, Ti);
+    for (int inner : {1, 100})
+        for (int dof : {5, 3, 10})
+            for (bool reports : {false, true}) {
+                ProbPointCloudRegistrationParams params;
+                params.radius = 0.4;
+                params.max_neighbours = 5;
+                params.n_iter = 7;
+                params.cost_drop_thresh = 0;
+                params.dof = dof;
+                params.inner_max_steps = inner;
+                params.summary = reports;
+                std::vector<Eigen::Affine3d> hist;
+                if (reports) {
+                    auto gt = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>(*target);
+                    ProbPointCloudRegistration reg(source, target, params, gt);
+                    reg.align();
+                    hist = reg.transformation_history();
+                    std::size_t lines = 0;
+                    for (char ch : reg.report()) lines += ch == '\n';
+                    EXPECT_TRUE(lines == hist.size() + 1);
+                } else {
+                    ProbPointCloudRegistration reg(source, target, params);
+                    reg.align();
+                    hist = reg.transformation_history();
+                    EXPECT_TRUE(reg.hasConverged());  // asking again after align() gives the same verdict
+                }
+                EXPECT_TRUE(hist.size() == 7);
+                ppcr_ctx *ctx = nullptr;
+                EXPECT_TRUE(ppcr_create(0, &ctx) == PPCR_OK);
+                ppcr_set_params(ctx, params.radius, params.max_neighbours, params.dof, 3);
+                ppcr_set_target(ctx, &(*target)[0].x, (int64_t)target->size(), sizeof(pcl::PointXYZ));
+                ppcr_set_source(ctx, &(*source)[0].x, (int64_t)source->size(), sizeof(pcl::PointXYZ));
+                std::vector<double> H(12 * 7);
+                int done = 0;
+                EXPECT_TRUE(ppcr_align(ctx, 7, 0.0, params.n_cost_drop_it, params.initial_rotation, params.initial_translation,
+                                       inner, 10e-6, H.data(), nullptr, nullptr, &done) == PPCR_OK);
+                EXPECT_TRUE(done == 7);
+                // the class composes the increments itself (delta * previous): same products, same order -> same bits
+                for (std::size_t k = 0; k < hist.size() && k < 7; k++)
+                    for (int r = 0; r < 3; r++) {
+                        for (int c = 0; c < 3; c++) EXPECT_NEAR(hist[k].rotation()(r, c), H[12 * k + 4 * r + c], 0);
+                        EXPECT_NEAR(hist[k].translation()(r), H[12 * k + 4 * r + 3], 0);
+                    }
+                ppcr_destroy(ctx);
+            }
+}
+
 int main()
 {
     hostUtilitiesTest();
@@ -275,6 +334,7 @@ int main()
     exactAssociationTest(5);
     errorTermTest();
     alignTest();
+    alignIsTheDevicePacedLoop();
     std::printf("%d checks, %d failed\n", g_checks, g_failed);
     return g_failed;
 }

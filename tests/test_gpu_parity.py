@@ -831,14 +831,20 @@ def test_randomised_align_soak(ctx):
         m = int(rng.choice([3, 5, 10, 16, 24]))
         inner = int(rng.choice([1, 1, 30]))
         thresh = float(rng.choice([0.0, 0.0, 0.3]))
+        # (drawn after everything else so that the trials of earlier rounds stay what they were)
+        side = np.random.default_rng(1000 + trial)
+        if trial % 4 == 3:
+            m = int(side.choice([11, 12]))       # widths without a steady-state K1 variant
+        dev_steps = int(side.choice([0, 1, 3]))  # device's own IRLS step budget: 0 / 1 force the host to take iterations over
         n_iter = 5
         with _lib.Context(0) as c:
+            c.set_option("inner_dev_steps", dev_steps)
             c.set_params(1.0, m, dof, 3)
             c.set_target(tgt)
             c.set_source(src)
             res = c.align(n_iter, cost_drop_thresh=thresh, n_cost_drop_it=1, inner_steps=inner)
         ora = po.align(src, tgt, 1.0, m, dof, n_iter, cost_drop_thresh=thresh, n_cost_drop_it=1, inner_max_steps=inner)
-        tag = f"trial {trial}: n={n} dof={dof} m={m} inner={inner} thresh={thresh}"
+        tag = f"trial {trial}: n={n} dof={dof} m={m} inner={inner} thresh={thresh} dev_steps={dev_steps}"
         assert res["n_iter"] == len(ora["history"]), tag
         np.testing.assert_array_equal(res["inner_steps"], ora["inner_steps"], err_msg=tag)
         for k in range(res["n_iter"]):
