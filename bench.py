@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--pairs-per-gpu", type=int, default=0,
                     help="independent pairs per rank (0 = the config's own: 1, or 64 / N for config 5)")
     ap.add_argument("--no-verify", action="store_true", help="config 5: skip the single-rank re-run of every pair")
+    ap.add_argument("--settle-ms", type=float, default=250.0,
+                    help="untimed iterations run for at least this long before the first window (clocks settle)")
+    ap.add_argument("--no-cpp-api", action="store_true", help="skip the cpp_api block (the C++ classes timed in a child process)")
     return ap.parse_args()
 
 
@@ -73,11 +76,30 @@ def free_port():
         return s.getsockname()[1]
 
 
+def visible_gpu_count():
+    """GPUs this process tree can use, counted WITHOUT the HIP runtime (the parent of the ranks stays GPU-clean): the
+    KFD topology lists one node per agent, GPU nodes are those with SIMDs; ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES narrow the set the usual way (a comma-separated list; empty = none)."""
+    import glob
+    n = 0
+    for props in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            kv = dict(line.split()[:2] for line in open(props) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(kv.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if var in os.environ:
+            ids = [x for x in os.environ[var].split(",") if x.strip() != ""]
+            n = min(n, len(ids))
+    return n
+
+
 def spawn_ranks(a):
-    """--gpus N > 1 outside torchrun: start the N ranks as a CHILD process tree (never exec from a process that may
-    have touched the GPU; this one has not) and hand its exit status on."""
-    import torch  # device_count() does not initialise the GPU
-    have = torch.cuda.device_count()
+    """--gpus N > 1 outside torchrun: start the N ranks as a CHILD process (subprocess, never an exec) and hand its exit
+    status on.  This parent does not load the HIP runtime at all: devices are counted from the KFD topology."""
+    have = visible_gpu_count()
     if have < a.gpus:
         print(f"bench.py: --gpus {a.gpus} requested but {have} device(s) visible; refusing to run a smaller job "
               f"under the requested label", file=sys.stderr)
@@ -145,6 +167,33 @@ def cpu_baseline_refshape(src, tgt, cfg, iters=3):
                 seconds=dt, mean_inner_steps=float(np.mean(res["inner_steps"])))
 
 
+def cpp_api_block(src, tgt, cfg, a):
+    """ppcr_cpp_api_test --bench: the built C++ classes over libppcr_hip.so, in their own process."""
+    import tempfile
+    exe = os.path.join(ROOT, "probabilistic_point_clouds_registration_amd", "ppcr_cpp_api_test")
+    if not os.path.exists(exe):
+        return {"error": "ppcr_cpp_api_test is not built (python -m probabilistic_point_clouds_registration_amd.build)"}
+    block = {"program": "ppcr_cpp_api_test --bench (ProbPointCloudRegistration::align(), cost_drop_thresh = 0)",
+             "method": "steady it/s = steps / (align time of warm + steps iterations - align time of warm iterations), "
+                       "a fresh object per measurement, median of 5"}
+    with tempfile.TemporaryDirectory(prefix="ppcr_bench_") as d:
+        sp, tp = os.path.join(d, "src.f32"), os.path.join(d, "tgt.f32")
+        np.ascontiguousarray(src[:, :3], dtype=np.float32).tofile(sp)
+        np.ascontiguousarray(tgt[:, :3], dtype=np.float32).tofile(tp)
+        dof = "inf" if np.isinf(cfg["dof"]) else repr(float(cfg["dof"]))
+        for key, inner in (("inner_steps_1", 1), ("default_inner_to_f_tol", 100)):
+            cmd = [exe, "--bench", sp, tp, repr(float(cfg["radius"])), str(cfg["max_neighbours"]), dof, str(a.warmup),
+                   str(a.steps), str(inner), "5"]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                block[key] = json.loads(line[-1]) if (r.returncode == 0 and line) else {
+                    "error": f"exit {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+            except (OSError, subprocess.TimeoutExpired, ValueError) as e:
+                block[key] = {"error": str(e)}
+    return block
+
+
 def run_rank(a):
     from probabilistic_point_clouds_registration_amd import _lib, batch, synth
 
@@ -205,18 +254,20 @@ def run_rank(a):
         if dist is not None:
             dist.barrier()
 
-    def run_iterations(k, inner, f_tol=1e-5):
-        """k outer iterations on every pair of this rank -> {pair: final cumulative 3x4 of these k iterations}"""
+    def run_iterations(k, inner, f_tol=1e-5, thresh=0.0):
+        """k outer iterations on every pair of this rank -> {pair: final cumulative 3x4 of these k iterations}
+        (thresh = 0 runs exactly k iterations while the cost still falls; a converged pair, whose cost drop is rounding
+        noise of either sign, needs a negative threshold to keep going)"""
         out = {}
         if concurrent:
             # several resident pairs per GPU: a.lanes of them in flight, each on its own handle/stream
-            T_fin, done = _lib.align_many(ctxs, k, lanes=a.lanes, cost_drop_thresh=0.0, inner_steps=inner, f_tol=f_tol)
+            T_fin, done = _lib.align_many(ctxs, k, lanes=a.lanes, cost_drop_thresh=thresh, inner_steps=inner, f_tol=f_tol)
             assert all(int(d) == k for d in done), f"early stop: {list(done)}"
             for j, p in enumerate(my_pairs):
                 out[p] = T_fin[j]
         else:
             for p, c in zip(my_pairs, ctxs):
-                res = c.align(k, cost_drop_thresh=0.0, inner_steps=inner, f_tol=f_tol)
+                res = c.align(k, cost_drop_thresh=thresh, inner_steps=inner, f_tol=f_tol)
                 assert res["n_iter"] == k, f"early stop: {res['n_iter']}"
                 out[p] = res["history"][-1] if k > 0 else np.eye(4)[:3]
         return out
@@ -230,6 +281,17 @@ def run_rank(a):
     if dist is not None:
         # the collective is warmed up once (communicator set-up and its buffers are not part of a step)
         batch.gather_transforms({p: np.eye(4)[:3] for p in my_pairs}, n_pairs, dist=dist, device=dev)
+
+    # ---- settle: the first windows of a process used to come out ~8 % slow (clocks still ramping); run untimed
+    # iterations of the same workload until --settle-ms have passed
+    settle_iters = 0
+    if a.settle_ms > 0:
+        fresh_start(a.inner_steps)
+        ts = time.perf_counter()
+        while (time.perf_counter() - ts) * 1e3 < a.settle_ms:
+            run_iterations(max(a.steps, 50), a.inner_steps, thresh=-1.0)
+            settle_iters += max(a.steps, 50)
+        barrier()
 
     # ---- timed windows --------------------------------------------------------------------------------------------
     window_s, gathered, local = [], None, None
@@ -252,26 +314,64 @@ def run_rank(a):
         gathered = batch.gather_transforms(local, n_pairs)
     dt = float(np.median(window_s))
 
-    # ---- per-kernel durations with HIP events on the handle's own stream (separate pass so that the event records
-    # cannot perturb the headline number; same workload, same warm-up, same K)
-    prof = {}
+    # ---- per-kernel durations with HIP events on the handle's own stream (separate passes so that the event records
+    # cannot perturb the headline number; same workload, same warm-up, same K).  Pass A is the schedule of the timed
+    # windows (K23 folded into K1: the kernel the roofline is quoted for); pass B runs K23 as its own kernel, so that
+    # K1's duration is K1's alone (the stand-alone figure beside it).
+    prof, prof_alone = {}, {}
     nnz = ctx.association_size()[1]
     if not a.no_profile:
-        # K23 as its own kernel here, so that K1's duration is K1's alone (in the timed windows above it is folded into
-        # K1 — same arithmetic, one launch less); the rocprofv3 summary of this command lists both forms
-        ctx.set_option("fuse_k23", 0)
-        ctx.set_source(src)
-        if a.warmup > 0:
-            ctx.align(a.warmup, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
-        ctx.profile_enable(True)
-        tp0 = time.perf_counter()
-        ctx.align(a.steps, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
-        ctx.synchronize()
-        tp = time.perf_counter() - tp0
-        prof = ctx.profile_get()
-        ctx.profile_enable(False)
+        def profiled_pass(fuse):
+            ctx.set_option("fuse_k23", fuse)
+            ctx.set_source(src)
+            if a.warmup > 0:
+                ctx.align(a.warmup, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
+            ctx.profile_enable(True)
+            tp0 = time.perf_counter()
+            ctx.align(a.steps, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
+            ctx.synchronize()
+            tp = time.perf_counter() - tp0
+            out_ = ctx.profile_get()
+            ctx.profile_enable(False)
+            out_["_profiled_pass_ms_per_step"] = 1e3 * tp / a.steps
+            return out_
+        prof = profiled_pass(1)
+        prof_alone = profiled_pass(0)
         ctx.set_option("fuse_k23", 1)
-        prof["_profiled_pass_ms_per_step"] = 1e3 * tp / a.steps
+
+    # ---- set-up cost of one pair ("grid build of the static target reported separately"): wall time of the
+    # uploads (H2D + repack, synchronous) and of the first association on a fresh handle, with the HIP-event durations
+    # of the grid-build and source-sort kernels inside it
+    setup = None
+    if rank == 0 and not a.no_extras:
+        with _lib.Context(local_rank) as sc:
+            sc.set_params(cfg["radius"], cfg["max_neighbours"], cfg["dof"], 3)
+            sc.set_target(tgt)            # first touch of a new handle: allocations
+            sc.set_source(src)
+            sc.associate()
+            sc.synchronize()
+            reps = []
+            for _ in range(3):
+                sc.profile_enable(True)
+                t0 = time.perf_counter()
+                sc.set_target(tgt)
+                t1 = time.perf_counter()
+                sc.set_source(src)
+                t2 = time.perf_counter()
+                sc.associate()            # K0 (bbox, keys, sort, gather, cell_start) + source sort + first K1
+                sc.synchronize()
+                t3 = time.perf_counter()
+                ks = sc.profile_get()
+                sc.profile_enable(False)
+                ms = lambda *names: sum(ks[n]["total_ms"] for n in names if n in ks)
+                k0 = ms("bbox_kernel", "cell_key_kernel", "radix_sort", "gather_points_kernel", "cell_start_kernel")
+                reps.append(dict(h2d_target=1e3 * (t1 - t0), h2d_source=1e3 * (t2 - t1), first_associate_call=1e3 * (t3 - t2),
+                                 grid_and_source_sort_kernels=k0, first_association_kernel=ms("nn_fast_kernel", "nn_tile_cleanup_kernel")))
+            med = {k: float(np.median([r[k] for r in reps])) for k in reps[0]}
+            setup = dict(med, total=med["h2d_target"] + med["h2d_source"] + med["first_associate_call"],
+                         note="ms per pair, median of 3, host buffers in: uploads are synchronous PCIe copies + repack; "
+                              "first_associate_call = bounding box + grid build of the target + spatial sort of the source "
+                              "(their kernels: grid_and_source_sort_kernels) + the first association, wall time")
 
     if rank != 0:
         if dist is not None:
@@ -306,7 +406,9 @@ def run_rank(a):
         "windows": {"count": len(window_s), "statistic": "median",
                     "it_per_s": [n_pairs * a.steps / w for w in window_s],
                     "min_it_per_s": n_pairs * a.steps / max(window_s), "max_it_per_s": n_pairs * a.steps / min(window_s),
-                    "window_ms": 1e3 * dt},
+                    "window_ms": 1e3 * dt,
+                    "spread": (max(window_s) - min(window_s)) / dt,
+                    "settle": f"{settle_iters} untimed iterations (>= {a.settle_ms:g} ms) before the first window"},
         "nnz": int(nnz),
     }
     # roofline of the dominant kernel (K1, nn_fast_kernel): algorithmic bytes B_nn = 16*Ns + 12*Nt + 4*nnz
@@ -319,19 +421,29 @@ def run_rank(a):
         ach = b_nn / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch come from PMC counters, which need their own rocprofv3 --pmc passes
         # (tools/profile_round.sh); the committed summary of the latest passes is quoted, with its source named
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_alone = None, None, None
         tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
         if os.path.exists(tpath) and a.config in (3, 4) and a.n is None:
             tj = json.load(open(tpath))
-            traffic = tj.get("traffic_bytes_per_launch")
+            ent = tj.get("entries", {})
+            fused = ent.get("fused") or {}
+            traffic = fused.get("traffic_bytes_per_launch", tj.get("traffic_bytes_per_launch"))
+            traffic_alone = (ent.get("standalone") or {}).get("traffic_bytes_per_launch")
             traffic_source = "profiles/k1_traffic.json (%s)" % tj.get("source", "separate rocprofv3 --pmc passes")
-        out["roofline"] = {"bound": "hbm", "kernel": "nn_fast_kernel (K1, measured as a kernel of its own: FTM = -2; the "
-                                                     "timed windows run it with K23 folded in)",
+        out["roofline"] = {"bound": "hbm", "kernel": "nn_fast_kernel<10,16,1728,false,8> as the timed windows run it: K1 "
+                                                     "with the previous iteration's source move in its prologue and K23 "
+                                                     "(weights + 19 moments) folded in",
                            "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": traffic_source,
                            "avg_kernel_ms": avg_ms, "algorithmic_bytes_per_launch": b_nn,
                            "candidate_tests_per_s": 27 * 3.8147 * ns / (avg_ms * 1e-3)}
+        if "nn_fast_kernel" in prof_alone:
+            ka = prof_alone["nn_fast_kernel"]
+            alone_ms = ka["total_ms"] / max(1, ka["launches"])
+            out["roofline"]["standalone"] = {"kernel": "nn_fast_kernel<10,16,1728,false,-2> (K1 alone, K23 as its own kernel)",
+                                             "avg_kernel_ms": alone_ms, "achieved": b_nn / (alone_ms * 1e-3) / 1e9,
+                                             "frac": b_nn / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_alone}
     else:
         out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                            "traffic": None, "traffic_source": None}
@@ -342,8 +454,12 @@ def run_rank(a):
                                          "materialised); the fused kernels move about half of it"}
     out["kernels_ms_per_launch"] = {k: v["total_ms"] / max(1, v["launches"]) for k, v in prof.items()
                                     if isinstance(v, dict)}
+    out["kernels_ms_per_launch_k23_unfused"] = {k: v["total_ms"] / max(1, v["launches"]) for k, v in prof_alone.items()
+                                                if isinstance(v, dict)}
     if "_profiled_pass_ms_per_step" in prof:
         out["profiled_pass_ms_per_step"] = prof["_profiled_pass_ms_per_step"]
+    if setup is not None:
+        out["setup_ms"] = setup
 
     if not a.no_extras:
         # cold start: the first associations after an upload have no temporal cut-off yet and the source still moves
@@ -356,24 +472,49 @@ def run_rank(a):
             ctx.synchronize()
             cold.append(1e3 * (time.perf_counter() - tc))
         out["cold_ms_per_iteration"] = cold   # it0 also sorts the source into the grid's order (once per upload)
-        # the schedule a drop-in user of the C++ classes / CLI gets: inner IRLS to the reference's function_tolerance
-        ctx.set_source(src)
-        if a.warmup > 0:
-            ctx.align(a.warmup, cost_drop_thresh=0.0, inner_steps=100, f_tol=REF_F_TOL, want_history=False)
-        ctx.synchronize()
-        tc = time.perf_counter()
-        res = ctx.align(a.steps, cost_drop_thresh=0.0, inner_steps=100, f_tol=REF_F_TOL)
-        ctx.synchronize()
-        tc = time.perf_counter() - tc
-        out["converged_inner"] = {"it_per_s": a.steps / tc, "ms_per_iteration": 1e3 * tc / a.steps,
-                                  "mean_inner_steps": float(np.mean(res["inner_steps"])),
+        # the reference's own schedule (inner IRLS to its function_tolerance, cc:96-100): what ppcr_align(inner_steps = 100)
+        # — and with it the C++ class and the CLI by default — runs; the inner loop is paced by the device
+        rates, inner_mean = [], 0.0
+        for _ in range(max(1, a.windows)):
+            ctx.set_source(src)
+            if a.warmup > 0:
+                ctx.align(a.warmup, cost_drop_thresh=0.0, inner_steps=100, f_tol=REF_F_TOL, want_history=False)
+            ctx.synchronize()
+            tc = time.perf_counter()
+            res = ctx.align(a.steps, cost_drop_thresh=0.0, inner_steps=100, f_tol=REF_F_TOL)
+            ctx.synchronize()
+            rates.append(a.steps / (time.perf_counter() - tc))
+            inner_mean = float(np.mean(res["inner_steps"]))
+        out["converged_inner"] = {"it_per_s": float(np.median(rates)), "ms_per_iteration": 1e3 / float(np.median(rates)),
+                                  "min_it_per_s": min(rates), "max_it_per_s": max(rates),
+                                  "mean_inner_steps": inner_mean,
                                   "schedule": f"<=100 IRLS steps per association, f_tol={REF_F_TOL:g} "
-                                              "(the C++ layer's and the reference's default)"}
+                                              "(the C++ layer's and the reference's default); device-paced inner loop"}
+        # the drop-in surface itself: ProbPointCloudRegistration::align() (one call into ppcr_align_report) timed in a
+        # child process running the C++ API test program on the same clouds: -c 0 -i (warmup + steps), once with one
+        # inner step per association, once with the class's default (inner loop to function_tolerance)
+        if not a.no_cpp_api and not batch_cfg:
+            out["cpp_api"] = cpp_api_block(src, tgt, cfg, a)
 
     if batch_cfg or world > 1 or dist is not None:
         ok = np.isfinite(gathered).all(axis=(1, 2))
         out["gathered_transforms"] = int(ok.sum())
         assert out["gathered_transforms"] == n_pairs, f"gathered {int(ok.sum())} of {n_pairs} transforms"
+        if batch_cfg and world == 1 and not a.no_extras:
+            # pairs per second END TO END: host buffers in (upload, grid build, source sort, K iterations), several
+            # pairs in flight per GPU so that one pair's uploads overlap another pair's iterations (ppcr_batch_run)
+            host_pairs = [synth.make_pair(n, cfg=a.config, pair=p)[:2] for p in range(min(n_pairs, 16))]
+            _lib.batch_run(host_pairs[:2], cfg["radius"], cfg["max_neighbours"], cfg["dof"], n_iter=a.steps + a.warmup,
+                           inner_steps=a.inner_steps, device_ids=(local_rank,), lanes_per_device=2)   # warm-up
+            e2e = {}
+            for lanes in (1, 2, 4):
+                t0 = time.perf_counter()
+                _lib.batch_run(host_pairs, cfg["radius"], cfg["max_neighbours"], cfg["dof"], n_iter=a.steps + a.warmup,
+                               inner_steps=a.inner_steps, device_ids=(local_rank,), lanes_per_device=lanes)
+                e2e[f"lanes_{lanes}"] = len(host_pairs) / (time.perf_counter() - t0)
+            out["pairs_per_s_end_to_end"] = dict(e2e, pairs=len(host_pairs), iterations_per_pair=a.steps + a.warmup,
+                                                 note="ppcr_batch_run on one GPU, host buffers in: upload + grid build + "
+                                                      "source sort + iterations per pair, `lanes` pairs in flight")
         if batch_cfg and not a.no_verify:
             # every gathered transform against a single-rank, single-stream run of the same pair and schedule
             worst = 0.0

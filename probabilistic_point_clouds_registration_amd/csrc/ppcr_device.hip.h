@@ -403,8 +403,9 @@ struct FusedMoments {
 
 // HALVES = true folds ten sums, then nine, through a buffer half the size (20.6 KB instead of 39 KB: six instead of
 // four workgroups per CU for a kernel that is otherwise lean in registers) at the price of two more barriers.
-// The block's sums go to partials[j * stride + slot].
-template <int BLOCK = kBlock, bool HALVES = false>
+// The block's sums go to partials[j * stride + slot]; COHERENT: with agent-scope atomic stores (readers in the same
+// launch, on another XCD: see inner_steps_kernel).
+template <int BLOCK = kBlock, bool HALVES = false, bool COHERENT = false>
 __device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__restrict__ partials, int stride, int slot)
 {
     static_assert(BLOCK == 256, "fold layout assumes 256 lanes (8 parts of 32)");
@@ -439,7 +440,8 @@ __device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__
         double v = part[tid][0];
 #pragma unroll
         for (int q = 1; q < 8; q++) v += part[tid][q];
-        partials[(size_t)tid * stride + slot] = v;
+        if constexpr (COHERENT) __hip_atomic_store(&partials[(size_t)tid * stride + slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else partials[(size_t)tid * stride + slot] = v;
     }
 }
 
@@ -718,13 +720,14 @@ struct HostMailbox {
 // function_tolerance, ..._iteration.hpp:52-57 with cc:96-100): the lane that solves a step also decides whether the
 // loop is over — the same test the host loop makes (solve_impl) on the same numbers — and says so in device memory,
 // where the launches already enqueued behind it look before they do anything:
-//   finished  the inner loop is over: the remaining speculative step launches of this iteration return at once;
+//   finished  (= the iteration's sequence number) the inner loop is over: the remaining step workgroups of this
+//             iteration return at once;
 //   abort     the device cannot finish this iteration on its own (kIterationPending): EVERY later launch of the
 //             stream steps aside untouched (K1, cleanup, fold, inner steps, companion move) until the host, which has
 //             taken the iteration over, clears the flag in stream order.
 struct LoopState {
     unsigned abort;
-    unsigned finished;
+    unsigned finished;  // sequence number (FoldSolve::seq) of the last outer iteration whose inner loop ended on the device
     int steps;
     int pad;
     double cost_init;
@@ -853,7 +856,7 @@ __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int su
         fs.mbox->steps = steps;
         if (fin) {
             status = kIterationDone;
-            __hip_atomic_store(&st->finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->finished, fs.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (fs.loop.last_dev) {
             status = kIterationPending;
             __hip_atomic_store(&st->abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

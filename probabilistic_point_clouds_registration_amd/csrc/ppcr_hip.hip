@@ -61,7 +61,8 @@ const char *const kKernelNames[K_NUM] = {
     "nn_select_kernel", "csr_compact_kernel", "ell_count_sum_kernel", "weights_kernel", "accumulate_kernel",
     "reduce_partials_kernel", "transform_kernel", "inner_steps_kernel", "track_kernel"};
 
-constexpr int kMailboxRing = 4;    // at most two fold-and-solve launches are ever in flight
+constexpr int kMailboxRing = 4;    // mailbox / report slots; at most kMaxAhead iterations are ever in flight
+constexpr int kMaxAhead = 3;       // outer iterations ppcr_align may have enqueued beyond the last one the host has seen
 constexpr int kEllMaxWidth = 32;   // widest register-list NN variant / widest ELL association
 constexpr int kAccumMaxBlocks = 1024;
 
@@ -162,7 +163,7 @@ struct ppcr_ctx {
     int opt_mailbox = 1;               // 1: deliver the moments through the mailbox and spin (default)
     // device-paced inner loop (ppcr_align with inner_steps > 1): see LoopState / inner_steps_kernel
     DevBuf<LoopState> d_loop;
-    DevBuf<unsigned> d_inner_ctl;      // InnerCtl as words
+    DevBuf<unsigned> d_inner_ctl;      // [0] step_done, [1 ..] completion flags of inner_steps_kernel's K23 workgroups
     int opt_inner_dev_steps = 3;       // IRLS steps 2.. the device may take on its own per outer iteration (<= kMaxDevSteps)
     // per-iteration reports of the device-paced loop (track_kernel)
     HostReport *h_report = nullptr;    // pinned + device-mapped ring of kMailboxRing slots
@@ -644,8 +645,6 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             tl.split_flag = c->split_flag.p, tl.split_list = c->split_list.p, tl.split_state = c->split_state.p;
             tl.pm = pm, tl.fuse = fuse, tl.fold = fold;
             tl.loop_st = loop ? loop->st : nullptr;
-            tl.inner_ctl = (loop && loop->max_steps > 1) ? c->d_inner_ctl.p : nullptr;
-            tl.inner_ctl_words = (int)(sizeof(InnerCtl) / sizeof(unsigned));
             tl.between = [](void *scope) { static_cast<ProfScope *>(scope)->split(K_NN_CLEANUP); };
             tl.between_arg = &ps;
             if (m <= 4) launch_tile_m4(tl);
@@ -1007,9 +1006,14 @@ int ensure_loop_state(ppcr_ctx *c)
         HIP_TRY(c, c->d_loop.reserve(1));
         HIP_TRY(c, hipMemsetAsync(c->d_loop.p, 0, sizeof(LoopState), c->stream));
     }
-    if (!c->d_inner_ctl.p) {
-        HIP_TRY(c, c->d_inner_ctl.reserve(sizeof(InnerCtl) / sizeof(unsigned)));
-        HIP_TRY(c, hipMemsetAsync(c->d_inner_ctl.p, 0, sizeof(InnerCtl), c->stream));
+    {
+        // sized for the largest inner-step launch; words stamped with sequence numbers, so cleared only when (re)allocated
+        const size_t want = 1 + (size_t)kMaxDevSteps * kInnerMaxG;
+        if (c->d_inner_ctl.cap < want) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, c->d_inner_ctl.reserve(want));
+            HIP_TRY(c, hipMemsetAsync(c->d_inner_ctl.p, 0, c->d_inner_ctl.cap * sizeof(unsigned), c->stream));
+        }
     }
     if (!c->d_ticket.p) {
         HIP_TRY(c, c->d_ticket.reserve(2));
@@ -1044,7 +1048,11 @@ int launch_inner(ppcr_ctx *c, const StepTicket &tk, const LoopCtl &loop, int n_d
     if (c->assoc != ppcr_ctx::ASSOC_ELL || c->nt <= 0) return fail(c, PPCR_ERR_STATE, "internal: device-paced inner steps need an ELL association");
     const int ns = (int)c->ns;
     const int ntiles = nblocks(ns, kBlock);
-    const int G = std::max(1, std::min(ntiles, 1024));
+    // about five K23 workgroups per CU at a time, every one with the same number of tiles (+-1): the launch carries
+    // n_dev_steps * (G + 19) workgroups that all have to start and look at the loop state even when step 1 ended the
+    // loop (the common case), so G is not simply ntiles (3 x 3926 idle workgroups cost ~15 us per iteration at 1M)
+    const int per_wg = std::max(1, (ntiles + 1399) / 1400);
+    const int G = std::max(1, std::min((ntiles + per_wg - 1) / per_wg, kInnerMaxG));
     HIP_TRY(c, c->partials.reserve((size_t)std::max(G, nblocks(ns, 256) + kMaxSplit) * kNSums));
     InnerArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -1058,7 +1066,8 @@ int launch_inner(ppcr_ctx *c, const StepTicket &tk, const LoopCtl &loop, int n_d
     a.fs.seq = tk.seq;
     a.fs.mbox = c->d_mbox + (tk.seq % kMailboxRing);
     a.fs.loop.first = 0;
-    a.ctl = reinterpret_cast<InnerCtl *>(c->d_inner_ctl.p);
+    a.step_done = c->d_inner_ctl.p;
+    a.flags = c->d_inner_ctl.p + 1;
     a.G = G, a.n_steps = n_dev_steps;
     const K23Form f = k23_form(c, a.md);
     const int grid = n_dev_steps * (G + kNSums);
@@ -1855,7 +1864,7 @@ struct AlignJob {
     double Tcum[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     double T_last[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     Mat3 R0 = Mat3::identity();
-    StepTicket in_flight[2];
+    StepTicket in_flight[kMailboxRing];
     int enq = 0, done = 0;
     bool pipelined = false, finished = false;
     int max_steps = 1, n_dev_steps = 0;
@@ -1925,7 +1934,7 @@ struct AlignJob {
 
     int enqueue()
     {
-        StepTicket &tk = in_flight[enq & 1];
+        StepTicket &tk = in_flight[enq % kMailboxRing];
         // moves the source by the previous iteration's transform in its prologue and (steady state) leaves this
         // iteration's partial moments at (q0, t0) behind: K23 folded in
         PPCR_TRY(associate_impl(c, &R0, t0, &tk, &loop));
@@ -1941,11 +1950,12 @@ struct AlignJob {
     // a time, as solve_impl does, hand the pose back to the device and redo what follows an iteration.
     int take_over(StepResult &res)
     {
-        const unsigned seq = in_flight[done & 1].seq;
-        if (enq > done + 1) {
-            // the train of iteration done + 1 stepped aside: wait for its (empty) mailbox slot and take it back
+        const unsigned seq = in_flight[done % kMailboxRing].seq;
+        while (enq > done + 1) {
+            // the trains of the iterations behind this one stepped aside: wait for their (empty) mailbox slots and take
+            // them back, last first
             StepResult skipped;
-            PPCR_TRY(collect_step(c, in_flight[(done + 1) & 1], skipped));
+            PPCR_TRY(collect_step(c, in_flight[(enq - 1) % kMailboxRing], skipped));
             if (skipped.status != kLaunchSkipped) return fail(c, PPCR_ERR_STATE, "internal: a launch ran past an aborted iteration");
             enq--;
             c->ovf_parity ^= 1;  // its association had claimed the other counter of the pair
@@ -1986,8 +1996,8 @@ struct AlignJob {
     int consume()
     {
         StepResult res;
-        const unsigned seq = in_flight[done & 1].seq;
-        PPCR_TRY(collect_step(c, in_flight[done & 1], res));
+        const unsigned seq = in_flight[done % kMailboxRing].seq;
+        PPCR_TRY(collect_step(c, in_flight[done % kMailboxRing], res));
         if (res.status == kIterationPending) PPCR_TRY(take_over(res));
         if (res.status != kIterationDone) return fail(c, PPCR_ERR_STATE, "internal: unexpected mailbox status in the align loop");
         const double cost[2] = {res.cost_init, res.cost};
@@ -2023,13 +2033,18 @@ struct AlignJob {
             PPCR_TRY(enqueue());
             if (progressed) *progressed = true;
         }
-        // iteration `done` is in flight.  The check before iteration done + 1 cannot stop if the cap is not hit and the
-        // idle count (already updated by the check that let iteration `done` through) is within the patience.
-        if (enq == done + 1 && (rule.iteration + 1 != n_iter) && !((double)rule.idle > patience)) {
+        // Iterations done .. enq - 1 are in flight (a = enq - done of them).  One more may join them when the checks that
+        // will be replayed as they arrive cannot stop the loop whatever their costs turn out to be: the cap is not hit
+        // (the iteration count will be rule.iteration + a at the check in question), and the idle count — already
+        // updated by the check that let iteration `done` through, at worst one higher after every further check — stays
+        // within the patience.  Up to kMaxAhead in flight: the host's launch jitter no longer reaches the device.
+        while (enq - done < kMaxAhead) {
+            const int a = enq - done;
+            if (!((rule.iteration + a != n_iter) && !((double)(rule.idle + a - 1) > patience))) break;
             PPCR_TRY(enqueue());
             if (progressed) *progressed = true;
         }
-        if (may_block || step_arrived(c, in_flight[done & 1])) {
+        if (may_block || step_arrived(c, in_flight[done % kMailboxRing])) {
             PPCR_TRY(consume());
             if (progressed) *progressed = true;
         }

@@ -438,48 +438,55 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
 // function_tolerance, cc:96-100).  Step 1 of an outer iteration rides in the association (K23 folded into K1, or
 // accumulate_ell_kernel) and its fold-and-solve lane decides whether the loop is over (LoopCtl).  This ONE launch,
 // enqueued behind it, holds the next `n_steps` IRLS steps: per step G workgroups redo K23 at the pose the previous step
-// solved (rows dealt G-strided in tiles of 256) and kNSums workgroups fold and solve.  Workgroups take their role from
-// a ticket drawn at entry, so a workgroup only ever waits for workgroups that drew smaller tickets — which are running
-// or done: no co-residency is assumed and several such kernels (other handles) can share the chip.  When the loop
-// is over (the common case at its very first look) every remaining workgroup returns at once.
+// solved (rows dealt G-strided in tiles of 256) and kNSums workgroups fold and solve.  When the loop is over (the common case at
+// its very first look) every remaining workgroup returns at once.
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxDevSteps = 8;
-struct InnerCtl {  // device memory, zeroed by the association kernel that precedes the launch
-    unsigned ticket;
-    unsigned step_done;             // device steps of this launch that have been solved
-    unsigned k23_done[kMaxDevSteps];  // workgroups of step u whose partial sums are in place
-};
+constexpr int kInnerMaxG = 2048;  // upper bound of the K23 workgroups per step (rows are dealt G-strided in tiles of 256)
 struct InnerArgs {
     const int *nbr, *cnt;
     const float4 *src, *tgt;
     int ns, width;
     Model md;
     FoldSolve fs;     // partials = [kNSums][G], nslots = G; loop.first = 0; loop.last_dev is set per step here
-    InnerCtl *ctl;
+    unsigned *flags;  // [n_steps][G]: == fs.seq once that workgroup's partial sums of this launch are in place
+    unsigned *step_done;  // fs.seq * kMaxDevSteps + (device steps of this launch that have been solved)
     int G, n_steps;
 };
+// Workgroups take their role from blockIdx: [step][G K23 workgroups, kNSums fold workgroups].  A workgroup only ever
+// waits for workgroups with SMALLER indices, which the dispatcher has started before it (workgroups of a launch are
+// dispatched in index order on every XCD) — running or done: no co-residency is assumed and several such kernels (other
+// handles) can share the chip.  No read-modify-write atomics on shared counters: 3000 workgroups drawing tickets from
+// one counter cost ~150 us (same-address atomics serialise at the memory side); completion is one flag word per
+// workgroup, stamped with the launch's sequence number so that nothing has to be cleared between launches.
+// Cross-workgroup traffic inside the launch goes through agent-scope ATOMIC loads and stores (the chip's eight L2s are
+// not coherent with each other for ordinary accesses; an acquire / release FENCE invalidates / writes back a whole L2,
+// which K23's target gathers live in): waiting workgroups poll with relaxed loads — polling with acquire loads, tried
+// first, took a step from ~35 us to ~370 us.
 template <int W, int TM, bool ONEPASS>
 __global__ __launch_bounds__(kBlock) void inner_steps_kernel(InnerArgs a)
 {
-    __shared__ unsigned s_ticket;
     LoopState *const st = a.fs.loop.st;
-    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&a.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
     const int per_step = a.G + kNSums;
-    const int u = (int)s_ticket / per_step, r = (int)s_ticket % per_step;
+    const int u = (int)blockIdx.x / per_step, r = (int)blockIdx.x % per_step;
+    const unsigned seq = a.fs.seq;
+    // The common case: step 1 (an earlier launch) ended the loop, all these workgroups have nothing to do and their
+    // number times their lifetime is what the launch costs — an ordinary cached load is enough for a value written
+    // before the launch (the agent-scope loads below go to the memory side).
+    if (*reinterpret_cast<const volatile unsigned *>(&st->finished) == seq) return;
+    auto over = [&]() {  // the inner loop of THIS outer iteration has ended, or the device gave the iteration up
+        return __hip_atomic_load(&st->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq || loop_aborted(st);
+    };
     if (u > 0) {  // the previous device step must have been solved (step 1 was: it ran in an earlier launch)
         // (or the loop ended at an earlier step: then step u - 1 never runs and `finished` / `abort` is the news)
         if (threadIdx.x == 0)
-            while (__hip_atomic_load(&a.ctl->step_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)u &&
-                   __hip_atomic_load(&st->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && !loop_aborted(st))
-                __builtin_amdgcn_s_sleep(16);
+            while (__hip_atomic_load(a.step_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq * kMaxDevSteps + (unsigned)u && !over())
+                __builtin_amdgcn_s_sleep(64);
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    if (__hip_atomic_load(&st->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || loop_aborted(st)) return;
+    if (over()) return;
     if (r < a.G) {
-        // K23 at the pose the previous step solved (written by another workgroup, possibly of this launch: no
-        // scalar-cache / read-only path for it)
+        // K23 at the pose the previous step solved (written by another workgroup, possibly of this launch)
         Pose P;
 #pragma unroll
         for (int k = 0; k < 9; k++) P.R[k] = __hip_atomic_load(&a.fs.pose_out->R[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -493,26 +500,23 @@ __global__ __launch_bounds__(kBlock) void inner_steps_kernel(InnerArgs a)
         for (int tile = r; tile < ntiles; tile += a.G)
             accumulate_ell_rows<W, 1, kBlock, TM, ONEPASS>(acc, tile * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.tgt, a.ns, P,
                                                            a.md, a.width);
-        block_reduce_store<kBlock, true>(acc, const_cast<double *>(a.fs.partials), a.G, r);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_fetch_add(&a.ctl->k23_done[u], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        block_reduce_store<kBlock, true, true>(acc, const_cast<double *>(a.fs.partials), a.G, r);
+        __syncthreads();  // (waits for the 19 stores as well: vmcnt(0))
+        if (threadIdx.x == 0) __hip_atomic_store(&a.flags[(size_t)u * a.G + r], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     // fold role: every partial of this step must be in place
-    if (threadIdx.x == 0)
-        while (__hip_atomic_load(&a.ctl->k23_done[u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.G)
+    for (int k = threadIdx.x; k < a.G; k += kBlock)
+        while (__hip_atomic_load(&a.flags[(size_t)u * a.G + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq)
             __builtin_amdgcn_s_sleep(8);
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // kNSums of these per step: the fold reads the partials plainly
     FoldSolve fs = a.fs;
     fs.loop.first = 0;
     fs.loop.last_dev = (u == a.n_steps - 1) ? 1 : 0;
     if (fold_and_solve_block(fs, r - a.G)) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_store(&a.ctl->step_done, (unsigned)(u + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // one per step: pose, loop state
+        __hip_atomic_store(a.step_done, seq * kMaxDevSteps + (unsigned)(u + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

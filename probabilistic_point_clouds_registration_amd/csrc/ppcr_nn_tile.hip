@@ -45,7 +45,7 @@ void launch_tile(TileLaunch &t)
                                            : SplitTable{nullptr, nullptr, nullptr, nullptr, 0, INT_MAX};  // no steady-state variant to split for
     FusedMoments fm_none;
     std::memset(&fm_none, 0, sizeof(fm_none));
-    const LoopReset lr{t.loop_st, t.inner_ctl, t.inner_ctl_words};
+    const LoopReset lr{t.loop_st};
     // the steady-state (16-slot) variant runs with a halo capacity that gives FIVE workgroups per CU (31.3 KB of LDS)
     // and splits the few blocks that outgrow it; the first association (32 slots, three per CU) keeps the large one
 #define PPCR_FAST(Cc, STAMPc, FTMc, FMc)                                                                               \

@@ -640,11 +640,9 @@ struct SplitTable {
                               // (halos grow a few per cent per iteration as the source drifts: 15/16 of the capacity)
 };
 
-// what the first kernel of an outer iteration resets for the device-paced inner loop (all nullable)
+// the device-paced loop's state as the association kernel sees it (nullable): it only steps aside while abort is up
 struct LoopReset {
-    LoopState *st;
-    unsigned *ctl;   // InnerCtl of the inner-step launch that follows, as words
-    int ctl_words;
+    const LoopState *st;
 };
 
 // FTM >= 0 (0: Gaussian, k: t model with v + dim = k) folds K23 into this kernel: each lane finishes its row's
@@ -722,13 +720,8 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     // ---- prologue: query, pending move, temporal cut-off ---------------------------------------------------------
     float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (aborted) return;
-    if (tid == 0 && blockIdx.x == gridDim.x - 1) {  // (the last workgroup is never an idle split slot)
-        *ovf_count_next = 0;  // the other counter of the ping-pong pair: idle during this launch
-        // a new outer iteration of the device-paced loop: its inner loop has not finished, its step launch starts over
-        if (lr.st) lr.st->finished = 0u;
-        if (lr.ctl)
-            for (int k = 0; k < lr.ctl_words; k++) lr.ctl[k] = 0u;
-    }
+    // the other counter of the ping-pong pair: idle during this launch  (the last workgroup is never an idle split slot)
+    if (tid == 0 && blockIdx.x == gridDim.x - 1) *ovf_count_next = 0;
     float moved = 0.f;  // how far this query travelled since the association that produced dm2
     if (pm.enabled && valid) {
         const float4 q0 = q;

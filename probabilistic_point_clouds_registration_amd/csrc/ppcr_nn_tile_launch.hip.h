@@ -32,8 +32,6 @@ struct TileLaunch {
     const dev::FusedMoments *fuse;  // fold K23 into K1 at this pose / model when the steady-state variant runs
     const dev::FoldSolve *fold;     // ... and the fold-and-solve step into the cleanup launch
     dev::LoopState *loop_st;        // device-paced loop: every launch steps aside while its abort flag is up (nullable)
-    unsigned *inner_ctl;            // ... and the fast kernel zeroes the control words of the inner-step launch
-    int inner_ctl_words;
     void (*between)(void *);        // called between the two launches (profiling scopes), may be null
     void *between_arg;
     // out

@@ -2,8 +2,12 @@
 // test/PointCloudRegistrationTest.cc:30-116) restated against the drop-in classes, plus checks of the outer
 // driver.  No gtest here: a tiny assert harness; exit code = number of failed checks.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
 #include <limits>
 #include <memory>
 #include <vector>
@@ -325,8 +329,80 @@ static void alignIsTheDevicePacedLoop()
             }
 }
 
-int main()
+// --bench: the throughput a user of the C++ classes sees (bench.py's `cpp_api` block).  Clouds come as raw float32 xyz
+// triples; every measurement constructs a ProbPointCloudRegistration (upload, filters: not timed) and times align().
+// Steady-state rate = steps / (align time with warm + steps iterations - align time with warm iterations): both runs
+// pay the same cold start (grid build, source sort, first associations), the difference is `steps` steady iterations.
+static bool readCloud(const char *path, pcl::PointCloud<pcl::PointXYZ> &cloud)
 {
+    std::FILE *f = std::fopen(path, "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    const long bytes = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    std::vector<float> xyz((std::size_t)bytes / 4);
+    const std::size_t got = std::fread(xyz.data(), 4, xyz.size(), f);
+    std::fclose(f);
+    if (got != xyz.size() || xyz.size() % 3) return false;
+    cloud.points.resize(xyz.size() / 3);
+    for (std::size_t i = 0; i < cloud.points.size(); i++) cloud.points[i] = pcl::PointXYZ(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    return true;
+}
+
+static int benchMain(int argc, char **argv)
+{
+    if (argc < 10) {
+        std::fprintf(stderr, "usage: %s --bench src.f32 tgt.f32 radius max_neighbours dof warm steps inner_max_steps [repeats]\n", argv[0]);
+        return 2;
+    }
+    auto source = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+    auto target = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+    if (!readCloud(argv[2], *source) || !readCloud(argv[3], *target)) {
+        std::fprintf(stderr, "cannot read the clouds\n");
+        return 2;
+    }
+    ProbPointCloudRegistrationParams params;
+    params.radius = std::atof(argv[4]);
+    params.max_neighbours = std::atoi(argv[5]);
+    params.dof = std::strcmp(argv[6], "inf") == 0 ? std::numeric_limits<double>::infinity() : std::atof(argv[6]);
+    const int warm = std::atoi(argv[7]), steps = std::atoi(argv[8]);
+    params.inner_max_steps = std::atoi(argv[9]);
+    const int repeats = argc > 10 ? std::atoi(argv[10]) : 5;
+    params.cost_drop_thresh = 0;  // -c 0: exactly n_iter iterations
+    auto timed = [&](int n_iter, std::size_t *n_done) {
+        params.n_iter = n_iter;
+        ProbPointCloudRegistration reg(source, target, params);
+        const auto t0 = std::chrono::steady_clock::now();
+        reg.align();
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (n_done) *n_done = reg.transformation_history().size();
+        return dt;
+    };
+    std::size_t done = 0;
+    for (int k = 0; k < 3; k++) (void)timed(warm + steps, &done);  // code objects, allocations, clocks
+    std::vector<double> steady, whole;
+    for (int r = 0; r < repeats; r++) {
+        const double ta = timed(warm, nullptr);
+        const double tb = timed(warm + steps, &done);
+        if (done != (std::size_t)(warm + steps)) {
+            std::fprintf(stderr, "early stop: %zu iterations\n", done);
+            return 1;
+        }
+        steady.push_back(steps / (tb - ta));
+        whole.push_back((warm + steps) / tb);
+    }
+    std::sort(steady.begin(), steady.end());
+    std::sort(whole.begin(), whole.end());
+    std::printf("{\"steady_it_per_s\": %.3f, \"steady_min\": %.3f, \"steady_max\": %.3f, \"whole_align_it_per_s\": %.3f, "
+                "\"warm\": %d, \"steps\": %d, \"inner_max_steps\": %d, \"repeats\": %d, \"points\": [%zu, %zu]}\n",
+                steady[steady.size() / 2], steady.front(), steady.back(), whole[whole.size() / 2], warm, steps, params.inner_max_steps,
+                repeats, source->size(), target->size());
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1 && std::string(argv[1]) == "--bench") return benchMain(argc, argv);
     hostUtilitiesTest();
     weightsTests();
     closestPointMetricsTest();

@@ -19,8 +19,9 @@ def _run(args, env_extra=None, timeout=600):
 
 def test_more_gpus_than_devices_is_refused_not_downgraded():
     """Asking for more GPUs than the box has must fail loudly (here: 0 or 1 device), never run one rank and print a line."""
-    import torch
-    have = torch.cuda.device_count()
+    sys.path.insert(0, ROOT)
+    import bench
+    have = bench.visible_gpu_count()   # counted from the KFD topology: the launcher never loads the HIP runtime
     r = _run(["--gpus", str(have + 2), "--steps", "1", "--warmup", "0"])
     assert r.returncode != 0
     assert "n_gpus" not in r.stdout
@@ -53,6 +54,23 @@ def test_bench_line_has_the_agreed_blocks():
     assert out["converged_inner"]["mean_inner_steps"] >= 1 and out["converged_inner"]["it_per_s"] > 0
     assert out["parity"]["rot_err_rad"] < 1e-5 and out["parity"]["trans_err_m"] < 1e-5
     assert out["gathered_transforms"] == 1
+    # round 3: the timed instantiation is the roofline's kernel (stand-alone figure beside it), set-up cost per pair,
+    # window spread, and the C++ classes timed in a child process on both inner schedules
+    assert "folded in" in out["roofline"]["kernel"] and out["roofline"]["standalone"]["avg_kernel_ms"] > 0
+    assert out["setup_ms"]["total"] > 0 and out["setup_ms"]["grid_and_source_sort_kernels"] > 0
+    assert out["windows"]["spread"] >= 0 and "settle" in out["windows"]
+    for key in ("inner_steps_1", "default_inner_to_f_tol"):
+        assert out["cpp_api"][key]["steady_it_per_s"] > 0, out["cpp_api"]
+
+
+def test_launcher_counts_devices_without_the_hip_runtime():
+    """spawn_ranks' device count must not load libamdhip64 (the parent of the ranks stays GPU-clean)."""
+    code = ("import sys; sys.path.insert(0, %r); import bench; n = bench.visible_gpu_count(); "
+            "import os; maps = open('/proc/self/maps').read(); "
+            "assert 'libamdhip64' not in maps and 'libhsa-runtime' not in maps, 'HIP/HSA runtime loaded'; print(n)") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert int(r.stdout.strip()) >= 0
 
 
 @pytest.mark.gpu

@@ -1,35 +1,45 @@
 #!/usr/bin/env python3
 """profiles/k1_traffic.json from the FETCH_SIZE / WRITE_SIZE summary that tools/profile_round.sh writes
-(pmc_hbm_traffic.txt): HBM bytes per launch of the steady-state K1 kernel, with the gfx950 correction the
-MI355X_MICROARCH.md HBM section prescribes (FETCH_SIZE counts wide coalesced reads at half size)."""
+(pmc_hbm_traffic.txt): HBM bytes per launch of the steady-state K1 kernel — one entry per instantiation: "fused" (K23
+folded in: what ppcr_align and the benchmark's timed windows launch) and "standalone" (K1 alone) — with the gfx950
+correction the MI355X_MICROARCH.md HBM section prescribes (FETCH_SIZE counts wide coalesced reads at half size)."""
 import json
 import re
 import sys
+
+CORRECTION = ("gfx950: FETCH_SIZE counts 128-B fabric requests at 64 B for wide coalesced reads -> x2 "
+              "(MI355X_MICROARCH.md HBM section); WRITE_SIZE taken as is; Infinity-Cache hits are included in both")
+
+
+def entry(block):
+    vals = {m.group(1): (float(m.group(2)), int(m.group(3))) for m in re.finditer(r"(\w+)\s+([0-9.]+)\s+\(n=(\d+)\)", block)}
+    fetch_kb, n = vals["FETCH_SIZE"]
+    write_kb, _ = vals["WRITE_SIZE"]
+    return {"kernel": block.splitlines()[0].strip(), "dispatches": n, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+            "traffic_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0}
 
 
 def main(summary, out, tag):
     txt = open(summary).read()
     blocks = re.split(r"\n(?=\S)", txt)
-    pick = None
+    entries = {}
     for b in blocks:
         head = b.splitlines()[0]
-        if head.startswith("nn_fast_kernel<10, 16"):
-            pick = b
-    if pick is None:
+        if not head.startswith("nn_fast_kernel<10, 16"):
+            continue
+        if re.search(r"false, (8|0)>", head):
+            entries["fused"] = entry(b)
+        elif "false, -2>" in head:
+            entries["standalone"] = entry(b)
+    if not entries:
         raise SystemExit("no nn_fast_kernel<10, 16, ...> block in " + summary)
-    vals = {m.group(1): (float(m.group(2)), int(m.group(3))) for m in re.finditer(r"(\w+)\s+([0-9.]+)\s+\(n=(\d+)\)", pick)}
-    fetch_kb, n = vals["FETCH_SIZE"]
-    write_kb, _ = vals["WRITE_SIZE"]
     doc = {
-        "kernel": pick.splitlines()[0].strip() + " (steady-state K1: nn_fast_kernel, 16-slot lists, deferred source move and "
-                  "temporal cut-off folded in)",
-        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, MI355X, profiles/{tag}_pmc_hbm_traffic.txt; "
-                  f"tools/profile_round.sh), mean over {n} dispatches",
-        "FETCH_SIZE_KB": fetch_kb,
-        "WRITE_SIZE_KB": write_kb,
-        "correction": "gfx950: FETCH_SIZE counts 128-B fabric requests at 64 B for wide coalesced reads -> x2 "
-                      "(MI355X_MICROARCH.md HBM section); WRITE_SIZE taken as is; Infinity-Cache hits are included in both",
-        "traffic_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
+        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes over tools/exp_align.py, MI355X, "
+                  f"profiles/{tag}_pmc_hbm_traffic.txt; tools/profile_round.sh)",
+        "correction": CORRECTION,
+        "entries": entries,
+        # the figure bench.py quotes by default: the instantiation its timed windows run
+        "traffic_bytes_per_launch": (entries.get("fused") or entries.get("standalone"))["traffic_bytes_per_launch"],
     }
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps(doc))
