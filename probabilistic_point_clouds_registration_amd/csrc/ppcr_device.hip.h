@@ -404,9 +404,11 @@ struct FusedMoments {
 // HALVES = true folds ten sums, then nine, through a buffer half the size (20.6 KB instead of 39 KB: six instead of
 // four workgroups per CU for a kernel that is otherwise lean in registers) at the price of two more barriers.
 // The block's sums go to partials[j * stride + slot]; COHERENT: with agent-scope atomic stores (readers in the same
-// launch, on another XCD: see inner_steps_kernel).
+// launch, on another XCD: see inner_steps_kernel).  lds_acc (nullable): the sums are ADDED to lds_acc[j] in LDS instead
+// (a workgroup that walks several tiles keeps its running sums there, not in 38 VGPRs across the loop).
 template <int BLOCK = kBlock, bool HALVES = false, bool COHERENT = false>
-__device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__restrict__ partials, int stride, int slot)
+__device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__restrict__ partials, int stride, int slot,
+                                                   double *lds_acc = nullptr)
 {
     static_assert(BLOCK == 256, "fold layout assumes 256 lanes (8 parts of 32)");
     constexpr int STRIDE = BLOCK + 1;
@@ -440,7 +442,8 @@ __device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__
         double v = part[tid][0];
 #pragma unroll
         for (int q = 1; q < 8; q++) v += part[tid][q];
-        if constexpr (COHERENT) __hip_atomic_store(&partials[(size_t)tid * stride + slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lds_acc) lds_acc[tid] += v;
+        else if constexpr (COHERENT) __hip_atomic_store(&partials[(size_t)tid * stride + slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else partials[(size_t)tid * stride + slot] = v;
     }
 }
@@ -594,7 +597,12 @@ __device__ __forceinline__ bool polar_rotation(const double (&h)[3][3], double (
     return settled;
 }
 
-__device__ inline DeviceSolve solve_rigid_device(const double (&S)[kNSums], const double (&c)[3])
+// S points to the 19 moments.  Two uses: a plain pointer to a register array (the fold kernels, where the solve sits on
+// the outer loop's critical path: 120 VGPRs, everything at hand), or a VOLATILE pointer into LDS, read where a value is
+// needed and not hoisted, so that nothing of S occupies registers while the rotation is solved: 74 VGPRs — the form for
+// inner_steps_kernel, whose K23 role must not pay for the solve's registers (the LDS round trips cost the lane ~4 us).
+template <class SumsPtr>
+__device__ inline DeviceSolve solve_rigid_device(SumsPtr S, const double (&c)[3])
 {
     DeviceSolve out;
 #pragma unroll
@@ -606,17 +614,30 @@ __device__ inline DeviceSolve solve_rigid_device(const double (&S)[kNSums], cons
     if (!(W > 0) || !isfinite(W)) return out;
     out.degenerate = false;
     const double iW = fast_rcp(W);
-    const double mx[3] = {S[1] * iW, S[2] * iW, S[3] * iW}, my[3] = {S[4] * iW, S[5] * iW, S[6] * iW};
-    double w[3][3], v[3][3];  // w = H = sum w (x - mx)(y - my)^T, columns rotated in place; v accumulates V
+    // H = sum w (x - mx)(y - my)^T
+    auto load_H = [&](double (&h)[3][3]) {
+        const double my0 = S[4] * iW, my1 = S[5] * iW, my2 = S[6] * iW;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double sx = S[1 + a];
+            h[a][0] = S[7 + 3 * a] - sx * my0;
+            h[a][1] = S[8 + 3 * a] - sx * my1;
+            h[a][2] = S[9 + 3 * a] - sx * my2;
+        }
+    };
+    bool polar_ok;
+    {
+        double h[3][3];
+        load_H(h);
+        polar_ok = polar_rotation(h, out.R);
+    }
+    if (!polar_ok) {
+    double w[3][3], v[3][3];  // w = H, columns rotated in place; v accumulates V
+    load_H(w);
 #pragma unroll
     for (int a = 0; a < 3; a++)
 #pragma unroll
-        for (int b = 0; b < 3; b++) {
-            w[a][b] = S[7 + 3 * a + b] - S[1 + a] * my[b];
-            v[a][b] = (a == b) ? 1.0 : 0.0;
-        }
-    const bool polar_ok = polar_rotation(w, out.R);
-    if (!polar_ok) {
+        for (int b = 0; b < 3; b++) v[a][b] = (a == b) ? 1.0 : 0.0;
 #pragma unroll
     for (int k = 0; k < 9; k++) out.R[k] = (k % 4 == 0) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 64; ++sweep) {
@@ -669,6 +690,8 @@ __device__ inline DeviceSolve solve_rigid_device(const double (&S)[kNSums], cons
             for (int b = 0; b < 3; b++) out.R[3 * a + b] = v[a][0] * u[b][0] + v[a][1] * u[b][1] + d * v[a][2] * u[b][2];
     }
     }
+    // translation and cost: the moments come back from LDS now
+    const double mx[3] = {S[1] * iW, S[2] * iW, S[3] * iW}, my[3] = {S[4] * iW, S[5] * iW, S[6] * iW};
     double Rmx[3], Rc[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -678,10 +701,11 @@ __device__ inline DeviceSolve solve_rigid_device(const double (&S)[kNSums], cons
     }
     // 0.5 * sum w |y - R x - t|^2 from the moments (cost_from_moments)
     double tp[3], RSx[3], yRx = 0, tpRSx = 0, tptp = 0, tpSy = 0;
+    const double S1 = S[1], S2 = S[2], S3 = S[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         tp[a] = out.t[a] + Rc[a] - c[a];
-        RSx[a] = out.R[3 * a] * S[1] + out.R[3 * a + 1] * S[2] + out.R[3 * a + 2] * S[3];
+        RSx[a] = out.R[3 * a] * S1 + out.R[3 * a + 1] * S2 + out.R[3 * a + 2] * S3;
 #pragma unroll
         for (int b = 0; b < 3; b++) yRx += out.R[3 * a + b] * S[7 + 3 * b + a];
     }
@@ -777,8 +801,12 @@ __device__ __forceinline__ void publish_skipped(const FoldSolve &fs)
     __hip_atomic_store(&fs.mbox->seq, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+template <class SumsPtr>
+__device__ __forceinline__ void solve_and_publish(const FoldSolve &fs, SumsPtr S);
+
 // one of the kNSums fold blocks (256 threads): fold row `sum_index` of the partials; the last block to finish solves.
-// Returns true on the ONE lane that solved (after everything it had to write is written).
+// Returns true on the ONE lane that solved (after everything it had to write is written).  LEAN: see solve_rigid_device.
+template <bool LEAN = false>
 __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int sum_index)
 {
     __shared__ double sh[kBlock / 64];
@@ -806,9 +834,25 @@ __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int su
     if (tk != kNSums - 1) return false;
     __hip_atomic_store(fs.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(fs.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every fold block is past its wait
-    double S[kNSums];
+    if constexpr (LEAN) {
+        __shared__ double s_S[kNSums];  // the moments for the one lane that solves (see solve_rigid_device)
 #pragma unroll
-    for (int j = 0; j < kNSums; j++) S[j] = __hip_atomic_load(&fs.sums[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < kNSums; j++) s_S[j] = __hip_atomic_load(&fs.sums[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        solve_and_publish(fs, static_cast<const volatile double *>(s_S));
+    } else {
+        double S[kNSums];
+#pragma unroll
+        for (int j = 0; j < kNSums; j++) S[j] = __hip_atomic_load(&fs.sums[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        solve_and_publish(fs, static_cast<const double *>(S));
+    }
+    return true;
+}
+
+// The solve lane's work once the 19 moments are in LDS (S): closed-form solve, pose for the next association, the
+// device-paced loop's decision, the mailbox.  One lane; everything it must write is written when it returns.
+template <class SumsPtr>
+__device__ __forceinline__ void solve_and_publish(const FoldSolve &fs, SumsPtr S)
+{
     const double c[3] = {fs.origin.x, fs.origin.y, fs.origin.z};
     const DeviceSolve rs = solve_rigid_device(S, c);
 #pragma unroll
@@ -864,13 +908,12 @@ __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int su
             publish = false;  // an intermediate step: the next device step takes the pose from *pose_out
         }
     }
-    if (!publish) return true;
+    if (!publish) return;
     fs.mbox->cost = rs.cost;
     fs.mbox->status = status;
     fs.mbox->degenerate = rs.degenerate ? 1u : 0u;
     fs.mbox->handed_over = fs.handed_over ? *fs.handed_over : 0u;
     __hip_atomic_store(&fs.mbox->seq, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    return true;
 }
 
 }  // namespace dev

@@ -165,6 +165,10 @@ struct ppcr_ctx {
     DevBuf<LoopState> d_loop;
     DevBuf<unsigned> d_inner_ctl;      // [0] step_done, [1 ..] completion flags of inner_steps_kernel's K23 workgroups
     int opt_inner_dev_steps = 3;       // IRLS steps 2.. the device may take on its own per outer iteration (<= kMaxDevSteps)
+    // what inner_steps_kernel reads from device memory instead of taking it as kernel arguments, and the host's copy
+    DevBuf<InnerConst> d_inner_const;
+    InnerConst h_inner_const{};
+    bool inner_const_valid = false;
     // per-iteration reports of the device-paced loop (track_kernel)
     HostReport *h_report = nullptr;    // pinned + device-mapped ring of kMailboxRing slots
     HostReport *d_report = nullptr;
@@ -533,6 +537,18 @@ void launch_accumulate_ell(ppcr_ctx *c, int nb, const Pose &P, const Model &md, 
 
 int flush_pending_move(ppcr_ctx *c);
 
+// the K1 translation unit compiled for the narrowest list width that holds max_neighbours
+void dispatch_tile(TileLaunch &tl, int m)
+{
+    if (m <= 4) launch_tile_m4(tl);
+    else if (m <= 5) launch_tile_m5(tl);
+    else if (m <= 8) launch_tile_m8(tl);
+    else if (m <= 10) launch_tile_m10(tl);
+    else if (m <= 16) launch_tile_m16(tl);
+    else if (m <= 20) launch_tile_m20(tl);
+    else launch_tile_m32(tl);
+}
+
 // K1 (or the generic count/scan/fill path for unbounded searches and max_neighbours > 32).
 // fuse_R / fuse_t (nullable): the pose the first IRLS half-step will be evaluated at; when given, the steady-state K1
 // also produces that step's partial moments (c->assoc_fused, c->fused_slots) and the caller skips the K23 launch.
@@ -647,13 +663,7 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             tl.loop_st = loop ? loop->st : nullptr;
             tl.between = [](void *scope) { static_cast<ProfScope *>(scope)->split(K_NN_CLEANUP); };
             tl.between_arg = &ps;
-            if (m <= 4) launch_tile_m4(tl);
-            else if (m <= 5) launch_tile_m5(tl);
-            else if (m <= 8) launch_tile_m8(tl);
-            else if (m <= 10) launch_tile_m10(tl);
-            else if (m <= 16) launch_tile_m16(tl);
-            else if (m <= 20) launch_tile_m20(tl);
-            else launch_tile_m32(tl);
+            dispatch_tile(tl, m);
             fused = tl.fused, merged = tl.merged;
             c->assoc_fused = fused;
             c->assoc_folded = merged;
@@ -1059,16 +1069,30 @@ int launch_inner(ppcr_ctx *c, const StepTicket &tk, const LoopCtl &loop, int n_d
     a.nbr = c->nbr.p, a.cnt = c->cnt.p, a.src = c->src.p, a.tgt = c->tgt_cur();
     a.ns = ns, a.width = c->ell_width;
     a.md = make_model(c);
+    InnerConst ic;
+    std::memset(&ic, 0, sizeof(ic));
     StepTicket same = tk;
     const unsigned seq_keep = c->mbox_seq;
-    PPCR_TRY(prepare_fold(c, G, same, a.fs, &loop));  // (draws a sequence number: handed back below — the steps share tk.seq)
+    PPCR_TRY(prepare_fold(c, G, same, ic.fs, &loop));  // (draws a sequence number: handed back — the steps share tk.seq)
     c->mbox_seq = seq_keep;
-    a.fs.seq = tk.seq;
-    a.fs.mbox = c->d_mbox + (tk.seq % kMailboxRing);
-    a.fs.loop.first = 0;
-    a.step_done = c->d_inner_ctl.p;
-    a.flags = c->d_inner_ctl.p + 1;
-    a.G = G, a.n_steps = n_dev_steps;
+    ic.fs.seq = 0, ic.fs.mbox = nullptr, ic.fs.handed_over = nullptr;  // per launch
+    ic.fs.loop.first = 0, ic.fs.loop.last_dev = 0;                     // per step
+    ic.flags = c->d_inner_ctl.p + 1, ic.step_done = c->d_inner_ctl.p;
+    ic.mbox_ring = c->d_mbox, ic.mbox_slots = kMailboxRing;
+    ic.ovf_state = c->ovf_state.p;
+    ic.G = G;
+    HIP_TRY(c, c->d_inner_const.reserve(1));
+    if (!c->inner_const_valid || std::memcmp(&ic, &c->h_inner_const, sizeof(ic)) != 0) {
+        // (once per change of buffers or loop control: launches already in flight read the old contents)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->h_inner_const = ic;
+        HIP_TRY(c, hipMemcpy(c->d_inner_const.p, &c->h_inner_const, sizeof(ic), hipMemcpyHostToDevice));
+        c->inner_const_valid = true;
+    }
+    a.ic = c->d_inner_const.p;
+    a.seq = tk.seq;
+    a.ovf_index = c->ovf_parity;
+    a.n_steps = n_dev_steps;
     const K23Form f = k23_form(c, a.md);
     const int grid = n_dev_steps * (G + kNSums);
     {
@@ -1355,6 +1379,7 @@ int ppcr_destroy(ppcr_ctx *c)
     c->d_s.release();
     c->mse_part.release();
     c->d_loop.release();
+    c->d_inner_const.release();
     c->d_inner_ctl.release();
     c->track_part.release();
     c->track_ticket.release();
@@ -1946,20 +1971,26 @@ struct AlignJob {
         return PPCR_OK;
     }
 
-    // The device could not finish iteration `done` by itself (kIterationPending): finish its inner loop one IRLS step at
-    // a time, as solve_impl does, hand the pose back to the device and redo what follows an iteration.
-    int take_over(StepResult &res)
+    // LoopState::abort is up: the trains of the iterations behind iteration `done` stepped aside.  Wait for their
+    // (empty) mailbox slots and take them back, last first.
+    int recall_later_trains()
     {
-        const unsigned seq = in_flight[done % kMailboxRing].seq;
         while (enq > done + 1) {
-            // the trains of the iterations behind this one stepped aside: wait for their (empty) mailbox slots and take
-            // them back, last first
             StepResult skipped;
             PPCR_TRY(collect_step(c, in_flight[(enq - 1) % kMailboxRing], skipped));
             if (skipped.status != kLaunchSkipped) return fail(c, PPCR_ERR_STATE, "internal: a launch ran past an aborted iteration");
             enq--;
             c->ovf_parity ^= 1;  // its association had claimed the other counter of the pair
         }
+        return PPCR_OK;
+    }
+
+    // The device could not finish iteration `done` by itself (kIterationPending): finish its inner loop one IRLS step at
+    // a time, as solve_impl does, hand the pose back to the device and redo what follows an iteration.
+    int take_over(StepResult &res)
+    {
+        const unsigned seq = in_flight[done % kMailboxRing].seq;
+        PPCR_TRY(recall_later_trains());
         HIP_TRY(c, hipMemsetAsync(&c->d_loop.p->abort, 0, sizeof(unsigned), c->stream));
         c->move_on_device = false;
         Mat3 R;
@@ -1996,8 +2027,8 @@ struct AlignJob {
     int consume()
     {
         StepResult res;
-        const unsigned seq = in_flight[done % kMailboxRing].seq;
         PPCR_TRY(collect_step(c, in_flight[done % kMailboxRing], res));
+        const unsigned seq = in_flight[done % kMailboxRing].seq;
         if (res.status == kIterationPending) PPCR_TRY(take_over(res));
         if (res.status != kIterationDone) return fail(c, PPCR_ERR_STATE, "internal: unexpected mailbox status in the align loop");
         const double cost[2] = {res.cost_init, res.cost};

@@ -443,16 +443,47 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxDevSteps = 8;
 constexpr int kInnerMaxG = 2048;  // upper bound of the K23 workgroups per step (rows are dealt G-strided in tiles of 256)
+// what the launch reads from DEVICE memory instead of taking it as kernel arguments (as by-value arguments FoldSolve's
+// ~40 words sat in SGPRs through the K23 role and pushed its uniforms into VGPRs: 138 VGPRs, three waves per SIMD)
+struct InnerConst {
+    FoldSolve fs;        // partials = [kNSums][G], nslots = G, loop.first = 0; seq, mbox, handed_over, last_dev: per launch / step
+    unsigned *flags;     // [n_steps][G]: == seq once that workgroup's partial sums of this launch are in place
+    unsigned *step_done; // seq * kMaxDevSteps + (device steps of this launch that have been solved)
+    HostMailbox *mbox_ring;
+    int mbox_slots;
+    unsigned *ovf_state;
+    int G;
+};
 struct InnerArgs {
     const int *nbr, *cnt;
     const float4 *src, *tgt;
     int ns, width;
     Model md;
-    FoldSolve fs;     // partials = [kNSums][G], nslots = G; loop.first = 0; loop.last_dev is set per step here
-    unsigned *flags;  // [n_steps][G]: == fs.seq once that workgroup's partial sums of this launch are in place
-    unsigned *step_done;  // fs.seq * kMaxDevSteps + (device steps of this launch that have been solved)
-    int G, n_steps;
+    const InnerConst *ic;
+    unsigned seq;
+    int ovf_index, n_steps;
 };
+// the fold role (inlined: a called function is compiled without the kernel's register budget and took 210 VGPRs)
+__device__ __forceinline__ void inner_fold_role(const InnerConst *ic, unsigned seq, int ovf_index, int u, int row, int n_steps)
+{
+    const int G = ic->G;
+    // every partial of this step must be in place
+    for (int k = threadIdx.x; k < G; k += kBlock)
+        while (__hip_atomic_load(&ic->flags[(size_t)u * G + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq)
+            __builtin_amdgcn_s_sleep(8);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // kNSums of these per step: the fold reads the partials plainly
+    FoldSolve fs = ic->fs;
+    fs.seq = seq;
+    fs.mbox = ic->mbox_ring + (seq % (unsigned)ic->mbox_slots);
+    fs.handed_over = ic->ovf_state + ovf_index;
+    fs.loop.first = 0;
+    fs.loop.last_dev = (u == n_steps - 1) ? 1 : 0;
+    if (fold_and_solve_block<true>(fs, row)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // one per step: pose, loop state
+        __hip_atomic_store(ic->step_done, seq * kMaxDevSteps + (unsigned)(u + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 // Workgroups take their role from blockIdx: [step][G K23 workgroups, kNSums fold workgroups].  A workgroup only ever
 // waits for workgroups with SMALLER indices, which the dispatcher has started before it (workgroups of a launch are
 // dispatched in index order on every XCD) — running or done: no co-residency is assumed and several such kernels (other
@@ -464,12 +495,14 @@ struct InnerArgs {
 // which K23's target gathers live in): waiting workgroups poll with relaxed loads — polling with acquire loads, tried
 // first, took a step from ~35 us to ~370 us.
 template <int W, int TM, bool ONEPASS>
-__global__ __launch_bounds__(kBlock) void inner_steps_kernel(InnerArgs a)
+__global__ __launch_bounds__(kBlock, ONEPASS ? 5 : 3) void inner_steps_kernel(InnerArgs a)
 {
-    LoopState *const st = a.fs.loop.st;
-    const int per_step = a.G + kNSums;
+    const InnerConst *const ic = a.ic;
+    LoopState *const st = ic->fs.loop.st;
+    const int G = ic->G;
+    const int per_step = G + kNSums;
     const int u = (int)blockIdx.x / per_step, r = (int)blockIdx.x % per_step;
-    const unsigned seq = a.fs.seq;
+    const unsigned seq = a.seq;
     // The common case: step 1 (an earlier launch) ended the loop, all these workgroups have nothing to do and their
     // number times their lifetime is what the launch costs — an ordinary cached load is enough for a value written
     // before the launch (the agent-scope loads below go to the memory side).
@@ -480,44 +513,48 @@ __global__ __launch_bounds__(kBlock) void inner_steps_kernel(InnerArgs a)
     if (u > 0) {  // the previous device step must have been solved (step 1 was: it ran in an earlier launch)
         // (or the loop ended at an earlier step: then step u - 1 never runs and `finished` / `abort` is the news)
         if (threadIdx.x == 0)
-            while (__hip_atomic_load(a.step_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq * kMaxDevSteps + (unsigned)u && !over())
+            while (__hip_atomic_load(ic->step_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq * kMaxDevSteps + (unsigned)u && !over())
                 __builtin_amdgcn_s_sleep(64);
         __syncthreads();
     }
     if (over()) return;
-    if (r < a.G) {
-        // K23 at the pose the previous step solved (written by another workgroup, possibly of this launch)
-        Pose P;
+    if (r >= G) {
+        inner_fold_role(ic, seq, a.ovf_index, u, r - G, a.n_steps);
+        return;
+    }
+    // K23 at the pose the previous step solved (written by another workgroup, possibly of this launch).  Uniform: moved
+    // to scalar registers, where accumulate_ell_kernel has it as a kernel argument.
+    auto uniform = [](double v) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    Pose P;
+    {
+        const Pose *pose = ic->fs.pose_out;
 #pragma unroll
-        for (int k = 0; k < 9; k++) P.R[k] = __hip_atomic_load(&a.fs.pose_out->R[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < 9; k++) P.R[k] = uniform(__hip_atomic_load(&pose->R[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
-        for (int k = 0; k < 3; k++) P.t[k] = __hip_atomic_load(&a.fs.pose_out->t[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        P.c[0] = a.fs.origin.x, P.c[1] = a.fs.origin.y, P.c[2] = a.fs.origin.z;
+        for (int k = 0; k < 3; k++) P.t[k] = uniform(__hip_atomic_load(&pose->t[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        P.c[0] = ic->fs.origin.x, P.c[1] = ic->fs.origin.y, P.c[2] = ic->fs.origin.z;
+    }
+    // tile by tile, exactly as accumulate_ell_kernel does one tile; the running sums of the workgroup live in LDS
+    __shared__ double s_acc[kNSums];
+    if (threadIdx.x < kNSums) s_acc[threadIdx.x] = 0.0;
+    const int ntiles = (a.ns + kBlock - 1) / kBlock;
+    for (int tile = r; tile < ntiles; tile += G) {
         RowAcc acc;
 #pragma unroll
         for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
-        const int ntiles = (a.ns + kBlock - 1) / kBlock;
-        for (int tile = r; tile < ntiles; tile += a.G)
-            accumulate_ell_rows<W, 1, kBlock, TM, ONEPASS>(acc, tile * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.tgt, a.ns, P,
-                                                           a.md, a.width);
-        block_reduce_store<kBlock, true, true>(acc, const_cast<double *>(a.fs.partials), a.G, r);
-        __syncthreads();  // (waits for the 19 stores as well: vmcnt(0))
-        if (threadIdx.x == 0) __hip_atomic_store(&a.flags[(size_t)u * a.G + r], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
+        accumulate_ell_rows<W, 1, kBlock, TM, ONEPASS>(acc, tile * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.tgt, a.ns, P, a.md,
+                                                       a.width);
+        block_reduce_store<kBlock, true>(acc, nullptr, 0, 0, s_acc);  // (its own thread adds to s_acc[tid]: no barrier needed)
     }
-    // fold role: every partial of this step must be in place
-    for (int k = threadIdx.x; k < a.G; k += kBlock)
-        while (__hip_atomic_load(&a.flags[(size_t)u * a.G + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq)
-            __builtin_amdgcn_s_sleep(8);
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // kNSums of these per step: the fold reads the partials plainly
-    FoldSolve fs = a.fs;
-    fs.loop.first = 0;
-    fs.loop.last_dev = (u == a.n_steps - 1) ? 1 : 0;
-    if (fold_and_solve_block(fs, r - a.G)) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // one per step: pose, loop state
-        __hip_atomic_store(a.step_done, seq * kMaxDevSteps + (unsigned)(u + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x < kNSums)
+        __hip_atomic_store(const_cast<double *>(&ic->fs.partials[(size_t)threadIdx.x * G + r]), s_acc[threadIdx.x], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();  // (waits for the 19 stores as well: vmcnt(0))
+    if (threadIdx.x == 0) __hip_atomic_store(&ic->flags[(size_t)u * G + r], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // fold partials[19][nblocks] -> sums[19].  One 256-thread block PER SUM (grid = 19): every thread issues its

@@ -369,21 +369,31 @@ static int benchMain(int argc, char **argv)
     params.inner_max_steps = std::atoi(argv[9]);
     const int repeats = argc > 10 ? std::atoi(argv[10]) : 5;
     params.cost_drop_thresh = 0;  // -c 0: exactly n_iter iterations
-    auto timed = [&](int n_iter, std::size_t *n_done) {
+    // every object is constructed (clouds uploaded) before anything is timed, and the align() calls then run back to
+    // back: the device does not idle (and clock down) through uploads between two measurements
+    auto make = [&](int n_iter) {
         params.n_iter = n_iter;
-        ProbPointCloudRegistration reg(source, target, params);
+        return std::make_unique<ProbPointCloudRegistration>(source, target, params);
+    };
+    auto timed = [&](ProbPointCloudRegistration &reg, std::size_t *n_done) {
         const auto t0 = std::chrono::steady_clock::now();
         reg.align();
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (n_done) *n_done = reg.transformation_history().size();
         return dt;
     };
+    std::vector<std::unique_ptr<ProbPointCloudRegistration>> warmups, shorts, longs;
+    for (int k = 0; k < 3; k++) warmups.push_back(make(warm + steps));
+    for (int r = 0; r < repeats; r++) {
+        shorts.push_back(make(warm));
+        longs.push_back(make(warm + steps));
+    }
     std::size_t done = 0;
-    for (int k = 0; k < 3; k++) (void)timed(warm + steps, &done);  // code objects, allocations, clocks
+    for (auto &w : warmups) (void)timed(*w, &done);  // code objects, allocations, clocks
     std::vector<double> steady, whole;
     for (int r = 0; r < repeats; r++) {
-        const double ta = timed(warm, nullptr);
-        const double tb = timed(warm + steps, &done);
+        const double ta = timed(*shorts[(std::size_t)r], nullptr);
+        const double tb = timed(*longs[(std::size_t)r], &done);
         if (done != (std::size_t)(warm + steps)) {
             std::fprintf(stderr, "early stop: %zu iterations\n", done);
             return 1;
