@@ -46,8 +46,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps iterations (value = median)")
     ap.add_argument("--config", type=int, default=3,
-                    help="BASELINE.json config number (3 = 1M headline, 4 = Gaussian, 2 = 100k, 5 = 64 x 250k batch)")
-    ap.add_argument("--n", type=int, default=None, help="override the cloud size (debugging)")
+                    help="BASELINE.json config number (3 = 1M headline, 4 = Gaussian, 2 = 100k, 5 = 64 x 250k batch; "
+                         "6 / 7 = \"4b\": the 1M pair with -d 3 / -d 10, the other t models the fused kernel serves)")
+    ap.add_argument("--n", "--points", dest="n", type=int, default=None,
+                    help="override the cloud size (debugging; spell it --points behind torch.distributed.run, whose own "
+                         "parser trips over --n)")
     ap.add_argument("--inner-steps", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0,
@@ -64,6 +67,12 @@ def parse():
     ap.add_argument("--pairs-per-gpu", type=int, default=0,
                     help="independent pairs per rank (0 = the config's own: 1, or 64 / N for config 5)")
     ap.add_argument("--no-verify", action="store_true", help="config 5: skip the single-rank re-run of every pair")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="torch.distributed backend: nccl (= RCCL, the real thing) or gloo (CPU: only with --fake-register)")
+    ap.add_argument("--fake-register", action="store_true",
+                    help="TEST SWITCH: replace the GPU registration by a deterministic CPU stand-in so that the rank logic "
+                         "(shard, timed windows, gather, all_reduce(MAX), verification, teardown) can be run with real "
+                         "ranks on a box without GPUs; the line it prints is labelled and measures nothing")
     ap.add_argument("--settle-ms", type=float, default=250.0,
                     help="untimed iterations run for at least this long before the first window (clocks settle)")
     ap.add_argument("--no-cpp-api", action="store_true", help="skip the cpp_api block (the C++ classes timed in a child process)")
@@ -105,7 +114,8 @@ def spawn_ranks(a):
               f"under the requested label", file=sys.stderr)
         return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + [
+               "--points" if arg == "--n" else arg for arg in sys.argv[1:]]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode
@@ -194,8 +204,73 @@ def cpp_api_block(src, tgt, cfg, a):
     return block
 
 
+class FakeContext:
+    """Stand-in of _lib.Context for --fake-register (the rank-logic test): same calls, no GPU, results that depend only
+    on the clouds and the iteration count, a little sleep per iteration so that windows have a duration."""
+
+    def __init__(self, device_id=0):
+        self.src = self.tgt = None
+        self.iters = 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def close(self):
+        pass
+
+    def set_option(self, key, value):
+        pass
+
+    def set_params(self, *args):
+        pass
+
+    def set_target(self, tgt):
+        self.tgt = np.asarray(tgt, np.float64)[:, :3].mean(axis=0)
+
+    def set_source(self, src):
+        self.src = np.asarray(src, np.float64)[:, :3].mean(axis=0)
+        self.iters = 0
+
+    def synchronize(self):
+        pass
+
+    def association_size(self):
+        return 0, 0
+
+    def _T(self):
+        T = np.eye(4)[:3].copy()
+        T[:, 3] = (self.tgt - self.src) * (1.0 - 0.5 ** self.iters)
+        return T
+
+    def align(self, n_iter, cost_drop_thresh=0.0, inner_steps=1, f_tol=1e-5, want_history=True, **kw):
+        hist = []
+        for _ in range(int(n_iter)):
+            time.sleep(2e-4)
+            self.iters += 1
+            hist.append(self._T())
+        return dict(n_iter=int(n_iter), history=np.array(hist).reshape(-1, 3, 4), inner_steps=np.ones(int(n_iter), np.int32),
+                    costs=np.zeros((int(n_iter), 2)))
+
+
+def fake_align_many(ctxs, k, lanes=1, **kw):
+    out = [c.align(k)["history"][-1] if k > 0 else np.eye(4)[:3] for c in ctxs]
+    return np.array(out), [k] * len(ctxs)
+
+
 def run_rank(a):
-    from probabilistic_point_clouds_registration_amd import _lib, batch, synth
+    from probabilistic_point_clouds_registration_amd import batch, synth
+    if a.fake_register:
+        import types
+        _lib = types.SimpleNamespace(Context=FakeContext, align_many=fake_align_many)
+        a.no_profile = a.no_extras = a.no_cpu_baseline = a.no_cpp_api = True
+        a.settle_ms = 0.0
+    else:
+        from probabilistic_point_clouds_registration_amd import _lib
+        if a.backend != "nccl":
+            raise SystemExit("bench.py: --backend gloo is for --fake-register runs only (the product's collective is RCCL)")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -204,20 +279,26 @@ def run_rank(a):
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to mislabel the run")
 
     import torch  # device selection, synchronize, torch.distributed (RCCL)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    if torch.cuda.device_count() < (local_rank + 1):
-        raise SystemExit(f"bench.py: rank {rank} has no device {local_rank}")
-    torch.cuda.set_device(local_rank)
+    on_gpu = not a.fake_register
+    if on_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        if torch.cuda.device_count() < (local_rank + 1):
+            raise SystemExit(f"bench.py: rank {rank} has no device {local_rank}")
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if on_gpu:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=a.backend, rank=rank, world_size=world)
         assert dist.get_world_size() == a.gpus
 
     cfg = dict(synth.CONFIGS[a.config])
+    cloud_cfg = cfg.get("clouds", a.config)   # whose pinned seeds the clouds are drawn with
     n = a.n or cfg["n"]
     batch_cfg = "pairs" in cfg              # config 5: a fixed batch of independent pairs sharded over the ranks
     if a.pairs_per_gpu > 0:
@@ -232,7 +313,7 @@ def run_rank(a):
     my_pairs = batch.shard_pairs(n_pairs, world, rank)   # pair p lives on rank p % world
     ctxs, clouds = [], []
     for p in my_pairs:
-        src, tgt, _, _ = synth.make_pair(n, cfg=a.config, pair=p)
+        src, tgt, _, _ = synth.make_pair(n, cfg=cloud_cfg, pair=p)
         c = _lib.Context(local_rank)
         for kv in a.opt:
             k, v = kv.split("=")
@@ -245,12 +326,13 @@ def run_rank(a):
     ctx = ctxs[0]
     src, tgt = clouds[0]   # this rank's first pair (rank 0: cpu baselines / parity)
     concurrent = len(ctxs) > 1 and a.lanes > 1
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
 
     def barrier():
         for c in ctxs:
             c.synchronize()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
@@ -306,7 +388,7 @@ def run_rank(a):
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         window_s.append(dt)
@@ -373,9 +455,17 @@ def run_rank(a):
                               "first_associate_call = bounding box + grid build of the target + spatial sort of the source "
                               "(their kernels: grid_and_source_sort_kernels) + the first association, wall time")
 
+    # Every collective of the job is behind us.  All ranks leave the process group TOGETHER, here (a last barrier, then
+    # destroy): rank 0's remaining work (extras, CPU baselines, the single-rank re-run of every pair) is its own and can
+    # take minutes — no rank tears its communicator down while a peer may still be inside a collective, and no peer
+    # waits in a collective for a rank that has gone.
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+        dist_was, dist = True, None
+    else:
+        dist_was = False
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
         return 0
 
     ns, nt = src.shape[0], tgt.shape[0]
@@ -394,8 +484,9 @@ def run_rank(a):
         "scaling": "strong" if (batch_cfg and a.pairs_per_gpu == 0) else "weak",
         "vs_baseline": None,
         "dtype": "f32 (distances) + f64 (weights, moments, solve)",
-        "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[{a.config - 1}]: "
+        "data": "synthetic" if on_gpu else "FAKE REGISTRATION (--fake-register: rank-logic test, measures nothing)",
+        "config": {"workload": (f"BASELINE configs[{a.config - 1}]: " if a.config <= 5 else
+                                f"BASELINE configs[3] variant 4b (t model, dof {cfg['dof']:g}): ")
                                + (f"batch of {n_pairs} independent pairs of " if n_pairs > 1 else "")
                                + f"{ns}<->{nt} synthetic clouds, radius={cfg['radius']}, "
                                f"max_neighbours={cfg['max_neighbours']}, {model}, "
@@ -423,7 +514,7 @@ def run_rank(a):
         # (tools/profile_round.sh); the committed summary of the latest passes is quoted, with its source named
         traffic, traffic_source, traffic_alone = None, None, None
         tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
-        if os.path.exists(tpath) and a.config in (3, 4) and a.n is None:
+        if os.path.exists(tpath) and a.config in (3, 4, 6, 7) and a.n is None:
             tj = json.load(open(tpath))
             ent = tj.get("entries", {})
             fused = ent.get("fused") or {}
@@ -496,14 +587,14 @@ def run_rank(a):
         if not a.no_cpp_api and not batch_cfg:
             out["cpp_api"] = cpp_api_block(src, tgt, cfg, a)
 
-    if batch_cfg or world > 1 or dist is not None:
+    if batch_cfg or world > 1 or dist_was:
         ok = np.isfinite(gathered).all(axis=(1, 2))
         out["gathered_transforms"] = int(ok.sum())
         assert out["gathered_transforms"] == n_pairs, f"gathered {int(ok.sum())} of {n_pairs} transforms"
         if batch_cfg and world == 1 and not a.no_extras:
             # pairs per second END TO END: host buffers in (upload, grid build, source sort, K iterations), several
             # pairs in flight per GPU so that one pair's uploads overlap another pair's iterations (ppcr_batch_run)
-            host_pairs = [synth.make_pair(n, cfg=a.config, pair=p)[:2] for p in range(min(n_pairs, 16))]
+            host_pairs = [synth.make_pair(n, cfg=cloud_cfg, pair=p)[:2] for p in range(min(n_pairs, 16))]
             _lib.batch_run(host_pairs[:2], cfg["radius"], cfg["max_neighbours"], cfg["dof"], n_iter=a.steps + a.warmup,
                            inner_steps=a.inner_steps, device_ids=(local_rank,), lanes_per_device=2)   # warm-up
             e2e = {}
@@ -521,7 +612,7 @@ def run_rank(a):
             with _lib.Context(local_rank) as chk:
                 chk.set_params(cfg["radius"], cfg["max_neighbours"], cfg["dof"], 3)
                 for p in range(n_pairs):
-                    s, t, _, _ = synth.make_pair(n, cfg=a.config, pair=p)
+                    s, t, _, _ = synth.make_pair(n, cfg=cloud_cfg, pair=p)
                     chk.set_target(t)
                     chk.set_source(s)
                     if a.warmup > 0:
@@ -557,8 +648,6 @@ def run_rank(a):
     # library's stdout buffer until exit) is shut down and flushed first
     for c in ctxs:
         c.close()
-    if dist is not None:
-        dist.destroy_process_group()
     try:
         import ctypes
         ctypes.CDLL(None).fflush(None)

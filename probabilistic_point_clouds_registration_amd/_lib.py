@@ -351,6 +351,16 @@ class Context:
         self._ck(self._L.ppcr_mse_previous(self._h, C.byref(v)))
         return v.value
 
+    def debug_host_figures(self):
+        """ppcr_debug_get_host_times (diagnostic, not part of ppcr.h): 8 doubles about the last ppcr_align on this
+        handle; [7] = workgroups its associations handed over to the cleanup kernel, summed over the iterations."""
+        out = (C.c_double * 8)()
+        f = self._L.ppcr_debug_get_host_times
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        f.restype = C.c_int
+        self._ck(f(self._h, out))
+        return list(out)
+
     def synchronize(self):
         self._ck(self._L.ppcr_synchronize(self._h))
 

@@ -134,6 +134,11 @@ Job parseCommandLine(int argc, char **argv)
     if (!job.batch_path.empty()) {
         if (!files.empty()) throw BadArgument{"Positional arguments are not used with --batch", files[0]};
         if (job.lanes < 1) throw BadArgument{"--lanes must be at least 1", "--lanes"};
+        // the batch entry point takes clouds as they are and reports transforms only: refuse what it would silently drop
+        if (job.params.source_filter_size > 0) throw BadArgument{"Voxel filters belong to the single-pair form, not --batch", "-s"};
+        if (job.params.target_filter_size > 0) throw BadArgument{"Voxel filters belong to the single-pair form, not --batch", "-t"};
+        if (!job.truth_path.empty()) throw BadArgument{"The ground-truth report belongs to the single-pair form, not --batch", "-g"};
+        if (job.params.summary) throw BadArgument{"The registration report belongs to the single-pair form, not --batch", "--dump"};
     } else {
         if (files.size() < 2) throw BadArgument{"Required argument missing", kNames[files.size()]};
         if (files.size() > 2) throw BadArgument{"Too many positional arguments", files[2]};

@@ -178,6 +178,14 @@ __device__ __forceinline__ void rotate_point(const Pose &P, float4 xf, double xr
     xr[2] = (P.R[6] * px + P.R[7] * py + P.R[8] * pz) + P.t[2];
 }
 
+__device__ __forceinline__ double fast_rsqrt(double x)  // x > 0, finite
+{
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r;
+}
+
 // 1/x to ~1 ulp without the IEEE division sequence: v_rcp_f64 seed + two Newton steps (x finite, > 0)
 __device__ __forceinline__ double fast_rcp(double x)
 {
@@ -191,7 +199,8 @@ __device__ __forceinline__ double fast_rcp(double x)
 // v + d is an integer (every practical dof) this is an integer power times at most one sqrt — no
 // log1p/exp at all; otherwise the reference's exp(texp * log1p(s/v)) form.  Gaussian: exp(-(s-smin)/2).
 // inv_vs = 1/(v + s) (shared with the expected-weight factor; unused by the Gaussian model)
-// TM (compile-time model): -1 = read md at run time; 0 = Gaussian; k > 0 = t model with v + dim == k.
+// TM (compile-time model): -1 = read md at run time; 0 = Gaussian; k > 0 = t model with v + dim == k;
+// -3 = t model with an integer v + dim read at run time (md.vpd_int).
 // (The run-time form keeps the odd-power sqrt behind an opaque branch: as a plain ?: the compiler if-converts
 //  it and every pair pays the 20-instruction f64 sqrt expansion — measured: 220 of 970 VALU instructions per row.)
 // exp(x) for x <= 0 (the Gaussian model's likelihood ratios), ~1 ulp: x = k ln2 + r with |r| <= ln2 / 2, a degree-13
@@ -224,6 +233,21 @@ template <int TM = -1>
 __device__ __forceinline__ double rel_likelihood(const Model &md, double s, double smin, double lp_max, double inv_vs)
 {
     if constexpr (TM == 0) return exp_nonpositive(-0.5 * (s - smin));
+    if constexpr (TM == -3) {
+        // t model whose v + dim is an integer known only at run time (md.vpd_int: -d 3 -> 6, -d 10 -> 13 ...):
+        // rho^((v + dim) / 2) by squaring (wave-uniform trip count), the half power of an odd v + dim as
+        // rho * rsqrt(rho) from the v_rsq_f64 seed + two Newton steps — no sqrt / exp / log1p expansion in the kernel
+        // this is folded into
+        const double rho = (md.v + smin) * inv_vs;  // in (0, 1]
+        double r = 1.0;
+        if (md.vpd_int & 1) r = rho * fast_rsqrt(rho);  // (uniform branch)
+        double base = rho;
+        for (int k = md.vpd_int >> 1; k; k >>= 1) {
+            if (k & 1) r *= base;
+            base *= base;
+        }
+        return r;
+    }
     if constexpr (TM > 0) {
         const double rho = (md.v + smin) * inv_vs;
         double r = 1.0, base = rho;  // same multiplication sequence as the run-time loop below (1.0 * x is exact)
@@ -352,7 +376,7 @@ struct RowMoments {
             const double inv_vs = (TM == 0) ? 0.0 : rcp_1step(md.v + sk);
             const double e = rel_likelihood<TM>(md, sk, 0.0, 0.0, inv_vs);
             Z += e;
-            gk = (TM == 0 || (TM < 0 && md.is_normal)) ? e : e * (md.vpd * inv_vs);
+            gk = (TM == 0 || (TM == -1 && md.is_normal)) ? e : e * (md.vpd * inv_vs);
         }
         G += gk;
         Gs = fma(gk, sk, Gs);
@@ -478,13 +502,6 @@ struct PendingMove {
 // IEEE sequences (a Jacobi rotation only has to be orthogonal to rounding, and it is: c^2 (1 + t^2) = 1 to ~1 ulp).
 // Agrees with the host solve to a few ulp of the moments; the oracle tolerance on transforms is 1e-5.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double fast_rsqrt(double x)  // x > 0, finite
-{
-    double r = __builtin_amdgcn_rsq(x);
-    r = r * fma(-0.5 * x * r, r, 1.5);
-    r = r * fma(-0.5 * x * r, r, 1.5);
-    return r;
-}
 
 struct DeviceSolve {
     double R[9], t[3], cost;

@@ -109,6 +109,7 @@ struct ppcr_ctx {
     int opt_sort_source = 1;
     int opt_stamps = 0;
     DevBuf<unsigned long long> d_stamps;
+    size_t stamps_wgs = 0;  // workgroups of the last launch that wrote stamps (its grid, idle split slots included)
 
     // clouds
     int64_t ns = 0, nt = 0;
@@ -502,7 +503,7 @@ constexpr int kAccumBlock = 256;  // threads per block of accumulate_ell_kernel 
 // every s the association can hold (s < radius^2 up to the float rounding of d2 and the f64 re-evaluation at another
 // pose; the factor 4 on the radius covers residuals at a pose other than the one the association was made at).
 struct K23Form {
-    int tm;        // 0 Gaussian, 8 t with v + dim = 8, -1 run-time t model
+    int tm;        // 0 Gaussian, 8 t with v + dim = 8, -3 t with another integer v + dim (one-pass only), -1 run-time t model
     bool onepass;
 };
 K23Form k23_form(const ppcr_ctx *c, const Model &md)
@@ -512,6 +513,7 @@ K23Form k23_form(const ppcr_ctx *c, const Model &md)
     // (v / (v + s))^((v + d) / 2) > 1e-250
     const bool safe = 0.5 * md.vpd * std::log10((md.v + s_max) / md.v) < 250.0;
     if (md.vpd_int == 8) return K23Form{8, safe};
+    if (md.vpd_int != 0 && safe) return K23Form{-3, true};  // -d 3, -d 10, ...: integer power by squaring
     return K23Form{-1, safe};
 }
 
@@ -528,6 +530,8 @@ void launch_accumulate_ell(ppcr_ctx *c, int nb, const Pose &P, const Model &md, 
     } else if (f.tm == 8) {
         if (f.onepass) PPCR_K23(8, true);
         else PPCR_K23(8, false);
+    } else if (f.tm == -3) {
+        PPCR_K23(-3, true);
     } else {
         if (f.onepass) PPCR_K23(-1, true);
         else PPCR_K23(-1, false);
@@ -617,14 +621,16 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             // K23 folded in: only the two compiled-in models in their one-pass form (see launch_accumulate_ell)
             FusedMoments fm;
             const FusedMoments *fuse = nullptr;
+            int fuse_tm = -2;
             if (fuse_R && c->opt_fuse_k23 && c->nt > 0) {
                 const Model md = make_model(c);
                 const K23Form form = k23_form(c, md);
-                if (form.onepass && form.tm >= 0) {
+                if (form.onepass && form.tm != -1) {  // the three forms compiled into K1: Gaussian, v + dim = 8, integer v + dim
                     const int slots = nblocks(ns, 256) + kMaxSplit;
                     HIP_TRY(c, c->partials.reserve((size_t)slots * kNSums));
                     fm.P = make_pose(c, *fuse_R, fuse_t);
                     fm.md = md;
+                    fuse_tm = form.tm;
                     fm.partials = c->partials.p;
                     fm.nslots = slots;
                     fuse = &fm;
@@ -654,12 +660,25 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             tl.nbr = c->nbr.p, tl.cnt = c->cnt.p, tl.dm2 = c->dm2.p;
             tl.dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
             tl.short_lists = c->opt_short_lists;
+            if (c->opt_stamps) {
+                // sized from the grid this launch really has (the steady-state variant adds kMaxSplit workgroups in front):
+                // 8 words per wave, then one word per lane (its sorted run lengths)
+                const size_t nwg = (size_t)nblocks(ns, 256) + kMaxSplit;
+                const size_t nst = (nwg * (kBlock / 64) + 64) * 8 + nwg * 256;
+                if (c->d_stamps.cap < nst) {
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    HIP_TRY(c, c->d_stamps.reserve(nst));
+                }
+                HIP_TRY(c, hipMemsetAsync(c->d_stamps.p, 0, nst * sizeof(unsigned long long), c->stream));
+                c->stamps_wgs = nwg;
+            }
             tl.stamps = c->opt_stamps ? c->d_stamps.p : nullptr;
             tl.ovf_list = c->ovf_list.p;
             tl.ovf_now = c->ovf_state.p + c->ovf_parity, tl.ovf_next = c->ovf_state.p + (c->ovf_parity ^ 1);
             tl.quiet = c->ovf_last == 0;
             tl.split_flag = c->split_flag.p, tl.split_list = c->split_list.p, tl.split_state = c->split_state.p;
             tl.pm = pm, tl.fuse = fuse, tl.fold = fold;
+            tl.fuse_tm = fuse_tm;
             tl.loop_st = loop ? loop->st : nullptr;
             tl.between = [](void *scope) { static_cast<ProfScope *>(scope)->split(K_NN_CLEANUP); };
             tl.between_arg = &ps;
@@ -975,7 +994,8 @@ int collect_step(ppcr_ctx *c, const StepTicket &tk, StepResult &out)
             // a short wait is spun through (an iteration lasts ~0.1 ms); past that the core is offered to whoever
             // else wants it, so many handles driven from more threads than cores do not starve each other
             if (spin > 4096) std::this_thread::yield();
-            if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(c->stream) != hipErrorNotReady) {
+            // (a device fault must not take seconds to surface: look at the stream every 2^16 polls, a few milliseconds)
+            if ((spin & 0xFFFF) == 0xFFFF && hipStreamQuery(c->stream) != hipErrorNotReady) {
                 arrived = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == tk.seq;
                 break;
             }
@@ -991,7 +1011,10 @@ int collect_step(ppcr_ctx *c, const StepTicket &tk, StepResult &out)
         out.status = mb->status;
         out.steps = mb->steps;
         out.cost_init = mb->cost_init;
-        if (out.status != kLaunchSkipped) c->ovf_last = mb->handed_over;
+        if (out.status != kLaunchSkipped) {
+            c->ovf_last = mb->handed_over;
+            c->dbg_host[7] += (double)mb->handed_over;  // workgroups the associations of this ppcr_align handed to the cleanup kernel
+        }
         const double w = std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
         c->dbg_host[0] += 1;
         c->dbg_host[1] += w;
@@ -1046,6 +1069,8 @@ void launch_inner_w(ppcr_ctx *c, const InnerArgs &a, const K23Form &f, int grid)
     } else if (f.tm == 8) {
         if (f.onepass) PPCR_INNER(8, true);
         else PPCR_INNER(8, false);
+    } else if (f.tm == -3) {
+        PPCR_INNER(-3, true);
     } else {
         if (f.onepass) PPCR_INNER(-1, true);
         else PPCR_INNER(-1, false);
@@ -1155,7 +1180,7 @@ int collect_report(ppcr_ctx *c, unsigned seq, double *mse_truth, double *moved)
             break;
         }
         if (spin > 4096) std::this_thread::yield();
-        if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(c->stream) != hipErrorNotReady) {
+        if ((spin & 0xFFFF) == 0xFFFF && hipStreamQuery(c->stream) != hipErrorNotReady) {
             arrived = __atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) == seq;
             break;
         }
@@ -1468,12 +1493,7 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
         c->opt_temporal = value ? 1 : 0;
         return PPCR_OK;
     }
-    if (std::strcmp(key, "stamps") == 0) {  // diagnostic: per-phase cycle totals of nn_fast_kernel
-        // 8 words per wave, then one word per lane (its sorted run lengths)
-        const size_t nwg = (size_t)nblocks(std::max<int64_t>(c->ns, 1)) + kMaxSplit;
-        const size_t nst = (nwg * (kBlock / 64) + 64) * 8 + nwg * 256;
-        HIP_TRY(c, c->d_stamps.reserve(nst));
-        HIP_TRY(c, hipMemsetAsync(c->d_stamps.p, 0, nst * sizeof(unsigned long long), c->stream));
+    if (std::strcmp(key, "stamps") == 0) {  // diagnostic: per-phase cycle totals of nn_fast_kernel (buffer: see associate_impl)
         c->opt_stamps = value;
         return PPCR_OK;
     }
@@ -2253,7 +2273,7 @@ int ppcr_debug_get_stamps(ppcr_ctx *c, unsigned long long out[8])
 {
     CTX_ENTER(c);
     if (!c->d_stamps.p) return fail(c, PPCR_ERR_STATE, "stamps not enabled");
-    const size_t nst = (size_t)(nblocks(std::max<int64_t>(c->ns, 1)) * (kBlock / 64)) * 8;
+    const size_t nst = c->stamps_wgs * (kBlock / 64) * 8;  // every workgroup of the launch (idle split slots wrote zeros)
     std::vector<unsigned long long> h(nst);
     HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_stamps.p, nst * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -2273,8 +2293,8 @@ int ppcr_debug_get_stamps_raw(ppcr_ctx *c, unsigned long long *out, size_t n)
     return PPCR_OK;
 }
 
-// diagnostic: host-side time of the last ppcr_align: {iterations, total wait (s), max wait, total launch+solve, max,
-// max associate call, max reduce launch call, max (accumulate launch + host solve)}
+// diagnostic: host-side figures of the last ppcr_align: {mailbox waits, total wait (s), max wait, -, -, -, max reduce
+// launch call, workgroups its associations handed over to the cleanup kernel (summed over the iterations)}
 int ppcr_debug_get_host_times(ppcr_ctx *c, double out[8])
 {
     CTX_ENTER(c);

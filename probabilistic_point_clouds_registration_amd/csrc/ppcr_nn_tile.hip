@@ -60,15 +60,17 @@ void launch_tile(TileLaunch &t)
         // overflowing lane tightens its threshold and scans again)
         if (t.dm2_in && t.short_lists) {
             steady = true;
-            if (t.fuse && !st) ftm = t.fuse->md.is_normal ? 0 : 8;
+            if (t.fuse && !st) ftm = t.fuse_tm;
             if constexpr (M == 10) {
                 if (st) PPCR_FAST(16, true, -2, fm_none);
                 else if (ftm == 0) PPCR_FAST(16, false, 0, *t.fuse);
                 else if (ftm == 8) PPCR_FAST(16, false, 8, *t.fuse);
+                else if (ftm == -3) PPCR_FAST(16, false, -3, *t.fuse);
                 else PPCR_FAST(16, false, -2, fm_none);
             } else {
                 if (ftm == 0) PPCR_FAST(16, false, 0, *t.fuse);
                 else if (ftm == 8) PPCR_FAST(16, false, 8, *t.fuse);
+                else if (ftm == -3) PPCR_FAST(16, false, -3, *t.fuse);
                 else PPCR_FAST(16, false, -2, fm_none);
             }
             t.fused = ftm != -2;
@@ -100,8 +102,10 @@ void launch_tile(TileLaunch &t)
         n_extra, FMc, FSc)
     if (ftm == 0 && merge) PPCR_CLEANUP(0, *t.fuse, true, fold_now);
     else if (ftm == 8 && merge) PPCR_CLEANUP(8, *t.fuse, true, fold_now);
+    else if (ftm == -3 && merge) PPCR_CLEANUP(-3, *t.fuse, true, fold_now);
     else if (ftm == 0) PPCR_CLEANUP(0, *t.fuse, false, fs_none);
     else if (ftm == 8) PPCR_CLEANUP(8, *t.fuse, false, fs_none);
+    else if (ftm == -3) PPCR_CLEANUP(-3, *t.fuse, false, fs_none);
     else PPCR_CLEANUP(-2, fm_none, false, fs_none);
 #undef PPCR_CLEANUP
 }

@@ -645,7 +645,8 @@ struct LoopReset {
     const LoopState *st;
 };
 
-// FTM >= 0 (0: Gaussian, k: t model with v + dim = k) folds K23 into this kernel: each lane finishes its row's
+// FTM != -2 (0: Gaussian, k > 0: t model with v + dim = k, -3: t model with an integer v + dim read at run time) folds
+// K23 into this kernel: each lane finishes its row's
 // contribution to the 19 moments from the winners' coordinates while they are still in LDS (no neighbour gathers, no
 // second pass over the source, no K23 launch) and the workgroup folds them into fm.partials.  FTM = -2: plain K1.
 template <int M, int C, int CAP, bool STAMPS, int FTM = -2>

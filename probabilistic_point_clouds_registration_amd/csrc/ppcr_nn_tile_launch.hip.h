@@ -30,6 +30,7 @@ struct TileLaunch {
     unsigned *split_state;        // {registrations, registrations visible to extra workgroups}
     dev::PendingMove pm;
     const dev::FusedMoments *fuse;  // fold K23 into K1 at this pose / model when the steady-state variant runs
+    int fuse_tm;                    // ... in this compiled form: 0 Gaussian, 8 t with v + dim = 8, -3 t with another integer v + dim
     const dev::FoldSolve *fold;     // ... and the fold-and-solve step into the cleanup launch
     dev::LoopState *loop_st;        // device-paced loop: every launch steps aside while its abort flag is up (nullable)
     void (*between)(void *);        // called between the two launches (profiling scopes), may be null

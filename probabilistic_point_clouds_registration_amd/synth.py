@@ -23,6 +23,9 @@ CONFIGS = {
     3: dict(n=1_000_000, max_neighbours=10, dof=5.0, radius=1.0),
     4: dict(n=1_000_000, max_neighbours=10, dof=float("inf"), radius=1.0),
     5: dict(n=250_000, max_neighbours=10, dof=5.0, radius=1.0, pairs=64),
+    # "4b": config 4's companion for the other weight models the CLI reaches (-d 3: v + dim = 6; the same clouds as 3)
+    6: dict(n=1_000_000, max_neighbours=10, dof=3.0, radius=1.0, clouds=3),
+    7: dict(n=1_000_000, max_neighbours=10, dof=10.0, radius=1.0, clouds=3),
 }
 
 

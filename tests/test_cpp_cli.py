@@ -114,6 +114,10 @@ def test_cli_argument_errors_exit_like_the_reference(programs):
     assert r.returncode == 1 and "Could not read the pair list" in r.stdout
     r = subprocess.run([cli, "--batch", "list.txt", "--lanes", "0"], capture_output=True, text=True)
     assert r.returncode == 1 and "--lanes must be at least 1" in r.stderr
+    # what the batch entry point cannot honour is refused, not dropped (round-2 advisor): filters, ground truth, report
+    for extra, flag in ((["-s", "0.5"], "-s"), (["-t", "0.5"], "-t"), (["-g", "gt.pcd"], "-g"), (["--dump"], "--dump")):
+        r = subprocess.run([cli, "--batch", "list.txt"] + extra, capture_output=True, text=True)
+        assert r.returncode == 1 and "single-pair form" in r.stderr and f"for arg {flag}" in r.stderr, r.stderr
 
 
 def test_cli_refuses_malformed_pcd_headers(programs, tmp_path):

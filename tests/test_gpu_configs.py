@@ -109,3 +109,93 @@ def test_config4_gaussian_1m_align_vs_oracle():
         o2 = po.align(src, tgt, 1.0, 10, cfg["dof"], 1, inner_max_steps=100, f_tol=10e-6)
         assert r2["inner_steps"][0] == o2["inner_steps"][0] > 1
         assert _close(r2["history"][0], o2["history"][0])
+
+
+def _moved_by(src, steps):
+    """the source after the given per-iteration increments, with the reference's f64 -> f32 move (cc:110-112)"""
+    cur = np.ascontiguousarray(src[:, :3]).copy()
+    for T in steps:
+        po.transform_cloud(cur, np.vstack([T, [0, 0, 0, 1]]))
+    return cur
+
+
+@pytest.mark.parametrize("cfg_id,pair", [(3, 0), (5, 11)])
+def test_timed_instantiation_association_vs_oracle(cfg_id, pair):
+    """The kernel the benchmark times — nn_fast_kernel<..., 8>: steady-state K1 with the previous move in its prologue
+    and K23 folded in, reached only through a pipelined ppcr_align — compared NEIGHBOUR FOR NEIGHBOUR (round-2 review):
+    after a pipelined align(5) the handle holds the association made by iteration 4 on the source as moved by the first
+    four increments; it must equal the oracle's search on that cloud, at 1M (configs[2]) and 250k (configs[4])."""
+    cfg = synth.CONFIGS[cfg_id]
+    src, tgt, _, _ = synth.make_pair(cfg["n"], cfg=cfg_id, pair=pair)
+    with _lib.Context(0) as c:
+        c.set_params(cfg["radius"], cfg["max_neighbours"], cfg["dof"], 3)
+        c.set_target(tgt)
+        c.set_source(src)
+        rep = c.align_report(5, cost_drop_thresh=0.0, inner_steps=1)
+        assert rep["n_iter"] == 5
+        rp, col, _ = c.get_association(want_d2=False)
+    cur = _moved_by(src, [r["T_step"] for r in rep["iterations"][:4]])
+    orp, ocol, _ = po.radius_search(cur, tgt[:, :3], cfg["radius"], cfg["max_neighbours"], method=1)
+    np.testing.assert_array_equal(rp, orp)
+    np.testing.assert_array_equal(col, ocol)
+
+
+def test_fused_association_with_handovers_on_a_clustered_cloud():
+    """The same on a strongly non-uniform cloud (blobs of very different densities far from the origin), where halos
+    outgrow the steady-state capacity: blocks are split and HANDED OVER to the cleanup kernel while K23 is folded in (the
+    count of handed-over workgroups is read back: the test proves nothing without one).  Per-iteration transforms follow
+    the oracle, the last association equals the oracle's."""
+    rng = np.random.default_rng(21)
+    centres = rng.uniform(-40, 40, size=(30, 3)) + np.array([800.0, -300.0, 50.0])
+    parts = [c + rng.normal(0, s, size=(n, 3)) for c, s, n in zip(centres, rng.uniform(0.2, 4.0, 30), rng.integers(500, 6000, 30))]
+    parts.append(rng.uniform(-60, 60, size=(5000, 3)) + np.array([800.0, -300.0, 50.0]))
+    tgt = np.concatenate(parts).astype(np.float32)
+    Rg = synth.rodrigues([0.2, -1.0, 0.4], 0.004)
+    src = ((tgt[rng.permutation(len(tgt))[:60000]].astype(np.float64) - [0.05, -0.02, 0.03]) @ Rg
+           + rng.normal(0, 0.01, size=(60000, 3))).astype(np.float32)
+    n_it = 9
+    with _lib.Context(0) as c:
+        c.set_params(1.0, 10, 5.0, 3)
+        c.set_target(tgt)
+        c.set_source(src)
+        rep = c.align_report(n_it, cost_drop_thresh=0.0, inner_steps=1)
+        handed = c.debug_host_figures()[7]
+        rp, col, _ = c.get_association(want_d2=False)
+    assert handed > 0, "no workgroup was handed over: choose a denser cloud"
+    ora = po.align(src, tgt, 1.0, 10, 5.0, n_it, inner_max_steps=1)
+    Tc = np.eye(4)
+    for k, row in enumerate(rep["iterations"]):
+        Tc = np.vstack([row["T_step"], [0, 0, 0, 1]]) @ Tc
+        assert synth.rotation_angle(Tc[:3, :3], ora["history"][k][:, :3]) < 1e-8, k
+        assert np.linalg.norm(Tc[:3, 3] - ora["history"][k][:, 3]) < 1e-7, k       # coordinates ~800
+    cur = _moved_by(src, [r["T_step"] for r in rep["iterations"][:n_it - 1]])
+    orp, ocol, _ = po.radius_search(cur, tgt, 1.0, 10, method=1)
+    np.testing.assert_array_equal(rp, orp)
+    np.testing.assert_array_equal(col, ocol)
+
+
+def test_cli_default_shape_through_align():
+    """The command line's own defaults (radius 3, max_neighbours 20, inner loop to function_tolerance; ..._ex.cc:43-49)
+    on a non-uniform 200k cloud: 20-wide lists have no steady-state K1 variant, so the device-paced loop runs on separate
+    launches; per-iteration transforms, costs and inner step counts follow the oracle."""
+    rng = np.random.default_rng(33)
+    n = 200_000
+    # a slab with a density gradient along x plus a few dense blobs
+    x = rng.beta(2.0, 5.0, size=n) * 160.0
+    base = np.stack([x, rng.uniform(0, 80, n), rng.uniform(0, 12, n)], axis=1)
+    blobs = np.concatenate([c + rng.normal(0, 1.5, size=(6000, 3)) for c in rng.uniform([20, 10, 2], [140, 70, 10], size=(5, 3))])
+    tgt = np.concatenate([base[: n - len(blobs)], blobs]).astype(np.float32)
+    Rg = synth.rodrigues([0.1, 0.3, 1.0], 0.01)
+    src = ((tgt[rng.permutation(n)].astype(np.float64) - [0.3, -0.2, 0.1]) @ Rg + rng.normal(0, 0.02, size=(n, 3))).astype(np.float32)
+    with _lib.Context(0) as c:
+        c.set_params(3.0, 20, 5.0, 3)
+        c.set_target(tgt)
+        c.set_source(src)
+        res = c.align(4, cost_drop_thresh=0.0, inner_steps=100, f_tol=10e-6)
+    ora = po.align(src, tgt, 3.0, 20, 5.0, 4, cost_drop_thresh=0.0, inner_max_steps=100, f_tol=10e-6)
+    assert res["n_iter"] == ora["n_iter"] == 4
+    np.testing.assert_array_equal(res["inner_steps"], ora["inner_steps"])
+    for k in range(4):
+        assert synth.rotation_angle(res["history"][k][:, :3], ora["history"][k][:, :3]) < 1e-8, k
+        assert np.linalg.norm(res["history"][k][:, 3] - ora["history"][k][:, 3]) < 1e-7, k
+    np.testing.assert_allclose(res["costs"], ora["costs"], rtol=1e-8)

@@ -35,7 +35,7 @@ def _run(src, tgt, opts, m=10, dof=5.0, radius=1.0, companion=None, **align_kw):
     return res, moved, comp
 
 
-@pytest.mark.parametrize("dof", [5.0, float("inf"), 3.0, 3.5])
+@pytest.mark.parametrize("dof", [5.0, float("inf"), 3.0, 10.0, 3.5])
 def test_device_paced_inner_loop_is_the_host_paced_loop(dof):
     """inner_steps > 1: the device decides about the inner loop (LoopCtl in the fold-and-solve lane) and walks the later
     IRLS steps itself (inner_steps_kernel).  With the same kernels on both sides (fuse_k23 = 0) histories, costs, step
