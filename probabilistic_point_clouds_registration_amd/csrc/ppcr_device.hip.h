@@ -544,74 +544,124 @@ __device__ __forceinline__ void swap_cols(double (&w)[3][3], double (&v)[3][3], 
     }
 }
 
-// Rotation of the weighted Kabsch problem by Newton's iteration for the polar decomposition,
-//     X <- (z X + X^-T / z) / 2,   z = sqrt(|X^-1|_F / |X|_F),   X_0 = H^T,
-// which converges quadratically to the orthogonal factor V U^T of H^T = V S U^T: the same R as the SVD route whenever
-// det H > 0 (no reflection to repair) — i.e. for every well-posed registration.  An iteration is a 3x3 adjugate with
-// all nine cofactors independent, so the dependent chain is ~a dozen operations (a Jacobi sweep is three rotations of
-// ~70 dependent operations each).  Returns false (and the caller takes the Jacobi SVD route with its rank handling)
-// when H is singular to working precision, contains a reflection, or the iteration has not settled.
-__device__ __forceinline__ bool polar_rotation(const double (&h)[3][3], double (&R)[9])
+// Rotation of the weighted Kabsch problem (R maximising trace(R H), H = sum w (x - mx)(y - my)^T) on ONE lane with the
+// whole chip waiting, so written for the length of its dependent chain:
+//   1. Horn's quaternion form: the optimal unit quaternion is the eigenvector of the symmetric 4x4 matrix N(H) for its
+//      largest eigenvalue; the eigenvalue by Newton's iteration on the characteristic quartic l^4 + c2 l^2 + c1 l + c0
+//      (trace N = 0) from the upper bound (Gx + Gy) / 2 — the start is within the residual of the root, two or three
+//      iterations of eight operations (Theobald's QCP); the eigenvector as the largest column of adj(N - l I), ten 3x3
+//      cofactors that are all independent of each other;
+//   2. ONE Newton step on SO(3) for the same objective (R H must be symmetric at the optimum): it squares the error of
+//      step 1, which is eps / (eigenvalue gap): 1e-12 for thin clouds, 1e-16 typically (checked against an SVD on
+//      4000 random weighted problems: worst 2e-13 rad, the conditioning of those problems).
+// About 150 dependent operations where the scaled Newton iteration for the polar factor (round 2) needed ~90 per
+// iteration and five to seven iterations.  Handles reflections (det H < 0) by itself.  Returns false — and the caller
+// takes the Jacobi SVD route with its rank handling — when the largest eigenvalue is (numerically) not simple: planar,
+// collinear or empty clouds.
+__device__ __forceinline__ double det3_rows(double a0, double a1, double a2, double b0, double b1, double b2, double c0, double c1, double c2)
 {
-    double x[3][3];
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int b = 0; b < 3; b++) x[a][b] = h[b][a];
+    return a0 * (b1 * c2 - b2 * c1) - a1 * (b0 * c2 - b2 * c0) + a2 * (b0 * c1 - b1 * c0);
+}
+__device__ __forceinline__ void quat_to_R(double w, double x, double y, double z, double (&R)[9])
+{
+    const double ww = w * w, xx = x * x, yy = y * y, zz = z * z;
+    const double xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+    R[0] = ww + xx - yy - zz, R[1] = 2.0 * (xy - wz), R[2] = 2.0 * (xz + wy);
+    R[3] = 2.0 * (xy + wz), R[4] = ww - xx + yy - zz, R[5] = 2.0 * (yz - wx);
+    R[6] = 2.0 * (xz - wy), R[7] = 2.0 * (yz + wx), R[8] = ww - xx - yy + zz;
+}
+__device__ __forceinline__ bool quaternion_rotation(const double (&h)[3][3], double G, double (&R)[9])
+{
+    if (!(G > 0) || !isfinite(G)) return false;
+    const double iG = fast_rcp(G);
+    const double Sxx = h[0][0] * iG, Sxy = h[0][1] * iG, Sxz = h[0][2] * iG;
+    const double Syx = h[1][0] * iG, Syy = h[1][1] * iG, Syz = h[1][2] * iG;
+    const double Szx = h[2][0] * iG, Szy = h[2][1] * iG, Szz = h[2][2] * iG;
+    // N (symmetric): n00 n01 n02 n03 / n11 n12 n13 / n22 n23 / n33
+    const double n00 = Sxx + Syy + Szz, n01 = Syz - Szy, n02 = Szx - Sxz, n03 = Sxy - Syx;
+    const double n11 = Sxx - Syy - Szz, n12 = Sxy + Syx, n13 = Szx + Sxz;
+    const double n22 = -Sxx + Syy - Szz, n23 = Syz + Szy;
+    const double n33 = -Sxx - Syy + Szz;
+    const double c2 = -2.0 * (((Sxx * Sxx + Sxy * Sxy) + (Sxz * Sxz + Syx * Syx)) + ((Syy * Syy + Syz * Syz) + (Szx * Szx + Szy * Szy)) + Szz * Szz);
+    const double c1 = -8.0 * det3_rows(Sxx, Sxy, Sxz, Syx, Syy, Syz, Szx, Szy, Szz);
+    // det N by cofactors of its first row
+    const double c0 = n00 * det3_rows(n11, n12, n13, n12, n22, n23, n13, n23, n33) - n01 * det3_rows(n01, n12, n13, n02, n22, n23, n03, n23, n33) +
+                      n02 * det3_rows(n01, n11, n13, n02, n12, n23, n03, n13, n33) - n03 * det3_rows(n01, n11, n12, n02, n12, n22, n03, n13, n23);
+    // lam = 1 is (Gx + Gy) / 2 in these units: an upper bound of the largest root, and within the fit's residual of it;
+    // Newton descends onto the root monotonically (two or three steps for a registration that fits, more for a poor
+    // fit).  Steps with the raw v_rcp_f64 seed (1e-8: it only scales the step), stopped at a relative 1e-9: whatever
+    // error is left in lam reaches the eigenvector divided by the eigenvalue gap, and the Newton step on SO(3) below
+    // squares it.
+    double lam = 1.0;
     bool settled = false;
-    for (int it = 0; it < 24; ++it) {
-        double cf[3][3];  // cofactors: X^-T = cf / det
-        cf[0][0] = x[1][1] * x[2][2] - x[1][2] * x[2][1];
-        cf[0][1] = x[1][2] * x[2][0] - x[1][0] * x[2][2];
-        cf[0][2] = x[1][0] * x[2][1] - x[1][1] * x[2][0];
-        cf[1][0] = x[0][2] * x[2][1] - x[0][1] * x[2][2];
-        cf[1][1] = x[0][0] * x[2][2] - x[0][2] * x[2][0];
-        cf[1][2] = x[0][1] * x[2][0] - x[0][0] * x[2][1];
-        cf[2][0] = x[0][1] * x[1][2] - x[0][2] * x[1][1];
-        cf[2][1] = x[0][2] * x[1][0] - x[0][0] * x[1][2];
-        cf[2][2] = x[0][0] * x[1][1] - x[0][1] * x[1][0];
-        const double det = x[0][0] * cf[0][0] + x[0][1] * cf[0][1] + x[0][2] * cf[0][2];
-        double nx = 0, nc = 0;
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) {
-                nx = fma(x[a][b], x[a][b], nx);
-                nc = fma(cf[a][b], cf[a][b], nc);
-            }
-        // well conditioned and orientation preserving?  (|X|_F^3 bounds |det|; 1e-9 leaves cond(H) up to ~1e4-1e9 here)
-        // Roots by the v_rsq_f64 seed alone (~1e-8): a threshold and a scaling factor do not need more — the scaling
-        // only steers the convergence, the fixed point X = X^-T does not depend on it as long as z and 1/z agree —
-        // and an IEEE f64 sqrt is ~25 dependent instructions on the one lane everybody is waiting for.
-        const double rs_nx = __builtin_amdgcn_rsq(nx);
-        if (!(det * (rs_nx * rs_nx * rs_nx) > 1e-9)) return false;
-        const double idet = fast_rcp(det);
-        // z^2 = |X^-T|_F / |X|_F = sqrt(nc) / (det sqrt(nx))
-        const double z2 = (nc * __builtin_amdgcn_rsq(nc)) * idet * rs_nx;
-        const double z = z2 * __builtin_amdgcn_rsq(z2), a_x = 0.5 * z, a_c = 0.5 * idet * fast_rcp(z);
-        double diff = 0, nn = 0;
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) {
-                const double nv = a_x * x[a][b] + a_c * cf[a][b];
-                const double d = nv - x[a][b];
-                diff = fma(d, d, diff);
-                nn = fma(nv, nv, nn);
-                x[a][b] = nv;
-            }
-        // |X_{k+1} - X_k| <= 1e-8 |X|: the convergence is quadratic, so X_{k+1} is already within ~1e-16 of the
-        // orthogonal factor — no further iteration just to see nothing change
-        if (diff <= 1e-16 * nn) {
+    for (int it = 0; it < 48; ++it) {
+        const double l2 = lam * lam;
+        const double P = (l2 + c2) * l2 + (c1 * lam + c0);
+        const double dP = (4.0 * l2 + 2.0 * c2) * lam + c1;
+        const double d = P * __builtin_amdgcn_rcp(dP);
+        lam -= d;
+        if (fabs(d) <= 1e-9 * fabs(lam)) {
             settled = true;
             break;
         }
     }
+    if (!settled || !isfinite(lam)) return false;
+    // A = N - lam I; its adjugate is (up to scale) q q^T: take the column with the largest diagonal cofactor
+    const double a00 = n00 - lam, a11 = n11 - lam, a22 = n22 - lam, a33 = n33 - lam;
+    const double d0 = det3_rows(a11, n12, n13, n12, a22, n23, n13, n23, a33);
+    const double d1 = det3_rows(a00, n02, n03, n02, a22, n23, n03, n23, a33);
+    const double d2 = det3_rows(a00, n01, n03, n01, a11, n13, n03, n13, a33);
+    const double d3 = det3_rows(a00, n01, n02, n01, a11, n12, n02, n12, a22);
+    // off-diagonal cofactors C_rc = (-1)^(r+c) det(A without row r and column c)
+    const double k01 = -det3_rows(n01, n12, n13, n02, a22, n23, n03, n23, a33);
+    const double k02 = det3_rows(n01, a11, n13, n02, n12, n23, n03, n13, a33);
+    const double k03 = -det3_rows(n01, a11, n12, n02, n12, a22, n03, n13, n23);
+    const double k12 = -det3_rows(a00, n01, n03, n02, n12, n23, n03, n13, a33);
+    const double k13 = det3_rows(a00, n01, n02, n02, n12, a22, n03, n13, n23);
+    const double k23 = -det3_rows(a00, n01, n02, n01, a11, n12, n03, n13, n23);
+    const double m0 = fabs(d0), m1 = fabs(d1), m2 = fabs(d2), m3 = fabs(d3);
+    double qw, qx, qy, qz, dm;
+    if (m0 >= m1 && m0 >= m2 && m0 >= m3) qw = d0, qx = k01, qy = k02, qz = k03, dm = m0;
+    else if (m1 >= m2 && m1 >= m3) qw = k01, qx = d1, qy = k12, qz = k13, dm = m1;
+    else if (m2 >= m3) qw = k02, qx = k12, qy = d2, qz = k23, dm = m2;
+    else qw = k03, qx = k13, qy = k23, qz = d3, dm = m3;
+    if (!(dm > 1e-10)) return false;  // adj ~ 0: the largest eigenvalue is (nearly) double — rank-deficient H
+    const double qn = fast_rsqrt((qw * qw + qx * qx) + (qy * qy + qz * qz));
+    double R0[9];
+    quat_to_R(qw * qn, qx * qn, qy * qn, qz * qn, R0);
+    // Newton step on SO(3): M = R0 S must become symmetric; omega = (tr(M) I - sym(M))^-1 axial(M^T - M)
+    double M[3][3];
 #pragma unroll
-    for (int a = 0; a < 3; a++)
+    for (int r = 0; r < 3; r++) {
+        M[r][0] = R0[3 * r] * Sxx + R0[3 * r + 1] * Syx + R0[3 * r + 2] * Szx;
+        M[r][1] = R0[3 * r] * Sxy + R0[3 * r + 1] * Syy + R0[3 * r + 2] * Szy;
+        M[r][2] = R0[3 * r] * Sxz + R0[3 * r + 1] * Syz + R0[3 * r + 2] * Szz;
+    }
+    const double tr = M[0][0] + M[1][1] + M[2][2];
+    const double b00 = tr - M[0][0], b11 = tr - M[1][1], b22 = tr - M[2][2];
+    const double b01 = -0.5 * (M[0][1] + M[1][0]), b02 = -0.5 * (M[0][2] + M[2][0]), b12 = -0.5 * (M[1][2] + M[2][1]);
+    const double ax = M[1][2] - M[2][1], ay = M[2][0] - M[0][2], az = M[0][1] - M[1][0];
+    // symmetric 3x3 solve by cofactors
+    const double e00 = b11 * b22 - b12 * b12, e01 = b02 * b12 - b01 * b22, e02 = b01 * b12 - b02 * b11;
+    const double e11 = b00 * b22 - b02 * b02, e12 = b01 * b02 - b00 * b12, e22 = b00 * b11 - b01 * b01;
+    const double detB = b00 * e00 + b01 * e01 + b02 * e02;
+    if (!(fabs(detB) > 1e-300)) return false;
+    const double iB = __builtin_amdgcn_rcp(detB);  // (omega is a correction of ~1e-6 .. 1e-12: a 1e-8 relative error in it is nothing)
+    const double ox = (e00 * ax + e01 * ay + e02 * az) * iB, oy = (e01 * ax + e11 * ay + e12 * az) * iB,
+                 oz = (e02 * ax + e12 * ay + e22 * az) * iB;
+    // retraction exp([omega]x) ~ the rotation of the unit quaternion (1, omega / 2) / |.|  (omega is ~1e-12 .. 1e-6)
+    const double hx = 0.5 * ox, hy = 0.5 * oy, hz = 0.5 * oz;
+    const double hn = fast_rsqrt(1.0 + (hx * hx + hy * hy + hz * hz));
+    double dR[9];
+    quat_to_R(hn, hx * hn, hy * hn, hz * hn, dR);
 #pragma unroll
-        for (int b = 0; b < 3; b++) R[3 * a + b] = x[a][b];
-    return settled;
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) R[3 * r + c] = dR[3 * r] * R0[c] + dR[3 * r + 1] * R0[3 + c] + dR[3 * r + 2] * R0[6 + c];
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < 9; k++) finite = finite && isfinite(R[k]);
+    return finite;
 }
 
 // S points to the 19 moments.  Two uses: a plain pointer to a register array (the fold kernels, where the solve sits on
@@ -646,7 +696,10 @@ __device__ inline DeviceSolve solve_rigid_device(SumsPtr S, const double (&c)[3]
     {
         double h[3][3];
         load_H(h);
-        polar_ok = polar_rotation(h, out.R);
+        // (Gx + Gy) / 2 with Gx = sum w |x - mx|^2 = S17 - |S1..3|^2 / W, Gy likewise: bounds the largest eigenvalue
+        const double s1 = S[1], s2 = S[2], s3 = S[3], s4 = S[4], s5 = S[5], s6 = S[6];
+        const double G = 0.5 * ((S[17] + S[18]) - ((s1 * s1 + s2 * s2 + s3 * s3) + (s4 * s4 + s5 * s5 + s6 * s6)) * iW);
+        polar_ok = quaternion_rotation(h, G, out.R);
     }
     if (!polar_ok) {
     double w[3][3], v[3][3];  // w = H, columns rotated in place; v accumulates V
@@ -809,6 +862,7 @@ struct FoldSolve {  // everything the fold-and-solve step needs
     const unsigned *split_total;
     unsigned *split_visible;
     LoopCtl loop;
+    unsigned long long *dbg;  // diagnostic (nullable): wall-clock stamps of the solve lane
 };
 
 // a launch that steps aside still owes the host its mailbox slot (the host counts sequence numbers)
@@ -827,28 +881,35 @@ template <bool LEAN = false>
 __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int sum_index)
 {
     __shared__ double sh[kBlock / 64];
+    const unsigned long long t_entry = fs.dbg ? wall_clock64() : 0ull;
     const double *row = fs.partials + (size_t)sum_index * fs.nslots;
     double v = 0.0;
-    for (int b0 = 0; b0 < fs.nslots; b0 += 8 * kBlock) {
-        double t[8];
+    // sixteen loads per lane in flight (4096 slots: ONE memory round trip at 1M points), added in slot order
+    for (int b0 = 0; b0 < fs.nslots; b0 += 16 * kBlock) {
+        double t[16];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < 16; u++) {
             const int b = b0 + u * kBlock + threadIdx.x;
             t[u] = (b < fs.nslots) ? row[b] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) v += t[u];
+        for (int u = 0; u < 16; u++) v += t[u];
     }
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x != 0) return false;
+    const unsigned long long t_folded = fs.dbg ? wall_clock64() : 0ull;
     double x = sh[0];
     for (int w = 1; w < kBlock / 64; w++) x += sh[w];
+    // The sum travels as an agent-scope atomic store (written through to the memory side) and is waited for before the
+    // ticket is drawn; the ticket itself is relaxed.  (A release fence + acq_rel ticket, as in round 2, write back and
+    // invalidate the whole L2 for the sake of one double: ~2 us on the outer loop's critical path.)
     __hip_atomic_store(&fs.sums[sum_index], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __atomic_thread_fence(__ATOMIC_RELEASE);
-    const unsigned tk = __hip_atomic_fetch_add(fs.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned tk = __hip_atomic_fetch_add(fs.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tk != kNSums - 1) return false;
+    const unsigned long long t_ticket = fs.dbg ? wall_clock64() : 0ull;
     __hip_atomic_store(fs.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(fs.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every fold block is past its wait
     if constexpr (LEAN) {
@@ -860,7 +921,15 @@ __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int su
         double S[kNSums];
 #pragma unroll
         for (int j = 0; j < kNSums; j++) S[j] = __hip_atomic_load(&fs.sums[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fs.dbg) {
+            __builtin_amdgcn_s_waitcnt(0);
+            fs.dbg[0] = t_entry, fs.dbg[1] = t_folded, fs.dbg[2] = t_ticket, fs.dbg[3] = wall_clock64();
+        }
         solve_and_publish(fs, static_cast<const double *>(S));
+        if (fs.dbg) {
+            __builtin_amdgcn_s_waitcnt(0);
+            fs.dbg[5] = wall_clock64();
+        }
     }
     return true;
 }
@@ -870,8 +939,20 @@ __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int su
 template <class SumsPtr>
 __device__ __forceinline__ void solve_and_publish(const FoldSolve &fs, SumsPtr S)
 {
+    // what the publication needs from device memory is asked for BEFORE the solve, so that these round trips (~0.5 us
+    // each, and dependent on nothing) run under it instead of behind it
+    const unsigned split_total = fs.split_visible ? min(*fs.split_total, 64u) : 0u;
+    const unsigned split_seen = fs.split_visible ? *fs.split_visible : 0u;
+    const unsigned handed = fs.handed_over ? *fs.handed_over : 0u;
+    int prev_steps = 0;
+    double prev_cost_init = 0.0;
+    if (fs.loop.st != nullptr && !fs.loop.first) {
+        prev_steps = fs.loop.st->steps;
+        prev_cost_init = fs.loop.st->cost_init;
+    }
     const double c[3] = {fs.origin.x, fs.origin.y, fs.origin.z};
     const DeviceSolve rs = solve_rigid_device(S, c);
+    if (fs.dbg) fs.dbg[4] = wall_clock64();
 #pragma unroll
     for (int a = 0; a < 3; a++) {
 #pragma unroll
@@ -889,8 +970,8 @@ __device__ __forceinline__ void solve_and_publish(const FoldSolve &fs, SumsPtr S
     }
     // new registrations only (most launches bring none: then the list is sorted and published already, and walking it
     // would be a chain of dependent loads on the lane the next launch is waiting for)
-    if (fs.split_visible && min(*fs.split_total, 64u) != *fs.split_visible) {
-        const int n_split = (int)min(*fs.split_total, 64u);
+    if (fs.split_visible && split_total != split_seen) {
+        const int n_split = (int)split_total;
         for (int a = 1; a < n_split; a++) {  // insertion sort: the list is nearly sorted, at most 64 long
             const int key = fs.split_list[a];
             int b = a - 1;
@@ -907,8 +988,8 @@ __device__ __forceinline__ void solve_and_publish(const FoldSolve &fs, SumsPtr S
         LoopState *st = fs.loop.st;
         const double cost_old = 0.5 * S[16];
         const double fc = rs.degenerate ? cost_old : rs.cost;
-        const int steps = fs.loop.first ? 1 : st->steps + 1;
-        const double c0 = fs.loop.first ? cost_old : st->cost_init;
+        const int steps = fs.loop.first ? 1 : prev_steps + 1;
+        const double c0 = fs.loop.first ? cost_old : prev_cost_init;
         const bool fin = rs.degenerate || steps >= fs.loop.max_steps ||
                          (cost_old - fc) <= fmax(fs.loop.f_tol * cost_old, 1e-14 * 0.5 * (S[17] + S[18]));
         st->steps = steps;
@@ -929,7 +1010,7 @@ __device__ __forceinline__ void solve_and_publish(const FoldSolve &fs, SumsPtr S
     fs.mbox->cost = rs.cost;
     fs.mbox->status = status;
     fs.mbox->degenerate = rs.degenerate ? 1u : 0u;
-    fs.mbox->handed_over = fs.handed_over ? *fs.handed_over : 0u;
+    fs.mbox->handed_over = handed;
     __hip_atomic_store(&fs.mbox->seq, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

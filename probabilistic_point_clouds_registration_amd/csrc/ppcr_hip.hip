@@ -165,6 +165,8 @@ struct ppcr_ctx {
     // device-paced inner loop (ppcr_align with inner_steps > 1): see LoopState / inner_steps_kernel
     DevBuf<LoopState> d_loop;
     DevBuf<unsigned> d_inner_ctl;      // [0] step_done, [1 ..] completion flags of inner_steps_kernel's K23 workgroups
+    int opt_fold_stamps = 0;           // diagnostic: the solve lane leaves wall-clock stamps (ppcr_debug_get_fold_stamps)
+    DevBuf<unsigned long long> d_fold_dbg;
     int opt_inner_dev_steps = 3;       // IRLS steps 2.. the device may take on its own per outer iteration (<= kMaxDevSteps)
     // what inner_steps_kernel reads from device memory instead of taking it as kernel arguments, and the host's copy
     DevBuf<InnerConst> d_inner_const;
@@ -899,6 +901,7 @@ int prepare_fold(ppcr_ctx *c, int nslots, StepTicket &tk, FoldSolve &fs, const L
     fs.split_flag = c->split_clean ? c->split_flag.p : nullptr;
     fs.split_total = c->split_clean ? c->split_state.p : nullptr;
     fs.split_visible = c->split_clean ? c->split_state.p + 1 : nullptr;
+    fs.dbg = c->opt_fold_stamps ? c->d_fold_dbg.p : nullptr;
     if (loop) {
         fs.loop = *loop;
     } else {
@@ -1404,6 +1407,7 @@ int ppcr_destroy(ppcr_ctx *c)
     c->d_s.release();
     c->mse_part.release();
     c->d_loop.release();
+    c->d_fold_dbg.release();
     c->d_inner_const.release();
     c->d_inner_ctl.release();
     c->track_part.release();
@@ -1478,6 +1482,12 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
     }
     if (std::strcmp(key, "defer_moves") == 0) {
         c->opt_defer_moves = value ? 1 : 0;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "fold_stamps") == 0) {
+        HIP_TRY(c, c->d_fold_dbg.reserve(8));
+        HIP_TRY(c, hipMemsetAsync(c->d_fold_dbg.p, 0, 8 * sizeof(unsigned long long), c->stream));
+        c->opt_fold_stamps = value ? 1 : 0;
         return PPCR_OK;
     }
     if (std::strcmp(key, "inner_dev_steps") == 0) {
@@ -2279,6 +2289,17 @@ int ppcr_debug_get_stamps(ppcr_ctx *c, unsigned long long out[8])
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int k = 0; k < 8; k++) out[k] = 0;
     for (size_t i = 0; i < nst; i++) out[i % 8] += h[i];
+    return PPCR_OK;
+}
+
+// diagnostic: wall-clock stamps (100 MHz) of the last fold-and-solve: {entry of the solving block, folded, ticket drawn,
+// sums read back, solved, published}
+int ppcr_debug_get_fold_stamps(ppcr_ctx *c, unsigned long long out[8])
+{
+    CTX_ENTER(c);
+    if (!c->d_fold_dbg.p) return fail(c, PPCR_ERR_STATE, "fold_stamps not enabled");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->d_fold_dbg.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PPCR_OK;
 }
 
