@@ -885,15 +885,17 @@ __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int su
     const double *row = fs.partials + (size_t)sum_index * fs.nslots;
     double v = 0.0;
     // sixteen loads per lane in flight (4096 slots: ONE memory round trip at 1M points), added in slot order
-    for (int b0 = 0; b0 < fs.nslots; b0 += 16 * kBlock) {
-        double t[16];
+    // (LEAN: eight — inner_steps_kernel has at most 2048 slots, and registers to save)
+    constexpr int kInFlight = LEAN ? 8 : 16;
+    for (int b0 = 0; b0 < fs.nslots; b0 += kInFlight * kBlock) {
+        double t[kInFlight];
 #pragma unroll
-        for (int u = 0; u < 16; u++) {
+        for (int u = 0; u < kInFlight; u++) {
             const int b = b0 + u * kBlock + threadIdx.x;
             t[u] = (b < fs.nslots) ? row[b] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 16; u++) v += t[u];
+        for (int u = 0; u < kInFlight; u++) v += t[u];
     }
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
@@ -916,7 +918,15 @@ __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int su
         __shared__ double s_S[kNSums];  // the moments for the one lane that solves (see solve_rigid_device)
 #pragma unroll
         for (int j = 0; j < kNSums; j++) s_S[j] = __hip_atomic_load(&fs.sums[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fs.dbg) {
+            __builtin_amdgcn_s_waitcnt(0);
+            fs.dbg[0] = t_entry, fs.dbg[1] = t_folded, fs.dbg[2] = t_ticket, fs.dbg[3] = wall_clock64();
+        }
         solve_and_publish(fs, static_cast<const volatile double *>(s_S));
+        if (fs.dbg) {
+            __builtin_amdgcn_s_waitcnt(0);
+            fs.dbg[5] = wall_clock64();
+        }
     } else {
         double S[kNSums];
 #pragma unroll

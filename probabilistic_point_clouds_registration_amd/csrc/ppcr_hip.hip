@@ -1089,7 +1089,9 @@ int launch_inner(ppcr_ctx *c, const StepTicket &tk, const LoopCtl &loop, int n_d
     // about five K23 workgroups per CU at a time, every one with the same number of tiles (+-1): the launch carries
     // n_dev_steps * (G + 19) workgroups that all have to start and look at the loop state even when step 1 ended the
     // loop (the common case), so G is not simply ntiles (3 x 3926 idle workgroups cost ~15 us per iteration at 1M)
-    const int per_wg = std::max(1, (ntiles + 1399) / 1400);
+    // (and one step's G + 19 workgroups must be resident TOGETHER — five per CU, 1280 — or the step takes two rounds:
+    //  1303 + 19 of them cost 57 us per step, 977 + 19 cost 48)
+    const int per_wg = std::max(1, (ntiles + 1199) / 1200);
     const int G = std::max(1, std::min((ntiles + per_wg - 1) / per_wg, kInnerMaxG));
     HIP_TRY(c, c->partials.reserve((size_t)std::max(G, nblocks(ns, 256) + kMaxSplit) * kNSums));
     InnerArgs a;

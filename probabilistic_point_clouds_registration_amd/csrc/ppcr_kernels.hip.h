@@ -323,38 +323,56 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(A a, const float4 *_
 // stays in registers (the two-pass form keeps s[W] and the centred points: 130 VGPRs, three waves per SIMD).  The host
 // picks it only when that ratio cannot underflow for any s below radius^2; the weights w = g / Z are the same numbers
 // up to rounding.
-// the rows [base + r * BLOCK | r < ROWS] of one lane, added to acc
-template <int W, int ROWS, int BLOCK, int TM, bool ONEPASS>
-__device__ __forceinline__ void accumulate_ell_rows(RowAcc &acc, int base, const int *__restrict__ nbr,
-                                                    const int *__restrict__ cnt, const float4 *__restrict__ src,
-                                                    const float4 *__restrict__ tgt, int ns, const Pose &P,
-                                                    const Model &md, int width)
-{
-    // width = slots the association really has per row (<= W): slots beyond it do not exist in nbr
+// what a lane holds of its rows [base + r * BLOCK | r < ROWS] after the first memory round trip: header and neighbour slots
+template <int W, int ROWS>
+struct EllRowsHead {
     int n[ROWS];
     float4 xf[ROWS];
-    float yx[ROWS][W], yy[ROWS][W], yz[ROWS][W];
-    {
-        int idx[ROWS][W];
+    int idx[ROWS][W];
+};
+template <int W, int ROWS, int BLOCK>
+__device__ __forceinline__ void load_ell_rows_head(EllRowsHead<W, ROWS> &h, int base, const int *__restrict__ nbr,
+                                                   const int *__restrict__ cnt, const float4 *__restrict__ src, int ns, int width)
+{
+    // width = slots the association really has per row (<= W): slots beyond it do not exist in nbr
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            const int i = base + r * BLOCK;
-            const bool ok = i < ns;
-            n[r] = ok ? cnt[i] : 0;
-            xf[r] = src[ok ? i : 0];
+    for (int r = 0; r < ROWS; r++) {
+        const int i = base + r * BLOCK;
+        const bool ok = i < ns;
+        h.n[r] = ok ? cnt[i] : 0;
+        h.xf[r] = src[ok ? i : 0];
 #pragma unroll
-            for (int k = 0; k < W; k++) idx[r][k] = (ok && k < width) ? nbr[(size_t)k * ns + i] : 0;  // slots >= cnt: stale
-        }
-#pragma unroll
-        for (int r = 0; r < ROWS; r++)
-#pragma unroll
-            for (int k = 0; k < W; k++) {
-                const float4 y = tgt[(k < n[r]) ? idx[r][k] : 0];  // slot 0 of the target for unused slots: masked below
-                yx[r][k] = y.x;
-                yy[r][k] = y.y;
-                yz[r][k] = y.z;
-            }
+        for (int k = 0; k < W; k++) h.idx[r][k] = (ok && k < width) ? nbr[(size_t)k * ns + i] : 0;  // slots >= cnt: stale
     }
+}
+// the neighbours' coordinates of a lane's rows (second round trip: the gathers)
+template <int W, int ROWS>
+struct EllRowsPoints {
+    float yx[ROWS][W], yy[ROWS][W], yz[ROWS][W];
+};
+template <int W, int ROWS>
+__device__ __forceinline__ void gather_ell_rows(EllRowsPoints<W, ROWS> &p, const EllRowsHead<W, ROWS> &h, const float4 *__restrict__ tgt)
+{
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            const float4 y = tgt[(k < h.n[r]) ? h.idx[r][k] : 0];  // slot 0 of the target for unused slots: masked below
+            p.yx[r][k] = y.x;
+            p.yy[r][k] = y.y;
+            p.yz[r][k] = y.z;
+        }
+}
+// the rows of one lane added to acc: the row arithmetic, from registers
+template <int W, int ROWS, int BLOCK, int TM, bool ONEPASS>
+__device__ __forceinline__ void finish_ell_rows(RowAcc &acc, const EllRowsHead<W, ROWS> &h, const EllRowsPoints<W, ROWS> &pts,
+                                                const Pose &P, const Model &md)
+{
+    const int(&n)[ROWS] = h.n;
+    const float4(&xf)[ROWS] = h.xf;
+    const float(&yx)[ROWS][W] = pts.yx;
+    const float(&yy)[ROWS][W] = pts.yy;
+    const float(&yz)[ROWS][W] = pts.yz;
     // Row arithmetic, written for instruction count (the kernel is bound by VALU issue: 599 instructions per wave for
     // one row per lane at W = 10 before this form, ~57 % VALU busy):
     //   * explicit FMAs (the translation unit is compiled with contraction off for K1's sake);
@@ -412,6 +430,20 @@ __device__ __forceinline__ void accumulate_ell_rows(RowAcc &acc, int base, const
         const double Gyy = fma(-x2, G, fma(2.0, fma(xrc[2], Gy[2], fma(xrc[1], Gy[1], xrc[0] * Gy[0])), Gs));
         row_finish(acc, P, xf[r], Z, G, Gs, Gyy, Gy);
     }
+}
+
+// the rows [base + r * BLOCK | r < ROWS] of one lane, added to acc
+template <int W, int ROWS, int BLOCK, int TM, bool ONEPASS>
+__device__ __forceinline__ void accumulate_ell_rows(RowAcc &acc, int base, const int *__restrict__ nbr,
+                                                    const int *__restrict__ cnt, const float4 *__restrict__ src,
+                                                    const float4 *__restrict__ tgt, int ns, const Pose &P,
+                                                    const Model &md, int width)
+{
+    EllRowsHead<W, ROWS> h;
+    load_ell_rows_head<W, ROWS, BLOCK>(h, base, nbr, cnt, src, ns, width);
+    EllRowsPoints<W, ROWS> pts;
+    gather_ell_rows<W, ROWS>(pts, h, tgt);
+    finish_ell_rows<W, ROWS, BLOCK, TM, ONEPASS>(acc, h, pts, P, md);
 }
 
 template <int W, int ROWS, int BLOCK, int TM = -1, bool ONEPASS = false>
@@ -518,6 +550,10 @@ __global__ __launch_bounds__(kBlock, ONEPASS ? 5 : 3) void inner_steps_kernel(In
         __syncthreads();
     }
     if (over()) return;
+    if (ic->fs.dbg && u == 0 && threadIdx.x == 0) {  // diagnostic stamps of the launch's first step
+        if (r == 0) ic->fs.dbg[7] = wall_clock64();   // its first K23 workgroup starts
+        if (r == G) ic->fs.dbg[6] = wall_clock64();   // its first fold workgroup starts to wait
+    }
     if (r >= G) {
         inner_fold_role(ic, seq, a.ovf_index, u, r - G, a.n_steps);
         return;
@@ -542,12 +578,21 @@ __global__ __launch_bounds__(kBlock, ONEPASS ? 5 : 3) void inner_steps_kernel(In
     __shared__ double s_acc[kNSums];
     if (threadIdx.x < kNSums) s_acc[threadIdx.x] = 0.0;
     const int ntiles = (a.ns + kBlock - 1) / kBlock;
+    // (the next tile's header and neighbour slots are asked for before this tile's gathers and arithmetic: one of a
+    //  tile's three dependent round trips runs under the previous tile.  Keeping the next tile's GATHERS in flight as
+    //  well was measured: 72 spilled VGPRs even at a 128-register budget, the K23 phase 36 -> 40 us; so was the register
+    //  form of the solve at that budget: 70 spills.)
+    EllRowsHead<W, 1> head;
+    load_ell_rows_head<W, 1, kBlock>(head, r * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.ns, a.width);
     for (int tile = r; tile < ntiles; tile += G) {
+        const EllRowsHead<W, 1> cur = head;
+        if (tile + G < ntiles) load_ell_rows_head<W, 1, kBlock>(head, (tile + G) * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.ns, a.width);
+        EllRowsPoints<W, 1> pts;
+        gather_ell_rows<W, 1>(pts, cur, a.tgt);
         RowAcc acc;
 #pragma unroll
         for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
-        accumulate_ell_rows<W, 1, kBlock, TM, ONEPASS>(acc, tile * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.tgt, a.ns, P, a.md,
-                                                       a.width);
+        finish_ell_rows<W, 1, kBlock, TM, ONEPASS>(acc, cur, pts, P, a.md);
         block_reduce_store<kBlock, true>(acc, nullptr, 0, 0, s_acc);  // (its own thread adds to s_acc[tid]: no barrier needed)
     }
     if (threadIdx.x < kNSums)
