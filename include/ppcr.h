@@ -168,6 +168,7 @@ int ppcr_align(ppcr_ctx *ctx, int n_iter, double cost_drop_thresh, double n_cost
  *                 front end that owns a ppcr_stop_rule (the C++ class) sees what it would have seen driving
  *                 ppcr_stop_rule_check + ppcr_iterate itself.
  *   T_final       (nullable) the cumulative transform of the iterations of THIS call (identity when none ran).
+ *   n_done        (nullable) rule_io->iteration on return: the iterations counted so far, earlier calls included.
  * n_iter < 0 (no cap) is allowed with cost_drop_thresh > 0. */
 typedef struct ppcr_iteration_info {
     int32_t iteration;    /* index of the outer iteration (ppcr_stop_rule.iteration before it was counted) */
