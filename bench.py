@@ -184,8 +184,8 @@ def cpp_api_block(src, tgt, cfg, a):
     if not os.path.exists(exe):
         return {"error": "ppcr_cpp_api_test is not built (python -m probabilistic_point_clouds_registration_amd.build)"}
     block = {"program": "ppcr_cpp_api_test --bench (ProbPointCloudRegistration::align(), cost_drop_thresh = 0)",
-             "method": "steady it/s = steps / (align time of warm + steps iterations - align time of warm iterations), "
-                       "a fresh object per measurement, median of 5"}
+             "method": "steady it/s = S / (align time of warm + S iterations - align time of warm iterations), S = 3 x steps, "
+                       "a fresh object per measurement (all constructed before the first is timed), median of 7"}
     with tempfile.TemporaryDirectory(prefix="ppcr_bench_") as d:
         sp, tp = os.path.join(d, "src.f32"), os.path.join(d, "tgt.f32")
         np.ascontiguousarray(src[:, :3], dtype=np.float32).tofile(sp)
@@ -193,7 +193,7 @@ def cpp_api_block(src, tgt, cfg, a):
         dof = "inf" if np.isinf(cfg["dof"]) else repr(float(cfg["dof"]))
         for key, inner in (("inner_steps_1", 1), ("default_inner_to_f_tol", 100)):
             cmd = [exe, "--bench", sp, tp, repr(float(cfg["radius"])), str(cfg["max_neighbours"]), dof, str(a.warmup),
-                   str(a.steps), str(inner), "5"]
+                   str(a.steps), str(inner), "7"]
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
