@@ -366,8 +366,8 @@ int sort_by_cell(ppcr_ctx *c, const GridDesc &g, const float4 *in, int n, float4
         PPCR_TRY(check_launch(c, "cell_key_kernel"));
         long long nkeys = g.ncells;
         if (brick_order)
-            nkeys = (16ll << c->opt_brick_xshift) * (((g.n[0] >> g.xr_shift) + (1 << c->opt_brick_xshift) - 1) >> c->opt_brick_xshift) *
-                    ((g.n[1] + 3) / 4) * ((g.n[2] + 3) / 4);
+            nkeys = (64ll << c->opt_brick_xshift) * (((g.n[0] >> g.xr_shift) + (1 << c->opt_brick_xshift) - 1) >> c->opt_brick_xshift) *
+                    brick_count(g.n[1]) * brick_count(g.n[2]);
         int end_bit = 1;
         while (end_bit < 32 && (1ll << end_bit) < nkeys) end_bit++;
         size_t tmp_bytes = 0;

@@ -77,15 +77,20 @@ __global__ void cell_key_kernel(const float4 *__restrict__ pts, int n, GridDesc 
     vals[i] = i;
 }
 
-// Source ordering: (2^bxs)x4x4-cell bricks visited boustrophedon (x snakes per brick row, y snakes per
-// brick plane), cells x-fastest inside a brick.  Default bxs = 0: 4x4 columns of cells in (y,z) walked along x.  Any 256 consecutive queries then sit in one or two
-// ADJACENT bricks, so the cell bounding box of a workgroup — and with it the target halo it stages
-// into LDS (nn_fast_kernel) — stays small.  Only the order of the source changes, never a result.
+// Source ordering: bricks of (2^bxs) x ~4 x ~4 cells visited boustrophedon (x snakes per brick row, y snakes per brick
+// plane), cells x-fastest inside a brick.  Default bxs = 0: ~4x4 columns of cells in (y,z) walked along x.  Any 256
+// consecutive queries then sit in one or two ADJACENT bricks, so the cell bounding box of a workgroup — and with it the
+// target halo it stages into LDS (nn_fast_kernel) — stays small.  Only the order of the source changes, never a result.
+// The n cells of an axis are dealt EVENLY to round(n / 4) bricks (widths 3, 4 or 5: b = c * nb / n), not cut into fours
+// with a remainder: a grid of 41 x 41 cells (250k points at the benchmark density) used to end in a column ONE cell
+// wide, whose 256-query blocks stretch over ~17 cells in x, never fit a halo, and sent ~5 % of the workgroups to the
+// cleanup kernel in EVERY iteration (56 us of a 92 us iteration; 64-cell grids such as the 1M benchmark never showed it).
+__host__ __device__ inline int brick_count(int ncells) { return ncells + 2 >= 4 ? (ncells + 2) / 4 : 1; }
 __global__ void brick_key_kernel(const float4 *__restrict__ pts, int n, GridDesc g,
                                  unsigned *__restrict__ keys, int *__restrict__ vals, int bxs)
 {
-    // bxs = log2 of the brick's x extent in cells (2: 4x4x4 bricks; 0: 1x4x4 "bricks", i.e. 4x4 yz columns walked
-    // along x: 256 consecutive queries then span ~4 cells in x instead of up to 8)
+    // bxs = log2 of the brick's x extent in cells (2: 4 cells; 0: 1 cell, i.e. (y,z) columns walked along x: 256
+    // consecutive queries then span ~4 cells in x instead of up to 8)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float4 p = pts[i];
@@ -93,13 +98,14 @@ __global__ void brick_key_kernel(const float4 *__restrict__ pts, int n, GridDesc
     const int cx = clampi(cell_coord(p.x, g.org[0], g.inv_hx, g.n[0]), 0, g.n[0] - 1) >> g.xr_shift;
     const int cy = clampi(cell_coord(p.y, g.org[1], g.inv_h, g.n[1]), 0, g.n[1] - 1);
     const int cz = clampi(cell_coord(p.z, g.org[2], g.inv_h, g.n[2]), 0, g.n[2] - 1);
-    const int nbx = ((g.n[0] >> g.xr_shift) + (1 << bxs) - 1) >> bxs, nby = (g.n[1] + 3) >> 2;
-    const int bx = cx >> bxs, by = cy >> 2, bz = cz >> 2;
+    const int nbx = ((g.n[0] >> g.xr_shift) + (1 << bxs) - 1) >> bxs, nby = brick_count(g.n[1]), nbz = brick_count(g.n[2]);
+    const int bx = cx >> bxs, by = (cy * nby) / g.n[1], bz = (cz * nbz) / g.n[2];
+    const int ly = cy - (by * g.n[1] + nby - 1) / nby, lz = cz - (bz * g.n[2] + nbz - 1) / nbz;  // 0 .. 4 inside the brick
     const int byy = (bz & 1) ? nby - 1 - by : by;
     const int row = bz * nby + byy;
     const int bxx = (row & 1) ? nbx - 1 - bx : bx;
     const unsigned brick = (unsigned)(row * nbx + bxx);
-    keys[i] = (brick << (4 + bxs)) | (unsigned)(((cz & 3) << (2 + bxs)) | ((cy & 3) << bxs) | (cx & ((1 << bxs) - 1)));
+    keys[i] = (brick << (6 + bxs)) | (unsigned)((lz << (3 + bxs)) | (ly << bxs) | (cx & ((1 << bxs) - 1)));
     vals[i] = i;
 }
 
