@@ -290,6 +290,11 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *   "brick_x"      x extent in cells of the 4x4 (y,z) bricks the source is ordered by: 1 (default), 2 or 4;
  *   "short_lists"  1 once the temporal cut-off is valid K1 runs with 16-slot lists, a 1728-candidate halo and five
  *                  workgroups per CU (default), 0 always 32 slots / three workgroups;
+ *   "two_pass"     1 a bounded search whose radius holds far more than max_neighbours target points runs in two passes
+ *                  (default): the grid and the tiled kernel work with radius / k, chosen from the target's density, and
+ *                  only the rows that find fewer than max_neighbours there are searched again with the full radius;
+ *                  0 always one pass with radius-sized cells; 2..8 force that many first-pass cells per radius (set
+ *                  before the first association);
  *   "stamps"       1 collect per-phase cycle counts and per-lane run lengths of K1 (diagnostic build of the kernel). */
 int ppcr_set_option(ppcr_ctx *ctx, const char *key, int value);
 

@@ -94,6 +94,21 @@ __device__ __forceinline__ QueryCells query_cells(float4 q, const GridDesc &g)
     return c;
 }
 
+// One contiguous run [b, e) of the sorted target, eight loads in flight per lane (a lane that walks its runs one point at a
+// time is bound by memory latency: one round trip per candidate)
+template <int BATCH = 8, class F>
+__device__ __forceinline__ void for_each_in_run(int b, int e, const float4 *__restrict__ tgt, F &&f)
+{
+    for (int p = b; p < e; p += BATCH) {
+        float4 t[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) t[u] = tgt[min(p + u, e - 1)];
+#pragma unroll
+        for (int u = 0; u < BATCH; u++)
+            if (p + u < e) f(p + u, t[u]);
+    }
+}
+
 // Visits every candidate of the 27-cell stencil: f(position_in_sorted_target, float4 point)
 template <class F>
 __device__ __forceinline__ void for_each_candidate(float4 q, const GridDesc &g,
@@ -113,7 +128,42 @@ __device__ __forceinline__ void for_each_candidate(float4 q, const GridDesc &g,
             if ((unsigned)cy >= (unsigned)g.n[1]) continue;
             const int base = (cz * g.n[1] + cy) * g.n[0];
             const int b = cell_start[base + x0], e = cell_start[base + x1 + 1];
-            for (int p = b; p < e; p++) f(p, tgt[p]);
+            for_each_in_run(b, e, tgt, f);
+        }
+    }
+}
+
+// The same over a stencil that reaches up to `reach` cells either way (a search radius sqrt(R2) <= reach * h on a grid
+// whose cells were sized for a SMALLER radius: nn_wide_kernel).  Only the rows and, in every row, the x slices that the
+// sphere of squared radius R2 can touch are visited: a (dy, dz) row is at least (gy, gz) away in y and z (the gap between
+// the query and that row's slab, under-estimated by g.eps), so it matters only if gy^2 + gz^2 < R2, and then only for
+// |dx| <= sqrt(R2 - gy^2 - gz^2) (inflated for the float rounding of d2, as in nn_fast_kernel's windows).
+template <class F>
+__device__ __forceinline__ void for_each_candidate_wide(float4 q, const GridDesc &g, int reach, float R2,
+                                                        const int *__restrict__ cell_start,
+                                                        const float4 *__restrict__ tgt, F &&f)
+{
+    const QueryCells c = query_cells(q, g);
+    const float R2s = R2 * 1.000004f;
+    const int rows = min(reach, (int)(__builtin_amdgcn_sqrtf(R2s) * g.inv_h) + 1);  // cells the sphere can reach in y / z
+    const float fy = q.y - g.org[1], fz = q.z - g.org[2];
+    for (int dz = -rows; dz <= rows; dz++) {
+        const int cz = c.cz + dz;
+        if ((unsigned)cz >= (unsigned)g.n[2]) continue;
+        const float gz = dz < 0 ? fmaxf(fz - (float)(cz + 1) * g.h - g.eps, 0.f) : (dz > 0 ? fmaxf((float)cz * g.h - fz - g.eps, 0.f) : 0.f);
+        for (int dy = -rows; dy <= rows; dy++) {
+            const int cy = c.cy + dy;
+            if ((unsigned)cy >= (unsigned)g.n[1]) continue;
+            const float gy = dy < 0 ? fmaxf(fy - (float)(cy + 1) * g.h - g.eps, 0.f) : (dy > 0 ? fmaxf((float)cy * g.h - fy - g.eps, 0.f) : 0.f);
+            const float w2 = R2s - (gy * gy + gz * gz);
+            if (!(w2 > 0.f)) continue;
+            const float w = __builtin_amdgcn_sqrtf(w2) * 1.000001f + g.eps;
+            const int fa = max(cell_coord(q.x - w, g.org[0], g.inv_hx, g.n[0]), 0);
+            const int fb = min(cell_coord(q.x + w, g.org[0], g.inv_hx, g.n[0]), g.n[0] - 1);
+            if (fa > fb) continue;
+            const int base = (cz * g.n[1] + cy) * g.n[0];
+            const int b = cell_start[base + fa], e = cell_start[base + fb + 1];
+            for_each_in_run<16>(b, e, tgt, f);  // (few lanes of a wave are short rows: latency, not issue, is what counts)
         }
     }
 }

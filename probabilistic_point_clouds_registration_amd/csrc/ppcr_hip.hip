@@ -53,13 +53,14 @@ enum KernelId {
     K_TRANSFORM,
     K_INNER,
     K_TRACK,
+    K_NN_WIDE,
     K_NUM
 };
 const char *const kKernelNames[K_NUM] = {
     "repack_kernel",   "bbox_kernel",    "cell_key_kernel",   "radix_sort",       "gather_points_kernel",
     "cell_start_kernel", "nn_fast_kernel", "nn_tile_cleanup_kernel", "nn_count_kernel",  "nn_scan",          "nn_fill_kernel",
     "nn_select_kernel", "csr_compact_kernel", "ell_count_sum_kernel", "weights_kernel", "accumulate_kernel",
-    "reduce_partials_kernel", "transform_kernel", "inner_steps_kernel", "track_kernel"};
+    "reduce_partials_kernel", "transform_kernel", "inner_steps_kernel", "track_kernel", "nn_wide_kernel"};
 
 constexpr int kMailboxRing = 4;    // mailbox / report slots; at most kMaxAhead iterations are ever in flight
 constexpr int kMaxAhead = 3;       // outer iterations ppcr_align may have enqueued beyond the last one the host has seen
@@ -118,6 +119,12 @@ struct ppcr_ctx {
     DevBuf<float4> tgt_raw, tgt_sorted, src, src_alt;
     bool grid_valid = false;
     double grid_radius = -1;
+    int grid_max_nb = -1;
+    // two-pass radius search (see nn_wide_kernel): the grid is built for search_radius = radius / reach <= radius
+    double search_radius = 1.0;
+    int reach = 1;
+    int opt_two_pass = 1;
+    DevBuf<double> d_occupancy;
     bool src_sorted = false;
     GridDesc grid{};
     DevBuf<int> cell_start;
@@ -425,6 +432,26 @@ int cloud_bbox(ppcr_ctx *c, const float4 *pts, int n, float lo[3], float hi[3])
     return PPCR_OK;
 }
 
+constexpr int kMaxReach = 8;  // the second pass's stencil is (2 reach + 1)^2 rows
+
+// Cell occupancy the first pass of a two-pass search aims at (points per cell of edge r', where the points are): the
+// first-pass sphere holds 4.19 q points, ~1.7 max_neighbours of them answer nearly every row in the first pass; but a
+// cell must not hold more than ~8.5, or the halo of a 256-query block (36-49 rows of ~4 cells) outgrows the LDS tile
+// and workgroups are handed to the cleanup kernel (measured on a uniform cloud: none at 7.5 points per cell, 80 per
+// iteration at 12.9 — and a handed-over workgroup of that density takes the cleanup kernel ~0.3 ms).
+double target_occupancy(int max_nb) { return std::min(1.7 * (double)max_nb / 4.19, 8.5); }
+
+// First-pass search radius for a measured / estimated occupancy `per_cell` of cells of edge `radius`: the radius itself
+// when such cells are not too full, else the radius at which a cell holds target_occupancy() points (never less than
+// radius / kMaxReach).  The second pass then reaches ceil(radius / r') cells.
+double choose_search_radius(double radius, double per_cell, int max_nb)
+{
+    if (!(per_cell > 0) || !std::isfinite(per_cell)) return radius;
+    const double q = target_occupancy(max_nb);
+    if (per_cell <= std::max(q, 8.5)) return radius;
+    return std::max(radius * std::cbrt(q / per_cell), radius / kMaxReach);
+}
+
 // uniform grid over [lo, hi] whose 27-cell stencil covers a search of `cell_radius`
 void make_grid_desc(int n, const float lo[3], const float hi[3], double cell_radius, int xf, GridDesc &g)
 {
@@ -462,22 +489,66 @@ void make_grid_desc(int n, const float lo[3], const float hi[3], double cell_rad
     g.ncells = (int)ncells;
 }
 
-// K0: bounding box -> cell edge -> cell-sorted target + cell_start
+// occupancy of the grid just built where the dense part of the cloud lives (cell_occupancy_kernel): sum c^3 / sum c^2 - 2
+int grid_occupancy(ppcr_ctx *c, double *occ)
+{
+    *occ = 0;
+    if (c->nt <= 0) return PPCR_OK;
+    HIP_TRY(c, c->d_occupancy.reserve(2));
+    HIP_TRY(c, hipMemsetAsync(c->d_occupancy.p, 0, 2 * sizeof(double), c->stream));
+    cell_occupancy_kernel<<<std::min(1024, nblocks(c->grid.ncells)), kBlock, 0, c->stream>>>(c->cell_start.p, c->grid, c->d_occupancy.p);
+    PPCR_TRY(check_launch(c, "cell_occupancy_kernel"));
+    double sums[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(sums, c->d_occupancy.p, sizeof(sums), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *occ = sums[0] > 0 ? std::max(sums[1] / sums[0] - 2.0, 0.0) : 0.0;
+    return PPCR_OK;
+}
+
+// K0: bounding box -> cell edge -> cell-sorted target + cell_start.
+// The cell edge follows the SEARCH radius of the first pass, radius / reach (reach = 1: the radius itself).  A bounded
+// search whose radius holds far more than max_neighbours points is split in two passes (nn_wide_kernel): reach is chosen so
+// that a cell holds at most ~8 points where the points are (the halo of a 256-query block must fit the LDS tile) while the
+// first-pass radius still holds ~1.7 max_neighbours of them where it can.  The estimate starts from the bounding box and
+// is corrected with the occupancy measured on the grid it produced (dense blobs in a sparse box): at most three builds,
+// once per (target, radius, max_neighbours).
 int ensure_grid(ppcr_ctx *c)
 {
     if (!c->have_tgt) return fail(c, PPCR_ERR_STATE, "target cloud not set");
-    if (c->grid_valid && c->grid_radius == c->radius) return PPCR_OK;
+    if (c->grid_valid && c->grid_radius == c->radius && c->grid_max_nb == c->max_nb) return PPCR_OK;
     if (!(c->radius > 0) || !std::isfinite(c->radius)) return fail(c, PPCR_ERR_INVALID, "radius must be positive and finite");
     invalidate_association(c);
+    c->dm2_valid = false;
     const int n = (int)c->nt;
     PPCR_TRY(cloud_bbox(c, c->tgt_raw.p, n, c->tgt_lo, c->tgt_hi));
     for (int a = 0; a < 3; a++) c->origin[a] = 0.5 * ((double)c->tgt_lo[a] + (double)c->tgt_hi[a]);
     c->origin_valid = true;
-    make_grid_desc(n, c->tgt_lo, c->tgt_hi, c->radius, c->opt_grid_xf, c->grid);
     HIP_TRY(c, c->tgt_sorted.reserve((size_t)std::max(n, 1)));
-    PPCR_TRY(sort_by_cell(c, c->grid, c->tgt_raw.p, n, c->tgt_sorted.p, &c->cell_start));
+    const bool bounded = c->max_nb > 0 && (int64_t)c->max_nb < c->nt && c->max_nb <= kEllMaxWidth;
+    double search = c->radius;
+    if (bounded && c->opt_two_pass && n > 0) {
+        // points per cell of edge `radius` if the cloud filled its bounding box evenly (flat clouds: a slab one radius thick)
+        double vol = 1;
+        for (int a = 0; a < 3; a++) vol *= std::max((double)c->tgt_hi[a] - (double)c->tgt_lo[a], c->radius);
+        const double per_cell = (double)n * c->radius * c->radius * c->radius / vol;
+        search = c->opt_two_pass >= 2 ? c->radius / c->opt_two_pass : choose_search_radius(c->radius, per_cell, c->max_nb);
+    }
+    for (int attempt = 0;; attempt++) {
+        c->search_radius = search;
+        c->reach = search < c->radius ? std::min(kMaxReach, (int)std::ceil(c->radius / search - 1e-9)) : 1;
+        make_grid_desc(n, c->tgt_lo, c->tgt_hi, c->search_radius, c->opt_grid_xf, c->grid);
+        PPCR_TRY(sort_by_cell(c, c->grid, c->tgt_raw.p, n, c->tgt_sorted.p, &c->cell_start));
+        if (!(bounded && c->opt_two_pass == 1) || attempt == 2 || search <= c->radius / kMaxReach) break;
+        double q_here = 0;  // points per cell (edge ~search) where the dense part of the cloud lives
+        PPCR_TRY(grid_occupancy(c, &q_here));
+        const double q_want = target_occupancy(c->max_nb);
+        if (q_here <= 1.5 * std::max(q_want, 8.5) * (c->reach > 1 ? 1.0 : 1.0)) break;  // close enough: keep this grid
+        // dense blobs in a sparse box: the points live in fuller cells than the bounding box suggested
+        search = std::max(search * std::cbrt(q_want / q_here), c->radius / kMaxReach);
+    }
     c->grid_valid = true;
     c->grid_radius = c->radius;
+    c->grid_max_nb = c->max_nb;
     c->src_sorted = false;  // re-sort against the new grid at the next associate()
     return PPCR_OK;
 }
@@ -574,7 +645,9 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
     PPCR_TRY(ensure_source_sorted(c));
     invalidate_association(c);
     const int ns = (int)c->ns;
-    const float r2 = (float)(c->radius * c->radius);  // PCL: static_cast<float>(radius * radius)
+    const float r2_full = (float)(c->radius * c->radius);  // PCL: static_cast<float>(radius * radius)
+    // first pass of a two-pass search: a smaller radius on a grid built for it (see ensure_grid); one pass: the radius
+    const float r2 = c->reach > 1 ? std::min((float)(c->search_radius * c->search_radius), r2_full) : r2_full;
     const bool unbounded = (c->max_nb <= 0 || (int64_t)c->max_nb >= c->nt);
     const bool tiled = !unbounded && c->max_nb <= kEllMaxWidth && ns > 0;
     PendingMove pm;
@@ -624,7 +697,7 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             FusedMoments fm;
             const FusedMoments *fuse = nullptr;
             int fuse_tm = -2;
-            if (fuse_R && c->opt_fuse_k23 && c->nt > 0) {
+            if (fuse_R && c->opt_fuse_k23 && c->nt > 0 && c->reach == 1) {  // (two passes: the rows are final only after the second)
                 const Model md = make_model(c);
                 const K23Form form = k23_form(c, md);
                 if (form.onepass && form.tm != -1) {  // the three forms compiled into K1: Gaussian, v + dim = 8, integer v + dim
@@ -659,6 +732,7 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             tl.stream = c->stream;
             tl.src = c->src.p, tl.ns = (int)c->ns, tl.tgt = c->tgt_sorted.p, tl.cell_start = c->cell_start.p, tl.grid = c->grid;
             tl.r2 = r2, tl.m = m;
+            tl.reach = c->reach, tl.r2_full = r2_full;
             tl.nbr = c->nbr.p, tl.cnt = c->cnt.p, tl.dm2 = c->dm2.p;
             tl.dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
             tl.short_lists = c->opt_short_lists;
@@ -683,6 +757,7 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             tl.fuse_tm = fuse_tm;
             tl.loop_st = loop ? loop->st : nullptr;
             tl.between = [](void *scope) { static_cast<ProfScope *>(scope)->split(K_NN_CLEANUP); };
+            tl.between2 = [](void *scope) { static_cast<ProfScope *>(scope)->split(K_NN_WIDE); };
             tl.between_arg = &ps;
             dispatch_tile(tl, m);
             fused = tl.fused, merged = tl.merged;
@@ -1410,6 +1485,7 @@ int ppcr_destroy(ppcr_ctx *c)
     c->mse_part.release();
     c->d_loop.release();
     c->d_fold_dbg.release();
+    c->d_occupancy.release();
     c->d_inner_const.release();
     c->d_inner_ctl.release();
     c->track_part.release();
@@ -1484,6 +1560,12 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
     }
     if (std::strcmp(key, "defer_moves") == 0) {
         c->opt_defer_moves = value ? 1 : 0;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "two_pass") == 0) {
+        if (value < 0 || value > kMaxReach) return fail(c, PPCR_ERR_INVALID, "two_pass must be 0 (off), 1 (automatic) or a reach of 2..8");
+        c->opt_two_pass = value;
+        c->grid_valid = false;
         return PPCR_OK;
     }
     if (std::strcmp(key, "fold_stamps") == 0) {
@@ -2579,6 +2661,7 @@ int ppcr_nearest_sq_distances(int device_id, const float *queries, int64_t nq, i
         if (!std::isfinite(h) || !(h > 0)) h = 1.0;
         c->radius = h;
         c->opt_grid_xf = 1;
+        c->opt_two_pass = 0;  // (the cell edge chosen above is what the shell search wants)
         PPCR_TRY(ensure_grid(c));
         DevBuf<float> d2;
         struct Release {

@@ -37,6 +37,10 @@ void launch_tile(TileLaunch &t)
     unsigned long long *const st = t.stamps;
     constexpr int C = (M <= 24) ? 32 : 48;
     constexpr int CAP = (M <= 24) ? 2240 : 2048;
+    // the cleanup flavour and the second pass of a two-pass search meet neighbourhoods of 50+ in-radius candidates without
+    // a cut-off: lists of 64 (one scan and one selection where 32 slots need two or three rescans); 62 KB of LDS: two
+    // workgroups per CU for kernels that run on a few workgroups
+    constexpr int CC = 64;
     const int nb = (t.ns + 255) / 256;
     // the steady-state variant acts on the split table (extra workgroups) and extends it; the first association only
     // extends it (blocks whose fresh halo is already close to the steady-state capacity)
@@ -97,7 +101,7 @@ void launch_tile(TileLaunch &t)
     FoldSolve fold_now = t.fold ? *t.fold : fs_none;
     fold_now.handed_over = t.ovf_now;  // this launch's counter (the caller toggled the pair after the fold was prepared)
 #define PPCR_CLEANUP(FTMc, FMc, MERGEc, FSc)                                                                           \
-    nn_tile_cleanup_kernel<M, C, 256, CAP, FTMc, MERGEc><<<cleanup_grid + (MERGEc ? kNSums : 0), 256, 0, t.stream>>>(  \
+    nn_tile_cleanup_kernel<M, CC, 256, CAP, FTMc, MERGEc><<<cleanup_grid + (MERGEc ? kNSums : 0), 256, 0, t.stream>>>(  \
         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.dm2, t.ovf_list, t.ovf_now, t.split_list,  \
         n_extra, FMc, FSc)
     if (ftm == 0 && merge) PPCR_CLEANUP(0, *t.fuse, true, fold_now);
@@ -108,6 +112,10 @@ void launch_tile(TileLaunch &t)
     else if (ftm == -3) PPCR_CLEANUP(-3, *t.fuse, false, fs_none);
     else PPCR_CLEANUP(-2, fm_none, false, fs_none);
 #undef PPCR_CLEANUP
+    if (t.reach > 1 && t.between2) t.between2(t.between_arg);
+    if (t.reach > 1)  // second pass of a two-pass search: the rows that came back short, with the full radius
+        nn_wide_kernel<M, CC><<<nb, 256, 0, t.stream>>>(t.src, t.ns, t.tgt, t.cell_start, t.grid, t.reach, t.r2, t.r2_full, t.m, t.nbr, t.cnt,
+                                                      t.dm2, t.loop_st);
 }
 
 }  // namespace

@@ -135,6 +135,53 @@ __device__ __forceinline__ int select_top_m(const S &src, const float4 *__restri
     return w;
 }
 
+// Where the n-th accepted candidate of a scan goes: the first C fill the list in order, every further one overwrites a
+// pseudo-random slot (a hash of its position).  What is left after an overflowing scan is then a spread-out SAMPLE of the
+// accepted candidates, not the first C in scan order (which all come from the first one or two stencil rows: their m-th
+// smallest distance hardly bounds anything, and the threshold-and-rescan loop below crawled: 8 rounds, then the compacting
+// scan — 490 us for one workgroup).  The m-th smallest of ANY subset is a valid bound; of a random subset of C out of N
+// it is about the (m N / C)-th smallest of all: every round shrinks the count by m / C.
+template <int C>
+__device__ __forceinline__ int overflow_slot(int n, int id)
+{
+    static_assert((C & (C - 1)) == 0, "the overflow slot is a masked hash");
+    return n < C ? n : ((id ^ (id >> 5) ^ (id >> 11)) & (C - 1));
+}
+
+// A lane's scan over candidates from global memory into its list, for neighbourhoods that may hold far more than C
+// candidates: every accepted candidate (d2 bits <= thr) is counted and kept as overflow_slot() says; on overflow the
+// threshold drops to the m-th smallest of the C kept — genuine candidates, so a bound of the final m-th distance — and
+// the scan is repeated.  `scan(accept)` must call accept(position, d2) for every candidate.
+// No selection inside the scan loop: there, the whole wave pays whenever ANY lane's list fills.  Returns the list length
+// (<= C); after eight rounds (exact-tie floods) the compacting scan finishes the job.
+template <int M, int C, class Cands, class Scan>
+__device__ __forceinline__ int scan_global_with_threshold(const Cands &G, const float4 *__restrict__ tgt, float4 q, int m,
+                                                          unsigned &thr, Scan &&scan)
+{
+    int n = 0;
+    for (int attempt = 0;; attempt++) {
+        n = 0;
+        scan([&](int p, float d2) {
+            if (__float_as_uint(d2) <= thr) {
+                G.store(overflow_slot<C>(n, p), p);
+                n++;
+            }
+        });
+        if (n <= C) return n;
+        if (attempt == 7) break;
+        (void)select_top_m<M>(G, tgt, q, C, m, thr);
+    }
+    n = 0;
+    scan([&](int p, float d2) {
+        if (__float_as_uint(d2) <= thr) {
+            G.store(n, p);
+            n++;
+            if (n == C) n = select_top_m<M>(G, tgt, q, n, m, thr);
+        }
+    });
+    return n;
+}
+
 // Which block of 256 queries the g-th workgroup of a launch takes.  The dispatcher deals consecutive workgroups to the
 // eight XCDs in turn; blocks are spatially coherent in their index, and neighbouring blocks stage largely the same
 // target rows.  Giving XCD x the x-th eighth of the blocks (instead of every eighth block) lets those rows hit in that
@@ -199,6 +246,7 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
     const int bid = fast_slot < n_extra ? split_list[fast_slot] : xcd_block(fast_slot - n_extra, (ns + BLOCK - 1) / BLOCK);
     static_assert(C > M, "a compaction must leave room in the list");
     static_assert(CAP % 4 == 0 && CAP <= 65536 && C * 64 <= 3 * CAP && kTileRows <= 256, "the global fallback aliases the candidate buffer");
+    static_assert((C & (C - 1)) == 0, "overflow_slot() masks");
     static_assert(kTileRows == 128, "row table: two rows per lane of one wave");
     constexpr int kWaves = BLOCK / 64;
     constexpr int kStageUnroll = 8;  // halo rows in flight per wave
@@ -421,7 +469,7 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
                                 n++;
                                 if (n == C) n = select_top_m<M>(L, tgt, q, n, m, thr);
                             } else {
-                                L.store(min(n, C - 1), f);
+                                L.store(overflow_slot<C>(n, f), f);
                                 n++;
                             }
                         }
@@ -468,7 +516,18 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
                     }
                 };
                 scan_runs(std::false_type{});
-                if (n > C) {  // list overflow (slot C-1 was overwritten): redo this lane with in-loop compaction
+                // List overflow (dense neighbourhood and no usable cut-off): the C entries that were kept — a spread-out
+                // sample of the accepted candidates, see overflow_slot() — are genuine in-radius candidates, so the m-th
+                // smallest of them bounds the final m-th distance: tighten the threshold to it and scan again.  Each
+                // round keeps ~m / C of the candidates.  The compacting scan —
+                // whose in-loop selections are paid by the whole wave whenever ANY lane's list fills: ~1 ms per
+                // workgroup once every lane overflows — is only the last resort (floods of exact ties).
+                for (int attempt = 0; n > C && attempt < 8; attempt++) {
+                    (void)select_top_m<M>(L, tgt, q, C, m, thr);
+                    n = 0;
+                    scan_runs(std::false_type{});
+                }
+                if (n > C) {
                     n = 0;
                     thr = lim0;
                     scan_runs(std::true_type{});
@@ -493,14 +552,9 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
             // last resort for this wave: scan global memory (list of positions aliases the halo buffer)
             if (!done && wave == w0) {
                 const GlobalCands<64> G{tgt, s_glist, lane};
-                unsigned thr = thr0;
-                for_each_candidate(q, g, cell_start, tgt, [&](int p, float4 t) {
-                    const float d2 = dist2_flann(q, t);
-                    if (d2 < r2 && __float_as_uint(d2) <= thr) {
-                        G.store(n, p);
-                        n++;
-                        if (n == C) n = select_top_m<M>(G, tgt, q, n, m, thr);
-                    }
+                unsigned thr = min(thr0, __float_as_uint(r2) - 1u);
+                n = scan_global_with_threshold<M, C>(G, tgt, q, m, thr, [&](auto &&accept) {
+                    for_each_candidate(q, g, cell_start, tgt, [&](int p, float4 t) { accept(p, dist2_flann(q, t)); });
                 });
                 unsigned tm = 0xFFFFFFFFu;
                 if (n > m) {
@@ -548,6 +602,62 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
         }
     }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Second pass of a TWO-PASS radius search.  When the radius holds far more than max_neighbours target points (the
+// command line's defaults: radius 3, 20 neighbours, ~430 points in radius at the benchmark density), a grid of
+// radius-sized cells gives every 256-query block a halo of thousands of candidates — no LDS tile holds it and every block
+// used to fall through to the cleanup kernel's global-memory scan (15-50 ms per iteration at 200k points).  The grid is
+// then built for a SMALLER search radius r' = radius / reach (chosen from the target's density so that r' still holds
+// ~1.7 max_neighbours points) and the ordinary K1 runs with r': a row that finds max_neighbours points within r' has its
+// exact answer (its m nearest overall are among them: d2 < r'^2 <= radius^2, same (d2, index) order).  Only the rows
+// that came back SHORT are searched again here with the full radius, over a stencil reach cells wide on the same grid
+// (so both passes index the same sorted target): one lane per short row, candidates from global memory, the same list +
+// v_med3 selection as everywhere.  Short rows are the cloud's sparse fringe: few, and few candidates each.
+// ---------------------------------------------------------------------------------------------
+template <int M, int C>
+__global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt,
+                                                      const int *__restrict__ cell_start, GridDesc g, int reach, float r1_sq, float r2, int m,
+                                                      int *__restrict__ nbr, int *__restrict__ cnt, unsigned *__restrict__ dm2,
+                                                      const LoopState *loop_st)
+{
+    static_assert(C > M, "a compaction must leave room in the list");
+    if (loop_aborted(loop_st)) return;
+    __shared__ int s_glist[C * 256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ns || cnt[i] >= m) return;  // (rows that found max_neighbours within the first pass's radius are final)
+    const float4 q = src[i];
+    const GlobalCands<256> G{tgt, s_glist, (int)threadIdx.x};
+    // The row found fewer than m points within the first pass's radius r1; how far its m-th neighbour is, nobody knows.
+    // The search grows outwards: radius 1.5 r1, 2.25 r1, ... up to the full radius, each attempt a scan of just the rows
+    // and x windows its sphere touches; the first attempt that holds m candidates ends the search (the m nearest overall
+    // are among the candidates within ITS radius: everything beyond is farther than all of them).  A row of the cloud's
+    // fringe — half a sphere of neighbours — is done after one attempt over a few hundred candidates, where the full
+    // stencil has thousands; the attempts of a truly sparse row add up to ~1.4 scans of the full one.
+    unsigned thr;
+    int n;
+    float R2 = r1_sq;
+    for (;;) {
+        R2 = fminf(R2 * 2.25f, r2);
+        // d2 >= +0 and r2 > 0: "d2 < r2" is "bits(d2) <= bits(r2) - 1"; an intermediate radius may include its sphere's surface
+        thr = R2 < r2 ? __float_as_uint(R2) : __float_as_uint(r2) - 1u;
+        n = scan_global_with_threshold<M, C>(G, tgt, q, m, thr, [&](auto &&accept) {
+            for_each_candidate_wide(q, g, reach, R2, cell_start, tgt, [&](int p, float4 t) { accept(p, dist2_flann(q, t)); });
+        });
+        if (n >= m || !(R2 < r2)) break;
+    }
+    unsigned tm = 0xFFFFFFFFu;
+    if (n > m) {
+        n = select_top_m<M>(G, tgt, q, n, m, thr);
+        tm = thr;
+    } else if (n == m) {
+        tm = 0;
+        for_each_entry(G, q, n, [&](int, int, unsigned b) { tm = max(tm, b); });
+    }
+    for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = G.load(j);
+    cnt[i] = n;
+    dm2[i] = tm;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -15,7 +15,9 @@ struct TileLaunch {
     const float4 *tgt;            // the cell-sorted target
     const int *cell_start;
     dev::GridDesc grid;
-    float r2;
+    float r2;                     // search radius^2 of THIS pass (the first pass of a two-pass search: (radius / reach)^2)
+    int reach;                    // > 1: two-pass search — rows that come back short are searched again with r2_full over a
+    float r2_full;                //      stencil `reach` cells wide (nn_wide_kernel)
     int m;                        // max_neighbours (<= the M of the variant that is called)
     int *nbr, *cnt;               // the ELL association [m][ns], [ns]
     unsigned *dm2;                // per query: float bits of its m-th neighbour's d2 (the temporal cut-off)
@@ -34,6 +36,7 @@ struct TileLaunch {
     const dev::FoldSolve *fold;     // ... and the fold-and-solve step into the cleanup launch
     dev::LoopState *loop_st;        // device-paced loop: every launch steps aside while its abort flag is up (nullable)
     void (*between)(void *);        // called between the two launches (profiling scopes), may be null
+    void (*between2)(void *);       // ... and before the second pass of a two-pass search
     void *between_arg;
     // out
     bool fused, merged;
