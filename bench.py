@@ -47,11 +47,14 @@ def parse():
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps iterations (value = median)")
     ap.add_argument("--config", type=int, default=3,
                     help="BASELINE.json config number (3 = 1M headline, 4 = Gaussian, 2 = 100k, 5 = 64 x 250k batch; "
-                         "6 / 7 = \"4b\": the 1M pair with -d 3 / -d 10, the other t models the fused kernel serves)")
+                         "6 / 7 = \"4b\": the 1M pair with -d 3 / -d 10, the other t models the fused kernel serves; "
+                         "8 = the command line's own defaults: 200k points, radius 3, 20 neighbours, inner loop to f_tol)")
     ap.add_argument("--n", "--points", dest="n", type=int, default=None,
                     help="override the cloud size (debugging; spell it --points behind torch.distributed.run, whose own "
                          "parser trips over --n)")
-    ap.add_argument("--inner-steps", type=int, default=1)
+    ap.add_argument("--inner-steps", type=int, default=None,
+                    help="IRLS steps per association (default 1: the metric's definition; config 8 = the command line's own "
+                         "defaults: 100, to function_tolerance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0,
                     help="outer iterations of the CPU baseline sample (0 = auto: about 6 s of wall time, 3..30)")
@@ -299,6 +302,8 @@ def run_rank(a):
 
     cfg = dict(synth.CONFIGS[a.config])
     cloud_cfg = cfg.get("clouds", a.config)   # whose pinned seeds the clouds are drawn with
+    if a.inner_steps is None:
+        a.inner_steps = int(cfg.get("inner_steps", 1))
     n = a.n or cfg["n"]
     batch_cfg = "pairs" in cfg              # config 5: a fixed batch of independent pairs sharded over the ranks
     if a.pairs_per_gpu > 0:
@@ -336,11 +341,16 @@ def run_rank(a):
         if dist is not None:
             dist.barrier()
 
-    def run_iterations(k, inner, f_tol=1e-5, thresh=0.0):
+    # with the inner loop run to function_tolerance a pair converges inside the window and its cost drop becomes rounding
+    # noise of either sign: those workloads run their k iterations regardless of it
+    timed_thresh = -1.0 if a.inner_steps > 1 else 0.0
+
+    def run_iterations(k, inner, f_tol=1e-5, thresh=None):
         """k outer iterations on every pair of this rank -> {pair: final cumulative 3x4 of these k iterations}
         (thresh = 0 runs exactly k iterations while the cost still falls; a converged pair, whose cost drop is rounding
         noise of either sign, needs a negative threshold to keep going)"""
         out = {}
+        thresh = timed_thresh if thresh is None else thresh
         if concurrent:
             # several resident pairs per GPU: a.lanes of them in flight, each on its own handle/stream
             T_fin, done = _lib.align_many(ctxs, k, lanes=a.lanes, cost_drop_thresh=thresh, inner_steps=inner, f_tol=f_tol)
@@ -407,10 +417,10 @@ def run_rank(a):
             ctx.set_option("fuse_k23", fuse)
             ctx.set_source(src)
             if a.warmup > 0:
-                ctx.align(a.warmup, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
+                ctx.align(a.warmup, cost_drop_thresh=timed_thresh, inner_steps=a.inner_steps, want_history=False)
             ctx.profile_enable(True)
             tp0 = time.perf_counter()
-            ctx.align(a.steps, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
+            ctx.align(a.steps, cost_drop_thresh=timed_thresh, inner_steps=a.inner_steps, want_history=False)
             ctx.synchronize()
             tp = time.perf_counter() - tp0
             out_ = ctx.profile_get()
@@ -486,6 +496,7 @@ def run_rank(a):
         "dtype": "f32 (distances) + f64 (weights, moments, solve)",
         "data": "synthetic" if on_gpu else "FAKE REGISTRATION (--fake-register: rank-logic test, measures nothing)",
         "config": {"workload": (f"BASELINE configs[{a.config - 1}]: " if a.config <= 5 else
+                                "the reference CLI's default parameters (radius 3, 20 neighbours): " if a.config == 8 else
                                 f"BASELINE configs[3] variant 4b (t model, dof {cfg['dof']:g}): ")
                                + (f"batch of {n_pairs} independent pairs of " if n_pairs > 1 else "")
                                + f"{ns}<->{nt} synthetic clouds, radius={cfg['radius']}, "
@@ -521,15 +532,18 @@ def run_rank(a):
             traffic = fused.get("traffic_bytes_per_launch", tj.get("traffic_bytes_per_launch"))
             traffic_alone = (ent.get("standalone") or {}).get("traffic_bytes_per_launch")
             traffic_source = "profiles/k1_traffic.json (%s)" % tj.get("source", "separate rocprofv3 --pmc passes")
-        out["roofline"] = {"bound": "hbm", "kernel": "nn_fast_kernel<10,16,1728,false,8> as the timed windows run it: K1 "
+        two_pass = "nn_wide_kernel" in prof
+        out["roofline"] = {"bound": "hbm", "kernel": ("nn_fast_kernel, first pass of a two-pass radius search (rows that come back "
+                                                     "short go to nn_wide_kernel; K23 is its own kernel)" if two_pass else
+                                                     "nn_fast_kernel<10,16,1728,false,8> as the timed windows run it: K1 "
                                                      "with the previous iteration's source move in its prologue and K23 "
-                                                     "(weights + 19 moments) folded in",
+                                                     "(weights + 19 moments) folded in"),
                            "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": traffic_source,
                            "avg_kernel_ms": avg_ms, "algorithmic_bytes_per_launch": b_nn,
-                           "candidate_tests_per_s": 27 * 3.8147 * ns / (avg_ms * 1e-3)}
-        if "nn_fast_kernel" in prof_alone:
+                           "candidate_tests_per_s": None if two_pass else 27 * 3.8147 * ns / (avg_ms * 1e-3)}
+        if "nn_fast_kernel" in prof_alone and not two_pass:
             ka = prof_alone["nn_fast_kernel"]
             alone_ms = ka["total_ms"] / max(1, ka["launches"])
             out["roofline"]["standalone"] = {"kernel": "nn_fast_kernel<10,16,1728,false,-2> (K1 alone, K23 as its own kernel)",

@@ -26,6 +26,9 @@ CONFIGS = {
     # "4b": config 4's companion for the other weight models the CLI reaches (-d 3: v + dim = 6; the same clouds as 3)
     6: dict(n=1_000_000, max_neighbours=10, dof=3.0, radius=1.0, clouds=3),
     7: dict(n=1_000_000, max_neighbours=10, dof=10.0, radius=1.0, clouds=3),
+    # the command line's own defaults (..._ex.cc:43-49: radius 3, 20 neighbours, inner loop to function_tolerance) at the
+    # benchmark density: ~430 points in radius, a two-pass search (the 100k clouds of config 2)
+    8: dict(n=200_000, max_neighbours=20, dof=5.0, radius=3.0, clouds=2, inner_steps=100),
 }
 
 

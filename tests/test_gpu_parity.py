@@ -709,6 +709,61 @@ def test_nn_exact_for_every_grid_slicing(ctx, xf):
             c.set_option("grid_xf", 3)
 
 
+@pytest.mark.parametrize("two_pass", [1, 2, 3, 8, 0])
+def test_two_pass_radius_search_is_exact(two_pass):
+    """A radius that holds far more than max_neighbours points is searched in two passes (nn_wide_kernel): a smaller
+    first-pass radius on a finer grid, then only the rows that came back short again with the full radius over a wider
+    stencil.  Whatever the split (automatic, forced reach 2 / 3 / 8, or off), neighbour sets and float d2 are the oracle's,
+    bit for bit: uniform cloud at the command line's defaults (radius 3, 20 neighbours), sparse fringe and isolated
+    queries (rows that stay short at the full radius), a cloud with dense blobs, exact ties on a lattice, and the moving
+    source of a registration (temporal cut-off across both passes)."""
+    rng = np.random.default_rng(77)
+    L = 22.0
+    tgt = rng.uniform(-L / 2, L / 2, size=(40000, 3)).astype(np.float32)                      # 3.76 points per unit volume
+    src = np.concatenate([tgt[rng.permutation(40000)[:9000]] + rng.normal(0, 0.02, size=(9000, 3)),
+                          rng.uniform(-L / 2 - 4, L / 2 + 4, size=(600, 3)),                       # fringe and outside
+                          np.array([[200.0, 0, 0], [L / 2 + 2.9, 0, 0]])]).astype(np.float32)     # nothing / almost nothing in radius
+    blobs = np.concatenate([c + rng.normal(0, 0.4, size=(4000, 3)) for c in rng.uniform(-8, 8, size=(3, 3))] +
+                           [rng.uniform(-15, 15, size=(6000, 3))]).astype(np.float32)
+    lattice = (np.stack(np.meshgrid(*[np.arange(24)] * 3, indexing="ij"), -1).reshape(-1, 3) * 0.5).astype(np.float32)
+    cases = [(src, tgt, 3.0, 20), (src, tgt, 3.0, 5), (src, tgt, 2.0, 32),
+             (blobs[rng.permutation(len(blobs))[:5000]] + np.float32(0.01), blobs, 2.5, 10),
+             (lattice[::3] + np.float32(0.0), lattice, 1.75, 16)]
+    for s_, t_, r, m in cases:
+        with _lib.Context(0) as c:
+            c.set_option("two_pass", two_pass)
+            c.set_params(r, m, 5.0, 3)
+            c.set_target(t_)
+            c.set_source(s_)
+            c.associate()
+            rp, col, d2 = c.get_association()
+            orp, ocol, od2 = po.radius_search(s_, t_, r, m, method=1)
+            tag = f"two_pass={two_pass} r={r} m={m}"
+            np.testing.assert_array_equal(rp, orp, err_msg=tag)
+            np.testing.assert_array_equal(col, ocol, err_msg=tag)
+            np.testing.assert_array_equal(d2, od2, err_msg=tag)
+    # inside the registration loop: deferred moves, temporal cut-off, both passes every iteration
+    with _lib.Context(0) as c:
+        c.set_option("two_pass", two_pass)
+        c.set_params(3.0, 20, 5.0, 3)
+        c.set_target(tgt)
+        c.set_source(src)
+        rep = c.align_report(5, cost_drop_thresh=0.0, inner_steps=100, f_tol=10e-6)
+        rp, col, _ = c.get_association(want_d2=False)
+    cur = np.ascontiguousarray(src).copy()
+    for row in rep["iterations"][:4]:
+        po.transform_cloud(cur, np.vstack([row["T_step"], [0, 0, 0, 1]]))
+    orp, ocol, _ = po.radius_search(cur, tgt, 3.0, 20, method=1)
+    np.testing.assert_array_equal(rp, orp)
+    np.testing.assert_array_equal(col, ocol)
+    ora = po.align(src, tgt, 3.0, 20, 5.0, 5, cost_drop_thresh=0.0, inner_max_steps=100, f_tol=10e-6)
+    Tc = np.eye(4)
+    for k, row in enumerate(rep["iterations"]):
+        Tc = np.vstack([row["T_step"], [0, 0, 0, 1]]) @ Tc
+        assert synth.rotation_angle(Tc[:3, :3], ora["history"][k][:, :3]) < 1e-8 and np.linalg.norm(Tc[:3, 3] - ora["history"][k][:, 3]) < 1e-8
+        assert row["inner_steps"] == ora["inner_steps"][k]
+
+
 def test_nn_dense_and_clustered_stress(ctx):
     """Neighbourhoods far denser than the benchmark (hundreds of in-radius candidates, halos that do not fit LDS:
     per-wave passes and the global-memory fallback, list compactions) and a strongly non-uniform cloud."""
