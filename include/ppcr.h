@@ -295,6 +295,11 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *                  only the rows that find fewer than max_neighbours there are searched again with the full radius;
  *                  0 always one pass with radius-sized cells; 2..8 force that many first-pass cells per radius (set
  *                  before the first association);
+ *   "fuse_max_handed_over"  K23 is folded into K1 (and the rows of handed-over workgroups are redone by the cleanup role of
+ *                  the second launch) only while the last association heard from handed over at most this many workgroups
+ *                  (default 4); beyond, K23 runs as its own kernel and those rows go to nn_wide_kernel, one row per wave;
+ *   "first_pass_occupancy"  tenths of a target point per first-pass grid cell the automatic choice allows where the typical
+ *                  point lives (default 85); fuller cells: fewer short rows, more workgroups whose halo outgrows the LDS tile;
  *   "stamps"       1 collect per-phase cycle counts and per-lane run lengths of K1 (diagnostic build of the kernel). */
 int ppcr_set_option(ppcr_ctx *ctx, const char *key, int value);
 

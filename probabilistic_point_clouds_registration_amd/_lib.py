@@ -361,6 +361,15 @@ class Context:
         self._ck(f(self._h, out))
         return list(out)
 
+    def debug_short_rows(self):
+        """ppcr_debug_get_short_rows (diagnostic): rows the first pass of the most recent two-pass association left short."""
+        out = C.c_uint(0)
+        f = self._L.ppcr_debug_get_short_rows
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        f.restype = C.c_int
+        self._ck(f(self._h, C.byref(out)))
+        return int(out.value)
+
     def synchronize(self):
         self._ck(self._L.ppcr_synchronize(self._h))
 

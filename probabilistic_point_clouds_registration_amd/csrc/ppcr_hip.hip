@@ -124,7 +124,10 @@ struct ppcr_ctx {
     double search_radius = 1.0;
     int reach = 1;
     int opt_two_pass = 1;
-    DevBuf<double> d_occupancy;
+    int opt_fuse_max_handed_over = 4;  // more workgroups than this handed over last time: K23 is not folded into K1
+    int opt_first_pass_occ = 85;  // tenths of a point per first-pass cell (see target_occupancy)
+    DevBuf<unsigned long long> d_occupancy;
+    DevBuf<int> d_short;         // second pass: [0] the number of short rows, [1 ..] their list
     bool src_sorted = false;
     GridDesc grid{};
     DevBuf<int> cell_start;
@@ -434,21 +437,20 @@ int cloud_bbox(ppcr_ctx *c, const float4 *pts, int n, float lo[3], float hi[3])
 
 constexpr int kMaxReach = 8;  // the second pass's stencil is (2 reach + 1)^2 rows
 
-// Cell occupancy the first pass of a two-pass search aims at (points per cell of edge r', where the points are): the
-// first-pass sphere holds 4.19 q points, ~1.7 max_neighbours of them answer nearly every row in the first pass; but a
-// cell must not hold more than ~8.5, or the halo of a 256-query block (36-49 rows of ~4 cells) outgrows the LDS tile
-// and workgroups are handed to the cleanup kernel (measured on a uniform cloud: none at 7.5 points per cell, 80 per
-// iteration at 12.9 — and a handed-over workgroup of that density takes the cleanup kernel ~0.3 ms).
-double target_occupancy(int max_nb) { return std::min(1.7 * (double)max_nb / 4.19, 8.5); }
+// Cell occupancy the first pass of a two-pass search aims at (points per cell of edge r', where the typical point is): the
+// first-pass sphere holds 4.19 q points, ~1.7 max_neighbours of them answer nearly every row in the first pass; but the
+// fuller the cells, the more 256-query blocks' halos (36-49 rows of ~4 cells) outgrow the LDS tile and leave their rows
+// to the second pass as well (`cap`, option "first_pass_occupancy", in points per cell).
+double target_occupancy(int max_nb, double cap) { return std::min(1.7 * (double)max_nb / 4.19, cap); }
 
 // First-pass search radius for a measured / estimated occupancy `per_cell` of cells of edge `radius`: the radius itself
 // when such cells are not too full, else the radius at which a cell holds target_occupancy() points (never less than
 // radius / kMaxReach).  The second pass then reaches ceil(radius / r') cells.
-double choose_search_radius(double radius, double per_cell, int max_nb)
+double choose_search_radius(double radius, double per_cell, int max_nb, double cap)
 {
     if (!(per_cell > 0) || !std::isfinite(per_cell)) return radius;
-    const double q = target_occupancy(max_nb);
-    if (per_cell <= std::max(q, 8.5)) return radius;
+    const double q = target_occupancy(max_nb, cap);
+    if (per_cell <= std::max(q, cap)) return radius;
     return std::max(radius * std::cbrt(q / per_cell), radius / kMaxReach);
 }
 
@@ -489,19 +491,28 @@ void make_grid_desc(int n, const float lo[3], const float hi[3], double cell_rad
     g.ncells = (int)ncells;
 }
 
-// occupancy of the grid just built where the dense part of the cloud lives (cell_occupancy_kernel): sum c^3 / sum c^2 - 2
+// occupancy of the grid just built as the typical point sees it (cell_occupancy_kernel): the median over the points of
+// the count of the cell they live in, less one (a point of a uniform cloud of q per cell sits in a cell of q + 1)
 int grid_occupancy(ppcr_ctx *c, double *occ)
 {
     *occ = 0;
     if (c->nt <= 0) return PPCR_OK;
-    HIP_TRY(c, c->d_occupancy.reserve(2));
-    HIP_TRY(c, hipMemsetAsync(c->d_occupancy.p, 0, 2 * sizeof(double), c->stream));
+    HIP_TRY(c, c->d_occupancy.reserve(kOccBins));
+    HIP_TRY(c, hipMemsetAsync(c->d_occupancy.p, 0, kOccBins * sizeof(unsigned long long), c->stream));
     cell_occupancy_kernel<<<std::min(1024, nblocks(c->grid.ncells)), kBlock, 0, c->stream>>>(c->cell_start.p, c->grid, c->d_occupancy.p);
     PPCR_TRY(check_launch(c, "cell_occupancy_kernel"));
-    double sums[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(sums, c->d_occupancy.p, sizeof(sums), hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned long long> hist(kOccBins, 0ull);
+    HIP_TRY(c, hipMemcpyAsync(hist.data(), c->d_occupancy.p, kOccBins * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    *occ = sums[0] > 0 ? std::max(sums[1] / sums[0] - 2.0, 0.0) : 0.0;
+    unsigned long long total = 0, run = 0;
+    for (unsigned long long h : hist) total += h;
+    for (int b = 0; b < kOccBins; b++) {
+        run += hist[b];
+        if (2 * run >= total) {
+            *occ = std::max((double)b - 1.0, 0.0);
+            break;
+        }
+    }
     return PPCR_OK;
 }
 
@@ -531,7 +542,7 @@ int ensure_grid(ppcr_ctx *c)
         double vol = 1;
         for (int a = 0; a < 3; a++) vol *= std::max((double)c->tgt_hi[a] - (double)c->tgt_lo[a], c->radius);
         const double per_cell = (double)n * c->radius * c->radius * c->radius / vol;
-        search = c->opt_two_pass >= 2 ? c->radius / c->opt_two_pass : choose_search_radius(c->radius, per_cell, c->max_nb);
+        search = c->opt_two_pass >= 2 ? c->radius / c->opt_two_pass : choose_search_radius(c->radius, per_cell, c->max_nb, 0.1 * c->opt_first_pass_occ);
     }
     for (int attempt = 0;; attempt++) {
         c->search_radius = search;
@@ -541,9 +552,9 @@ int ensure_grid(ppcr_ctx *c)
         if (!(bounded && c->opt_two_pass == 1) || attempt == 2 || search <= c->radius / kMaxReach) break;
         double q_here = 0;  // points per cell (edge ~search) where the dense part of the cloud lives
         PPCR_TRY(grid_occupancy(c, &q_here));
-        const double q_want = target_occupancy(c->max_nb);
-        if (q_here <= 1.5 * std::max(q_want, 8.5) * (c->reach > 1 ? 1.0 : 1.0)) break;  // close enough: keep this grid
-        // dense blobs in a sparse box: the points live in fuller cells than the bounding box suggested
+        const double cap = 0.1 * c->opt_first_pass_occ, q_want = target_occupancy(c->max_nb, cap);
+        if (q_here <= 1.5 * std::max(q_want, cap)) break;  // close enough: keep this grid
+        // the points live in fuller cells than the bounding box suggested (a cloud that does not fill its box)
         search = std::max(search * std::cbrt(q_want / q_here), c->radius / kMaxReach);
     }
     c->grid_valid = true;
@@ -697,7 +708,10 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             FusedMoments fm;
             const FusedMoments *fuse = nullptr;
             int fuse_tm = -2;
-            if (fuse_R && c->opt_fuse_k23 && c->nt > 0 && c->reach == 1) {  // (two passes: the rows are final only after the second)
+            // (two passes: the rows are final only after the second; a cloud whose associations keep handing workgroups over
+            //  — dense parts whose halos outgrow the LDS tile — leaves those rows to nn_wide_kernel, which does not fold)
+            const bool many_handed_over = c->ovf_last != ~0u && c->ovf_last > (unsigned)c->opt_fuse_max_handed_over;
+            if (fuse_R && c->opt_fuse_k23 && c->nt > 0 && c->reach == 1 && !many_handed_over) {
                 const Model md = make_model(c);
                 const K23Form form = k23_form(c, md);
                 if (form.onepass && form.tm != -1) {  // the three forms compiled into K1: Gaussian, v + dim = 8, integer v + dim
@@ -733,6 +747,16 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             tl.src = c->src.p, tl.ns = (int)c->ns, tl.tgt = c->tgt_sorted.p, tl.cell_start = c->cell_start.p, tl.grid = c->grid;
             tl.r2 = r2, tl.m = m;
             tl.reach = c->reach, tl.r2_full = r2_full;
+            // who redoes the rows of handed-over workgroups: the cleanup role of the second launch (it can fold K23 for them,
+            // but walks a dense neighbourhood one candidate per lane at a time), or — whenever K23 is not folded in and the
+            // last association heard from handed something over, and always in a two-pass search — nn_wide_kernel
+            if (c->reach > 1 || (fuse == nullptr && c->ovf_last != ~0u && c->ovf_last > 0)) {
+                if (c->d_short.cap < (size_t)ns + 1) {
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    HIP_TRY(c, c->d_short.reserve((size_t)ns + 1));
+                }
+                tl.short_count = reinterpret_cast<unsigned *>(c->d_short.p), tl.short_list = c->d_short.p + 1;
+            }
             tl.nbr = c->nbr.p, tl.cnt = c->cnt.p, tl.dm2 = c->dm2.p;
             tl.dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
             tl.short_lists = c->opt_short_lists;
@@ -1486,6 +1510,7 @@ int ppcr_destroy(ppcr_ctx *c)
     c->d_loop.release();
     c->d_fold_dbg.release();
     c->d_occupancy.release();
+    c->d_short.release();
     c->d_inner_const.release();
     c->d_inner_ctl.release();
     c->track_part.release();
@@ -1565,6 +1590,17 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
     if (std::strcmp(key, "two_pass") == 0) {
         if (value < 0 || value > kMaxReach) return fail(c, PPCR_ERR_INVALID, "two_pass must be 0 (off), 1 (automatic) or a reach of 2..8");
         c->opt_two_pass = value;
+        c->grid_valid = false;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "fuse_max_handed_over") == 0) {
+        if (value < 0) return fail(c, PPCR_ERR_INVALID, "fuse_max_handed_over must be >= 0");
+        c->opt_fuse_max_handed_over = value;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "first_pass_occupancy") == 0) {
+        if (value < 10 || value > 640) return fail(c, PPCR_ERR_INVALID, "first_pass_occupancy is in tenths of a point per cell, 10..640");
+        c->opt_first_pass_occ = value;
         c->grid_valid = false;
         return PPCR_OK;
     }
@@ -2404,6 +2440,18 @@ int ppcr_debug_get_host_times(ppcr_ctx *c, double out[8])
 {
     CTX_ENTER(c);
     for (int k = 0; k < 8; k++) out[k] = c->dbg_host[k];
+    return PPCR_OK;
+}
+
+// diagnostic: rows the first pass of the most recent two-pass association left short (0 for a one-pass search)
+int ppcr_debug_get_short_rows(ppcr_ctx *c, unsigned *out)
+{
+    CTX_ENTER(c);
+    *out = 0;
+    if (c->d_short.p) {
+        HIP_TRY(c, hipMemcpyAsync(out, c->d_short.p, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     return PPCR_OK;
 }
 

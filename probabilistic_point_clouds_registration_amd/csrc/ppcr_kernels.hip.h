@@ -129,43 +129,29 @@ __global__ void cell_start_kernel(const unsigned *__restrict__ keys_sorted, int 
     for (int c = prev + 1; c <= cur; c++) cell_start[c] = i;
 }
 
-// Occupancy of the grid's WHOLE cells (x slices folded back) as the points see it: out[0] += sum count^2, out[1] += sum
-// count^3.  sum c^2 / N is the cell count the average POINT finds itself in; sum c^3 / sum c^2 weights the cells once more
-// by their count, i.e. it is the occupancy where the DENSE part of the cloud lives (q + 2 for a uniform cloud of q points
-// per cell; the blobs' own occupancy when 15 % of the points sit in blobs a hundred times denser than the rest).  The host
-// sizes the first-pass search radius with it.
-__global__ __launch_bounds__(kBlock) void cell_occupancy_kernel(const int *__restrict__ cell_start, GridDesc g, double *__restrict__ out)
+// Occupancy of the grid's WHOLE cells (x slices folded back) as the POINTS see it: hist[min(count, kOccBins - 1)] += count
+// for every cell, i.e. how many points live in a cell of that many.  The host takes the median over the points — the
+// cell the typical row finds itself in (q + 1 for a uniform cloud of q points per cell; unmoved by a few blobs a hundred
+// times denser than the rest, which weighted means follow) — and sizes the first-pass search radius for THAT row: rows of
+// much sparser and much denser neighbourhoods are what the second pass is for.
+constexpr int kOccBins = 256;
+__global__ __launch_bounds__(kBlock) void cell_occupancy_kernel(const int *__restrict__ cell_start, GridDesc g, unsigned long long *__restrict__ hist)
 {
-    __shared__ double sh[2][kBlock / 64];
+    __shared__ unsigned s_hist[kOccBins];
+    for (int b = threadIdx.x; b < kOccBins; b += kBlock) s_hist[b] = 0;
+    __syncthreads();
     const int ncx = g.n[0] >> g.xr_shift;
     const long long nwhole = (long long)ncx * g.n[1] * g.n[2];
-    double acc2 = 0.0, acc3 = 0.0;
     for (long long w = (long long)blockIdx.x * kBlock + threadIdx.x; w < nwhole; w += (long long)gridDim.x * kBlock) {
         const long long row = w / ncx;
         const int cx = (int)(w - row * ncx);
         const long long base = row * g.n[0] + ((long long)cx << g.xr_shift);
-        const double cnt = (double)(cell_start[base + g.xr] - cell_start[base]);
-        acc2 += cnt * cnt;
-        acc3 += cnt * cnt * cnt;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        acc2 += __shfl_down(acc2, off);
-        acc3 += __shfl_down(acc3, off);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        sh[0][threadIdx.x >> 6] = acc2;
-        sh[1][threadIdx.x >> 6] = acc3;
+        const int cnt = cell_start[base + g.xr] - cell_start[base];
+        if (cnt > 0) atomicAdd(&s_hist[min(cnt, kOccBins - 1)], (unsigned)cnt);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double v2 = sh[0][0], v3 = sh[1][0];
-        for (int w = 1; w < kBlock / 64; w++) {
-            v2 += sh[0][w];
-            v3 += sh[1][w];
-        }
-        atomicAdd(out, v2);
-        atomicAdd(out + 1, v3);
-    }
+    for (int b = threadIdx.x; b < kOccBins; b += kBlock)
+        if (s_hist[b]) atomicAdd(hist + b, (unsigned long long)s_hist[b]);
 }
 
 __global__ __launch_bounds__(kBlock) void reduce_solve_kernel(FoldSolve fs)

@@ -35,6 +35,33 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// wave-wide scans and reductions on the DPP row_shr / row_bcast network
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_pull(int identity, int v)
+{
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+// inclusive scan over the 64 lanes (ALL lanes must be active); lane 63 ends up with the reduction
+template <class Op>
+__device__ __forceinline__ int wave_scan(int v, int identity, Op op)
+{
+    v = op(v, dpp_pull<0x111, 0xf>(identity, v));  // row_shr:1
+    v = op(v, dpp_pull<0x112, 0xf>(identity, v));  // row_shr:2
+    v = op(v, dpp_pull<0x114, 0xf>(identity, v));  // row_shr:4
+    v = op(v, dpp_pull<0x118, 0xf>(identity, v));  // row_shr:8   -> inclusive within each row of 16
+    v = op(v, dpp_pull<0x142, 0xa>(identity, v));  // row_bcast:15 into rows 1 and 3
+    v = op(v, dpp_pull<0x143, 0xc>(identity, v));  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+struct OpMin { __device__ __forceinline__ int operator()(int a, int b) const { return a < b ? a : b; } };
+struct OpMax { __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; } };
+struct OpAdd { __device__ __forceinline__ int operator()(int a, int b) const { return a + b; } };
+template <class Op>
+__device__ __forceinline__ int wave_reduce(int v, int identity, Op op)  // wave-uniform result
+{
+    return __builtin_amdgcn_readlane(wave_scan(v, identity, op), 63);
+}
+
 template <int BLOCK>
 struct LdsCands {  // candidate source = staged halo (SoA in LDS); list entries are LDS indices
     const float *sx, *sy, *sz;
@@ -208,7 +235,7 @@ __device__ __forceinline__ int xcd_block(int g, int nb)
 // the cleanup role has finished every listed entry (nothing to wait for in the common case of an empty list) — which
 // saves the ~4 us a dependent launch costs even when it has nothing to do.
 template <int M, int C, int BLOCK, int CAP, int FTM = -2, bool MERGED = false>
-__global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 *__restrict__ src, int ns,
+__global__ __launch_bounds__(BLOCK, (C >= 64 ? 2 : 3)) void nn_tile_cleanup_kernel(const float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt,
                                                          const int *__restrict__ cell_start, GridDesc g,
                                                          float r2, int m, int *__restrict__ nbr,
@@ -216,7 +243,7 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
                                                          const int *__restrict__ ovf_list,
                                                          const unsigned *__restrict__ ovf_count,
                                                          const int *__restrict__ split_list, int n_extra, FusedMoments fm,
-                                                         FoldSolve fs)
+                                                         FoldSolve fs, unsigned *__restrict__ short_count)
 {
     static_assert(!MERGED || FTM != -2, "the merged launch folds the partials the fused kernels wrote");
     if (loop_aborted(fs.loop.st)) {  // an earlier launch handed the iteration to the host: step aside (see LoopState)
@@ -224,7 +251,12 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
             if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) publish_skipped(fs);
         return;
     }
-    const unsigned n_listed = *ovf_count;
+    // two-pass search: the list of short rows (short_rows_kernel, next in the stream) starts empty
+    if (short_count != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *short_count = 0;
+    // (two-pass search: the rows of handed-over workgroups are marked unsearched and go to nn_wide_kernel with the short ones
+    //  — one row per wave walks a dense neighbourhood's thousands of candidates in a few rounds, where this kernel's lanes
+    //  walk them one by one: 0.5 ms for 29 workgroups of a cloud with dense blobs)
+    const unsigned n_listed = short_count != nullptr ? 0u : *ovf_count;
     const unsigned n_cleanup = MERGED ? gridDim.x - kNSums : gridDim.x;  // workgroups in the cleanup role
     if constexpr (MERGED) {
         if (blockIdx.x >= n_cleanup) {
@@ -612,52 +644,280 @@ __global__ __launch_bounds__(BLOCK, 3) void nn_tile_cleanup_kernel(const float4 
 // then built for a SMALLER search radius r' = radius / reach (chosen from the target's density so that r' still holds
 // ~1.7 max_neighbours points) and the ordinary K1 runs with r': a row that finds max_neighbours points within r' has its
 // exact answer (its m nearest overall are among them: d2 < r'^2 <= radius^2, same (d2, index) order).  Only the rows
-// that came back SHORT are searched again here with the full radius, over a stencil reach cells wide on the same grid
-// (so both passes index the same sorted target): one lane per short row, candidates from global memory, the same list +
-// v_med3 selection as everywhere.  Short rows are the cloud's sparse fringe: few, and few candidates each.
+// that came back SHORT are searched again with the full radius, over a stencil reach cells wide on the same grid (so both
+// passes index the same sorted target).  Short rows are the cloud's fringe and its sparse parts: a few per cent of the
+// rows, scattered over every wave of the first pass — one lane per short row (the first form of this kernel) left 60 lanes
+// of every wave idle behind the slowest one (229 us at 200k points).  So the short rows are first COMPACTED into a list
+// (short_rows_kernel) and then searched ONE ROW PER WAVE: the 64 lanes walk the stencil's runs together, eight runs in
+// flight, accepted candidates are appended to a wave-shared list in LDS (ballot + prefix), and the selection of the m
+// smallest by (d2, original index) is a wave-wide bit-by-bit descent on ballot counts.
 // ---------------------------------------------------------------------------------------------
-template <int M, int C>
+template <int M>
+__global__ __launch_bounds__(256) void short_rows_kernel(const int *__restrict__ cnt, int ns, int m, int *__restrict__ list,
+                                                         unsigned *__restrict__ count, const LoopState *loop_st)
+{
+    if (loop_aborted(loop_st)) return;
+    __shared__ int s_n[4];
+    __shared__ unsigned s_base;
+    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool is_short = i < ns && cnt[i] < m;  // (m = 0: only the rows marked unsearched, a one-pass search's short rows are final)
+    const unsigned long long b = __ballot(is_short);
+    if (lane == 0) s_n[wave] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+        s_base = total ? atomicAdd(count, (unsigned)total) : 0u;
+    }
+    __syncthreads();
+    int at = (int)s_base + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+    for (int w = 0; w < wave; w++) at += s_n[w];
+    if (is_short) list[at] = i;
+}
+
+// The wave's list [0, n) in LDS (sorted-target position, d2 bits) -> its m smallest by (d2, original index), compacted in
+// place; returns the new length (min(n, m)) and the d2 bits of the m-th (thr is left alone when n < m).  PER * 64 >= n.
+// The m-th smallest d2 is found bit by bit from the top: "how many entries agree with the prefix so far and have a 0
+// here" is a ballot count per 64 entries, nothing else; ties at the m-th distance that do not all fit are settled by the
+// same descent on their original indices (the oracle's order).
+template <int PER>
+__device__ __forceinline__ int wave_select_top_m(int *s_pos, unsigned *s_d2, int n, int m, const float4 *__restrict__ tgt, int lane,
+                                                 unsigned &thr)
+{
+    if (n < m) return n;
+    unsigned d[PER];
+    int p[PER];
+    const int chunks = (n + 63) >> 6;  // uniform
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        d[j] = 0xFFFFFFFFu, p[j] = 0;
+        if (j < chunks) {
+            const int idx = j * 64 + lane;
+            d[j] = idx < n ? s_d2[idx] : 0xFFFFFFFFu;  // (a genuine d2 is a finite float: never all-ones)
+            p[j] = s_pos[min(idx, n - 1)];
+        }
+    }
+    auto descend = [&](const unsigned(&key)[PER], unsigned long long const(&in)[PER], int need) -> unsigned {
+        // the need-th smallest (1-based) key among the entries flagged in `in`
+        unsigned prefix = 0;
+        for (int bit = 31; bit >= 0; bit--) {
+            const unsigned above = bit == 31 ? 0u : ~((2u << bit) - 1u);
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < PER; j++)
+                if (j < chunks) {
+                    const bool on = (in[j] >> lane) & 1ull;
+                    c += __popcll(__ballot(on && (key[j] & above) == prefix && !((key[j] >> bit) & 1u)));
+                }
+            if (c < need) {
+                need -= c;
+                prefix |= 1u << bit;
+            }
+        }
+        return prefix;
+    };
+    unsigned long long all[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) all[j] = __ballot(j < chunks && j * 64 + lane < n);
+    const unsigned T = descend(d, all, m);
+    int below = 0, ties = 0;
+    unsigned long long tied[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        tied[j] = 0;
+        if (j < chunks) {
+            below += __popcll(__ballot(d[j] < T));
+            tied[j] = __ballot(d[j] == T);
+            ties += __popcll(tied[j]);
+        }
+    }
+    const int room = m - below;  // >= 1: T is the m-th smallest
+    unsigned U = 0xFFFFFFFFu;    // tied entries with original index <= U stay
+    if (ties > room) {
+        unsigned oi[PER];
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            oi[j] = 0xFFFFFFFFu;
+            if (j < chunks && d[j] == T) oi[j] = (unsigned)__float_as_int(tgt[p[j]].w);
+        }
+        U = descend(oi, tied, room);
+#pragma unroll
+        for (int j = 0; j < PER; j++) d[j] = (d[j] == T && oi[j] > U) ? 0xFFFFFFFFu : d[j];  // drop the losers of the tie
+    }
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++)
+        if (j < chunks) {
+            const bool keep = d[j] <= T;
+            const unsigned long long k = __ballot(keep);
+            const int at = base + __builtin_amdgcn_mbcnt_hi((unsigned)(k >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)k, 0u));
+            if (keep) s_pos[at] = p[j], s_d2[at] = d[j];
+            base += __popcll(k);
+        }
+    thr = T;
+    return base;
+}
+
+template <int M>
 __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt,
                                                       const int *__restrict__ cell_start, GridDesc g, int reach, float r1_sq, float r2, int m,
                                                       int *__restrict__ nbr, int *__restrict__ cnt, unsigned *__restrict__ dm2,
+                                                      const int *__restrict__ short_list, const unsigned *__restrict__ short_count,
                                                       const LoopState *loop_st)
 {
-    static_assert(C > M, "a compaction must leave room in the list");
+    constexpr int U = 4;             // chunks of 64 candidates (loads per lane) in flight
+    constexpr int CAPW = 512;        // list entries per wave; compacted to m whenever a round of U * 64 might not fit
+    constexpr int PER = CAPW / 64;
+    constexpr int CAPT = 1024;       // candidates of one batch of 64 runs that are walked as ONE flat sequence
+    static_assert(CAPW >= 2 * U * 64 && CAPW - U * 64 >= M, "a compaction leaves room for a round");
     if (loop_aborted(loop_st)) return;
-    __shared__ int s_glist[C * 256];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= ns || cnt[i] >= m) return;  // (rows that found max_neighbours within the first pass's radius are final)
-    const float4 q = src[i];
-    const GlobalCands<256> G{tgt, s_glist, (int)threadIdx.x};
-    // The row found fewer than m points within the first pass's radius r1; how far its m-th neighbour is, nobody knows.
-    // The search grows outwards: radius 1.5 r1, 2.25 r1, ... up to the full radius, each attempt a scan of just the rows
-    // and x windows its sphere touches; the first attempt that holds m candidates ends the search (the m nearest overall
-    // are among the candidates within ITS radius: everything beyond is farther than all of them).  A row of the cloud's
-    // fringe — half a sphere of neighbours — is done after one attempt over a few hundred candidates, where the full
-    // stencil has thousands; the attempts of a truly sparse row add up to ~1.4 scans of the full one.
-    unsigned thr;
-    int n;
-    float R2 = r1_sq;
-    for (;;) {
-        R2 = fminf(R2 * 2.25f, r2);
-        // d2 >= +0 and r2 > 0: "d2 < r2" is "bits(d2) <= bits(r2) - 1"; an intermediate radius may include its sphere's surface
-        thr = R2 < r2 ? __float_as_uint(R2) : __float_as_uint(r2) - 1u;
-        n = scan_global_with_threshold<M, C>(G, tgt, q, m, thr, [&](auto &&accept) {
-            for_each_candidate_wide(q, g, reach, R2, cell_start, tgt, [&](int p, float4 t) { accept(p, dist2_flann(q, t)); });
-        });
-        if (n >= m || !(R2 < r2)) break;
+    __shared__ int s_pos_all[4][CAPW];
+    __shared__ unsigned s_d2_all[4][CAPW];
+    __shared__ int s_pre_all[4][64], s_b_all[4][64];
+    __shared__ unsigned char s_mark_all[4][CAPT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int *const s_pos = s_pos_all[wave], *const s_pre = s_pre_all[wave], *const s_b = s_b_all[wave];
+    unsigned *const s_d2 = s_d2_all[wave];
+    unsigned char *const s_mark = s_mark_all[wave];
+    unsigned *const s_mark4 = reinterpret_cast<unsigned *>(s_mark);
+    const unsigned n_short = *short_count;
+    for (unsigned entry = blockIdx.x * 4 + wave; entry < n_short; entry += gridDim.x * 4) {
+        const int i = __builtin_amdgcn_readfirstlane(short_list[entry]);
+        const int found = __builtin_amdgcn_readfirstlane(cnt[i]);  // < 0: its workgroup left the first pass to this one
+        const float4 q = src[i];
+        const QueryCells c = query_cells(q, g);
+        const float fy = q.y - g.org[1], fz = q.z - g.org[2];
+        // How far this row's m-th neighbour is, nobody knows; the search starts from an ESTIMATE and grows outwards (radius
+        // x 1.5 per attempt, up to the full radius), each attempt a scan of just the rows and x windows its sphere touches;
+        // the first attempt that holds m candidates ends the search (the m nearest overall are among the candidates within
+        // ITS radius: everything beyond is farther than all of them).  The estimate: a row that found `found` < m points
+        // within the first pass's radius r1 has m of them within ~r1 cbrt(m / found) if the density holds; an unsearched
+        // row (a workgroup whose halo outgrew the LDS tile: a dense neighbourhood) takes the density of its own cell.
+        float R2;
+        if (found >= 0) {
+            const float k = cbrtf((float)m / fmaxf((float)found, 0.5f)) * 1.15f;
+            R2 = r1_sq * k * k;
+        } else {
+            const bool inside = (unsigned)c.cx < (unsigned)g.n[0] && (unsigned)c.cy < (unsigned)g.n[1] && (unsigned)c.cz < (unsigned)g.n[2];
+            const int cell = inside ? (c.cz * g.n[1] + c.cy) * g.n[0] + c.cx : 0;
+            const float in_cell = inside ? (float)max(cell_start[cell + 1] - cell_start[cell], 1) : 1.f;
+            const float cell_vol = g.h * g.h / g.inv_hx;
+            const float re = cbrtf(1.5f * (float)m * cell_vol / (4.19f * in_cell));
+            R2 = fminf(re * re, r1_sq);
+        }
+        R2 *= (1.0f / 2.25f);  // (the loop below grows before it scans)
+        unsigned thr = 0;
+        int n = 0;
+        for (;;) {
+            R2 = fminf(R2 * 2.25f, r2);
+            // d2 >= +0 and r2 > 0: "d2 < r2" is "bits(d2) <= bits(r2) - 1"; an intermediate radius may include its sphere's surface
+            thr = R2 < r2 ? __float_as_uint(R2) : __float_as_uint(r2) - 1u;
+            n = 0;
+            const float R2s = R2 * 1.000004f;
+            const int rows = min(reach, (int)(__builtin_amdgcn_sqrtf(R2s) * g.inv_h) + 1);  // cells the sphere can reach in y / z
+            const int side = 2 * rows + 1, nrun = side * side;
+            // lane l of batch k0: the (dy, dz) row k0 + l of the stencil, clipped to the x slices the sphere can touch there
+            auto run_bounds = [&](int k0, int &rb, int &re) {
+                rb = 0, re = 0;
+                const int k = k0 + lane;
+                const int dz = k / side - rows, dy = k % side - rows;
+                const int cz = c.cz + dz, cy = c.cy + dy;
+                if (k < nrun && (unsigned)cz < (unsigned)g.n[2] && (unsigned)cy < (unsigned)g.n[1]) {
+                    const float gz = dz < 0 ? fmaxf(fz - (float)(cz + 1) * g.h - g.eps, 0.f) : (dz > 0 ? fmaxf((float)cz * g.h - fz - g.eps, 0.f) : 0.f);
+                    const float gy = dy < 0 ? fmaxf(fy - (float)(cy + 1) * g.h - g.eps, 0.f) : (dy > 0 ? fmaxf((float)cy * g.h - fy - g.eps, 0.f) : 0.f);
+                    const float w2 = R2s - (gy * gy + gz * gz);
+                    if (w2 > 0.f) {
+                        const float w = __builtin_amdgcn_sqrtf(w2) * 1.000001f + g.eps;
+                        const int fa = max(cell_coord(q.x - w, g.org[0], g.inv_hx, g.n[0]), 0);
+                        const int fb = min(cell_coord(q.x + w, g.org[0], g.inv_hx, g.n[0]), g.n[0] - 1);
+                        if (fa <= fb) {
+                            const int base = (cz * g.n[1] + cy) * g.n[0];
+                            rb = cell_start[base + fa], re = cell_start[base + fb + 1];
+                        }
+                    }
+                }
+            };
+            // one candidate per lane: distance, acceptance, append to the wave's list
+            auto offer = [&](bool live, int pos, float4 t) {
+                const unsigned bits = __float_as_uint(dist2_flann(q, t));
+                const bool acc = live && bits <= thr;
+                const unsigned long long k = __ballot(acc);
+                const int at = n + __builtin_amdgcn_mbcnt_hi((unsigned)(k >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)k, 0u));
+                if (acc) s_pos[at] = pos, s_d2[at] = bits;
+                n += __popcll(k);
+            };
+            int nb_, ne_;
+            run_bounds(0, nb_, ne_);
+            for (int k0 = 0; k0 < nrun; k0 += 64) {
+                const int rb = nb_, len = ne_ - nb_;
+                if (k0 + 64 < nrun) run_bounds(k0 + 64, nb_, ne_);  // the next batch's bounds travel while this one is walked
+                const int incl = wave_scan(len, 0, OpAdd());
+                const int total = __builtin_amdgcn_readlane(incl, 63);
+                if (total == 0) continue;
+                if (total <= CAPT) {
+                    // the batch's candidates as ONE flat sequence [0, total): a byte per candidate marks where a run
+                    // starts (run + 1), a running maximum spreads the run over its candidates — sparse rows' runs hold
+                    // two or three points each, and a round per run is a memory round trip per run
+                    for (int w = lane; w * 4 < total; w += 64) s_mark4[w] = 0u;
+                    s_pre[lane] = incl - len, s_b[lane] = rb;
+                    if (len > 0) s_mark[incl - len] = (unsigned char)(lane + 1);
+                    int carry = 0;
+                    for (int j0 = 0; j0 < total; j0 += U * 64) {
+                        if (n > CAPW - U * 64) n = wave_select_top_m<PER>(s_pos, s_d2, n, m, tgt, lane, thr);
+                        int pos[U];
+                        float4 t[U];
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            const int j = j0 + u * 64 + lane;
+                            int run = j < total ? (int)s_mark[min(j, CAPT - 1)] : 0;
+                            run = max(wave_scan(run, 0, OpMax()), carry);
+                            carry = __builtin_amdgcn_readlane(run, 63);
+                            const int r = max(run - 1, 0);
+                            pos[u] = j < total ? s_b[r] + (j - s_pre[r]) : 0;
+                            t[u] = tgt[pos[u]];
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; u++)
+                            if (j0 + u * 64 < total) offer(j0 + u * 64 + lane < total, pos[u], t[u]);
+                    }
+                } else {
+                    // a dense batch: long runs, walked run by run, U at a time
+                    unsigned long long live = __ballot(len > 0);
+                    while (live) {
+                        int b[U], ln[U], longest = 0;
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            b[u] = 0, ln[u] = 0;
+                            if (live) {
+                                const int r = __builtin_ctzll(live);
+                                live &= live - 1;
+                                b[u] = __builtin_amdgcn_readlane(rb, r);
+                                ln[u] = __builtin_amdgcn_readlane(len, r);
+                                longest = max(longest, ln[u]);
+                            }
+                        }
+                        for (int off = 0; off < longest; off += 64) {
+                            if (n > CAPW - U * 64) n = wave_select_top_m<PER>(s_pos, s_d2, n, m, tgt, lane, thr);
+                            float4 t[U];
+#pragma unroll
+                            for (int u = 0; u < U; u++) t[u] = tgt[b[u] + min(off + lane, max(ln[u] - 1, 0))];
+#pragma unroll
+                            for (int u = 0; u < U; u++)
+                                if (off < ln[u]) offer(off + lane < ln[u], b[u] + off + lane, t[u]);
+                        }
+                    }
+                }
+            }
+            if (n >= m || !(R2 < r2)) break;
+        }
+        unsigned tm = 0xFFFFFFFFu;
+        if (n >= m) {
+            n = wave_select_top_m<PER>(s_pos, s_d2, n, m, tgt, lane, thr);
+            tm = thr;
+        }
+        if (lane < n) nbr[(size_t)lane * ns + i] = s_pos[lane];
+        if (lane == 0) cnt[i] = n, dm2[i] = tm;
     }
-    unsigned tm = 0xFFFFFFFFu;
-    if (n > m) {
-        n = select_top_m<M>(G, tgt, q, n, m, thr);
-        tm = thr;
-    } else if (n == m) {
-        tm = 0;
-        for_each_entry(G, q, n, [&](int, int, unsigned b) { tm = max(tm, b); });
-    }
-    for (int j = 0; j < n; j++) nbr[(size_t)j * ns + i] = G.load(j);
-    cnt[i] = n;
-    dm2[i] = tm;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -684,32 +944,6 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
 // Every d2 that is computed is computed with the same IEEE operations as dist2_flann, and the final selection is the
 // same code as before, so neighbour sets and cut-off states stay bit-identical to the general flavour and the oracle.
 // ---------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_pull(int identity, int v)
-{
-    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
-}
-// inclusive scan over the 64 lanes (ALL lanes must be active); lane 63 ends up with the reduction
-template <class Op>
-__device__ __forceinline__ int wave_scan(int v, int identity, Op op)
-{
-    v = op(v, dpp_pull<0x111, 0xf>(identity, v));  // row_shr:1
-    v = op(v, dpp_pull<0x112, 0xf>(identity, v));  // row_shr:2
-    v = op(v, dpp_pull<0x114, 0xf>(identity, v));  // row_shr:4
-    v = op(v, dpp_pull<0x118, 0xf>(identity, v));  // row_shr:8   -> inclusive within each row of 16
-    v = op(v, dpp_pull<0x142, 0xa>(identity, v));  // row_bcast:15 into rows 1 and 3
-    v = op(v, dpp_pull<0x143, 0xc>(identity, v));  // row_bcast:31 into rows 2 and 3
-    return v;
-}
-struct OpMin { __device__ __forceinline__ int operator()(int a, int b) const { return a < b ? a : b; } };
-struct OpMax { __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; } };
-struct OpAdd { __device__ __forceinline__ int operator()(int a, int b) const { return a + b; } };
-template <class Op>
-__device__ __forceinline__ int wave_reduce(int v, int identity, Op op)  // wave-uniform result
-{
-    return __builtin_amdgcn_readlane(wave_scan(v, identity, op), 63);
-}
-
 // candidate source of the fast flavour: list entries are byte offsets (4 * LDS index) into the SoA halo
 struct HaloList {
     const char *hx;                 // s_x as bytes; y and z follow at fixed strides
@@ -977,8 +1211,10 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         }
     }
     if (handed_over) {
-        // the cleanup kernel redoes this workgroup's queries (this launch): entry = grid index * 4 + half
+        // the cleanup kernel redoes this workgroup's queries (this launch): entry = grid index * 4 + half.  (A two-pass
+        // search has no cleanup role: its second pass takes every row that is marked unsearched or came back short.)
         if (tid == 0) ovf_list[atomicAdd(ovf_count, 1u)] = (int)blockIdx.x * 4 + half;
+        if (valid) cnt[i] = -1;
         flush_stamps();
         return;
     }
@@ -1182,7 +1418,8 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     }
     // a wave with a twice-overflowed lane registers the block (once) for the cleanup kernel; its other results are
     // simply overwritten there with identical values
-    if (__ballot(n < 0) != 0ull) {
+    const bool unanswered = n < 0;  // (marked unsearched, like the rows of a workgroup that bailed: see nn_wide_kernel)
+    if (__ballot(unanswered) != 0ull) {
         if (lane == 0 && atomicExch(&s_bail, 1) == 0) ovf_list[atomicAdd(ovf_count, 1u)] = (int)blockIdx.x * 4 + half;
         n = max(n, 0);
     }
@@ -1192,7 +1429,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
             *out = L.pos_of(L.load(j));
             out += ns;
         }
-        cnt[i] = n;
+        cnt[i] = unanswered ? -1 : n;
         dm2[i] = tm;
     }
     stamp(5);

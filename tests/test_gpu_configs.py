@@ -140,8 +140,12 @@ def test_timed_instantiation_association_vs_oracle(cfg_id, pair):
     np.testing.assert_array_equal(col, ocol)
 
 
-def test_fused_association_with_handovers_on_a_clustered_cloud():
-    """The same on a strongly non-uniform cloud (blobs of very different densities far from the origin), where halos
+@pytest.mark.parametrize("fuse_max_handed_over", [1 << 20, 4])
+def test_fused_association_with_handovers_on_a_clustered_cloud(fuse_max_handed_over):
+    """(fuse_max_handed_over = 2^20: K23 stays folded in however many workgroups are handed over, the cleanup role redoes
+    them; 4, the default: after the first report of more than four the associations run unfused and nn_wide_kernel takes
+    the rows of handed-over workgroups, one row per wave.)
+    The same on a strongly non-uniform cloud (blobs of very different densities far from the origin), where halos
     outgrow the steady-state capacity: blocks are split and HANDED OVER to the cleanup kernel while K23 is folded in (the
     count of handed-over workgroups is read back: the test proves nothing without one).  Per-iteration transforms follow
     the oracle, the last association equals the oracle's."""
@@ -155,6 +159,7 @@ def test_fused_association_with_handovers_on_a_clustered_cloud():
            + rng.normal(0, 0.01, size=(60000, 3))).astype(np.float32)
     n_it = 9
     with _lib.Context(0) as c:
+        c.set_option("fuse_max_handed_over", fuse_max_handed_over)
         c.set_params(1.0, 10, 5.0, 3)
         c.set_target(tgt)
         c.set_source(src)

@@ -32,8 +32,24 @@ for kind in ("slab", "uniform"):
         prof = {k: round(v["total_ms"] / v["launches"] * 1e3, 1) for k, v in c.profile_get().items()}
         nnz = c.association_size()[1]
         handed = c.debug_host_figures()[7] / 5
+        short = c.debug_short_rows()
         print(f"{kind} r={r} m={m} inner<={inner}: {15 / dt:8.0f} it/s ({dt / 15 * 1e6:7.1f} us/iteration) nnz/row {nnz / len(src):5.1f} "
-              f"mean inner {np.mean(res['inner_steps']):.1f} handed over/it {handed:.0f}  {prof}", flush=True)
+              f"mean inner {np.mean(res['inner_steps']):.1f} handed over/it {handed:.0f} short rows {short}  {prof}", flush=True)
+        c.close()
+
+# points per first-pass cell the automatic choice aims at
+for kind in ("slab", "uniform"):
+    src, tgt = clouds(kind)
+    for occ in (60, 85, 110, 140, 180):
+        c = _lib.Context(0)
+        c.set_option("first_pass_occupancy", occ)
+        c.set_params(3.0, 20, 5.0, 3); c.set_target(tgt); c.set_source(src)
+        c.align(3, inner_steps=1); c.synchronize()
+        t0 = time.perf_counter(); c.align(15, cost_drop_thresh=-1.0, inner_steps=1); c.synchronize()
+        dt = time.perf_counter() - t0
+        c.profile_enable(True); c.align(5, cost_drop_thresh=-1.0, inner_steps=1)
+        prof = {k: round(v["total_ms"] / v["launches"] * 1e3, 1) for k, v in c.profile_get().items()}
+        print(f"{kind} r=3 m=20 first_pass_occupancy {occ / 10}: {15 / dt:8.0f} it/s  handed over/it {c.debug_host_figures()[7] / 5:.0f} short rows {c.debug_short_rows()}  {prof}", flush=True)
         c.close()
 
 # forced reach at the CLI default shape on the uniform cloud: which first-pass cell size is best
