@@ -125,9 +125,10 @@ struct ppcr_ctx {
     int reach = 1;
     int opt_two_pass = 1;
     int opt_fuse_max_handed_over = 4;  // more workgroups than this handed over last time: K23 is not folded into K1
-    int opt_first_pass_occ = 85;  // tenths of a point per first-pass cell (see target_occupancy)
+    int opt_first_pass_fill = 22;  // tenths: the first-pass sphere should hold this many times max_neighbours points
+    int opt_first_pass_occ = 110;  // tenths of a point per first-pass cell (see target_occupancy)
     DevBuf<unsigned long long> d_occupancy;
-    DevBuf<int> d_short;         // second pass: [0] the number of short rows, [1 ..] their list
+    DevBuf<int> d_short;         // second pass: [0] the number of short rows, [1] finished workgroups, [2] last count, [3 ..] the list
     bool src_sorted = false;
     GridDesc grid{};
     DevBuf<int> cell_start;
@@ -441,15 +442,15 @@ constexpr int kMaxReach = 8;  // the second pass's stencil is (2 reach + 1)^2 ro
 // first-pass sphere holds 4.19 q points, ~1.7 max_neighbours of them answer nearly every row in the first pass; but the
 // fuller the cells, the more 256-query blocks' halos (36-49 rows of ~4 cells) outgrow the LDS tile and leave their rows
 // to the second pass as well (`cap`, option "first_pass_occupancy", in points per cell).
-double target_occupancy(int max_nb, double cap) { return std::min(1.7 * (double)max_nb / 4.19, cap); }
+double target_occupancy(int max_nb, double cap, double fill) { return std::min(fill * (double)max_nb / 4.19, cap); }
 
 // First-pass search radius for a measured / estimated occupancy `per_cell` of cells of edge `radius`: the radius itself
 // when such cells are not too full, else the radius at which a cell holds target_occupancy() points (never less than
 // radius / kMaxReach).  The second pass then reaches ceil(radius / r') cells.
-double choose_search_radius(double radius, double per_cell, int max_nb, double cap)
+double choose_search_radius(double radius, double per_cell, int max_nb, double cap, double fill)
 {
     if (!(per_cell > 0) || !std::isfinite(per_cell)) return radius;
-    const double q = target_occupancy(max_nb, cap);
+    const double q = target_occupancy(max_nb, cap, fill);
     if (per_cell <= std::max(q, cap)) return radius;
     return std::max(radius * std::cbrt(q / per_cell), radius / kMaxReach);
 }
@@ -542,7 +543,7 @@ int ensure_grid(ppcr_ctx *c)
         double vol = 1;
         for (int a = 0; a < 3; a++) vol *= std::max((double)c->tgt_hi[a] - (double)c->tgt_lo[a], c->radius);
         const double per_cell = (double)n * c->radius * c->radius * c->radius / vol;
-        search = c->opt_two_pass >= 2 ? c->radius / c->opt_two_pass : choose_search_radius(c->radius, per_cell, c->max_nb, 0.1 * c->opt_first_pass_occ);
+        search = c->opt_two_pass >= 2 ? c->radius / c->opt_two_pass : choose_search_radius(c->radius, per_cell, c->max_nb, 0.1 * c->opt_first_pass_occ, 0.1 * c->opt_first_pass_fill);
     }
     for (int attempt = 0;; attempt++) {
         c->search_radius = search;
@@ -552,7 +553,7 @@ int ensure_grid(ppcr_ctx *c)
         if (!(bounded && c->opt_two_pass == 1) || attempt == 2 || search <= c->radius / kMaxReach) break;
         double q_here = 0;  // points per cell (edge ~search) where the dense part of the cloud lives
         PPCR_TRY(grid_occupancy(c, &q_here));
-        const double cap = 0.1 * c->opt_first_pass_occ, q_want = target_occupancy(c->max_nb, cap);
+        const double cap = 0.1 * c->opt_first_pass_occ, q_want = target_occupancy(c->max_nb, cap, 0.1 * c->opt_first_pass_fill);
         if (q_here <= 1.5 * std::max(q_want, cap)) break;  // close enough: keep this grid
         // the points live in fuller cells than the bounding box suggested (a cloud that does not fill its box)
         search = std::max(search * std::cbrt(q_want / q_here), c->radius / kMaxReach);
@@ -751,11 +752,12 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             // but walks a dense neighbourhood one candidate per lane at a time), or — whenever K23 is not folded in and the
             // last association heard from handed something over, and always in a two-pass search — nn_wide_kernel
             if (c->reach > 1 || (fuse == nullptr && c->ovf_last != ~0u && c->ovf_last > 0)) {
-                if (c->d_short.cap < (size_t)ns + 1) {
+                if (c->d_short.cap < (size_t)ns + 3) {
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
-                    HIP_TRY(c, c->d_short.reserve((size_t)ns + 1));
+                    HIP_TRY(c, c->d_short.reserve((size_t)ns + 3));
+                    HIP_TRY(c, hipMemsetAsync(c->d_short.p, 0, 3 * sizeof(int), c->stream));  // (kept at zero by nn_wide_kernel from here on)
                 }
-                tl.short_count = reinterpret_cast<unsigned *>(c->d_short.p), tl.short_list = c->d_short.p + 1;
+                tl.short_count = reinterpret_cast<unsigned *>(c->d_short.p), tl.short_list = c->d_short.p + 3;
             }
             tl.nbr = c->nbr.p, tl.cnt = c->cnt.p, tl.dm2 = c->dm2.p;
             tl.dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
@@ -1596,6 +1598,12 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
     if (std::strcmp(key, "fuse_max_handed_over") == 0) {
         if (value < 0) return fail(c, PPCR_ERR_INVALID, "fuse_max_handed_over must be >= 0");
         c->opt_fuse_max_handed_over = value;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "first_pass_fill") == 0) {
+        if (value < 10 || value > 100) return fail(c, PPCR_ERR_INVALID, "first_pass_fill is in tenths of max_neighbours, 10..100");
+        c->opt_first_pass_fill = value;
+        c->grid_valid = false;
         return PPCR_OK;
     }
     if (std::strcmp(key, "first_pass_occupancy") == 0) {
@@ -2449,7 +2457,7 @@ int ppcr_debug_get_short_rows(ppcr_ctx *c, unsigned *out)
     CTX_ENTER(c);
     *out = 0;
     if (c->d_short.p) {
-        HIP_TRY(c, hipMemcpyAsync(out, c->d_short.p, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(out, c->d_short.p + 2, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return PPCR_OK;

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(BLOCK, (C >= 64 ? 2 : 3)) void nn_tile_cleanup_kern
                                                          const int *__restrict__ ovf_list,
                                                          const unsigned *__restrict__ ovf_count,
                                                          const int *__restrict__ split_list, int n_extra, FusedMoments fm,
-                                                         FoldSolve fs, unsigned *__restrict__ short_count)
+                                                         FoldSolve fs)
 {
     static_assert(!MERGED || FTM != -2, "the merged launch folds the partials the fused kernels wrote");
     if (loop_aborted(fs.loop.st)) {  // an earlier launch handed the iteration to the host: step aside (see LoopState)
@@ -251,12 +251,7 @@ __global__ __launch_bounds__(BLOCK, (C >= 64 ? 2 : 3)) void nn_tile_cleanup_kern
             if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) publish_skipped(fs);
         return;
     }
-    // two-pass search: the list of short rows (short_rows_kernel, next in the stream) starts empty
-    if (short_count != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *short_count = 0;
-    // (two-pass search: the rows of handed-over workgroups are marked unsearched and go to nn_wide_kernel with the short ones
-    //  — one row per wave walks a dense neighbourhood's thousands of candidates in a few rounds, where this kernel's lanes
-    //  walk them one by one: 0.5 ms for 29 workgroups of a cloud with dense blobs)
-    const unsigned n_listed = short_count != nullptr ? 0u : *ovf_count;
+    const unsigned n_listed = *ovf_count;
     const unsigned n_cleanup = MERGED ? gridDim.x - kNSums : gridDim.x;  // workgroups in the cleanup role
     if constexpr (MERGED) {
         if (blockIdx.x >= n_cleanup) {
@@ -761,7 +756,7 @@ template <int M>
 __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt,
                                                       const int *__restrict__ cell_start, GridDesc g, int reach, float r1_sq, float r2, int m,
                                                       int *__restrict__ nbr, int *__restrict__ cnt, unsigned *__restrict__ dm2,
-                                                      const int *__restrict__ short_list, const unsigned *__restrict__ short_count,
+                                                      const int *__restrict__ short_list, unsigned *__restrict__ short_count,
                                                       const LoopState *loop_st)
 {
     constexpr int U = 4;             // chunks of 64 candidates (loads per lane) in flight
@@ -917,6 +912,13 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
         }
         if (lane < n) nbr[(size_t)lane * ns + i] = s_pos[lane];
         if (lane == 0) cnt[i] = n, dm2[i] = tm;
+    }
+    // the last workgroup to finish empties the list for the next association (every workgroup has read the count by then)
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(short_count + 1, 1u) == gridDim.x - 1) {
+        short_count[2] = n_short;  // (diagnostic: ppcr_debug_get_short_rows)
+        short_count[1] = 0;
+        short_count[0] = 0;
     }
 }
 

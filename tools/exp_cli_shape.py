@@ -37,20 +37,22 @@ for kind in ("slab", "uniform"):
               f"mean inner {np.mean(res['inner_steps']):.1f} handed over/it {handed:.0f} short rows {short}  {prof}", flush=True)
         c.close()
 
-# points per first-pass cell the automatic choice aims at
+# how many times max_neighbours the first-pass sphere should hold, and the cap on points per cell
 for kind in ("slab", "uniform"):
     src, tgt = clouds(kind)
-    for occ in (60, 85, 110, 140, 180):
-        c = _lib.Context(0)
-        c.set_option("first_pass_occupancy", occ)
-        c.set_params(3.0, 20, 5.0, 3); c.set_target(tgt); c.set_source(src)
-        c.align(3, inner_steps=1); c.synchronize()
-        t0 = time.perf_counter(); c.align(15, cost_drop_thresh=-1.0, inner_steps=1); c.synchronize()
-        dt = time.perf_counter() - t0
-        c.profile_enable(True); c.align(5, cost_drop_thresh=-1.0, inner_steps=1)
-        prof = {k: round(v["total_ms"] / v["launches"] * 1e3, 1) for k, v in c.profile_get().items()}
-        print(f"{kind} r=3 m=20 first_pass_occupancy {occ / 10}: {15 / dt:8.0f} it/s  handed over/it {c.debug_host_figures()[7] / 5:.0f} short rows {c.debug_short_rows()}  {prof}", flush=True)
-        c.close()
+    for m in (20, 10):
+        for fill, occ in ((17, 85), (22, 110), (27, 130), (32, 160), (40, 200)):
+            c = _lib.Context(0)
+            c.set_option("first_pass_fill", fill)
+            c.set_option("first_pass_occupancy", occ)
+            c.set_params(3.0, m, 5.0, 3); c.set_target(tgt); c.set_source(src)
+            c.align(3, inner_steps=1); c.synchronize()
+            t0 = time.perf_counter(); c.align(15, cost_drop_thresh=-1.0, inner_steps=1); c.synchronize()
+            dt = time.perf_counter() - t0
+            c.profile_enable(True); c.align(5, cost_drop_thresh=-1.0, inner_steps=1)
+            prof = {k: round(v["total_ms"] / v["launches"] * 1e3, 1) for k, v in c.profile_get().items()}
+            print(f"{kind} r=3 m={m} fill {fill / 10} cap {occ / 10}: {15 / dt:8.0f} it/s  handed over/it {c.debug_host_figures()[7] / 5:.0f} short rows {c.debug_short_rows()}  {prof}", flush=True)
+            c.close()
 
 # forced reach at the CLI default shape on the uniform cloud: which first-pass cell size is best
 src, tgt = clouds("uniform")
