@@ -128,7 +128,7 @@ struct ppcr_ctx {
     int opt_first_pass_fill = 22;  // tenths: the first-pass sphere should hold this many times max_neighbours points
     int opt_first_pass_occ = 110;  // tenths of a point per first-pass cell (see target_occupancy)
     DevBuf<unsigned long long> d_occupancy;
-    DevBuf<int> d_short;         // second pass: [0] the number of short rows, [1] finished workgroups, [2] last count, [3 ..] the list
+    DevBuf<int> d_short;         // second pass: [0], [1] the number of listed rows (ping-pong pair, see ovf_parity), [2] last count seen, [3 ..] the list
     bool src_sorted = false;
     GridDesc grid{};
     DevBuf<int> cell_start;
@@ -755,10 +755,13 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
                 if (c->d_short.cap < (size_t)ns + 3) {
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
                     HIP_TRY(c, c->d_short.reserve((size_t)ns + 3));
-                    HIP_TRY(c, hipMemsetAsync(c->d_short.p, 0, 3 * sizeof(int), c->stream));  // (kept at zero by nn_wide_kernel from here on)
+                    HIP_TRY(c, hipMemsetAsync(c->d_short.p, 0, 3 * sizeof(int), c->stream));
                 }
-                tl.short_count = reinterpret_cast<unsigned *>(c->d_short.p), tl.short_list = c->d_short.p + 3;
+                // (the list's counters alternate with the hand-over counters: ovf_parity, rolled back with recalled trains)
+                tl.short_count = reinterpret_cast<unsigned *>(c->d_short.p) + c->ovf_parity, tl.short_list = c->d_short.p + 3;
+                tl.short_seen = reinterpret_cast<unsigned *>(c->d_short.p) + 2;
             }
+            if (c->d_short.p) tl.short_next = reinterpret_cast<unsigned *>(c->d_short.p) + (c->ovf_parity ^ 1);
             tl.nbr = c->nbr.p, tl.cnt = c->cnt.p, tl.dm2 = c->dm2.p;
             tl.dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
             tl.short_lists = c->opt_short_lists;

@@ -95,11 +95,12 @@ void launch_tile(TileLaunch &t)
         // search, those that came back short — are listed (in place of the cleanup launch: nothing is folded in this mode),
         // then searched one row per wave (a fixed grid of waves strides over the list: its length is only known on the device)
         t.merged = false;
-        short_rows_kernel<M><<<nb, 256, 0, t.stream>>>(t.cnt, t.ns, (t.reach > 1 ? t.m : 0), t.short_list, t.short_count, t.loop_st);
+        constexpr int kWideGrid = 256 * 7;  // seven workgroups per CU are resident (71 VGPRs, 22 KB of LDS): 7168 waves, a row each
+        short_rows_kernel<M><<<nb, 256, 0, t.stream>>>(t.cnt, t.ns, (t.reach > 1 ? t.m : 0), t.short_list, t.short_count, t.short_next, t.loop_st);
         if (t.between2) t.between2(t.between_arg);
-        nn_wide_kernel<M><<<std::min(std::max(nb, 1), 1280), 256, 0, t.stream>>>(t.src, t.ns, t.tgt, t.cell_start, t.grid, t.reach, t.r2,
+        nn_wide_kernel<M><<<kWideGrid, 256, 0, t.stream>>>(t.src, t.ns, t.tgt, t.cell_start, t.grid, t.reach, t.r2,
                                                                                t.r2_full, t.m, t.nbr, t.cnt, t.dm2, t.short_list,
-                                                                               t.short_count, t.loop_st);
+                                                                               t.short_count, t.short_seen, t.loop_st);
         return;
     }
     // persistent workgroups over the list: few when the last association this handle heard from handed nothing over
@@ -115,7 +116,7 @@ void launch_tile(TileLaunch &t)
 #define PPCR_CLEANUP(FTMc, FMc, MERGEc, FSc)                                                                           \
     nn_tile_cleanup_kernel<M, CC, 256, CAP, FTMc, MERGEc><<<cleanup_grid + (MERGEc ? kNSums : 0), 256, 0, t.stream>>>(  \
         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.dm2, t.ovf_list, t.ovf_now, t.split_list,  \
-        n_extra, FMc, FSc)
+        n_extra, FMc, FSc, t.short_next)
     if (ftm == 0 && merge) PPCR_CLEANUP(0, *t.fuse, true, fold_now);
     else if (ftm == 8 && merge) PPCR_CLEANUP(8, *t.fuse, true, fold_now);
     else if (ftm == -3 && merge) PPCR_CLEANUP(-3, *t.fuse, true, fold_now);

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(BLOCK, (C >= 64 ? 2 : 3)) void nn_tile_cleanup_kern
                                                          const int *__restrict__ ovf_list,
                                                          const unsigned *__restrict__ ovf_count,
                                                          const int *__restrict__ split_list, int n_extra, FusedMoments fm,
-                                                         FoldSolve fs)
+                                                         FoldSolve fs, unsigned *__restrict__ short_next)
 {
     static_assert(!MERGED || FTM != -2, "the merged launch folds the partials the fused kernels wrote");
     if (loop_aborted(fs.loop.st)) {  // an earlier launch handed the iteration to the host: step aside (see LoopState)
@@ -251,6 +251,9 @@ __global__ __launch_bounds__(BLOCK, (C >= 64 ? 2 : 3)) void nn_tile_cleanup_kern
             if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) publish_skipped(fs);
         return;
     }
+    // (the unanswered-rows list of the row-per-wave search, when the handle has one: the next association's counter of its
+    //  ping-pong pair starts empty — short_rows_kernel does this in the launches that list rows)
+    if (short_next != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *short_next = 0;
     const unsigned n_listed = *ovf_count;
     const unsigned n_cleanup = MERGED ? gridDim.x - kNSums : gridDim.x;  // workgroups in the cleanup role
     if constexpr (MERGED) {
@@ -649,9 +652,12 @@ __global__ __launch_bounds__(BLOCK, (C >= 64 ? 2 : 3)) void nn_tile_cleanup_kern
 // ---------------------------------------------------------------------------------------------
 template <int M>
 __global__ __launch_bounds__(256) void short_rows_kernel(const int *__restrict__ cnt, int ns, int m, int *__restrict__ list,
-                                                         unsigned *__restrict__ count, const LoopState *loop_st)
+                                                         unsigned *__restrict__ count, unsigned *__restrict__ count_next,
+                                                         const LoopState *loop_st)
 {
     if (loop_aborted(loop_st)) return;
+    // the other counter of the ping-pong pair (idle during this association) is the next association's: it starts empty
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_next = 0;
     __shared__ int s_n[4];
     __shared__ unsigned s_base;
     const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -756,8 +762,8 @@ template <int M>
 __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt,
                                                       const int *__restrict__ cell_start, GridDesc g, int reach, float r1_sq, float r2, int m,
                                                       int *__restrict__ nbr, int *__restrict__ cnt, unsigned *__restrict__ dm2,
-                                                      const int *__restrict__ short_list, unsigned *__restrict__ short_count,
-                                                      const LoopState *loop_st)
+                                                      const int *__restrict__ short_list, const unsigned *__restrict__ short_count,
+                                                      unsigned *__restrict__ short_seen, const LoopState *loop_st)
 {
     constexpr int U = 4;             // chunks of 64 candidates (loads per lane) in flight
     constexpr int CAPW = 512;        // list entries per wave; compacted to m whenever a round of U * 64 might not fit
@@ -776,8 +782,11 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
     unsigned char *const s_mark = s_mark_all[wave];
     unsigned *const s_mark4 = reinterpret_cast<unsigned *>(s_mark);
     const unsigned n_short = *short_count;
-    for (unsigned entry = blockIdx.x * 4 + wave; entry < n_short; entry += gridDim.x * 4) {
-        const int i = __builtin_amdgcn_readfirstlane(short_list[entry]);
+    const unsigned entry0 = blockIdx.x * 4 + wave;
+    int i_next = entry0 < n_short ? short_list[entry0] : 0;
+    for (unsigned entry = entry0; entry < n_short; entry += gridDim.x * 4) {
+        const int i = __builtin_amdgcn_readfirstlane(i_next);
+        i_next = entry + gridDim.x * 4 < n_short ? short_list[entry + gridDim.x * 4] : 0;  // (travels under this row's search)
         const int found = __builtin_amdgcn_readfirstlane(cnt[i]);  // < 0: its workgroup left the first pass to this one
         const float4 q = src[i];
         const QueryCells c = query_cells(q, g);
@@ -913,13 +922,7 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
         if (lane < n) nbr[(size_t)lane * ns + i] = s_pos[lane];
         if (lane == 0) cnt[i] = n, dm2[i] = tm;
     }
-    // the last workgroup to finish empties the list for the next association (every workgroup has read the count by then)
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(short_count + 1, 1u) == gridDim.x - 1) {
-        short_count[2] = n_short;  // (diagnostic: ppcr_debug_get_short_rows)
-        short_count[1] = 0;
-        short_count[0] = 0;
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *short_seen = n_short;  // (diagnostic: ppcr_debug_get_short_rows)
 }
 
 // ---------------------------------------------------------------------------------------------

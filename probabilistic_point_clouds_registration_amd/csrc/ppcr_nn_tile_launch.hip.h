@@ -19,8 +19,10 @@ struct TileLaunch {
     int reach;                    // > 1: two-pass search — rows that come back short are searched again with r2_full over a
     float r2_full;                //      stencil `reach` cells wide (nn_wide_kernel) ...
     int *short_list;              // when short_count is given: the rows of handed-over workgroups (and the short rows of a two-pass
-    unsigned *short_count;        //      search) are listed here [ns] + counted ([0]; [1] counts nn_wide_kernel's finished workgroups,
-                                  //      the last of which zeroes both; [2] the last count) and nn_wide_kernel searches them; there is no cleanup launch then
+    unsigned *short_count;        //      search) are listed here [ns] + counted and nn_wide_kernel searches them; there is no cleanup
+                                  //      launch then
+    unsigned *short_next;         // the other counter of that list's ping-pong pair (nullable): every launch leaves it at zero
+    unsigned *short_seen;         // diagnostic: the count nn_wide_kernel saw
     int m;                        // max_neighbours (<= the M of the variant that is called)
     int *nbr, *cnt;               // the ELL association [m][ns], [ns]
     unsigned *dm2;                // per query: float bits of its m-th neighbour's d2 (the temporal cut-off)
