@@ -361,6 +361,15 @@ class Context:
         self._ck(f(self._h, out))
         return list(out)
 
+    def search_reach(self):
+        """ppcr_debug_get_search (diagnostic): cells per radius of the grid in use — 1: one-pass search, > 1: two passes."""
+        out = (C.c_double * 2)()
+        f = self._L.ppcr_debug_get_search
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        f.restype = C.c_int
+        self._ck(f(self._h, out))
+        return int(out[0])
+
     def debug_short_rows(self):
         """ppcr_debug_get_short_rows (diagnostic): rows the first pass of the most recent two-pass association left short."""
         out = C.c_uint(0)

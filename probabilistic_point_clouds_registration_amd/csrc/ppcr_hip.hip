@@ -2454,6 +2454,15 @@ int ppcr_debug_get_host_times(ppcr_ctx *c, double out[8])
     return PPCR_OK;
 }
 
+// diagnostic: {reach (cells per radius: 1 = one-pass search), first-pass search radius} of the grid in use
+int ppcr_debug_get_search(ppcr_ctx *c, double out[2])
+{
+    CTX_ENTER(c);
+    out[0] = c->grid_valid ? (double)c->reach : 0.0;
+    out[1] = c->grid_valid ? c->search_radius : 0.0;
+    return PPCR_OK;
+}
+
 // diagnostic: rows the first pass of the most recent two-pass association left short (0 for a one-pass search)
 int ppcr_debug_get_short_rows(ppcr_ctx *c, unsigned *out)
 {

@@ -50,12 +50,14 @@ void launch_tile(TileLaunch &t)
     FusedMoments fm_none;
     std::memset(&fm_none, 0, sizeof(fm_none));
     const LoopReset lr{t.loop_st};
+    // (one-pass search: only rows marked unsearched are listed, its short rows are final)
+    const UnansweredRows un{(t.short_count ? t.short_list : nullptr), t.short_count, t.short_next, (t.reach > 1 ? t.m : 0)};
     // the steady-state (16-slot) variant runs with a halo capacity that gives FIVE workgroups per CU (31.3 KB of LDS)
     // and splits the few blocks that outgrow it; the first association (32 slots, three per CU) keeps the large one
 #define PPCR_FAST(Cc, STAMPc, FTMc, FMc)                                                                               \
     nn_fast_kernel<M, Cc, (Cc <= 16 ? kCapSteady : CAP), STAMPc, FTMc><<<nb + (Cc <= 16 ? kMaxSplit : 0), 256, 0, t.stream>>>( \
         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,  \
-        t.ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc, lr)
+        t.ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc, lr, un)
     t.fused = false;
     int ftm = -2;  // model folded into this launch (-2: none)
     bool steady = false;
@@ -89,18 +91,17 @@ void launch_tile(TileLaunch &t)
         }
     }
 #undef PPCR_FAST
-    if (t.between) t.between(t.between_arg);
+    if (t.short_count == nullptr && t.between) t.between(t.between_arg);
     if (t.short_count != nullptr) {
-        // the rows the tiled kernel did not answer — those of handed-over workgroups (marked unsearched) and, in a two-pass
-        // search, those that came back short — are listed (in place of the cleanup launch: nothing is folded in this mode),
-        // then searched one row per wave (a fixed grid of waves strides over the list: its length is only known on the device)
-        t.merged = false;
-        constexpr int kWideGrid = 256 * 7;  // seven workgroups per CU are resident (71 VGPRs, 22 KB of LDS): 7168 waves, a row each
-        short_rows_kernel<M><<<nb, 256, 0, t.stream>>>(t.cnt, t.ns, (t.reach > 1 ? t.m : 0), t.short_list, t.short_count, t.short_next, t.loop_st);
         if (t.between2) t.between2(t.between_arg);
-        nn_wide_kernel<M><<<kWideGrid, 256, 0, t.stream>>>(t.src, t.ns, t.tgt, t.cell_start, t.grid, t.reach, t.r2,
-                                                                               t.r2_full, t.m, t.nbr, t.cnt, t.dm2, t.short_list,
-                                                                               t.short_count, t.short_seen, t.loop_st);
+        // the rows the tiled kernel did not answer — those of handed-over workgroups (marked unsearched) and, in a two-pass
+        // search, those that came back short — were listed by the kernel itself; they are searched one row per wave, in
+        // place of the cleanup launch (nothing is folded in this mode).  A fixed grid of waves strides over the list: its
+        // length is only known on the device.
+        t.merged = false;
+        constexpr int kWideGrid = 256 * 6;  // six workgroups per CU are resident (74 VGPRs, 22 KB of LDS): 6144 waves, a row each
+        nn_wide_kernel<M><<<kWideGrid, 256, 0, t.stream>>>(t.src, t.ns, t.tgt, t.cell_start, t.grid, t.reach, t.r2, t.r2_full, t.m, t.nbr,
+                                                            t.cnt, t.dm2, t.short_list, t.short_count, t.short_seen, t.loop_st);
         return;
     }
     // persistent workgroups over the list: few when the last association this handle heard from handed nothing over
@@ -116,7 +117,7 @@ void launch_tile(TileLaunch &t)
 #define PPCR_CLEANUP(FTMc, FMc, MERGEc, FSc)                                                                           \
     nn_tile_cleanup_kernel<M, CC, 256, CAP, FTMc, MERGEc><<<cleanup_grid + (MERGEc ? kNSums : 0), 256, 0, t.stream>>>(  \
         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.dm2, t.ovf_list, t.ovf_now, t.split_list,  \
-        n_extra, FMc, FSc, t.short_next)
+        n_extra, FMc, FSc)
     if (ftm == 0 && merge) PPCR_CLEANUP(0, *t.fuse, true, fold_now);
     else if (ftm == 8 && merge) PPCR_CLEANUP(8, *t.fuse, true, fold_now);
     else if (ftm == -3 && merge) PPCR_CLEANUP(-3, *t.fuse, true, fold_now);

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(BLOCK, (C >= 64 ? 2 : 3)) void nn_tile_cleanup_kern
                                                          const int *__restrict__ ovf_list,
                                                          const unsigned *__restrict__ ovf_count,
                                                          const int *__restrict__ split_list, int n_extra, FusedMoments fm,
-                                                         FoldSolve fs, unsigned *__restrict__ short_next)
+                                                         FoldSolve fs)
 {
     static_assert(!MERGED || FTM != -2, "the merged launch folds the partials the fused kernels wrote");
     if (loop_aborted(fs.loop.st)) {  // an earlier launch handed the iteration to the host: step aside (see LoopState)
@@ -251,9 +251,6 @@ __global__ __launch_bounds__(BLOCK, (C >= 64 ? 2 : 3)) void nn_tile_cleanup_kern
             if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) publish_skipped(fs);
         return;
     }
-    // (the unanswered-rows list of the row-per-wave search, when the handle has one: the next association's counter of its
-    //  ping-pong pair starts empty — short_rows_kernel does this in the launches that list rows)
-    if (short_next != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *short_next = 0;
     const unsigned n_listed = *ovf_count;
     const unsigned n_cleanup = MERGED ? gridDim.x - kNSums : gridDim.x;  // workgroups in the cleanup role
     if constexpr (MERGED) {
@@ -650,31 +647,6 @@ __global__ __launch_bounds__(BLOCK, (C >= 64 ? 2 : 3)) void nn_tile_cleanup_kern
 // flight, accepted candidates are appended to a wave-shared list in LDS (ballot + prefix), and the selection of the m
 // smallest by (d2, original index) is a wave-wide bit-by-bit descent on ballot counts.
 // ---------------------------------------------------------------------------------------------
-template <int M>
-__global__ __launch_bounds__(256) void short_rows_kernel(const int *__restrict__ cnt, int ns, int m, int *__restrict__ list,
-                                                         unsigned *__restrict__ count, unsigned *__restrict__ count_next,
-                                                         const LoopState *loop_st)
-{
-    if (loop_aborted(loop_st)) return;
-    // the other counter of the ping-pong pair (idle during this association) is the next association's: it starts empty
-    if (blockIdx.x == 0 && threadIdx.x == 0) *count_next = 0;
-    __shared__ int s_n[4];
-    __shared__ unsigned s_base;
-    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool is_short = i < ns && cnt[i] < m;  // (m = 0: only the rows marked unsearched, a one-pass search's short rows are final)
-    const unsigned long long b = __ballot(is_short);
-    if (lane == 0) s_n[wave] = __popcll(b);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int total = s_n[0] + s_n[1] + s_n[2] + s_n[3];
-        s_base = total ? atomicAdd(count, (unsigned)total) : 0u;
-    }
-    __syncthreads();
-    int at = (int)s_base + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
-    for (int w = 0; w < wave; w++) at += s_n[w];
-    if (is_short) list[at] = i;
-}
-
 // The wave's list [0, n) in LDS (sorted-target position, d2 bits) -> its m smallest by (d2, original index), compacted in
 // place; returns the new length (min(n, m)) and the d2 bits of the m-th (thr is left alone when n < m).  PER * 64 >= n.
 // The m-th smallest d2 is found bit by bit from the top: "how many entries agree with the prefix so far and have a 0
@@ -994,6 +966,17 @@ struct LoopReset {
     const LoopState *st;
 };
 
+// The rows this kernel does not answer, for nn_wide_kernel (row-per-wave search): rows of a workgroup that hands itself
+// over or of a lane whose list overflowed twice (marked cnt = -1), and rows that found fewer than m_list neighbours (a
+// two-pass search's short rows; m_list = 0 in a one-pass search, whose short rows are final).  `list` null: nobody takes
+// them (the cleanup kernel redoes handed-over workgroups).  The counters are a ping-pong pair: this launch appends under
+// `count` and leaves `next`, the following association's, at zero.
+struct UnansweredRows {
+    int *list;
+    unsigned *count, *next;
+    int m_list;
+};
+
 // FTM != -2 (0: Gaussian, k > 0: t model with v + dim = k, -3: t model with an integer v + dim read at run time) folds
 // K23 into this kernel: each lane finishes its row's
 // contribution to the 19 moments from the winners' coordinates while they are still in LDS (no neighbour gathers, no
@@ -1008,7 +991,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
                                                          int *__restrict__ ovf_list, unsigned *__restrict__ ovf_count,
                                                          unsigned *__restrict__ ovf_count_next, SplitTable split,
                                                          unsigned long long *__restrict__ stamps, FusedMoments fm,
-                                                         LoopReset lr)
+                                                         LoopReset lr, UnansweredRows un)
 {
     // an earlier launch may have handed the iteration to the host (LoopState::abort, set before this kernel started):
     // then this one must touch nothing.  A uniform scalar load, tested below once the query load is in flight.
@@ -1071,7 +1054,10 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (aborted) return;
     // the other counter of the ping-pong pair: idle during this launch  (the last workgroup is never an idle split slot)
-    if (tid == 0 && blockIdx.x == gridDim.x - 1) *ovf_count_next = 0;
+    if (tid == 0 && blockIdx.x == gridDim.x - 1) {
+        *ovf_count_next = 0;
+        if (un.next != nullptr) *un.next = 0;
+    }
     float moved = 0.f;  // how far this query travelled since the association that produced dm2
     if (pm.enabled && valid) {
         const float4 q0 = q;
@@ -1215,11 +1201,22 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
             split.flag[bid] = 1;
         }
     }
+    // a wave's unanswered rows go to the list in one piece: one atomic per wave that has any
+    auto list_rows = [&](bool mine) {
+        const unsigned long long b = __ballot(mine);
+        if (b != 0ull) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(un.count, (unsigned)__popcll(b));
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (mine) un.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))] = i;
+        }
+    };
     if (handed_over) {
-        // the cleanup kernel redoes this workgroup's queries (this launch): entry = grid index * 4 + half.  (A two-pass
-        // search has no cleanup role: its second pass takes every row that is marked unsearched or came back short.)
+        // the cleanup kernel redoes this workgroup's queries (this launch): entry = grid index * 4 + half — or, when the
+        // unanswered rows are listed, nn_wide_kernel searches them (marked unsearched)
         if (tid == 0) ovf_list[atomicAdd(ovf_count, 1u)] = (int)blockIdx.x * 4 + half;
         if (valid) cnt[i] = -1;
+        if (un.list != nullptr) list_rows(valid);
         flush_stamps();
         return;
     }
@@ -1437,6 +1434,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         cnt[i] = unanswered ? -1 : n;
         dm2[i] = tm;
     }
+    if (un.list != nullptr) list_rows(valid && (unanswered || n < un.m_list));
     stamp(5);
     if constexpr (FTM != -2) {
         // ---- K23 for this row, from LDS: weights at fm.P, the row's share of the 19 moments ----------------------

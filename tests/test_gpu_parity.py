@@ -869,6 +869,65 @@ def test_randomised_association_soak(ctx):
                 po.transform_cloud(cur, T)
 
 
+def test_randomised_row_per_wave_soak():
+    """Seeded random sweep aimed at the row-per-wave search (short_rows_kernel + nn_wide_kernel): radii that hold many
+    times max_neighbours points (two-pass searches with automatic and forced reach), clouds with blobs hundreds of times
+    denser than the rest (workgroups whose halo outgrows the LDS tile, in one-pass searches too), quantised coordinates
+    (floods of exact ties at the m-th distance, settled by original index), every list width, sources that move between
+    associations.  Neighbour sets and float d2 equal the oracle's, bit for bit."""
+    rng = np.random.default_rng(int(os.environ.get("PPCR_SOAK_SEED", "424242")))
+    listed_two_pass, listed_one_pass = 0, 0   # rows the row-per-wave kernel searched (the sweep proves nothing without them)
+    for trial in range(int(os.environ.get("PPCR_SOAK_TRIALS", "14"))):
+        nt = int(rng.integers(3000, 40000))
+        ext = rng.uniform(3.0, 25.0, size=3) * rng.choice([1.0, 0.03], size=3, p=[0.85, 0.15])
+        off = rng.uniform(-300, 300, size=3) * rng.choice([0.0, 1.0])
+        tgt = rng.uniform(0, 1, size=(nt, 3)) * ext
+        nblob = int(rng.integers(0, 4))
+        for _ in range(nblob):                                 # blobs far denser than the rest
+            k = int(rng.integers(300, 4000))
+            tgt[rng.integers(0, nt, size=k)] = rng.uniform(0, 1, size=3) * ext + rng.normal(0, rng.uniform(0.02, 0.3), size=(k, 3))
+        tgt = (tgt + off).astype(np.float32)
+        if trial % 3 == 1:                                     # quantised: exact ties, duplicated points
+            tgt = (np.round(tgt * 8) / 8).astype(np.float32)
+        ns = int(rng.integers(200, 9000))
+        src = (tgt[rng.integers(0, nt, size=ns)] + rng.normal(0, rng.choice([0.0, 0.01, 0.3]), size=(ns, 3))).astype(np.float32)
+        if trial % 4 == 0:                                     # some queries far outside the target's box
+            src[: max(1, ns // 50)] += np.float32(3.0 * ext.max())
+        radius = float(rng.uniform(0.5, 4.0))
+        m = int(rng.choice([1, 3, 5, 10, 12, 16, 20, 32]))
+        two_pass = int(rng.choice([1, 1, 1, 0, 2, 3, 5, 8]))
+        with _lib.Context(0) as c:
+            c.set_option("two_pass", two_pass)
+            c.set_option("defer_moves", trial % 2)
+            c.set_option("first_pass_fill", int(rng.choice([22, 12, 40])))
+            c.set_params(radius, m, 5.0, 3)
+            c.set_target(tgt)
+            c.set_source(src)
+            cur = src.copy()
+            for step in range(4):
+                if step == 2:
+                    c.accumulate(np.array([1.0, 0, 0, 0]), np.zeros(3))   # (a mailbox round trip: the hand-over count reaches the host)
+                c.associate()
+                rp, col, d2 = c.get_association()
+                orp, ocol, od2 = po.radius_search(cur, tgt, radius, m, method=1)
+                tag = f"trial {trial} step {step} (nt {nt} ns {ns} r {radius:.3f} m {m} two_pass {two_pass} blobs {nblob})"
+                np.testing.assert_array_equal(rp, orp, err_msg=tag)
+                np.testing.assert_array_equal(col, ocol, err_msg=tag)
+                np.testing.assert_array_equal(d2, od2, err_msg=tag)
+                if c.search_reach() > 1:
+                    listed_two_pass += c.debug_short_rows()
+                elif step == 3:
+                    listed_one_pass += c.debug_short_rows()
+                T = np.eye(4)
+                T[:3, :3] = synth.rodrigues(rng.normal(size=3), float(rng.choice([0.0, 0.003, 0.05])))
+                T[:3, 3] = rng.normal(0, float(rng.choice([0.0, 0.01, 0.3])) * radius, size=3)
+                c.apply_transform(T)
+                po.transform_cloud(cur, T)
+    assert listed_two_pass > 1000, listed_two_pass
+    if "PPCR_SOAK_SEED" not in os.environ:
+        assert listed_one_pass > 0, "no one-pass search left rows to the row-per-wave kernel: choose denser blobs"
+
+
 def test_randomised_align_soak(ctx):
     """Seeded random sweep of whole registrations (weight models incl. odd and non-integer v + dim and Gaussian,
     max_neighbours, inner step counts, the early-stop rule): per-iteration transforms, costs and step counts follow
