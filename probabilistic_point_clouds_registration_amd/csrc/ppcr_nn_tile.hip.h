@@ -636,16 +636,17 @@ __global__ __launch_bounds__(BLOCK, (C >= 64 ? 2 : 3)) void nn_tile_cleanup_kern
 // command line's defaults: radius 3, 20 neighbours, ~430 points in radius at the benchmark density), a grid of
 // radius-sized cells gives every 256-query block a halo of thousands of candidates — no LDS tile holds it and every block
 // used to fall through to the cleanup kernel's global-memory scan (15-50 ms per iteration at 200k points).  The grid is
-// then built for a SMALLER search radius r' = radius / reach (chosen from the target's density so that r' still holds
-// ~1.7 max_neighbours points) and the ordinary K1 runs with r': a row that finds max_neighbours points within r' has its
+// then built for a SMALLER search radius r' <= radius (chosen from the target's density so that r' still holds
+// ~2.2 max_neighbours points) and the ordinary K1 runs with r': a row that finds max_neighbours points within r' has its
 // exact answer (its m nearest overall are among them: d2 < r'^2 <= radius^2, same (d2, index) order).  Only the rows
 // that came back SHORT are searched again with the full radius, over a stencil reach cells wide on the same grid (so both
 // passes index the same sorted target).  Short rows are the cloud's fringe and its sparse parts: a few per cent of the
 // rows, scattered over every wave of the first pass — one lane per short row (the first form of this kernel) left 60 lanes
-// of every wave idle behind the slowest one (229 us at 200k points).  So the short rows are first COMPACTED into a list
-// (short_rows_kernel) and then searched ONE ROW PER WAVE: the 64 lanes walk the stencil's runs together, eight runs in
-// flight, accepted candidates are appended to a wave-shared list in LDS (ballot + prefix), and the selection of the m
-// smallest by (d2, original index) is a wave-wide bit-by-bit descent on ballot counts.
+// of every wave idle behind the slowest one (229 us at 200k points).  So K1 appends the rows it leaves unanswered to a LIST
+// (UnansweredRows: short rows, rows of handed-over workgroups) and they are searched ONE ROW PER WAVE: the 64 lanes walk
+// the stencil's runs together as one flat candidate sequence, accepted candidates are appended to a wave-shared list in
+// LDS (ballot + prefix), and the selection of the m smallest by (d2, original index) is a wave-wide bit-by-bit descent on
+// ballot counts.
 // ---------------------------------------------------------------------------------------------
 // The wave's list [0, n) in LDS (sorted-target position, d2 bits) -> its m smallest by (d2, original index), compacted in
 // place; returns the new length (min(n, m)) and the d2 bits of the m-th (thr is left alone when n < m).  PER * 64 >= n.

@@ -870,7 +870,7 @@ def test_randomised_association_soak(ctx):
 
 
 def test_randomised_row_per_wave_soak():
-    """Seeded random sweep aimed at the row-per-wave search (short_rows_kernel + nn_wide_kernel): radii that hold many
+    """Seeded random sweep aimed at the row-per-wave search (K1's list of unanswered rows + nn_wide_kernel): radii that hold many
     times max_neighbours points (two-pass searches with automatic and forced reach), clouds with blobs hundreds of times
     denser than the rest (workgroups whose halo outgrows the LDS tile, in one-pass searches too), quantised coordinates
     (floods of exact ties at the m-th distance, settled by original index), every list width, sources that move between
