@@ -751,7 +751,9 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             // who redoes the rows of handed-over workgroups: the cleanup role of the second launch (it can fold K23 for them,
             // but walks a dense neighbourhood one candidate per lane at a time), or — whenever K23 is not folded in and the
             // last association heard from handed something over, and always in a two-pass search — nn_wide_kernel
-            if (c->reach > 1 || (fuse == nullptr && c->ovf_last != ~0u && c->ovf_last > 0)) {
+            // (K23 can only be folded in by the steady-state variant: widths up to 10, a valid cut-off, short lists)
+            const bool may_fuse = fuse != nullptr && m <= 10 && c->opt_temporal && c->dm2_valid && c->opt_short_lists && !c->opt_stamps;
+            if (c->reach > 1 || (!may_fuse && c->ovf_last != ~0u && c->ovf_last > 0)) {
                 if (c->d_short.cap < (size_t)ns + 3) {
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
                     HIP_TRY(c, c->d_short.reserve((size_t)ns + 3));

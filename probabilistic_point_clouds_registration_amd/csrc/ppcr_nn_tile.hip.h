@@ -983,7 +983,7 @@ struct UnansweredRows {
 // contribution to the 19 moments from the winners' coordinates while they are still in LDS (no neighbour gathers, no
 // second pass over the source, no K23 launch) and the workgroup folds them into fm.partials.  FTM = -2: plain K1.
 template <int M, int C, int CAP, bool STAMPS, int FTM = -2>
-__global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 4) : 3)) void nn_fast_kernel(float4 *__restrict__ src, int ns,
+__global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 4) : (CAP * 13 + C * 512 <= 39000 ? 4 : 3))) void nn_fast_kernel(float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt,
                                                          const int *__restrict__ cell_start, GridDesc g,
                                                          float r2, int m, int *__restrict__ nbr,
