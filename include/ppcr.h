@@ -221,6 +221,10 @@ int ppcr_batch_run(const ppcr_pair *pairs, int64_t n_pairs, const ppcr_batch_opt
                    const int *device_ids, int n_devices, int lanes_per_device, double *T_all,
                    int32_t *n_iter_done, char *err, int64_t err_capacity);
 
+/* ppcr_batch_run keeps its handles (streams, mailboxes, device buffers) between calls; this frees them.  Call it before
+ * unloading the library or to give the memory back; never required for correctness. */
+int ppcr_batch_release(void);
+
 /* The same loop over handles whose clouds are already resident (set_source/set_target done by the caller):
  * ppcr_align on each of the n handles, `lanes` of them in flight at a time on their own streams.
  * T_final: n*12 doubles; n_done: n ints or NULL.  Handles may live on different devices.

@@ -22,7 +22,7 @@ SYMBOLS = [
     "ppcr_iterate", "ppcr_align", "ppcr_get_source", "ppcr_synchronize", "ppcr_profile_enable",
     "ppcr_profile_get", "ppcr_set_option", "ppcr_batch_run", "ppcr_align_many", "ppcr_set_companion",
     "ppcr_get_companion", "ppcr_set_ground_truth", "ppcr_mse_ground_truth", "ppcr_mse_previous", "ppcr_voxel_filter",
-    "ppcr_nearest_sq_distances", "ppcr_stop_rule_check", "ppcr_align_report",
+    "ppcr_nearest_sq_distances", "ppcr_stop_rule_check", "ppcr_align_report", "ppcr_batch_release",
 ]
 
 
@@ -447,6 +447,13 @@ def batch_run(pairs, radius, max_neighbours, dof=5.0, n_iter=20, cost_drop_thres
     if rc != 0:
         raise PpcrError(rc, err.value.decode())
     return T, done
+
+
+def batch_release():
+    """ppcr_batch_release: frees the handles ppcr_batch_run keeps between calls."""
+    rc = load().ppcr_batch_release()
+    if rc != 0:
+        raise PpcrError(rc, "ppcr_batch_release failed")
 
 
 def align_many(ctxs, n_iter, lanes=2, cost_drop_thresh=0.0, n_cost_drop_it=5, q0=(1, 0, 0, 0), t0=(0, 0, 0),

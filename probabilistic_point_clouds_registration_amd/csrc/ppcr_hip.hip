@@ -215,7 +215,6 @@ struct ppcr_ctx {
     int opt_short_lists = 1;
     int opt_fuse_k23 = 1;        // ppcr_align's one-step iterations fold K23 into the steady-state K1
     int opt_merge_fold = 1;      // ... and the fold-and-solve step rides in the cleanup launch
-    bool shares_device = false;  // set by ppcr_align_many / ppcr_batch_run while other handles run on the same GPU
     bool assoc_folded = false;   // the last association's launches included the fold-and-solve step
     bool assoc_fused = false;    // the last association also left the partial moments of the pose it was given
     int fused_slots = 0;         // ... in this many partial vectors
@@ -731,11 +730,11 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             // in, i.e. for the steady-state variant (dm2 valid, short lists, m <= 12)
             FoldSolve fs;
             const FoldSolve *fold = nullptr;
-            // (not when several handles share the GPU: the merged launch has the cleanup kernel's LDS / register
-            //  footprint, and its fold workgroups then queue behind other pairs' K1 blocks: 64 x 250k, 8 in flight:
-            //  24.0 k it/s merged against 28.2 k with the small fold kernel)
+            // (also when several handles share the GPU: before the source-order fix of round 3 the merged launch lost there,
+            //  24.0 k it/s against 28.2 k with the small fold kernel for 64 x 250k, 8 in flight; now 41.5 k against 41.0 k,
+            //  and 1.33 k against 0.88 k pairs/s end to end with four pairs in flight)
             // (m <= 10: the widths that HAVE a steady-state variant are 4, 5, 8 and 10 — launch_tile<M> with M <= 12)
-            const bool steady_next = fuse && c->opt_merge_fold && !c->shares_device && c->opt_mailbox && c->opt_temporal && c->dm2_valid &&
+            const bool steady_next = fuse && c->opt_merge_fold && c->opt_mailbox && c->opt_temporal && c->dm2_valid &&
                                      c->opt_short_lists && m <= 10 && !c->opt_stamps;
             if (merge_tk && steady_next) {
                 PPCR_TRY(prepare_fold(c, fm.nslots, *merge_tk, fs, loop));
@@ -2789,6 +2788,48 @@ struct FirstError {
 
 }  // namespace
 
+// Handles of ppcr_batch_run, kept between calls: creating one (a stream, the pinned mailbox ring, ~30 device buffers
+// that grow on first use) costs ~10 ms, and the allocator serialises the lanes — more than the registrations of a small
+// batch themselves (16 pairs of 250k with four in flight: 60 ms with fresh handles every call, 12 ms with pooled ones).
+namespace {
+struct HandlePool {
+    std::mutex mu;
+    std::vector<std::pair<int, ppcr_ctx *>> idle;  // (device, handle)
+    static constexpr size_t kMaxIdle = 64;
+    ppcr_ctx *take(int device)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t k = 0; k < idle.size(); k++)
+            if (idle[k].first == device) {
+                ppcr_ctx *c = idle[k].second;
+                idle.erase(idle.begin() + (long)k);
+                return c;
+            }
+        return nullptr;
+    }
+    bool give(int device, ppcr_ctx *c)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (idle.size() >= kMaxIdle) return false;
+        idle.emplace_back(device, c);
+        return true;
+    }
+    std::vector<ppcr_ctx *> drain()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        std::vector<ppcr_ctx *> all;
+        for (auto &e : idle) all.push_back(e.second);
+        idle.clear();
+        return all;
+    }
+};
+HandlePool &batch_pool()
+{
+    static HandlePool *pool = new HandlePool;  // never destroyed: the HIP runtime may be gone by the time statics are
+    return *pool;
+}
+}  // namespace
+
 extern "C" {
 
 int ppcr_align_many(ppcr_ctx *const *ctxs, int n, int lanes, int n_iter, double cost_drop_thresh,
@@ -2816,15 +2857,6 @@ int ppcr_align_many(ppcr_ctx *const *ctxs, int n, int lanes, int n_iter, double 
             all_pipelined = jobs.back().pipelined;
         }
         if (all_pipelined) {
-            for (int k = 0; k < n; k++) ctxs[k]->shares_device = lanes > 1;
-            struct Unshare {  // whatever way this scope is left
-                ppcr_ctx *const *ctxs;
-                int n;
-                ~Unshare()
-                {
-                    for (int k = 0; k < n; k++) ctxs[k]->shares_device = false;
-                }
-            } unshare{ctxs, n};
             int next_job = 0, retired = 0;
             std::vector<int> window;  // indices of the jobs in flight
             while (retired < n) {
@@ -2882,6 +2914,12 @@ int ppcr_align_many(ppcr_ctx *const *ctxs, int n, int lanes, int n_iter, double 
     return first.rc;
 }
 
+int ppcr_batch_release(void)
+{
+    for (ppcr_ctx *c : batch_pool().drain()) ppcr_destroy(c);
+    return PPCR_OK;
+}
+
 int ppcr_batch_run(const ppcr_pair *pairs, int64_t n_pairs, const ppcr_batch_options *opt, const int *device_ids,
                    int n_devices, int lanes_per_device, double *T_all, int32_t *n_iter_done, char *err,
                    int64_t err_capacity)
@@ -2908,13 +2946,12 @@ int ppcr_batch_run(const ppcr_pair *pairs, int64_t n_pairs, const ppcr_batch_opt
     for (auto &a : next) a.store(0);
     FirstError first;
     auto worker = [&](int d) {
-        ppcr_ctx *c = nullptr;
-        int rc = ppcr_create(device_ids[d], &c);
+        ppcr_ctx *c = batch_pool().take(device_ids[d]);
+        int rc = c ? PPCR_OK : ppcr_create(device_ids[d], &c);
         if (rc != PPCR_OK) {
             first.set(rc, ppcr_last_error(nullptr));
             return;
         }
-        c->shares_device = lanes_per_device > 1;
         for (;;) {
             const int64_t k = next[d].fetch_add(1);
             const int64_t p = (int64_t)d + k * n_devices;
@@ -2932,7 +2969,9 @@ int ppcr_batch_run(const ppcr_pair *pairs, int64_t n_pairs, const ppcr_batch_opt
                 break;
             }
         }
-        ppcr_destroy(c);
+        // a handle that worked goes back to the pool (its buffers stay allocated for the next batch); one that failed is
+        // not trusted again
+        if (rc != PPCR_OK || hipStreamSynchronize(c->stream) != hipSuccess || !batch_pool().give(device_ids[d], c)) ppcr_destroy(c);
     };
     std::vector<std::thread> pool;
     for (int d = 0; d < n_devices; d++) {

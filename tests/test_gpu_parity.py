@@ -566,6 +566,14 @@ def test_batch_run_and_align_many(ctx):
         assert list(done) == [5] * 5
         for p in range(5):
             np.testing.assert_array_equal(T[p], solo[p])          # same kernels, same order: bit-identical
+    # the handles of a batch are kept for the next one (other pair sizes, other lane counts) until they are released
+    Tb, _ = _lib.batch_run(pairs[::-1], n_iter=5, device_ids=(0,), lanes_per_device=2, **prm)
+    for p in range(5):
+        np.testing.assert_array_equal(Tb[4 - p], solo[p])
+    _lib.batch_release()
+    _lib.batch_release()                                           # (nothing left: a no-op)
+    Tc, _ = _lib.batch_run(pairs[:2], n_iter=5, device_ids=(0,), lanes_per_device=1, **prm)
+    np.testing.assert_array_equal(Tc[1], solo[1])
     ora = po.align(pairs[2][0][:, :3], pairs[2][1][:, :3], 1.0, 10, 5.0, 5, inner_max_steps=1)
     assert synth.rotation_angle(T[2][:, :3], ora["history"][-1][:, :3]) < ROT_TOL
     assert np.linalg.norm(T[2][:, 3] - ora["history"][-1][:, 3]) < TRANS_TOL
