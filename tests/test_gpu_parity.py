@@ -728,9 +728,11 @@ def test_two_pass_radius_search_is_exact(two_pass):
     rng = np.random.default_rng(77)
     L = 22.0
     tgt = rng.uniform(-L / 2, L / 2, size=(40000, 3)).astype(np.float32)                      # 3.76 points per unit volume
+    tgt[17] = [np.nan, 1, 1]                                                                   # (never anybody's neighbour)
     src = np.concatenate([tgt[rng.permutation(40000)[:9000]] + rng.normal(0, 0.02, size=(9000, 3)),
                           rng.uniform(-L / 2 - 4, L / 2 + 4, size=(600, 3)),                       # fringe and outside
-                          np.array([[200.0, 0, 0], [L / 2 + 2.9, 0, 0]])]).astype(np.float32)     # nothing / almost nothing in radius
+                          np.array([[200.0, 0, 0], [L / 2 + 2.9, 0, 0],                          # nothing / almost nothing in radius
+                                    [np.nan, 0, 0], [0, np.inf, 0], [-1e30, 1e30, 0]])]).astype(np.float32)   # not a point at all
     blobs = np.concatenate([c + rng.normal(0, 0.4, size=(4000, 3)) for c in rng.uniform(-8, 8, size=(3, 3))] +
                            [rng.uniform(-15, 15, size=(6000, 3))]).astype(np.float32)
     lattice = (np.stack(np.meshgrid(*[np.arange(24)] * 3, indexing="ij"), -1).reshape(-1, 3) * 0.5).astype(np.float32)
