@@ -1217,7 +1217,8 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         // unanswered rows are listed, nn_wide_kernel searches them (marked unsearched)
         if (tid == 0) ovf_list[atomicAdd(ovf_count, 1u)] = (int)blockIdx.x * 4 + half;
         if (valid) cnt[i] = -1;
-        if (un.list != nullptr) list_rows(valid);
+        if constexpr (FTM == -2)  // (a launch that folds K23 in never lists: the cleanup role redoes its hand-overs)
+            if (un.list != nullptr) list_rows(valid);
         flush_stamps();
         return;
     }
@@ -1435,7 +1436,8 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         cnt[i] = unanswered ? -1 : n;
         dm2[i] = tm;
     }
-    if (un.list != nullptr) list_rows(valid && (unanswered || n < un.m_list));
+    if constexpr (FTM == -2)
+        if (un.list != nullptr) list_rows(valid && (unanswered || n < un.m_list));
     stamp(5);
     if constexpr (FTM != -2) {
         // ---- K23 for this row, from LDS: weights at fm.P, the row's share of the 19 moments ----------------------
