@@ -1235,6 +1235,7 @@ int launch_inner(ppcr_ctx *c, const StepTicket &tk, const LoopCtl &loop, int n_d
         const int w = c->ell_width;
         if (w <= 10) launch_inner_w<10>(c, a, f, grid);
         else if (w <= 16) launch_inner_w<16>(c, a, f, grid);
+        else if (w <= 20) launch_inner_w<20>(c, a, f, grid);  // (the command line's default width)
         else launch_inner_w<32>(c, a, f, grid);
     }
     return check_launch(c, "inner_steps_kernel");
