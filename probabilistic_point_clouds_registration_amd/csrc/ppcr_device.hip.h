@@ -911,6 +911,8 @@ struct FoldSolve {  // everything the fold-and-solve step needs
     unsigned char *split_flag;
     const unsigned *split_total;
     unsigned *split_visible;
+    unsigned *split_rebuilt;  // the value of *split_total the list was last rebuilt for
+    int split_nblocks;        // 256-query blocks of the source (length of split_flag)
     LoopCtl loop;
     unsigned long long *dbg;  // diagnostic (nullable): wall-clock stamps of the solve lane
 };
@@ -925,6 +927,46 @@ __device__ __forceinline__ void publish_skipped(const FoldSolve &fs)
 template <class SumsPtr>
 __device__ __forceinline__ void solve_and_publish(const FoldSolve &fs, SumsPtr S);
 
+// The split table after an association that registered new blocks: ALL threads of one workgroup rebuild the list from
+// the flags — the registered blocks in ascending id, the first kMaxSplit of them split (flag 2), the rest registered
+// but whole (flag 1) — so that which blocks are split, the order of their partial-sum slots and with it every sum do not
+// depend on the order in which the registrations arrived (an atomic counter used to hand out the slots: with more than
+// kMaxSplit candidates two runs of one registration differed in their last bits).
+__device__ __forceinline__ void rebuild_split_list(const FoldSolve &fs, unsigned total)
+{
+    __shared__ int s_cnt[kBlock];
+    const int nb = fs.split_nblocks, per = (nb + kBlock - 1) / kBlock;
+    const int b0 = min((int)threadIdx.x * per, nb), b1 = min(b0 + per, nb);
+    int mine = 0;
+    for (int b = b0; b < b1; b++) mine += fs.split_flag[b] != 0 ? 1 : 0;
+    s_cnt[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {  // exclusive prefix over 256 counts (once per change of the table: not worth a tree)
+        int run = 0;
+        for (int t = 0; t < kBlock; t++) {
+            const int v = s_cnt[t];
+            s_cnt[t] = run;
+            run += v;
+        }
+        *fs.split_visible = (unsigned)min(run, kMaxSplit);
+        *fs.split_rebuilt = total;
+    }
+    __syncthreads();
+    int at = s_cnt[threadIdx.x];
+    for (int b = b0; b < b1; b++) {
+        if (fs.split_flag[b] != 0) {
+            if (at < kMaxSplit) {
+                fs.split_list[at] = b;
+                fs.split_flag[b] = 2;
+            } else {
+                fs.split_flag[b] = 1;
+            }
+            at++;
+        }
+    }
+    __syncthreads();
+}
+
 // one of the kNSums fold blocks (256 threads): fold row `sum_index` of the partials; the last block to finish solves.
 // Returns true on the ONE lane that solved (after everything it had to write is written).  LEAN: see solve_rigid_device.
 template <bool LEAN = false>
@@ -932,6 +974,10 @@ __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int su
 {
     __shared__ double sh[kBlock / 64];
     const unsigned long long t_entry = fs.dbg ? wall_clock64() : 0ull;
+    // (the first fold block also keeps the split table: the two words that say whether it has to are asked for here and
+    //  looked at behind the row's loads)
+    const bool keeps_table = sum_index == 0 && fs.split_visible != nullptr;
+    const unsigned split_total = keeps_table ? *fs.split_total : 0u, split_rebuilt = keeps_table ? *fs.split_rebuilt : 0u;
     const double *row = fs.partials + (size_t)sum_index * fs.nslots;
     double v = 0.0;
     // sixteen loads per lane in flight (4096 slots: ONE memory round trip at 1M points), added in slot order
@@ -950,6 +996,7 @@ __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int su
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
+    if (split_total != split_rebuilt) rebuild_split_list(fs, split_total);  // (uniform; a handful of launches per registration)
     if (threadIdx.x != 0) return false;
     const unsigned long long t_folded = fs.dbg ? wall_clock64() : 0ull;
     double x = sh[0];
@@ -1001,8 +1048,6 @@ __device__ __forceinline__ void solve_and_publish(const FoldSolve &fs, SumsPtr S
 {
     // what the publication needs from device memory is asked for BEFORE the solve, so that these round trips (~0.5 us
     // each, and dependent on nothing) run under it instead of behind it
-    const unsigned split_total = fs.split_visible ? min(*fs.split_total, 64u) : 0u;
-    const unsigned split_seen = fs.split_visible ? *fs.split_visible : 0u;
     const unsigned handed = fs.handed_over ? *fs.handed_over : 0u;
     int prev_steps = 0;
     double prev_cost_init = 0.0;
@@ -1027,19 +1072,6 @@ __device__ __forceinline__ void solve_and_publish(const FoldSolve &fs, SumsPtr S
 #pragma unroll
         for (int b = 0; b < 3; b++) fs.mbox->T[4 * a + b] = rs.R[3 * a + b];
         fs.mbox->T[4 * a + 3] = rs.t[a];
-    }
-    // new registrations only (most launches bring none: then the list is sorted and published already, and walking it
-    // would be a chain of dependent loads on the lane the next launch is waiting for)
-    if (fs.split_visible && split_total != split_seen) {
-        const int n_split = (int)split_total;
-        for (int a = 1; a < n_split; a++) {  // insertion sort: the list is nearly sorted, at most 64 long
-            const int key = fs.split_list[a];
-            int b = a - 1;
-            for (; b >= 0 && fs.split_list[b] > key; b--) fs.split_list[b + 1] = fs.split_list[b];
-            fs.split_list[b + 1] = key;
-        }
-        for (int a = 0; a < n_split; a++) fs.split_flag[fs.split_list[a]] = 2;  // ... and from now on they ARE split
-        *fs.split_visible = (unsigned)n_split;
     }
     // device-paced inner loop: the test of solve_impl / the oracle's po_solve, on the same numbers
     unsigned status = kStepResult;

@@ -146,8 +146,8 @@ struct ppcr_ctx {
     int ell_width = 0;
     DevBuf<int> nbr, cnt, row_ptr;
     DevBuf<unsigned char> split_flag;  // per 256-query block: scanned in two halves (its halo outgrew the steady-state capacity)
-    DevBuf<int> split_list;            // the split blocks (<= kMaxSplit), in order of registration
-    DevBuf<unsigned> split_state;      // [0] registrations so far, [1] registrations visible to the next launch's extra workgroups
+    DevBuf<int> split_list;            // the split blocks (<= kMaxSplit), in ascending id
+    DevBuf<unsigned> split_state;      // [0] registrations so far, [1] blocks in the list, [2] registrations the list was last rebuilt for
     bool split_clean = false;          // the three buffers above are zeroed for the current source order
     DevBuf<int> ovf_list;        // blocks nn_fast_kernel handed over to nn_tile_cleanup_kernel
     DevBuf<unsigned> ovf_state;  // two list counters used alternately (ovf_parity): the idle one is cleared by the fast kernel
@@ -690,9 +690,9 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             const size_t nbk = (size_t)nblocks(std::max(ns, 1), 256);
             HIP_TRY(c, c->split_flag.reserve(nbk));
             HIP_TRY(c, c->split_list.reserve(kMaxSplit));
-            HIP_TRY(c, c->split_state.reserve(2));
+            HIP_TRY(c, c->split_state.reserve(3));
             HIP_TRY(c, hipMemsetAsync(c->split_flag.p, 0, nbk, c->stream));
-            HIP_TRY(c, hipMemsetAsync(c->split_state.p, 0, 2 * sizeof(unsigned), c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->split_state.p, 0, 3 * sizeof(unsigned), c->stream));
             c->split_clean = true;
         }
         if (!c->ovf_state.p) {
@@ -1006,6 +1006,8 @@ int prepare_fold(ppcr_ctx *c, int nslots, StepTicket &tk, FoldSolve &fs, const L
     fs.split_flag = c->split_clean ? c->split_flag.p : nullptr;
     fs.split_total = c->split_clean ? c->split_state.p : nullptr;
     fs.split_visible = c->split_clean ? c->split_state.p + 1 : nullptr;
+    fs.split_rebuilt = c->split_clean ? c->split_state.p + 2 : nullptr;
+    fs.split_nblocks = nblocks(std::max((int)c->ns, 1), 256);
     fs.dbg = c->opt_fold_stamps ? c->d_fold_dbg.p : nullptr;
     if (loop) {
         fs.loop = *loop;

@@ -955,7 +955,7 @@ struct HaloList {
 struct SplitTable {
     unsigned char *flag;      // [nblocks] 0: whole, 1: registered for splitting, 2: split (an extra workgroup scans waves 2-3)
     int *list;                // [kMaxSplit] block ids, in order of registration
-    unsigned *total;          // registrations so far (may exceed kMaxSplit: the surplus is not split)
+    unsigned *total;          // registrations so far (may exceed kMaxSplit: the blocks with the largest ids are not split)
     const unsigned *visible;  // registrations the extra workgroups of THIS launch may act on (set by the cleanup kernel)
     int n_extra;              // extra workgroups at the front of this launch's grid (0: no splitting in this launch)
     int presplit;             // a whole block whose halo exceeds this is registered for splitting BEFORE it overflows
@@ -1194,13 +1194,11 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     }
     const bool handed_over = !shape_ok || total > CAP;  // uniform: derived from the shared boxes and cell_start only
     if (tid == 0 && half == 0 && split.flag != nullptr && (handed_over || total > split.presplit) && !split.flag[bid]) {
-        // once the fold-and-solve step has published the registration (flag 2, sorted list) this block is scanned in
-        // two halves
-        const unsigned slot = atomicAdd(split.total, 1u);
-        if (slot < (unsigned)kMaxSplit) {
-            split.list[slot] = bid;
-            split.flag[bid] = 1;
-        }
+        // once the fold-and-solve step has rebuilt the list from the flags (the kMaxSplit registered blocks with the
+        // smallest ids are split, flag 2: which ones does not depend on the order the registrations arrived in) this
+        // block is scanned in two halves
+        split.flag[bid] = 1;
+        atomicAdd(split.total, 1u);  // (only says that there is something new)
     }
     // a wave's unanswered rows go to the list in one piece: one atomic per wave that has any
     auto list_rows = [&](bool mine) {
