@@ -747,12 +747,13 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             tl.src = c->src.p, tl.ns = (int)c->ns, tl.tgt = c->tgt_sorted.p, tl.cell_start = c->cell_start.p, tl.grid = c->grid;
             tl.r2 = r2, tl.m = m;
             tl.reach = c->reach, tl.r2_full = r2_full;
-            // who redoes the rows of handed-over workgroups: the cleanup role of the second launch (it can fold K23 for them,
-            // but walks a dense neighbourhood one candidate per lane at a time), or — whenever K23 is not folded in and the
-            // last association heard from handed something over, and always in a two-pass search — nn_wide_kernel
+            // who redoes the rows of handed-over workgroups: the cleanup role of the second launch when K23 is folded in (it
+            // folds K23 for them as well, but walks a dense neighbourhood one candidate per lane at a time), nn_wide_kernel
+            // otherwise — every launch that cannot fold, every two-pass search (an idle nn_wide_kernel costs what an idle
+            // cleanup launch costs, and the choice does not depend on when a hand-over count reaches the host)
             // (K23 can only be folded in by the steady-state variant: widths up to 10, a valid cut-off, short lists)
             const bool may_fuse = fuse != nullptr && m <= 10 && c->opt_temporal && c->dm2_valid && c->opt_short_lists && !c->opt_stamps;
-            if (c->reach > 1 || (!may_fuse && c->ovf_last != ~0u && c->ovf_last > 0)) {
+            if (c->reach > 1 || !may_fuse) {
                 if (c->d_short.cap < (size_t)ns + 3) {
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
                     HIP_TRY(c, c->d_short.reserve((size_t)ns + 3));
