@@ -153,6 +153,11 @@ struct ppcr_ctx {
     DevBuf<unsigned> ovf_state;  // two list counters used alternately (ovf_parity): the idle one is cleared by the fast kernel
     int ovf_parity = 0;
     unsigned ovf_last = ~0u;     // blocks handed over by the most recent association whose count reached the host (~0: unknown)
+    // ... and the count the NEXT association's choices go by.  Inside the device-paced loop that is the count of the
+    // iteration kMaxAhead back — always consumed by the time an iteration is enqueued, whatever the scheduler's timing —
+    // so that two runs of one registration take the same path (see AlignJob::enqueue); elsewhere the latest.
+    unsigned ovf_decide = ~0u;
+    bool ovf_decide_pinned = false;
     DevBuf<unsigned> dm2;    // per (sorted) source row: float d2 bits of its m-th neighbour in the last tiled K1
     bool dm2_valid = false;  // dm2 matches the current source order / target / radius / max_neighbours
     int opt_temporal = 1;
@@ -710,7 +715,8 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             int fuse_tm = -2;
             // (two passes: the rows are final only after the second; a cloud whose associations keep handing workgroups over
             //  — dense parts whose halos outgrow the LDS tile — leaves those rows to nn_wide_kernel, which does not fold)
-            const bool many_handed_over = c->ovf_last != ~0u && c->ovf_last > (unsigned)c->opt_fuse_max_handed_over;
+            const unsigned ovf_known = c->ovf_decide_pinned ? c->ovf_decide : c->ovf_last;
+            const bool many_handed_over = ovf_known != ~0u && ovf_known > (unsigned)c->opt_fuse_max_handed_over;
             if (fuse_R && c->opt_fuse_k23 && c->nt > 0 && c->reach == 1 && !many_handed_over) {
                 const Model md = make_model(c);
                 const K23Form form = k23_form(c, md);
@@ -2058,6 +2064,8 @@ struct AlignJob {
     StepTicket in_flight[kMailboxRing];
     int enq = 0, done = 0;
     bool pipelined = false, finished = false;
+    unsigned handed_over_of[kMailboxRing] = {~0u, ~0u, ~0u, ~0u};  // per iteration in flight / just consumed (index % ring)
+    static_assert(kMailboxRing == 4, "initialiser above");
     int max_steps = 1, n_dev_steps = 0;
     LoopCtl loop{};
     Pose handback{};  // take_over: the pose the host solved, on its way back to the device
@@ -2126,9 +2134,15 @@ struct AlignJob {
     int enqueue()
     {
         StepTicket &tk = in_flight[enq % kMailboxRing];
+        // (choices that go by hand-over counts use the count of the iteration kMaxAhead back: consumed for sure, however
+        //  far ahead of the results this thread happens to be — the same path in every run)
+        c->ovf_decide = enq >= kMaxAhead ? handed_over_of[(enq - kMaxAhead) % kMailboxRing] : ~0u;
+        c->ovf_decide_pinned = true;
         // moves the source by the previous iteration's transform in its prologue and (steady state) leaves this
         // iteration's partial moments at (q0, t0) behind: K23 folded in
-        PPCR_TRY(associate_impl(c, &R0, t0, &tk, &loop));
+        const int rc_assoc = associate_impl(c, &R0, t0, &tk, &loop);
+        c->ovf_decide_pinned = false;
+        PPCR_TRY(rc_assoc);
         if (!c->assoc_folded) PPCR_TRY(launch_step(c, R0, t0, tk, c->assoc_fused, &loop));
         PPCR_TRY(launch_inner(c, tk, loop, n_dev_steps));
         c->move_on_device = true;     // ... and this iteration's transform is the next pending move
@@ -2202,6 +2216,7 @@ struct AlignJob {
         if (report_flags) PPCR_TRY(collect_report(c, seq, &mse_truth, &moved));
         std::memcpy(T_last, res.T, sizeof(T_last));
         record(res.T, cost, res.steps, mse_truth, moved);
+        handed_over_of[done % kMailboxRing] = c->ovf_last;  // (collect_step has just read it from this iteration's mailbox)
         done++;
         // an iteration enqueued ahead was let through on the strength of the idle count: replay its check now
         if (enq > done && ppcr_stop_rule_check(&rule, n_iter, thresh, patience) != PPCR_CONTINUE)
