@@ -18,7 +18,7 @@ namespace dev {
 
 constexpr int kNSums = 19;
 constexpr int kBlock = 256;
-constexpr int kMaxSplit = 64;  // K1: blocks that can be scanned as two half-blocks (SplitTable in ppcr_nn_tile.hip.h)
+constexpr int kMaxSplit = 128;  // K1: blocks that can be scanned as two half-blocks (SplitTable in ppcr_nn_tile.hip.h)
 
 // Uniform grid over the target's bounding box.  Cells are cubes of edge h >= radius in y and z; in x every cell is
 // split into xr slices (edge h / xr, inv_hx = xr * inv_h): a (dy, dz) row of the stencil is one contiguous run

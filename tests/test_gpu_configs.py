@@ -212,7 +212,7 @@ def test_two_runs_of_one_registration_are_bit_identical():
                 c.set_target(tgt)
                 c.set_source(src)
                 res = c.align(n_it, cost_drop_thresh=-1.0, inner_steps=1)
-                assert c.debug_host_figures()[7] > 64 * (1 if two_pass else 10)   # (hand-overs: the test proves nothing without)
+                assert c.debug_host_figures()[7] > 128 * (1 if two_pass else 10)   # (hand-overs: the test proves nothing without)
                 runs.append(np.array(res["history"]))
         np.testing.assert_array_equal(runs[0], runs[1], err_msg=f"two_pass={two_pass}")
 
