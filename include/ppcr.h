@@ -303,7 +303,9 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *                  the second launch) only while the last association heard from handed over at most this many workgroups
  *                  (default 4); beyond, K23 runs as its own kernel and those rows go to nn_wide_kernel, one row per wave;
  *   "first_pass_occupancy"  tenths of a target point per first-pass grid cell the automatic choice allows where the typical
- *                  point lives (default 85); fuller cells: fewer short rows, more workgroups whose halo outgrows the LDS tile;
+ *                  point lives (default 110); fuller cells: fewer short rows, more workgroups whose halo outgrows the LDS tile;
+ *   "first_pass_fill"  tenths: the first-pass sphere of a two-pass search should hold this many times max_neighbours points
+ *                  where the density allows (default 22: ~2.2 m candidates answer nearly every row in the first pass);
  *   "stamps"       1 collect per-phase cycle counts and per-lane run lengths of K1 (diagnostic build of the kernel). */
 int ppcr_set_option(ppcr_ctx *ctx, const char *key, int value);
 

@@ -226,6 +226,18 @@ private:
 
 namespace ceres {
 enum LinearSolverType { DENSE_QR, SPARSE_NORMAL_CHOLESKY };
+// the callback protocol WeightUpdaterCallback is written against (weight_updater_callback.hpp:15,36)
+enum CallbackReturnType { SOLVER_CONTINUE, SOLVER_ABORT, SOLVER_TERMINATE_SUCCESSFULLY };
+struct IterationSummary {
+    int iteration = 0;
+    bool step_is_successful = true;
+    double cost = 0, cost_change = 0;
+};
+class IterationCallback {
+public:
+    virtual ~IterationCallback() {}
+    virtual CallbackReturnType operator()(const IterationSummary &summary) = 0;
+};
 struct Solver {
     struct Options {
         LinearSolverType linear_solver_type = DENSE_QR;  // accepted, unused: the solve is closed form

@@ -52,7 +52,15 @@ public:
     }
 
     void updateWeight(double new_weight) { weight_.Reset(new_weight); }
+    // The reference returns the term's ceres::LossFunctionWrapper * here (error_term.hpp:45) for AddResidualBlock; this
+    // library never builds a Ceres problem, so the handle is its own rho(s) = w s object ("Behavioural
+    // differences").
     ScaledLossHandle *weight() { return &weight_; }
+
+    // additions of this implementation: the two points as the functor holds them (float values widened to double,
+    // error_term.hpp:15-16) — what WeightUpdaterCallback uploads for its device route
+    const double *source() const { return source_; }
+    const double *target() const { return target_; }
 
 private:
     double source_[3];

@@ -12,6 +12,7 @@
 #include "prob_point_cloud_registration/error_term.hpp"
 #include "prob_point_cloud_registration/prob_point_cloud_registration_params.hpp"
 #include "prob_point_cloud_registration/probabilistic_weights.hpp"
+#include "prob_point_cloud_registration/weight_updater_callback.hpp"  // (as the reference's header does, :14)
 
 #define DIMENSIONS 3
 

@@ -42,6 +42,9 @@ public:
     }
 
     bool isNormal() const { return !(v_ < std::numeric_limits<double>::infinity()); }
+    // additions of this implementation: the model's two constructor arguments (WeightUpdaterCallback's device route)
+    double dof() const { return v_; }
+    int dimension() const { return dimension_; }
 
 private:
     double v_;

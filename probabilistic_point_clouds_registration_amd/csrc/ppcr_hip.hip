@@ -180,7 +180,7 @@ struct ppcr_ctx {
     int opt_mailbox = 1;               // 1: deliver the moments through the mailbox and spin (default)
     // device-paced inner loop (ppcr_align with inner_steps > 1): see LoopState / inner_steps_kernel
     DevBuf<LoopState> d_loop;
-    DevBuf<unsigned> d_inner_ctl;      // [0] step_done, [1 ..] completion flags of inner_steps_kernel's K23 workgroups
+    DevBuf<unsigned> d_inner_ctl;      // [0..1] step_done (one 64-bit word), [2 ..] completion flags of inner_steps_kernel's K23 workgroups
     int opt_fold_stamps = 0;           // diagnostic: the solve lane leaves wall-clock stamps (ppcr_debug_get_fold_stamps)
     DevBuf<unsigned long long> d_fold_dbg;
     int opt_inner_dev_steps = 3;       // IRLS steps 2.. the device may take on its own per outer iteration (<= kMaxDevSteps)
@@ -443,9 +443,10 @@ int cloud_bbox(ppcr_ctx *c, const float4 *pts, int n, float lo[3], float hi[3])
 constexpr int kMaxReach = 8;  // the second pass's stencil is (2 reach + 1)^2 rows
 
 // Cell occupancy the first pass of a two-pass search aims at (points per cell of edge r', where the typical point is): the
-// first-pass sphere holds 4.19 q points, ~1.7 max_neighbours of them answer nearly every row in the first pass; but the
-// fuller the cells, the more 256-query blocks' halos (36-49 rows of ~4 cells) outgrow the LDS tile and leave their rows
-// to the second pass as well (`cap`, option "first_pass_occupancy", in points per cell).
+// first-pass sphere holds 4.19 q points, `fill` x max_neighbours of them (option "first_pass_fill", default 2.2) answer
+// nearly every row in the first pass; but the fuller the cells, the more 256-query blocks' halos (36-49 rows of ~4 cells)
+// outgrow the LDS tile and leave their rows to the second pass as well (`cap`, option "first_pass_occupancy", default 11
+// points per cell).
 double target_occupancy(int max_nb, double cap, double fill) { return std::min(fill * (double)max_nb / 4.19, cap); }
 
 // First-pass search radius for a measured / estimated occupancy `per_cell` of cells of edge `radius`: the radius itself
@@ -524,8 +525,9 @@ int grid_occupancy(ppcr_ctx *c, double *occ)
 // K0: bounding box -> cell edge -> cell-sorted target + cell_start.
 // The cell edge follows the SEARCH radius of the first pass, radius / reach (reach = 1: the radius itself).  A bounded
 // search whose radius holds far more than max_neighbours points is split in two passes (nn_wide_kernel): reach is chosen so
-// that a cell holds at most ~8 points where the points are (the halo of a 256-query block must fit the LDS tile) while the
-// first-pass radius still holds ~1.7 max_neighbours of them where it can.  The estimate starts from the bounding box and
+// that a cell holds at most ~11 points where the points are (option "first_pass_occupancy": the halo of a 256-query block
+// must fit the LDS tile) while the first-pass radius still holds ~2.2 max_neighbours of them (option "first_pass_fill")
+// where it can.  The estimate starts from the bounding box and
 // is corrected with the occupancy measured on the grid it produced (dense blobs in a sparse box): at most three builds,
 // once per (target, radius, max_neighbours).
 int ensure_grid(ppcr_ctx *c)
@@ -1158,7 +1160,7 @@ int ensure_loop_state(ppcr_ctx *c)
     }
     {
         // sized for the largest inner-step launch; words stamped with sequence numbers, so cleared only when (re)allocated
-        const size_t want = 1 + (size_t)kMaxDevSteps * kInnerMaxG;
+        const size_t want = 2 + (size_t)kMaxDevSteps * kInnerMaxG;
         if (c->d_inner_ctl.cap < want) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             HIP_TRY(c, c->d_inner_ctl.reserve(want));
@@ -1221,7 +1223,7 @@ int launch_inner(ppcr_ctx *c, const StepTicket &tk, const LoopCtl &loop, int n_d
     c->mbox_seq = seq_keep;
     ic.fs.seq = 0, ic.fs.mbox = nullptr, ic.fs.handed_over = nullptr;  // per launch
     ic.fs.loop.first = 0, ic.fs.loop.last_dev = 0;                     // per step
-    ic.flags = c->d_inner_ctl.p + 1, ic.step_done = c->d_inner_ctl.p;
+    ic.flags = c->d_inner_ctl.p + 2, ic.step_done = reinterpret_cast<unsigned long long *>(c->d_inner_ctl.p);
     ic.mbox_ring = c->d_mbox, ic.mbox_slots = kMailboxRing;
     ic.ovf_state = c->ovf_state.p;
     ic.G = G;
@@ -1665,8 +1667,26 @@ static int set_target_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, in
     return PPCR_OK;
 }
 
+// Sequence numbers (mailbox slots, completion flags, LoopState::finished, the report ring) grow by one per fold for the
+// life of a handle and are compared for equality or order; long before the 32-bit counter could wrap — at a new
+// source, i.e. between registrations, when nothing is in flight — everything stamped with them starts again from zero.
+static int restart_sequence_numbers(ppcr_ctx *c)
+{
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->mbox_seq = 0;
+    if (c->h_mbox)
+        for (int k = 0; k < kMailboxRing; k++) c->h_mbox[k].seq = 0;
+    if (c->h_report)
+        for (int k = 0; k < kMailboxRing; k++) c->h_report[k].seq = 0;
+    if (c->d_inner_ctl.p) HIP_TRY(c, hipMemsetAsync(c->d_inner_ctl.p, 0, c->d_inner_ctl.cap * sizeof(unsigned), c->stream));
+    if (c->d_loop.p) HIP_TRY(c, hipMemsetAsync(c->d_loop.p, 0, sizeof(LoopState), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PPCR_OK;
+}
+
 static int set_source_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, int64_t stride)
 {
+    if (c->mbox_seq > (1u << 30)) PPCR_TRY(restart_sequence_numbers(c));
     c->ovf_last = ~0u;
     c->split_clean = false;
     c->move_pending = false;  // a deferred move of the previous source dies with it

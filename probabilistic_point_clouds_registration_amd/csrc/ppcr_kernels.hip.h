@@ -511,7 +511,8 @@ constexpr int kInnerMaxG = 2048;  // upper bound of the K23 workgroups per step 
 struct InnerConst {
     FoldSolve fs;        // partials = [kNSums][G], nslots = G, loop.first = 0; seq, mbox, handed_over, last_dev: per launch / step
     unsigned *flags;     // [n_steps][G]: == seq once that workgroup's partial sums of this launch are in place
-    unsigned *step_done; // seq * kMaxDevSteps + (device steps of this launch that have been solved)
+    unsigned long long *step_done;  // seq * kMaxDevSteps + (device steps of this launch that have been solved), as a 64-bit
+                                    // word: the product outgrows 32 bits long before seq does (pooled handles live for days)
     HostMailbox *mbox_ring;
     int mbox_slots;
     unsigned *ovf_state;
@@ -544,7 +545,7 @@ __device__ __forceinline__ void inner_fold_role(const InnerConst *ic, unsigned s
     fs.loop.last_dev = (u == n_steps - 1) ? 1 : 0;
     if (fold_and_solve_block<true>(fs, row)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // one per step: pose, loop state
-        __hip_atomic_store(ic->step_done, seq * kMaxDevSteps + (unsigned)(u + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ic->step_done, (unsigned long long)seq * kMaxDevSteps + (unsigned)(u + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 // Workgroups take their role from blockIdx: [step][G K23 workgroups, kNSums fold workgroups].  A workgroup only ever
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(kBlock, ONEPASS ? 5 : 3) void inner_steps_kernel(In
     if (u > 0) {  // the previous device step must have been solved (step 1 was: it ran in an earlier launch)
         // (or the loop ended at an earlier step: then step u - 1 never runs and `finished` / `abort` is the news)
         if (threadIdx.x == 0)
-            while (__hip_atomic_load(ic->step_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq * kMaxDevSteps + (unsigned)u && !over())
+            while (__hip_atomic_load(ic->step_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)seq * kMaxDevSteps + (unsigned)u && !over())
                 __builtin_amdgcn_s_sleep(64);
         __syncthreads();
     }

@@ -196,6 +196,80 @@ static void errorTermTest()
     EXPECT_NEAR(e.weight()->scale(), 0.25, 0);
 }
 
+// weight_updater_callback.hpp:15-64 driven the way ..._iteration.hpp:37-49 drives it: one ErrorTerm per nonzero of the
+// association, the callback called with an empty summary; every term's weight must be what ProbabilisticWeights gives
+// for the squared residuals of the terms themselves (evaluated here through the functor).  Both routes of the class.
+static void weightUpdaterCallbackTest(double dof)
+{
+    auto source = generateCloud();
+    pcl::PointCloud<pcl::PointXYZ> target;
+    pcl::transformPointCloud(source, target, testTransform());
+    // three target candidates per source point (its own image and two neighbours), empty rows in between
+    const int rows = 200;
+    Eigen::SparseMatrix<double, Eigen::RowMajor> assoc(rows, (long)target.size());
+    std::vector<Eigen::Triplet<double>> tl;
+    for (int i = 0; i < rows; ++i) {
+        if (i % 7 == 3) continue;
+        for (int d = 0; d < 1 + i % 3; ++d) tl.push_back(Eigen::Triplet<double>(i, (i * 5 + d * 11) % (int)target.size(), 1));
+    }
+    assoc.setFromTriplets(tl.begin(), tl.end());
+    assoc.makeCompressed();
+    ProbPointCloudRegistrationParams params;
+    params.dof = dof;
+    std::vector<std::unique_ptr<ErrorTerm>> owned;
+    std::vector<ErrorTerm *> terms;
+    for (long i = 0; i < assoc.outerSize(); ++i)
+        for (Eigen::SparseMatrix<double, Eigen::RowMajor>::InnerIterator it(assoc, i); it; ++it) {
+            owned.emplace_back(new ErrorTerm(source[(std::size_t)it.row()], target[(std::size_t)it.col()]));
+            terms.push_back(owned.back().get());
+        }
+    double rotation[4] = {1.9 * std::cos(0.15), 0, 0, 1.9 * std::sin(0.15)};  // un-normalised Rz(0.3)
+    double translation[3] = {2.3, 0.4, -0.1};
+    ProbabilisticWeights weight_updater(dof, 3, params.max_neighbours);
+    std::vector<double> sq;
+    for (ErrorTerm *e : terms) {
+        double r[3];
+        (*e)(rotation, translation, r);
+        sq.push_back(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    }
+    const auto expected = weight_updater.updateWeights(assoc, sq);
+    {
+        WeightUpdaterCallback callback(&assoc, &params, &terms, &weight_updater, rotation, translation);
+        EXPECT_TRUE(callback(ceres::IterationSummary()) == ceres::SOLVER_CONTINUE);
+        EXPECT_TRUE(callback.onDevice());  // rows share their source point: K2 on the device
+        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(terms[k]->weight()->scale(), expected.valuePtr()[k], 1e-12);
+        // the pose is read through the pointers at every call (the reference's callback sees Ceres' live state)
+        translation[0] += 0.25;
+        callback(ceres::IterationSummary());
+        sq.clear();
+        for (ErrorTerm *e : terms) {
+            double r[3];
+            (*e)(rotation, translation, r);
+            sq.push_back(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        }
+        const auto moved = weight_updater.updateWeights(assoc, sq);
+        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(terms[k]->weight()->scale(), moved.valuePtr()[k], 1e-12);
+    }
+    {
+        // a row whose terms hold different source points cannot be one row of a device association: host residuals
+        ErrorTerm odd(source[199], target[0]);
+        ErrorTerm *keep = terms[1];
+        terms[1] = &odd;
+        WeightUpdaterCallback callback(&assoc, &params, &terms, &weight_updater, rotation, translation);
+        callback(ceres::IterationSummary());
+        EXPECT_TRUE(!callback.onDevice());
+        sq.clear();
+        for (ErrorTerm *e : terms) {
+            double r[3];
+            (*e)(rotation, translation, r);
+            sq.push_back(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        }
+        const auto mixed = weight_updater.updateWeights(assoc, sq);
+        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(terms[k]->weight()->scale(), mixed.valuePtr()[k], 1e-15);
+        terms[1] = keep;
+    }
+}
+
 // utilities.hpp:28-234: closest-point metrics against a brute-force nearest neighbour computed right here
 static void closestPointMetricsTest()
 {
@@ -422,6 +496,8 @@ int main(int argc, char **argv)
     exactAssociationTest(std::numeric_limits<double>::infinity());
     exactAssociationTest(5);
     errorTermTest();
+    weightUpdaterCallbackTest(5);
+    weightUpdaterCallbackTest(std::numeric_limits<double>::infinity());
     alignTest();
     alignIsTheDevicePacedLoop();
     std::printf("%d checks, %d failed\n", g_checks, g_failed);

@@ -85,6 +85,49 @@ def test_batch_run_over_all_visible_devices():
             np.testing.assert_array_equal(c.align(4, cost_drop_thresh=0.0, inner_steps=1)["history"][-1], T[0])
 
 
+def test_config5_batch_entry_points_at_full_size_vs_oracle():
+    """BASELINE configs[4] through ITS entry points at ITS size (round-3 review, item 1a): 8 of the 64 pairs of
+    250k<->250k points — pairs 0, 9, 18, ... 63: every eighth, each with its own seed and its own scaled ground truth —
+    through ppcr_batch_run (host buffers in, four pairs in flight per device, device_ids = every visible device: with more
+    than one device this is the n_devices > 1 branch) and through ppcr_align_many (resident handles spread over the
+    visible devices, four in flight).  Each final transform is compared with the ORACLE's registration of the same pair
+    (not with a solo GPU run) within 1e-5 rad / 1e-5 m, under two schedules: one inner step per association (the
+    benchmark's) and the inner loop to the reference's function_tolerance (the command line's)."""
+    cfg = synth.CONFIGS[5]
+    n_dev = _lib.device_count()
+    devices = tuple(range(n_dev))
+    which = [0, 9, 18, 27, 36, 45, 54, 63]
+    pairs = [synth.make_pair(cfg["n"], cfg=5, pair=p)[:2] for p in which]
+    assert all(s.shape[0] == 250_000 and t.shape[0] == 250_000 for s, t in pairs)
+    prm = dict(radius=cfg["radius"], max_neighbours=cfg["max_neighbours"], dof=cfg["dof"])
+    for iters, inner, f_tol in ((8, 1, 1e-5), (4, 100, 10e-6)):
+        oracle = [po.align(s, t, cfg["radius"], cfg["max_neighbours"], cfg["dof"], iters, cost_drop_thresh=0.0,
+                           inner_max_steps=inner, f_tol=f_tol) for s, t in pairs]
+        assert all(o["n_iter"] == iters for o in oracle)
+        T, done = _lib.batch_run(pairs, n_iter=iters, inner_steps=inner, f_tol=f_tol, device_ids=devices, lanes_per_device=4, **prm)
+        assert list(done) == [iters] * len(pairs)
+        for k, o in enumerate(oracle):
+            assert _close(T[k], o["history"][-1]), ("ppcr_batch_run", which[k], inner)
+        ctxs = []
+        try:
+            for k, (s, t) in enumerate(pairs):
+                c = _lib.Context(devices[k % n_dev])
+                ctxs.append(c)
+                c.set_params(cfg["radius"], cfg["max_neighbours"], cfg["dof"], 3)
+                c.set_target(t)
+                c.set_source(s)
+            T2, done2 = _lib.align_many(ctxs, iters, lanes=4, cost_drop_thresh=0.0, inner_steps=inner, f_tol=f_tol)
+        finally:
+            for c in ctxs:
+                c.close()
+        assert list(done2) == [iters] * len(pairs)
+        for k, o in enumerate(oracle):
+            assert _close(T2[k], o["history"][-1]), ("ppcr_align_many", which[k], inner)
+            # and the two entry points agree with each other to the last bit (same kernels, fixed summation order)
+            np.testing.assert_array_equal(T2[k], T[k])
+    _lib.batch_release()
+
+
 def test_config4_gaussian_1m_align_vs_oracle():
     """BASELINE configs[3] (1M<->1M, Gaussian weights, -u): three outer iterations of the whole loop against the
     oracle, iteration by iteration, plus the converged-inner schedule on the first association."""
