@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 REF_F_TOL = 10e-6      # function_tolerance of the reference (src/prob_point_cloud_registration.cc:97)
+SIMD_CLOCK_GHZ = 2.4   # MI355X peak engine clock (MI355X_MICROARCH.md); prices roofline.valu_issue_frac
 
 
 def parse():
@@ -124,6 +125,28 @@ def spawn_ranks(a):
     return subprocess.run(cmd, env=env).returncode
 
 
+def k1_instantiation(cfg, inner_steps, two_pass, fused=True):
+    """Template string of the nn_fast_kernel instantiation a config's steady-state iterations launch (mirrors
+    launch_tile<M> in csrc/ppcr_nn_tile.hip and k23_form in csrc/ppcr_hip.hip): list width M = the narrowest compiled
+    width holding max_neighbours; widths <= 10 have the steady-state variant (16-slot lists, 1728-candidate halo), wider
+    ones keep 32 slots and the 2240-candidate halo; FTM = the K23 form folded in (8: t with v + dim = 8, 0: Gaussian,
+    -3: another integer v + dim, -2: none — two-pass searches, wide lists, non-integer v + dim, fuse_k23 = 0)."""
+    m = cfg["max_neighbours"]
+    width = next(w for w in (4, 5, 8, 10, 16, 20, 32) if m <= w)
+    steady = width <= 10
+    ftm = -2
+    if fused and steady and not two_pass:
+        vpd = cfg["dof"] + 3
+        if np.isinf(cfg["dof"]):
+            ftm = 0
+        elif vpd == 8:
+            ftm = 8
+        elif vpd == int(vpd) and 1 <= vpd <= 64:
+            ftm = -3
+    c, cap = (16, 1728) if steady else ((32, 2240) if width <= 24 else (48, 2048))
+    return f"nn_fast_kernel<{width}, {c}, {cap}, false, {ftm}>"
+
+
 def effective_cores():
     """Host cores this process can really use: the affinity mask capped by the container's CFS quota
     (the GPU boxes expose all hardware threads but cap CPU time, /sys/fs/cgroup/cpu.max)."""
@@ -138,20 +161,20 @@ def effective_cores():
     return (min(n, quota) if quota else n), n, quota
 
 
-def cpu_baseline(src, tgt, cfg, iters, inner_steps):
+def cpu_baseline(src, tgt, cfg, iters, inner_steps, thresh=0.0):
     """The oracle (kind 'port': OpenMP-generous variant — every loop parallel over the host cores) timed on this
     box on a bounded sample: `iters` outer iterations of the SAME workload."""
     from oracle import binding as po  # checker-side import, only on this leg
     cores, visible, quota = effective_cores()
     threads = max(1, min(po.num_threads(), cores))
     tw = time.perf_counter()
-    po.align(src, tgt, cfg["radius"], cfg["max_neighbours"], cfg["dof"], 1, inner_max_steps=inner_steps,
+    po.align(src, tgt, cfg["radius"], cfg["max_neighbours"], cfg["dof"], 1, cost_drop_thresh=thresh, inner_max_steps=inner_steps,
              threads=threads)  # warm-up (page-in, thread pool)
     tw = time.perf_counter() - tw
     if iters <= 0:
         iters = int(min(30, max(3, round(6.0 / max(tw, 1e-3)))))
     t0 = time.perf_counter()
-    res = po.align(src, tgt, cfg["radius"], cfg["max_neighbours"], cfg["dof"], iters,
+    res = po.align(src, tgt, cfg["radius"], cfg["max_neighbours"], cfg["dof"], iters, cost_drop_thresh=thresh,
                    inner_max_steps=inner_steps, threads=threads)
     dt = time.perf_counter() - t0
     iters = len(res["history"])   # iterations really performed (hasConverged may stop a converged run early)
@@ -521,42 +544,63 @@ def run_rank(a):
         k = prof["nn_fast_kernel"]
         avg_ms = k["total_ms"] / max(1, k["launches"])
         ach = b_nn / (avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch come from PMC counters, which need their own rocprofv3 --pmc passes
-        # (tools/profile_round.sh); the committed summary of the latest passes is quoted, with its source named
-        traffic, traffic_source, traffic_alone = None, None, None
+        # HBM bytes per launch and instruction counts come from PMC counters, which need their own rocprofv3 --pmc
+        # passes (tools/profile_round.sh); the committed summary of the latest passes is quoted — only for the very
+        # instantiation these windows ran (entries are keyed by the kernel's template string)
+        two_pass = "nn_wide_kernel" in prof
+        fused_on = not any(kv.split("=")[0] == "fuse_k23" and int(kv.split("=")[1]) == 0 for kv in a.opt)
+        kname = k1_instantiation(cfg, a.inner_steps, two_pass, fused_on)
+        kname_alone = k1_instantiation(cfg, a.inner_steps, two_pass, False)
+        traffic, traffic_source, traffic_alone, pmc = None, None, None, {}
         tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
-        if os.path.exists(tpath) and a.config in (3, 4, 6, 7) and a.n is None:
+        if os.path.exists(tpath) and ns == nt == 1000000 and not two_pass:
             tj = json.load(open(tpath))
             ent = tj.get("entries", {})
-            fused = ent.get("fused") or {}
-            traffic = fused.get("traffic_bytes_per_launch", tj.get("traffic_bytes_per_launch"))
-            traffic_alone = (ent.get("standalone") or {}).get("traffic_bytes_per_launch")
-            traffic_source = "profiles/k1_traffic.json (%s)" % tj.get("source", "separate rocprofv3 --pmc passes")
-        two_pass = "nn_wide_kernel" in prof
-        out["roofline"] = {"bound": "hbm", "kernel": ("nn_fast_kernel, first pass of a two-pass radius search (rows that come back "
-                                                     "short go to nn_wide_kernel; K23 is its own kernel)" if two_pass else
-                                                     "nn_fast_kernel<10,16,1728,false,8> as the timed windows run it: K1 "
-                                                     "with the previous iteration's source move in its prologue and K23 "
-                                                     "(weights + 19 moments) folded in"),
+            pmc = ent.get(kname) or {}
+            traffic = pmc.get("traffic_bytes_per_launch")
+            traffic_alone = (ent.get(kname_alone) or {}).get("traffic_bytes_per_launch")
+            if traffic is not None:
+                traffic_source = "profiles/k1_traffic.json (%s)" % tj.get("source", "separate rocprofv3 --pmc passes")
+        out["roofline"] = {"bound": "hbm",
+                           "kernel": kname + (": first pass of a two-pass radius search (rows that come back short go to "
+                                              "nn_wide_kernel; K23 is its own kernel)" if two_pass else
+                                              ": K1 with the previous iteration's source move in its prologue" +
+                                              (" and K23 (weights + 19 moments) folded in" if not kname.endswith("-2>") else "")),
                            "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": traffic_source,
                            "avg_kernel_ms": avg_ms, "algorithmic_bytes_per_launch": b_nn,
                            "candidate_tests_per_s": None if two_pass else 27 * 3.8147 * ns / (avg_ms * 1e-3)}
+        if traffic is not None:
+            # what the kernel really pulled through the memory side, as a fraction of peak (the honest bandwidth figure)
+            out["roofline"]["measured_traffic_frac"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if pmc.get("valu_per_wave"):
+            # VALU issue: a wave64 VALU instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs at SIMD_CLOCK_GHZ
+            simd_cycles = 1024 * avg_ms * 1e-3 * SIMD_CLOCK_GHZ * 1e9
+            out["roofline"]["valu_issue_frac"] = pmc["valu_insts"] * 4.0 / simd_cycles
+            out["roofline"]["valu_per_wave"] = pmc["valu_per_wave"]
+            if pmc.get("lds_active_cycles"):
+                out["roofline"]["lds_bank_conflict_share"] = pmc.get("lds_bank_conflict_cycles", 0.0) / pmc["lds_active_cycles"]
+            out["roofline"]["counters_note"] = ("instruction counts per launch from the committed --pmc passes of this instantiation; "
+                                               f"issue fraction priced at {SIMD_CLOCK_GHZ} GHz over this run's HIP-event duration")
         if "nn_fast_kernel" in prof_alone and not two_pass:
             ka = prof_alone["nn_fast_kernel"]
             alone_ms = ka["total_ms"] / max(1, ka["launches"])
-            out["roofline"]["standalone"] = {"kernel": "nn_fast_kernel<10,16,1728,false,-2> (K1 alone, K23 as its own kernel)",
+            out["roofline"]["standalone"] = {"kernel": kname_alone + " (K1 alone, K23 as its own kernel)",
                                              "avg_kernel_ms": alone_ms, "achieved": b_nn / (alone_ms * 1e-3) / 1e9,
                                              "frac": b_nn / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_alone}
     else:
         out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                            "traffic": None, "traffic_source": None}
     out["iteration_roofline"] = {"algorithmic_bytes_per_iteration": b_iter,
-                                 "achieved_GBs_per_gpu": b_iter * a.steps * pairs_per_gpu / dt / 1e9,
-                                 "frac_of_hbm_peak": b_iter * a.steps * pairs_per_gpu / dt / 1e9 / HBM_PEAK_GBS,
-                                 "note": "B_iter is SURVEY §8(d)'s definition (weights and correspondences "
-                                         "materialised); the fused kernels move about half of it"}
+                                 "notional_materialised_GBs_per_gpu": b_iter * a.steps * pairs_per_gpu / dt / 1e9,
+                                 "notional_materialised_frac": b_iter * a.steps * pairs_per_gpu / dt / 1e9 / HBM_PEAK_GBS,
+                                 "measured_traffic_frac": ((out["roofline"].get("traffic") or 0.0) * a.steps * pairs_per_gpu / dt / 1e9
+                                                           / HBM_PEAK_GBS) if out["roofline"].get("traffic") else None,
+                                 "note": "notional_*: B_iter is SURVEY §8(d)'s definition (weights and correspondences "
+                                         "MATERIALISED, 600 MB at 1M) over the iteration time — NOT achieved bandwidth: the "
+                                         "fused kernels never move those bytes; measured_traffic_frac: the PMC-counted bytes "
+                                         "of K1 (the iteration's only large kernel) per iteration over the iteration time"}
     out["kernels_ms_per_launch"] = {k: v["total_ms"] / max(1, v["launches"]) for k, v in prof.items()
                                     if isinstance(v, dict)}
     out["kernels_ms_per_launch_k23_unfused"] = {k: v["total_ms"] / max(1, v["launches"]) for k, v in prof_alone.items()
@@ -631,16 +675,19 @@ def run_rank(a):
                     s, t, _, _ = synth.make_pair(n, cfg=cloud_cfg, pair=p)
                     chk.set_target(t)
                     chk.set_source(s)
+                    # (the schedule of the timed windows: same stopping threshold, same function_tolerance)
                     if a.warmup > 0:
-                        chk.align(a.warmup, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
-                    one = chk.align(a.steps, cost_drop_thresh=0.0, inner_steps=a.inner_steps)["history"][-1]
+                        chk.align(a.warmup, cost_drop_thresh=timed_thresh, inner_steps=a.inner_steps, want_history=False)
+                    one_res = chk.align(a.steps, cost_drop_thresh=timed_thresh, inner_steps=a.inner_steps)
+                    assert one_res["n_iter"] == a.steps, f"pair {p}: early stop in the re-run: {one_res['n_iter']}"
+                    one = one_res["history"][-1]
                     worst = max(worst, float(np.abs(one - gathered[p]).max()))
             out["batch_verification"] = {"pairs_checked": n_pairs, "max_abs_diff_vs_single_rank_run": worst}
             assert worst < 1e-9, f"a gathered transform differs from its single-rank run by {worst}"
 
     if world == 1 and not a.no_cpu_baseline:
         from oracle import binding as po  # noqa: F401  (checker side)
-        cb, ora = cpu_baseline(src, tgt, cfg, a.cpu_iters, a.inner_steps)
+        cb, ora = cpu_baseline(src, tgt, cfg, a.cpu_iters, a.inner_steps, timed_thresh)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
         if not a.no_extras:
@@ -654,7 +701,7 @@ def run_rank(a):
             chk.set_target(tgt)
             chk.set_source(src)
             n_par = len(ora["history"])
-            g = chk.align(n_par, cost_drop_thresh=0.0, inner_steps=a.inner_steps)
+            g = chk.align(n_par, cost_drop_thresh=timed_thresh, inner_steps=a.inner_steps)  # the oracle ran the same schedule
         assert g["n_iter"] == n_par, (g["n_iter"], n_par)
         out["parity"] = {"iterations": n_par,
                          "rot_err_rad": synth.rotation_angle(g["history"][-1][:, :3], ora["history"][-1][:, :3]),

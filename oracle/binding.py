@@ -6,7 +6,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libppcr_oracle.so")
+# PPCR_ORACLE_LIB: another build of the same source (the sanitizer build `make -C oracle asan`, tests/test_sanitizers.py)
+_LIB_PATH = os.environ.get("PPCR_ORACLE_LIB") or os.path.join(_HERE, "libppcr_oracle.so")
 NSUMS = 19
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
@@ -16,6 +17,8 @@ _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 def build(force=False):
     """Compile the oracle with gcc (no reference sources involved)."""
+    if os.environ.get("PPCR_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or (
         os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "ppcr_oracle.c"))
     ):

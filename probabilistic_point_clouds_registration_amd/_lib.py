@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libppcr_hip.so")
+# PPCR_HIP_LIB: another BUILD of the same HIP library (tools/build_variant.py: A/B kernel experiments); unset = the product
+LIB_PATH = os.environ.get("PPCR_HIP_LIB") or os.path.join(PKG, "libppcr_hip.so")
 NSUMS = 19
 
 # every symbol include/ppcr.h declares (tests check that the built library exports them all)

@@ -523,6 +523,18 @@ __device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__
 }
 
 
+// Which block (K1) or tile (K23) of 256 source rows the g-th workgroup of a launch takes.  The dispatcher deals consecutive workgroups to the
+// eight XCDs in turn; blocks are spatially coherent in their index, and neighbouring blocks stage largely the same
+// target rows.  Giving XCD x the x-th eighth of the blocks (instead of every eighth block) lets those rows hit in that
+// XCD's L2 instead of being fetched once per XCD.  A bijection on [0, nb): the first 8 * (nb / 8) ids are permuted,
+// the remainder keeps its place.  K23 uses the same map for its tiles of rows: a tile's gathers touch the target points
+// around its rows, and with every eighth tile per XCD each XCD's 4 MB L2 saw the whole 16 MB target.
+__device__ __forceinline__ int xcd_block(int g, int nb)
+{
+    const int per = nb >> 3;
+    return g < 8 * per ? (g & 7) * per + (g >> 3) : g;
+}
+
 // rigid move of one point: f64 arithmetic summed left to right, f32 store (pcl::transformPointCloud
 // semantics, src/prob_point_cloud_registration.cc:110-112); the w lane (original index) is preserved
 __device__ __forceinline__ float4 move_point(float4 p, const Pose &P)
@@ -1065,29 +1077,21 @@ __device__ __forceinline__ void solve_and_publish(const FoldSolve &fs, SumsPtr S
         fs.pose_out->t[a] = rs.t[a];
         fs.pose_out->c[a] = 0.0;
     }
-#pragma unroll
-    for (int j = 0; j < kNSums; j++) fs.mbox->sums[j] = S[j];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-#pragma unroll
-        for (int b = 0; b < 3; b++) fs.mbox->T[4 * a + b] = rs.R[3 * a + b];
-        fs.mbox->T[4 * a + 3] = rs.t[a];
-    }
     // device-paced inner loop: the test of solve_impl / the oracle's po_solve, on the same numbers
     unsigned status = kStepResult;
     bool publish = true;
+    int steps = 0;
+    double c0 = 0.0;
     if (fs.loop.st != nullptr) {
         LoopState *st = fs.loop.st;
         const double cost_old = 0.5 * S[16];
         const double fc = rs.degenerate ? cost_old : rs.cost;
-        const int steps = fs.loop.first ? 1 : prev_steps + 1;
-        const double c0 = fs.loop.first ? cost_old : prev_cost_init;
+        steps = fs.loop.first ? 1 : prev_steps + 1;
+        c0 = fs.loop.first ? cost_old : prev_cost_init;
         const bool fin = rs.degenerate || steps >= fs.loop.max_steps ||
                          (cost_old - fc) <= fmax(fs.loop.f_tol * cost_old, 1e-14 * 0.5 * (S[17] + S[18]));
         st->steps = steps;
         st->cost_init = c0;
-        fs.mbox->cost_init = c0;
-        fs.mbox->steps = steps;
         if (fin) {
             status = kIterationDone;
             __hip_atomic_store(&st->finished, fs.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1098,7 +1102,20 @@ __device__ __forceinline__ void solve_and_publish(const FoldSolve &fs, SumsPtr S
             publish = false;  // an intermediate step: the next device step takes the pose from *pose_out
         }
     }
+    // (an intermediate step sends nothing to the host: its 33 words over PCIe used to sit between two device steps)
     if (!publish) return;
+#pragma unroll
+    for (int j = 0; j < kNSums; j++) fs.mbox->sums[j] = S[j];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int b = 0; b < 3; b++) fs.mbox->T[4 * a + b] = rs.R[3 * a + b];
+        fs.mbox->T[4 * a + 3] = rs.t[a];
+    }
+    if (fs.loop.st != nullptr) {
+        fs.mbox->cost_init = c0;
+        fs.mbox->steps = steps;
+    }
     fs.mbox->cost = rs.cost;
     fs.mbox->status = status;
     fs.mbox->degenerate = rs.degenerate ? 1u : 0u;

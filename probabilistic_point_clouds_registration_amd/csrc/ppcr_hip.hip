@@ -1208,7 +1208,8 @@ int launch_inner(ppcr_ctx *c, const StepTicket &tk, const LoopCtl &loop, int n_d
     // (and one step's G + 19 workgroups must be resident TOGETHER — five per CU, 1280 — or the step takes two rounds:
     //  1303 + 19 of them cost 57 us per step, 977 + 19 cost 48)
     const int per_wg = std::max(1, (ntiles + 1199) / 1200);
-    const int G = std::max(1, std::min((ntiles + per_wg - 1) / per_wg, kInnerMaxG));
+    int G = std::max(1, std::min((ntiles + per_wg - 1) / per_wg, kInnerMaxG));
+    if (per_wg > 1) G = std::min((G + 7) & ~7, kInnerMaxG);  // (a multiple of eight: the kernel's XCD-aware tile map)
     HIP_TRY(c, c->partials.reserve((size_t)std::max(G, nblocks(ns, 256) + kMaxSplit) * kNSums));
     InnerArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -1240,7 +1241,7 @@ int launch_inner(ppcr_ctx *c, const StepTicket &tk, const LoopCtl &loop, int n_d
     a.ovf_index = c->ovf_parity;
     a.n_steps = n_dev_steps;
     const K23Form f = k23_form(c, a.md);
-    const int grid = n_dev_steps * (G + kNSums);
+    const int grid = n_dev_steps * (G + kInnerFoldSlots);
     {
         ProfScope ps(c, K_INNER);
         const int w = c->ell_width;

@@ -489,8 +489,9 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
     RowAcc acc;
 #pragma unroll
     for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
-    accumulate_ell_rows<W, ROWS, BLOCK, TM, ONEPASS>(acc, blockIdx.x * (BLOCK * ROWS) + threadIdx.x, nbr, cnt, src, tgt, ns, P,
-                                                     md, width);
+    // (XCD-aware tile map; the partial sums stay in launch order: slot = blockIdx)
+    accumulate_ell_rows<W, ROWS, BLOCK, TM, ONEPASS>(acc, xcd_block((int)blockIdx.x, (int)gridDim.x) * (BLOCK * ROWS) + threadIdx.x, nbr, cnt,
+                                                     src, tgt, ns, P, md, width);
     // (an in-kernel last-block fold was measured and removed: its register footprint cost this kernel more than
     //  the separate fold kernel does: 101.6 us vs 67.6 + 17.2 us at the time; the fold kernel is 4.4 us now)
     block_reduce_store<BLOCK, ONEPASS>(acc, partials, gridDim.x, blockIdx.x);  // the lean form is worth six workgroups per CU
@@ -506,6 +507,10 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxDevSteps = 8;
 constexpr int kInnerMaxG = 2048;  // upper bound of the K23 workgroups per step (rows are dealt G-strided in tiles of 256)
+// workgroups a step carries behind its G K23 workgroups: kNSums fold workgroups + idle ones, so that a step is a multiple
+// of eight workgroups and workgroup r of EVERY step runs on XCD r % 8 (the tile map below relies on it)
+constexpr int kInnerFoldSlots = 24;
+static_assert(kInnerFoldSlots >= kNSums && kInnerFoldSlots % 8 == 0, "a step's workgroups: a multiple of the XCD count");
 // what the launch reads from DEVICE memory instead of taking it as kernel arguments (as by-value arguments FoldSolve's
 // ~40 words sat in SGPRs through the K23 role and pushed its uniforms into VGPRs: 138 VGPRs, three waves per SIMD)
 struct InnerConst {
@@ -564,8 +569,9 @@ __global__ __launch_bounds__(kBlock, ONEPASS ? 5 : 3) void inner_steps_kernel(In
     const InnerConst *const ic = a.ic;
     LoopState *const st = ic->fs.loop.st;
     const int G = ic->G;
-    const int per_step = G + kNSums;
+    const int per_step = G + kInnerFoldSlots;
     const int u = (int)blockIdx.x / per_step, r = (int)blockIdx.x % per_step;
+    if (r >= G + kNSums) return;  // (padding: see kInnerFoldSlots)
     const unsigned seq = a.seq;
     // The common case: step 1 (an earlier launch) ended the loop, all these workgroups have nothing to do and their
     // number times their lifetime is what the launch costs — an ordinary cached load is enough for a value written
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(kBlock, ONEPASS ? 5 : 3) void inner_steps_kernel(In
         // (or the loop ended at an earlier step: then step u - 1 never runs and `finished` / `abort` is the news)
         if (threadIdx.x == 0)
             while (__hip_atomic_load(ic->step_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)seq * kMaxDevSteps + (unsigned)u && !over())
-                __builtin_amdgcn_s_sleep(64);
+                __builtin_amdgcn_s_sleep(16);
         __syncthreads();
     }
     if (over()) return;
@@ -614,11 +620,13 @@ __global__ __launch_bounds__(kBlock, ONEPASS ? 5 : 3) void inner_steps_kernel(In
     //  tile's three dependent round trips runs under the previous tile.  Keeping the next tile's GATHERS in flight as
     //  well was measured: 72 spilled VGPRs even at a 128-register budget, the K23 phase 36 -> 40 us; so was the register
     //  form of the solve at that budget: 70 spills.)
+    // XCD-aware tile map (xcd_block): workgroup r runs on XCD r % 8 (a step is a multiple of eight workgroups, G is one
+    // too whenever a workgroup walks several tiles), and tile g = r + j G goes to the (g % 8)-th eighth of the rows
     EllRowsHead<W, 1> head;
-    load_ell_rows_head<W, 1, kBlock>(head, r * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.ns, a.width);
+    load_ell_rows_head<W, 1, kBlock>(head, xcd_block(r, ntiles) * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.ns, a.width);
     for (int tile = r; tile < ntiles; tile += G) {
         const EllRowsHead<W, 1> cur = head;
-        if (tile + G < ntiles) load_ell_rows_head<W, 1, kBlock>(head, (tile + G) * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.ns, a.width);
+        if (tile + G < ntiles) load_ell_rows_head<W, 1, kBlock>(head, xcd_block(tile + G, ntiles) * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.ns, a.width);
         EllRowsPoints<W, 1> pts;
         gather_ell_rows<W, 1>(pts, cur, a.tgt);
         RowAcc acc;

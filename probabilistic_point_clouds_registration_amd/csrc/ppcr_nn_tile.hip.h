@@ -209,17 +209,6 @@ __device__ __forceinline__ int scan_global_with_threshold(const Cands &G, const 
     return n;
 }
 
-// Which block of 256 queries the g-th workgroup of a launch takes.  The dispatcher deals consecutive workgroups to the
-// eight XCDs in turn; blocks are spatially coherent in their index, and neighbouring blocks stage largely the same
-// target rows.  Giving XCD x the x-th eighth of the blocks (instead of every eighth block) lets those rows hit in that
-// XCD's L2 instead of being fetched once per XCD.  A bijection on [0, nb): the first 8 * (nb / 8) ids are permuted,
-// the remainder keeps its place.
-__device__ __forceinline__ int xcd_block(int g, int nb)
-{
-    const int per = nb >> 3;
-    return g < 8 * per ? (g & 7) * per + (g >> 3) : g;
-}
-
 // GENERAL flavour of K1, run on the workgroups nn_fast_kernel hands over (ovf_list[0 .. *ovf_count)): halos of any
 // shape (up to 128 rows), binary subdivision when a halo does not fit, global-memory scan as the last resort, in-loop
 // list compaction for dense neighbourhoods.  The source has already been moved by the fast kernel and the temporal
@@ -922,6 +911,12 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
 // Every d2 that is computed is computed with the same IEEE operations as dist2_flann, and the final selection is the
 // same code as before, so neighbour sets and cut-off states stay bit-identical to the general flavour and the oracle.
 // ---------------------------------------------------------------------------------------------
+#ifndef PPCR_LIST_PERM
+#define PPCR_LIST_PERM 1
+#endif
+#ifndef PPCR_LIST_NOCLAMP
+#define PPCR_LIST_NOCLAMP 0
+#endif
 // candidate source of the fast flavour: list entries are byte offsets (4 * LDS index) into the SoA halo
 struct HaloList {
     const char *hx;                 // s_x as bytes; y and z follow at fixed strides
@@ -1001,6 +996,21 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     static_assert(FTM == -2 || (3 * CAP + CAP / 4) * 4 >= kFoldScratchBytes, "the final fold borrows the halo buffer");
     static_assert(CAP % 4 == 0 && CAP * 4 < 65536, "list entries are 16-bit byte offsets into the halo arrays");
     constexpr int BLOCK = 256, kWaves = 4, kRows = 128, kStageUnroll = 6;
+#if PPCR_LIST_NOCLAMP
+    // EXPERIMENT (tools/build_variant.py -DPPCR_LIST_NOCLAMP=1): ONE allocation with the list LAST, so that a store beyond
+    // the list's spare slot leaves the workgroup's LDS allocation — which the hardware drops (tools/micro/lds_oob.hip) —
+    // and the scan does not have to clamp its cursor.
+    constexpr int kHaloBytes = (3 * CAP + CAP / 4) * 4, kListBytes = (C + 1) * BLOCK * 2;
+    constexpr int kOffGbo = kHaloBytes, kOffBox = kOffGbo + kRows * 4, kOffBail = kOffBox + kWaves * 6 * 4, kOffList = (kOffBail + 4 + 15) & ~15;
+    __shared__ __attribute__((aligned(16))) unsigned char s_all[kOffList + kListBytes];
+    float *const s_halo = reinterpret_cast<float *>(s_all);
+    int *const s_gbo = reinterpret_cast<int *>(s_all + kOffGbo);
+    int(*const s_box)[6] = reinterpret_cast<int(*)[6]>(s_all + kOffBox);
+    int &s_bail = *reinterpret_cast<int *>(s_all + kOffBail);
+    unsigned short *const s_list = reinterpret_cast<unsigned short *>(s_all + kOffList);
+    static_assert(sizeof(int2) * kRows <= kListBytes, "row table aliases the list area");
+    int2 *const s_rowtab = reinterpret_cast<int2 *>(s_list);
+#else
     __shared__ __attribute__((aligned(16))) float s_halo[3 * CAP + CAP / 4];
     __shared__ unsigned short s_list[(C + 1) * BLOCK];  // C slots per lane + one that rejected candidates land in
     __shared__ int s_gbo[kRows];
@@ -1010,6 +1020,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     int2 *const s_rowtab = reinterpret_cast<int2 *>(s_list);
     __shared__ int s_box[kWaves][6];
     __shared__ int s_bail;
+#endif
     float *const s_x = s_halo, *const s_y = s_halo + CAP, *const s_z = s_halo + 2 * CAP;
     unsigned char *const s_rowid = reinterpret_cast<unsigned char *>(s_halo + 3 * CAP);
 
@@ -1275,7 +1286,16 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
 
     int n = 0;
     unsigned tm = 0xFFFFFFFFu;  // d2 bits of the m-th neighbour (all-ones: fewer than m found)
-    const HaloList L{reinterpret_cast<const char *>(s_x), CAP * 4, s_rowid, reinterpret_cast<const char *>(s_gbo), s_list + tid};
+    // A lane's column of the list.  With column = tid the lanes 2k and 2k + 1 of a wave share a 32-bit LDS word, and in
+    // the scan every lane writes at its own cursor (another slot = another address in the same bank): the two u16 stores
+    // of the pair collide whenever their cursors differ.  The columns of a wave are therefore dealt so that a word is
+    // shared by lanes l and l + 32 — the two halves of the wave the LDS serves in different cycles.
+#if PPCR_LIST_PERM
+    const int lcol = (tid & ~63) | ((tid & 31) << 1) | ((tid >> 5) & 1);
+#else
+    const int lcol = tid;
+#endif
+    const HaloList L{reinterpret_cast<const char *>(s_x), CAP * 4, s_rowid, reinterpret_cast<const char *>(s_gbo), s_list + lcol};
     if (valid) {
         // the nine runs as ONE 32-bit key each, (length << 16) | LDS byte offset of the run's first candidate, sorted
         // by DESCENDING length: every lane of the wave walks its longest run first, ... — a run's trip count is the
@@ -1319,7 +1339,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         typedef __attribute__((address_space(3))) unsigned short *lds_u16p;
         typedef __attribute__((address_space(3))) const float *lds_f32p;
         // (the casts go through uintptr_t so that the host pass, where every pointer is 64-bit, parses them too)
-        const unsigned list0 = (unsigned)(__UINTPTR_TYPE__)(lds_u16p)(s_list + tid), list_last = list0 + C * 512;
+        const unsigned list0 = (unsigned)(__UINTPTR_TYPE__)(lds_u16p)(s_list + lcol), list_last = list0 + C * 512;
         const unsigned halo0 = (unsigned)(__UINTPTR_TYPE__)(lds_f32p)s_x;
         for (int attempt = 0;; attempt++) {
             // the list's write cursor counts every accepted candidate (so n is exact), the store slot is clamped to
@@ -1341,10 +1361,18 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
                         d = d + dz * dz;
                         // every candidate is written to the list's next free slot; only an accepted one moves the cursor
                         // (a rejected one is overwritten by whatever comes next): no branch, no exec juggling
+#if PPCR_LIST_NOCLAMP
+                        const unsigned slot_x = wp;
+#else
                         const unsigned slot_x = min(wp, list_last);
+#endif
                         *(lds_u16p)(__UINTPTR_TYPE__)slot_x = (unsigned short)(a - halo0);
                         wp += (__float_as_uint(d.x) <= thr) ? 512u : 0u;
+#if PPCR_LIST_NOCLAMP
+                        const unsigned slot_y = wp;
+#else
                         const unsigned slot_y = min(wp, list_last);
+#endif
                         *(lds_u16p)(__UINTPTR_TYPE__)slot_y = (unsigned short)(a - halo0 + 4);
                         wp += (bool(a < a_pair) & bool(__float_as_uint(d.y) <= thr)) ? 512u : 0u;
                     }

@@ -3,7 +3,8 @@
 windows launch them — ppcr_align with one inner step (nn_fast_kernel<...,8>: K23 folded in, fold-and-solve merged into
 the cleanup launch), then the reference's schedule (inner loop to function_tolerance: the same K1 + inner_steps_kernel),
 then the host-paced ppcr_iterate chain (nn_fast_kernel<...,-2> + accumulate_ell_kernel + reduce_solve_kernel), so that
-every instantiation has its own rows in one pass.  usage: exp_align.py [n] [key=value options ...]"""
+every instantiation has its own rows in one pass.  usage: exp_align.py [n] [dof=<v|inf>] [key=value options ...]
+(dof: the weight model, hence which fused form of K1 is profiled: 5 -> <..., 8>, inf -> <..., 0>, 3 / 10 -> <..., -3>)"""
 import os
 import sys
 
@@ -14,10 +15,14 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 cfg = 3 if n >= 1_000_000 else 2
 src, tgt, _, _ = synth.make_pair(n, cfg=cfg)
 c = _lib.Context(0)
+dof = 5.0
 for kv in sys.argv[2:]:
     k, v = kv.split("=")
-    c.set_option(k, int(v))
-c.set_params(1.0, 10, 5.0, 3)
+    if k == "dof":
+        dof = float(v)
+    else:
+        c.set_option(k, int(v))
+c.set_params(1.0, 10, dof, 3)
 c.set_target(tgt)
 for rep in range(2):
     c.set_source(src)

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""profiles/k1_traffic.json from the FETCH_SIZE / WRITE_SIZE summary that tools/profile_round.sh writes
-(pmc_hbm_traffic.txt): HBM bytes per launch of the steady-state K1 kernel — one entry per instantiation: "fused" (K23
-folded in: what ppcr_align and the benchmark's timed windows launch) and "standalone" (K1 alone) — with the gfx950
-correction the MI355X_MICROARCH.md HBM section prescribes (FETCH_SIZE counts wide coalesced reads at half size)."""
+"""profiles/k1_traffic.json from the PMC summaries tools/profile_round.sh writes: per INSTANTIATION of nn_fast_kernel
+(keyed by its full template string, e.g. "nn_fast_kernel<10, 16, 1728, false, 8>") the HBM bytes per launch
+(pmc_hbm_traffic.txt: FETCH_SIZE / WRITE_SIZE, with the gfx950 correction the MI355X_MICROARCH.md HBM section
+prescribes: FETCH_SIZE counts wide coalesced reads at half size) and, when the instruction-mix passes ran
+(pmc_instruction_mix.txt), VALU / LDS instructions, waves and LDS bank-conflict cycles per launch.  bench.py quotes an
+entry only for the instantiation its timed windows really ran.
+usage: make_k1_traffic.py <pmc_hbm_traffic.txt> <out.json> <tag> [pmc_instruction_mix.txt]"""
 import json
 import re
 import sys
@@ -11,39 +14,48 @@ CORRECTION = ("gfx950: FETCH_SIZE counts 128-B fabric requests at 64 B for wide 
               "(MI355X_MICROARCH.md HBM section); WRITE_SIZE taken as is; Infinity-Cache hits are included in both")
 
 
-def entry(block):
-    vals = {m.group(1): (float(m.group(2)), int(m.group(3))) for m in re.finditer(r"(\w+)\s+([0-9.]+)\s+\(n=(\d+)\)", block)}
-    fetch_kb, n = vals["FETCH_SIZE"]
-    write_kb, _ = vals["WRITE_SIZE"]
-    return {"kernel": block.splitlines()[0].strip(), "dispatches": n, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
-            "traffic_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0}
-
-
-def main(summary, out, tag):
-    txt = open(summary).read()
-    blocks = re.split(r"\n(?=\S)", txt)
-    entries = {}
-    for b in blocks:
-        head = b.splitlines()[0]
-        if not head.startswith("nn_fast_kernel<10, 16"):
+def blocks(path):
+    """{kernel head line: {counter: (mean, n)}} of one pmc_summary.py output"""
+    out = {}
+    for b in re.split(r"\n(?=\S)", open(path).read()):
+        lines = b.splitlines()
+        if not lines:
             continue
-        if re.search(r"false, (8|0)>", head):
-            entries["fused"] = entry(b)
-        elif "false, -2>" in head:
-            entries["standalone"] = entry(b)
+        out[lines[0].strip()] = {m.group(1): (float(m.group(2)), int(m.group(3)))
+                                 for m in re.finditer(r"(\w+)\s+([0-9.]+)\s+\(n=(\d+)\)", b)}
+    return out
+
+
+def main(summary, out, tag, mix=None):
+    entries = {}
+    for head, vals in blocks(summary).items():
+        if not head.startswith("nn_fast_kernel<") or "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+            continue
+        fetch_kb, n = vals["FETCH_SIZE"]
+        write_kb, _ = vals["WRITE_SIZE"]
+        entries[head] = {"dispatches": n, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+                         "traffic_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0}
     if not entries:
-        raise SystemExit("no nn_fast_kernel<10, 16, ...> block in " + summary)
-    doc = {
-        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes over tools/exp_align.py, MI355X, "
-                  f"profiles/{tag}_pmc_hbm_traffic.txt; tools/profile_round.sh)",
-        "correction": CORRECTION,
-        "entries": entries,
-        # the figure bench.py quotes by default: the instantiation its timed windows run
-        "traffic_bytes_per_launch": (entries.get("fused") or entries.get("standalone"))["traffic_bytes_per_launch"],
-    }
+        raise SystemExit("no nn_fast_kernel<...> block in " + summary)
+    if mix:
+        for head, vals in blocks(mix).items():
+            if head in entries and "SQ_INSTS_VALU" in vals and "SQ_WAVES" in vals:
+                e = entries[head]
+                e["waves"] = vals["SQ_WAVES"][0]
+                e["valu_insts"] = vals["SQ_INSTS_VALU"][0]
+                e["valu_per_wave"] = vals["SQ_INSTS_VALU"][0] / max(vals["SQ_WAVES"][0], 1.0)
+                for k_in, k_out in (("SQ_INSTS_LDS", "lds_insts"), ("SQ_LDS_BANK_CONFLICT", "lds_bank_conflict_cycles"),
+                                    ("SQ_LDS_IDX_ACTIVE", "lds_active_cycles"), ("SQ_THREAD_CYCLES_VALU", "valu_thread_cycles"),
+                                    ("SQ_INSTS_VALU_INT32", "valu_int32_insts")):
+                    if k_in in vals:
+                        e[k_out] = vals[k_in][0]
+    doc = {"source": f"rocprofv3 --pmc passes over tools/exp_align.py (one pass per counter group, --kernel-trace only), MI355X, "
+                     f"profiles/{tag}_pmc_hbm_traffic.txt" + (f" + profiles/{tag}_pmc_instruction_mix.txt" if mix else "")
+                     + "; tools/profile_round.sh",
+           "correction": CORRECTION, "entries": entries}
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps(doc))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "rXX")
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "rXX", sys.argv[4] if len(sys.argv) > 4 else None)
