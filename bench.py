@@ -49,7 +49,8 @@ def parse():
     ap.add_argument("--config", type=int, default=3,
                     help="BASELINE.json config number (3 = 1M headline, 4 = Gaussian, 2 = 100k, 5 = 64 x 250k batch; "
                          "6 / 7 = \"4b\": the 1M pair with -d 3 / -d 10, the other t models the fused kernel serves; "
-                         "8 = the command line's own defaults: 200k points, radius 3, 20 neighbours, inner loop to f_tol)")
+                         "8 = the command line's own defaults: 200k points, radius 3, 20 neighbours, inner loop to f_tol; "
+                         "9 / 10 = the same on non-uniform clouds: a LiDAR-like scene / a slab with a density gradient and dense blobs)")
     ap.add_argument("--n", "--points", dest="n", type=int, default=None,
                     help="override the cloud size (debugging; spell it --points behind torch.distributed.run, whose own "
                          "parser trips over --n)")
@@ -324,7 +325,6 @@ def run_rank(a):
         assert dist.get_world_size() == a.gpus
 
     cfg = dict(synth.CONFIGS[a.config])
-    cloud_cfg = cfg.get("clouds", a.config)   # whose pinned seeds the clouds are drawn with
     if a.inner_steps is None:
         a.inner_steps = int(cfg.get("inner_steps", 1))
     n = a.n or cfg["n"]
@@ -341,7 +341,7 @@ def run_rank(a):
     my_pairs = batch.shard_pairs(n_pairs, world, rank)   # pair p lives on rank p % world
     ctxs, clouds = [], []
     for p in my_pairs:
-        src, tgt, _, _ = synth.make_pair(n, cfg=cloud_cfg, pair=p)
+        src, tgt, _, _ = synth.make_config(a.config, pair=p, n=n)
         c = _lib.Context(local_rank)
         for kv in a.opt:
             k, v = kv.split("=")
@@ -520,6 +520,7 @@ def run_rank(a):
         "data": "synthetic" if on_gpu else "FAKE REGISTRATION (--fake-register: rank-logic test, measures nothing)",
         "config": {"workload": (f"BASELINE configs[{a.config - 1}]: " if a.config <= 5 else
                                 "the reference CLI's default parameters (radius 3, 20 neighbours): " if a.config == 8 else
+                                f"the reference CLI's default parameters on a NON-UNIFORM cloud ({cfg['scene']} scene, synth.make_scene): " if "scene" in cfg else
                                 f"BASELINE configs[3] variant 4b (t model, dof {cfg['dof']:g}): ")
                                + (f"batch of {n_pairs} independent pairs of " if n_pairs > 1 else "")
                                + f"{ns}<->{nt} synthetic clouds, radius={cfg['radius']}, "
@@ -652,7 +653,7 @@ def run_rank(a):
         if batch_cfg and world == 1 and not a.no_extras:
             # pairs per second END TO END: host buffers in (upload, grid build, source sort, K iterations), several
             # pairs in flight per GPU so that one pair's uploads overlap another pair's iterations (ppcr_batch_run)
-            host_pairs = [synth.make_pair(n, cfg=cloud_cfg, pair=p)[:2] for p in range(min(n_pairs, 16))]
+            host_pairs = [synth.make_config(a.config, pair=p, n=n)[:2] for p in range(min(n_pairs, 16))]
             for _ in range(2):   # warm-up: ppcr_batch_run keeps its handles, four of them have grown their buffers after this
                 _lib.batch_run(host_pairs[:8], cfg["radius"], cfg["max_neighbours"], cfg["dof"], n_iter=a.steps + a.warmup,
                                inner_steps=a.inner_steps, device_ids=(local_rank,), lanes_per_device=4)
@@ -672,7 +673,7 @@ def run_rank(a):
             with _lib.Context(local_rank) as chk:
                 chk.set_params(cfg["radius"], cfg["max_neighbours"], cfg["dof"], 3)
                 for p in range(n_pairs):
-                    s, t, _, _ = synth.make_pair(n, cfg=cloud_cfg, pair=p)
+                    s, t, _, _ = synth.make_config(a.config, pair=p, n=n)
                     chk.set_target(t)
                     chk.set_source(s)
                     # (the schedule of the timed windows: same stopping threshold, same function_tolerance)

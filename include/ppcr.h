@@ -234,6 +234,25 @@ int ppcr_align_many(ppcr_ctx *const *ctxs, int n, int lanes, int n_iter, double 
                     double n_cost_drop_it, const double q0[4], const double t0[3], int inner_steps,
                     double f_tol, double *T_final, int32_t *n_done);
 
+/* ---- the one collective of the multi-GPU deployment, native (north star: "RCCL over xGMI only for the final gather of
+ * transforms") ----
+ * One process per GPU: rank r registers the pairs p with p % world == r on its device (ppcr_batch_run with n_devices = 1,
+ * or ppcr_align_many), then every rank calls ppcr_gather_transforms and holds all n_pairs transforms.  The communicator
+ * is an RCCL communicator (ncclCommInitRank); RCCL is bound at run time (librccl.so.1), so single-GPU users of this
+ * library do not need it.  Bootstrap: rank 0 draws an id (ppcr_comm_get_id = ncclGetUniqueId) and hands its 128 bytes to
+ * the other ranks by whatever means the launcher has (the command line's --rendezvous file); ppcr_comm_create is
+ * collective over the ranks.  The reference has no counterpart (it registers one pair per process run). */
+#define PPCR_COMM_ID_BYTES 128
+typedef struct ppcr_comm ppcr_comm;
+int ppcr_comm_get_id(unsigned char id[PPCR_COMM_ID_BYTES]);
+int ppcr_comm_create(int device_id, int rank, int world, const unsigned char id[PPCR_COMM_ID_BYTES], ppcr_comm **out);
+int ppcr_comm_destroy(ppcr_comm *comm);
+/* T_local: this rank's pairs in ascending pair index, 12 doubles each ([R|t] rows); T_all: n_pairs * 12 doubles, filled
+ * on EVERY rank (one ncclAllGather of ceil(n_pairs / world) * 12 doubles per rank: a few hundred bytes, latency-bound). */
+int ppcr_gather_transforms(ppcr_comm *comm, const double *T_local, int64_t n_pairs, double *T_all);
+/* message of the last failing ppcr_comm_* / ppcr_gather_transforms call on this thread */
+const char *ppcr_comm_last_error(void);
+
 /* current (moved) source in the caller's original point order */
 int ppcr_get_source(ppcr_ctx *ctx, float *xyz, int64_t stride_bytes);
 
@@ -294,6 +313,9 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *   "brick_x"      x extent in cells of the 4x4 (y,z) bricks the source is ordered by: 1 (default), 2 or 4;
  *   "short_lists"  1 once the temporal cut-off is valid K1 runs with 16-slot lists, a 1728-candidate halo and five
  *                  workgroups per CU (default), 0 always 32 slots / three workgroups;
+ *   "k1_halves"    the steady-state K1 scans every block of 256 queries as two half-blocks on two workgroups: -1 automatic
+ *                  (default: clouds of up to 640 blocks, 164k points — small clouds leave most of the chip idle and an
+ *                  iteration lasts as long as one workgroup's dependent chain), 0 never, 1 always;
  *   "two_pass"     1 a bounded search whose radius holds far more than max_neighbours target points runs in two passes
  *                  (default): the grid and the tiled kernel work with radius / k, chosen from the target's density, and
  *                  only the rows that find fewer than max_neighbours there are searched again with the full radius;

@@ -24,6 +24,7 @@ SYMBOLS = [
     "ppcr_profile_get", "ppcr_set_option", "ppcr_batch_run", "ppcr_align_many", "ppcr_set_companion",
     "ppcr_get_companion", "ppcr_set_ground_truth", "ppcr_mse_ground_truth", "ppcr_mse_previous", "ppcr_voxel_filter",
     "ppcr_nearest_sq_distances", "ppcr_stop_rule_check", "ppcr_align_report", "ppcr_batch_release",
+    "ppcr_comm_get_id", "ppcr_comm_create", "ppcr_comm_destroy", "ppcr_gather_transforms", "ppcr_comm_last_error",
 ]
 
 
@@ -124,9 +125,14 @@ def load():
     L.ppcr_batch_run.argtypes = [C.POINTER(Pair), i64, C.POINTER(BatchOptions), C.POINTER(i32), i32, i32, vp, vp,
                                  C.c_char_p, i64]
     L.ppcr_align_many.argtypes = [C.POINTER(vp), i32, i32, i32, dbl, dbl, vp, vp, i32, dbl, vp, vp]
+    L.ppcr_comm_get_id.argtypes = [vp]
+    L.ppcr_comm_create.argtypes = [i32, i32, i32, vp, C.POINTER(vp)]
+    L.ppcr_comm_destroy.argtypes = [vp]
+    L.ppcr_gather_transforms.argtypes = [vp, vp, i64, vp]
+    L.ppcr_comm_last_error.restype = C.c_char_p
     for name in SYMBOLS:
         f = getattr(L, name)
-        if name not in ("ppcr_last_error", "ppcr_cost_from_moments"):
+        if name not in ("ppcr_last_error", "ppcr_cost_from_moments", "ppcr_comm_last_error"):
             f.restype = i32
     _lib = L
     return L
@@ -473,6 +479,49 @@ def align_many(ctxs, n_iter, lanes=2, cost_drop_thresh=0.0, n_cost_drop_it=5, q0
         msgs = [L.ppcr_last_error(c._h).decode() for c in ctxs]
         raise PpcrError(rc, next((m for m in msgs if m), "ppcr_align_many failed"))
     return T, done
+
+
+class Comm:
+    """ppcr_comm: the native RCCL communicator of the one-process-per-GPU deployment (ppcr_gather_transforms).
+    Rank 0 draws the id (Comm.new_id()) and hands its 128 bytes to the other ranks; creation is collective."""
+
+    @staticmethod
+    def new_id():
+        buf = (C.c_ubyte * 128)()
+        rc = load().ppcr_comm_get_id(buf)
+        if rc != 0:
+            raise PpcrError(rc, load().ppcr_comm_last_error().decode())
+        return bytes(buf)
+
+    def __init__(self, device_id, rank, world, comm_id):
+        self._L = load()
+        h = C.c_void_p()
+        buf = (C.c_ubyte * 128).from_buffer_copy(comm_id)
+        rc = self._L.ppcr_comm_create(int(device_id), int(rank), int(world), buf, C.byref(h))
+        if rc != 0:
+            raise PpcrError(rc, self._L.ppcr_comm_last_error().decode())
+        self._h, self.rank, self.world = h, int(rank), int(world)
+
+    def gather_transforms(self, T_local, n_pairs):
+        """T_local: this rank's pairs (p % world == rank, ascending) as [k, 3, 4] -> every pair's transform [n_pairs, 3, 4]"""
+        loc = np.ascontiguousarray(np.asarray(T_local, np.float64).reshape(-1, 12))
+        out = np.zeros((int(n_pairs), 3, 4))
+        rc = self._L.ppcr_gather_transforms(self._h, loc.ctypes.data if loc.size else None, int(n_pairs), out.ctypes.data)
+        if rc != 0:
+            raise PpcrError(rc, self._L.ppcr_comm_last_error().decode())
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ppcr_comm_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
 
 def voxel_filter(cloud, leaf, device_id=0):

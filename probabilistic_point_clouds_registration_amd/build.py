@@ -15,9 +15,10 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "libppcr_hip.so")
 MAIN_TU = os.path.join(CSRC, "ppcr_hip.hip")
+COMM_TU = os.path.join(CSRC, "ppcr_comm.hip")   # the native RCCL gather (host code only; RCCL bound at run time)
 TILE_TU = os.path.join(CSRC, "ppcr_nn_tile.hip")
 TILE_WIDTHS = (10, 4, 5, 8, 16, 20, 32)   # K1's compiled-in list widths, one object each (the default first)
-SOURCES = [MAIN_TU, TILE_TU]
+SOURCES = [MAIN_TU, TILE_TU, COMM_TU]
 DEPS = SOURCES + [os.path.join(CSRC, h) for h in ("ppcr_device.hip.h", "ppcr_kernels.hip.h", "ppcr_nn_tile.hip.h",
                                                   "ppcr_nn_tile_launch.hip.h", "ppcr_host_math.hpp")] + [
     os.path.join(ROOT, "include", "ppcr.h")]
@@ -45,7 +46,7 @@ def needs_build():
 def _jobs():
     """(object, compile command) for every translation unit: the C-ABI unit and K1 once per list width."""
     cc = [hipcc()] + flags() + ["-c"]
-    jobs = [(os.path.join(OBJ, "ppcr_hip.o"), cc + [MAIN_TU])]
+    jobs = [(os.path.join(OBJ, "ppcr_hip.o"), cc + [MAIN_TU]), (os.path.join(OBJ, "ppcr_comm.o"), cc + [COMM_TU])]
     for m in TILE_WIDTHS:
         jobs.append((os.path.join(OBJ, "ppcr_nn_tile_m%d.o" % m), cc + ["-DPPCR_TILE_M=%d" % m, TILE_TU]))
     return [(obj, cmd + ["-o", obj]) for obj, cmd in jobs]
@@ -67,7 +68,7 @@ def build(force=False, verbose=False):
     workers = max(1, min(len(jobs), os.cpu_count() or 1))
     with concurrent.futures.ThreadPoolExecutor(workers) as pool:
         objects = list(pool.map(compile_one, jobs))
-    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objects
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objects + ["-ldl"]
     if verbose:
         print(" ".join(link), file=sys.stderr)
     subprocess.check_call(link)

@@ -1,7 +1,8 @@
 // PCD reader/writer for x y z float clouds (the on-disk format of the reference CLI:
 // pcl::io::loadPCDFile / savePCDFile at src/prob_point_cloud_registration_ex.cc:113,123,132,164).
-// Supported: DATA ascii and DATA binary, any field list that contains float32 x, y, z.
-// Not supported: binary_compressed (LZF) — loadPCDFile returns -1 with a message on stderr.
+// Supported: DATA ascii, binary and binary_compressed (LZF), any field list that contains float32 x, y, z.
+// Anything malformed — truncated data, a header that promises more than the file holds, a corrupt LZF stream — makes
+// loadPCDFile return -1 with a message on stderr (tests/test_sanitizers.py runs the reader under ASan + UBSan).
 #pragma once
 #include <string>
 

@@ -19,7 +19,7 @@ struct Field {
     int size = 4;
     char type = 'F';
     int count = 1;
-    int offset = 0;
+    long long offset = 0;  // bytes from the start of a point's record
 };
 
 // LZF decoder (the stream format of liblzf, which PCL bundles for DATA binary_compressed).  A control byte c:
@@ -116,12 +116,14 @@ int loadChecked(const std::string &file_name, pcl::PointCloud<pcl::PointXYZ> &cl
             std::cerr << "[pcd] " << file_name << ": bad SIZE / COUNT in the header" << std::endl;
             return -1;
         }
-    int ix = -1, iy = -1, iz = -1, col = 0, off = 0;
-    std::vector<int> first_col(fields.size(), 0);
+    // (64-bit running sums: 400 fields of 8 x 2^20 bytes wrap an int — found by the UBSan run of tests/test_sanitizers.py)
+    int ix = -1, iy = -1, iz = -1;
+    long long col = 0, off = 0;
+    std::vector<long long> first_col(fields.size(), 0);
     for (std::size_t f = 0; f < fields.size(); f++) {
         fields[f].offset = off;
         first_col[f] = col;
-        off += fields[f].size * fields[f].count;
+        off += static_cast<long long>(fields[f].size) * fields[f].count;
         col += fields[f].count;
         if (fields[f].name == "x") ix = static_cast<int>(f);
         if (fields[f].name == "y") iy = static_cast<int>(f);
@@ -129,6 +131,10 @@ int loadChecked(const std::string &file_name, pcl::PointCloud<pcl::PointXYZ> &cl
     }
     if (ix < 0 || iy < 0 || iz < 0 || points < 0) {
         std::cerr << "[pcd] " << file_name << ": header lacks x/y/z fields or a point count" << std::endl;
+        return -1;
+    }
+    if (off > (1ll << 24) || col > (1ll << 22)) {
+        std::cerr << "[pcd] " << file_name << ": a point record of " << off << " bytes / " << col << " columns is refused" << std::endl;
         return -1;
     }
     for (int f : {ix, iy, iz})
@@ -139,13 +145,13 @@ int loadChecked(const std::string &file_name, pcl::PointCloud<pcl::PointXYZ> &cl
     // a point needs at least one byte of data whatever the encoding's best case (LZF expands <= ~ 264x): a header
     // that promises more points than the file could hold is refused before anything is allocated
     const long long left = remainingBytes(in);
-    if (left >= 0 && (points > left * 512 + 16 || (data_mode == "binary" && points > left / std::max(off, 1)))) {
+    if (left >= 0 && (points > left * 512 + 16 || (data_mode == "binary" && points > left / std::max(off, 1ll)))) {
         std::cerr << "[pcd] " << file_name << ": header promises more points than the file holds" << std::endl;
         return -1;
     }
     cloud.points.assign(static_cast<std::size_t>(points), pcl::PointXYZ());
     if (data_mode == "ascii") {
-        const int ncols = col;
+        const long long ncols = col;
         std::vector<double> row(static_cast<std::size_t>(ncols));
         for (long long i = 0; i < points; i++) {
             if (!std::getline(in, line)) {
@@ -153,7 +159,7 @@ int loadChecked(const std::string &file_name, pcl::PointCloud<pcl::PointXYZ> &cl
                 return -1;
             }
             std::istringstream is(line);
-            for (int k = 0; k < ncols; k++) {
+            for (long long k = 0; k < ncols; k++) {
                 std::string tok;
                 if (!(is >> tok)) {
                     std::cerr << "[pcd] " << file_name << ": short ascii row " << i << std::endl;
@@ -167,8 +173,8 @@ int loadChecked(const std::string &file_name, pcl::PointCloud<pcl::PointXYZ> &cl
             p.z = static_cast<float>(row[static_cast<std::size_t>(first_col[iz])]);
         }
     } else if (data_mode == "binary") {
-        const int stride = off;
-        std::vector<char> buf(static_cast<std::size_t>(stride) * static_cast<std::size_t>(points));
+        const std::size_t stride = static_cast<std::size_t>(off);
+        std::vector<char> buf(stride * static_cast<std::size_t>(points));
         in.read(buf.data(), static_cast<std::streamsize>(buf.size()));
         if (static_cast<std::size_t>(in.gcount()) != buf.size()) {
             std::cerr << "[pcd] " << file_name << ": truncated binary data" << std::endl;

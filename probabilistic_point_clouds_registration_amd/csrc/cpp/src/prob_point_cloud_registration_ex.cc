@@ -15,6 +15,8 @@
 #include <memory>
 #include <sstream>
 #include <string>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "prob_point_cloud_registration/pcd_io.hpp"
@@ -32,6 +34,11 @@ struct Job {
     std::string source_path, target_path, truth_path;  // truth_path empty: no -g
     std::string batch_path;                            // --batch: a list of pairs instead of one pair
     int lanes = 2;                                     // --lanes: pairs in flight per device (batch mode)
+    // one process per GPU (batch mode): this process is rank `rank` of `world`, registers the pairs p with p % world == rank
+    // on its device and takes part in the final RCCL all-gather of the transforms; rank 0 prints them
+    int rank = 0, world = 1;
+    std::string rendezvous;                            // --rendezvous: a file rank 0 leaves the communicator id in
+    bool device_given = false;                         // --device on the command line (rank mode: default rank % devices)
     bool gaussian = false;
 };
 
@@ -45,7 +52,8 @@ struct BadArgument {
     std::cerr << "usage: probabilistic_point_cloud_registration [--dump] [-g <string>] [-v] [-u] [-n <int>] [-c <float>]\n"
                  "         [-r <float>] [-d <float>] [-i <int>] [-m <int>] [-t <float>] [-s <float>] [--device <int>]\n"
                  "         [--inner-steps <int>] <source_file_name> <target_file_name>\n"
-                 "   or: probabilistic_point_cloud_registration --batch <pair_list_file> [--lanes <int>] [options as above]"
+                 "   or: probabilistic_point_cloud_registration --batch <pair_list_file> [--lanes <int>] [options as above]\n"
+                 "         [--rank <int> --world <int> --rendezvous <file>]   (one process per GPU, RCCL gather of the transforms)"
               << std::endl;
     std::exit(EXIT_FAILURE);
 }
@@ -122,10 +130,13 @@ Job parseCommandLine(int argc, char **argv)
         else if (is("-u", "--use_gaussian")) job.gaussian = true;
         else if (is("-v", "--verbose")) job.params.verbose = true;
         else if (a == "--dump") job.params.summary = true;
-        else if (a == "--device") job.params.device_id = cur.integer(a);
+        else if (a == "--device") job.params.device_id = cur.integer(a), job.device_given = true;
         else if (a == "--inner-steps") job.params.inner_max_steps = cur.integer(a);
         else if (a == "--batch") job.batch_path = cur.valueOf(a);
         else if (a == "--lanes") job.lanes = cur.integer(a);
+        else if (a == "--rank") job.rank = cur.integer(a);
+        else if (a == "--world") job.world = cur.integer(a);
+        else if (a == "--rendezvous") job.rendezvous = cur.valueOf(a);
         else if (is("-h", "--help")) throw BadArgument{"help requested", a};
         else if (looksLikeFlag(a)) throw BadArgument{"Couldn't find match for argument", a};
         else files.push_back(a);
@@ -134,6 +145,8 @@ Job parseCommandLine(int argc, char **argv)
     if (!job.batch_path.empty()) {
         if (!files.empty()) throw BadArgument{"Positional arguments are not used with --batch", files[0]};
         if (job.lanes < 1) throw BadArgument{"--lanes must be at least 1", "--lanes"};
+        if (job.world < 1 || job.rank < 0 || job.rank >= job.world) throw BadArgument{"--rank must lie in [0, --world)", "--rank"};
+        if (job.world > 1 && job.rendezvous.empty()) throw BadArgument{"--world > 1 needs --rendezvous <file>", "--world"};
         // the batch entry point takes clouds as they are and reports transforms only: refuse what it would silently drop
         if (job.params.source_filter_size > 0) throw BadArgument{"Voxel filters belong to the single-pair form, not --batch", "-s"};
         if (job.params.target_filter_size > 0) throw BadArgument{"Voxel filters belong to the single-pair form, not --batch", "-t"};
@@ -212,7 +225,46 @@ void writeSummary(const Job &job, const std::string &table)
     out << table;
 }
 
-// --batch: every pair of the list through ppcr_batch_run on all visible devices
+// one-process-per-GPU mode of --batch: the communicator of the final gather.  Rank 0 draws the RCCL id and leaves its
+// 128 bytes in the rendezvous file (written under another name and renamed, so a reader never sees half of it); the
+// other ranks wait for the file.  ppcr_comm_create is collective.
+ppcr_comm *joinRanks(const Job &job, int device)
+{
+    unsigned char id[PPCR_COMM_ID_BYTES];
+    if (job.rank == 0) {
+        if (ppcr_comm_get_id(id) != PPCR_OK) return nullptr;
+        const std::string tmp = job.rendezvous + ".tmp";
+        {
+            std::ofstream out(tmp, std::ios::binary);
+            out.write(reinterpret_cast<const char *>(id), sizeof id);
+            if (!out) return nullptr;
+        }
+        std::error_code ec;
+        fs::rename(tmp, job.rendezvous, ec);
+        if (ec) return nullptr;
+    } else {
+        bool have = false;
+        for (int tries = 0; tries < 1200 && !have; tries++) {  // two minutes
+            std::error_code ec;
+            if (fs::exists(job.rendezvous, ec) && fs::file_size(job.rendezvous, ec) == sizeof id) {
+                std::ifstream in(job.rendezvous, std::ios::binary);
+                in.read(reinterpret_cast<char *>(id), sizeof id);
+                have = in.gcount() == static_cast<std::streamsize>(sizeof id);
+            }
+            if (!have) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        }
+        if (!have) {
+            std::cerr << "rank " << job.rank << ": no communicator id appeared in " << job.rendezvous << std::endl;
+            return nullptr;
+        }
+    }
+    ppcr_comm *comm = nullptr;
+    if (ppcr_comm_create(device, job.rank, job.world, id, &comm) != PPCR_OK) return nullptr;
+    return comm;
+}
+
+// --batch: every pair of the list through ppcr_batch_run — on all visible devices of this process, or (with --rank /
+// --world / --rendezvous: one process per GPU) this rank's share on its device, then the RCCL gather of the transforms
 int runBatch(const Job &job)
 {
     std::ifstream list(job.batch_path);
@@ -220,8 +272,8 @@ int runBatch(const Job &job)
         std::cout << "Could not read the pair list " << job.batch_path << ", closing" << std::endl;
         return EXIT_FAILURE;
     }
-    std::vector<Cloud::Ptr> clouds;  // source, target, source, target, ...
-    std::vector<std::string> names;
+    const bool ranked = job.world > 1 || !job.rendezvous.empty();
+    std::vector<std::pair<std::string, std::string>> files;
     std::string line;
     while (std::getline(list, line)) {
         std::istringstream fields(line);
@@ -232,7 +284,16 @@ int runBatch(const Job &job)
             std::cout << "Pair list line without a target: " << line << std::endl;
             return EXIT_FAILURE;
         }
-        for (const std::string *name : {&src_name, &tgt_name}) {
+        files.emplace_back(src_name, tgt_name);
+    }
+    const std::size_t n_pairs = files.size();
+    // the pairs THIS process registers: all of them, or p % world == rank (the deal of ppcr_batch_run and batch.py)
+    std::vector<std::size_t> mine;
+    for (std::size_t p = 0; p < n_pairs; p++)
+        if (!ranked || static_cast<int>(p % static_cast<std::size_t>(job.world)) == job.rank) mine.push_back(p);
+    std::vector<Cloud::Ptr> clouds;  // source, target, source, target, ... of `mine`
+    for (std::size_t p : mine)
+        for (const std::string *name : {&files[p].first, &files[p].second}) {
             Cloud::Ptr cloud = readCloud(*name);
             if (!cloud) {
                 std::cout << "Could not load " << *name << ", closing" << std::endl;
@@ -240,13 +301,10 @@ int runBatch(const Job &job)
             }
             clouds.push_back(cloud);
         }
-        names.push_back(src_name + " -> " + tgt_name);
-    }
-    const std::size_t n_pairs = names.size();
-    std::vector<ppcr_pair> pairs(n_pairs);
-    for (std::size_t p = 0; p < n_pairs; p++) {
-        const Cloud &s = *clouds[2 * p], &t = *clouds[2 * p + 1];
-        pairs[p] = ppcr_pair{s.empty() ? nullptr : &s[0].x, static_cast<int64_t>(s.size()), sizeof(pcl::PointXYZ),
+    std::vector<ppcr_pair> pairs(mine.size());
+    for (std::size_t k = 0; k < mine.size(); k++) {
+        const Cloud &s = *clouds[2 * k], &t = *clouds[2 * k + 1];
+        pairs[k] = ppcr_pair{s.empty() ? nullptr : &s[0].x, static_cast<int64_t>(s.size()), sizeof(pcl::PointXYZ),
                              t.empty() ? nullptr : &t[0].x, static_cast<int64_t>(t.size()), sizeof(pcl::PointXYZ)};
     }
     const auto &p = job.params;
@@ -268,25 +326,52 @@ int runBatch(const Job &job)
         std::cerr << "registration failed: no HIP device visible (this library has no CPU fallback)" << std::endl;
         return EXIT_FAILURE;
     }
-    std::vector<int> devices(static_cast<std::size_t>(n_devices));
-    for (int d = 0; d < n_devices; d++) devices[static_cast<std::size_t>(d)] = d;
-    std::vector<double> T(12 * n_pairs);
-    std::vector<int32_t> iterations(n_pairs);
+    std::vector<int> devices;
+    if (ranked) devices.push_back(job.device_given ? p.device_id : job.rank % n_devices);
+    else
+        for (int d = 0; d < n_devices; d++) devices.push_back(d);
+    std::vector<double> T_mine(12 * mine.size());
+    std::vector<int32_t> it_mine(mine.size());
     char err[512] = {0};
     if (job.params.verbose)
-        std::cout << "Registering " << n_pairs << " pairs on " << n_devices << " device(s), " << job.lanes << " in flight each" << std::endl;
-    const int rc = ppcr_batch_run(pairs.data(), static_cast<int64_t>(n_pairs), &opt, devices.data(), n_devices, job.lanes,
-                                  T.data(), iterations.data(), err, sizeof err);
+        std::cout << "Registering " << mine.size() << " of " << n_pairs << " pairs on " << devices.size() << " device(s), " << job.lanes
+                  << " in flight each" << (ranked ? " (rank " + std::to_string(job.rank) + " of " + std::to_string(job.world) + ")" : std::string())
+                  << std::endl;
+    const int rc = ppcr_batch_run(pairs.data(), static_cast<int64_t>(pairs.size()), &opt, devices.data(), static_cast<int>(devices.size()),
+                                  job.lanes, T_mine.data(), it_mine.data(), err, sizeof err);
     if (rc != PPCR_OK) {
         std::cerr << "registration failed: " << err << std::endl;
         return EXIT_FAILURE;
     }
+    std::vector<double> T(12 * n_pairs);
+    std::vector<int32_t> iterations(n_pairs);
+    if (ranked) {
+        // the job's ONE collective: every rank ends up with every transform (and, in a second record, iteration count)
+        ppcr_comm *comm = joinRanks(job, devices[0]);
+        std::vector<double> counts_mine(12 * mine.size(), 0.0), counts(12 * n_pairs, 0.0);
+        for (std::size_t k = 0; k < mine.size(); k++) counts_mine[12 * k] = it_mine[k];
+        const bool ok = comm != nullptr &&
+                        ppcr_gather_transforms(comm, T_mine.data(), static_cast<int64_t>(n_pairs), T.data()) == PPCR_OK &&
+                        ppcr_gather_transforms(comm, counts_mine.data(), static_cast<int64_t>(n_pairs), counts.data()) == PPCR_OK;
+        if (!ok) std::cerr << "gather of the transforms failed: " << ppcr_comm_last_error() << std::endl;
+        ppcr_comm_destroy(comm);
+        if (job.rank == 0) {
+            std::error_code ec;
+            fs::remove(job.rendezvous, ec);
+        }
+        if (!ok) return EXIT_FAILURE;
+        for (std::size_t k = 0; k < n_pairs; k++) iterations[k] = static_cast<int32_t>(counts[12 * k]);
+        if (job.rank != 0) return EXIT_SUCCESS;  // rank 0 reports
+    } else {
+        T = T_mine;
+        iterations = it_mine;
+    }
     for (std::size_t k = 0; k < n_pairs; k++) {
         const Eigen::Affine3d A = Eigen::Affine3d::from_rows(&T[12 * k]);
         const Eigen::Quaterniond q(A.rotation());
-        std::cout << "pair " << k << " (" << names[k] << "), " << iterations[k] << " iterations: T: " << A.translation().x() << ", "
-                  << A.translation().y() << ", " << A.translation().z() << " ||| R: " << q.x() << ", " << q.y() << ", " << q.z() << ", "
-                  << q.w() << std::endl;
+        std::cout << "pair " << k << " (" << files[k].first << " -> " << files[k].second << "), " << iterations[k]
+                  << " iterations: T: " << A.translation().x() << ", " << A.translation().y() << ", " << A.translation().z()
+                  << " ||| R: " << q.x() << ", " << q.y() << ", " << q.z() << ", " << q.w() << std::endl;
     }
     return EXIT_SUCCESS;
 }

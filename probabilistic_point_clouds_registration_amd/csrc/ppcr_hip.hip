@@ -218,6 +218,7 @@ struct ppcr_ctx {
     bool have_companion = false, have_ground_truth = false, have_previous = false;
     DevBuf<double> mse_part;
     int opt_short_lists = 1;
+    int opt_k1_halves = -1;      // steady-state K1 scans every block as two half-blocks: -1 automatic (small clouds), 0 never, 1 always
     int opt_fuse_k23 = 1;        // ppcr_align's one-step iterations fold K23 into the steady-state K1
     int opt_merge_fold = 1;      // ... and the fold-and-solve step rides in the cleanup launch
     bool assoc_folded = false;   // the last association's launches included the fold-and-solve step
@@ -644,6 +645,18 @@ void dispatch_tile(TileLaunch &tl, int m)
     else launch_tile_m32(tl);
 }
 
+// Small clouds leave most of the chip idle with one workgroup per 256 queries (100k points: 391 workgroups on 1280 resident
+// slots) and an iteration lasts as long as ONE workgroup's dependent chain: the steady-state K1 then scans every block as
+// two half-blocks (SplitTable::all_halves).  Automatic up to 640 blocks (164k points): beyond, the halves' duplicated
+// staging costs more than the shorter chain gives.
+bool k1_all_halves(const ppcr_ctx *c)
+{
+    if (c->opt_k1_halves >= 0) return c->opt_k1_halves != 0;
+    return nblocks(std::max<int64_t>(c->ns, 1), 256) <= 640;
+}
+// workgroups of a steady-state K1 launch = slots of the partial sums it leaves when K23 is folded in
+int k1_steady_slots(const ppcr_ctx *c) { return steady_grid(nblocks(std::max<int64_t>(c->ns, 1), 256), k1_all_halves(c)); }
+
 // K1 (or the generic count/scan/fill path for unbounded searches and max_neighbours > 32).
 // fuse_R / fuse_t (nullable): the pose the first IRLS half-step will be evaluated at; when given, the steady-state K1
 // also produces that step's partial moments (c->assoc_fused, c->fused_slots) and the caller skips the K23 launch.
@@ -692,7 +705,7 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
         HIP_TRY(c, c->nbr.reserve((size_t)m * (size_t)std::max(ns, 1)));
         HIP_TRY(c, c->cnt.reserve((size_t)std::max(ns, 1)));
         HIP_TRY(c, c->dm2.reserve((size_t)std::max(ns, 1)));
-        HIP_TRY(c, c->ovf_list.reserve((size_t)nblocks(std::max(ns, 1), 256) + kMaxSplit));
+        HIP_TRY(c, c->ovf_list.reserve((size_t)std::max(nblocks(std::max(ns, 1), 256) + kMaxSplit, k1_steady_slots(c))));
         if (!c->split_clean) {
             const size_t nbk = (size_t)nblocks(std::max(ns, 1), 256);
             HIP_TRY(c, c->split_flag.reserve(nbk));
@@ -723,7 +736,7 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
                 const Model md = make_model(c);
                 const K23Form form = k23_form(c, md);
                 if (form.onepass && form.tm != -1) {  // the three forms compiled into K1: Gaussian, v + dim = 8, integer v + dim
-                    const int slots = nblocks(ns, 256) + kMaxSplit;
+                    const int slots = k1_steady_slots(c);
                     HIP_TRY(c, c->partials.reserve((size_t)slots * kNSums));
                     fm.P = make_pose(c, *fuse_R, fuse_t);
                     fm.md = md;
@@ -775,10 +788,11 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             tl.nbr = c->nbr.p, tl.cnt = c->cnt.p, tl.dm2 = c->dm2.p;
             tl.dm2_in = (c->opt_temporal && c->dm2_valid) ? 1 : 0;
             tl.short_lists = c->opt_short_lists;
+            tl.all_halves = k1_all_halves(c) ? 1 : 0;
             if (c->opt_stamps) {
                 // sized from the grid this launch really has (the steady-state variant adds kMaxSplit workgroups in front):
                 // 8 words per wave, then one word per lane (its sorted run lengths)
-                const size_t nwg = (size_t)nblocks(ns, 256) + kMaxSplit;
+                const size_t nwg = (size_t)std::max(nblocks(ns, 256) + kMaxSplit, k1_steady_slots(c));
                 const size_t nst = (nwg * (kBlock / 64) + 64) * 8 + nwg * 256;
                 if (c->d_stamps.cap < nst) {
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1210,7 +1224,7 @@ int launch_inner(ppcr_ctx *c, const StepTicket &tk, const LoopCtl &loop, int n_d
     const int per_wg = std::max(1, (ntiles + 1199) / 1200);
     int G = std::max(1, std::min((ntiles + per_wg - 1) / per_wg, kInnerMaxG));
     if (per_wg > 1) G = std::min((G + 7) & ~7, kInnerMaxG);  // (a multiple of eight: the kernel's XCD-aware tile map)
-    HIP_TRY(c, c->partials.reserve((size_t)std::max(G, nblocks(ns, 256) + kMaxSplit) * kNSums));
+    HIP_TRY(c, c->partials.reserve((size_t)std::max(G, k1_steady_slots(c)) * kNSums));
     InnerArgs a;
     std::memset(&a, 0, sizeof(a));
     a.nbr = c->nbr.p, a.cnt = c->cnt.p, a.src = c->src.p, a.tgt = c->tgt_cur();
@@ -1600,6 +1614,11 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
     }
     if (std::strcmp(key, "short_lists") == 0) {
         c->opt_short_lists = value ? 1 : 0;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "k1_halves") == 0) {
+        if (value < -1 || value > 1) return fail(c, PPCR_ERR_INVALID, "k1_halves must be -1 (automatic), 0 or 1");
+        c->opt_k1_halves = value;
         return PPCR_OK;
     }
     if (std::strcmp(key, "defer_moves") == 0) {

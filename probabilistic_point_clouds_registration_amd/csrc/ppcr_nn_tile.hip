@@ -44,9 +44,13 @@ void launch_tile(TileLaunch &t)
     const int nb = (t.ns + 255) / 256;
     // the steady-state variant acts on the split table (extra workgroups) and extends it; the first association only
     // extends it (blocks whose fresh halo is already close to the steady-state capacity)
-    const SplitTable split_on{t.split_flag, t.split_list, t.split_state, t.split_state + 1, kMaxSplit, kCapSteady * 15 / 16};
-    const SplitTable split_off = (M <= 12) ? SplitTable{t.split_flag, t.split_list, t.split_state, t.split_state + 1, 0, kCapSteady * 15 / 16}
-                                           : SplitTable{nullptr, nullptr, nullptr, nullptr, 0, INT_MAX};  // no steady-state variant to split for
+    // (small clouds, steady state: every block as two half-blocks, see SplitTable::all_halves)
+    const bool halves = t.all_halves != 0;
+    const SplitTable split_on = halves ? SplitTable{nullptr, nullptr, nullptr, nullptr, 0, INT_MAX, 1}
+                                       : SplitTable{t.split_flag, t.split_list, t.split_state, t.split_state + 1, kMaxSplit, kCapSteady * 15 / 16, 0};
+    const SplitTable split_off = (M <= 12 && !halves) ? SplitTable{t.split_flag, t.split_list, t.split_state, t.split_state + 1, 0, kCapSteady * 15 / 16, 0}
+                                                      : SplitTable{nullptr, nullptr, nullptr, nullptr, 0, INT_MAX, 0};  // no steady-state variant to split for
+    const int grid_steady = steady_grid(nb, halves);
     FusedMoments fm_none;
     std::memset(&fm_none, 0, sizeof(fm_none));
     const LoopReset lr{t.loop_st};
@@ -55,7 +59,7 @@ void launch_tile(TileLaunch &t)
     // the steady-state (16-slot) variant runs with a halo capacity that gives FIVE workgroups per CU (31.3 KB of LDS)
     // and splits the few blocks that outgrow it; the first association (32 slots, three per CU) keeps the large one
 #define PPCR_FAST(Cc, STAMPc, FTMc, FMc)                                                                               \
-    nn_fast_kernel<M, Cc, (Cc <= 16 ? kCapSteady : CAP), STAMPc, FTMc><<<nb + (Cc <= 16 ? kMaxSplit : 0), 256, 0, t.stream>>>( \
+    nn_fast_kernel<M, Cc, (Cc <= 16 ? kCapSteady : CAP), STAMPc, FTMc><<<(Cc <= 16 ? grid_steady : nb), 256, 0, t.stream>>>( \
         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,  \
         t.ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc, lr, un)
     t.fused = false;
@@ -106,7 +110,7 @@ void launch_tile(TileLaunch &t)
     }
     // persistent workgroups over the list: few when the last association this handle heard from handed nothing over
     const int cleanup_grid = t.quiet ? std::min(nb, 32) : std::min(nb, 512);
-    const int n_extra = steady ? kMaxSplit : 0;
+    const int n_extra = steady ? (halves ? -1 : kMaxSplit) : 0;
     FoldSolve fs_none;
     std::memset(&fs_none, 0, sizeof(fs_none));
     fs_none.loop.st = t.loop_st;  // the cleanup role steps aside with everybody else

@@ -209,6 +209,7 @@ __device__ __forceinline__ int scan_global_with_threshold(const Cands &G, const 
     return n;
 }
 
+__device__ __forceinline__ int halves_slot(int g);  // (SplitTable::all_halves, below)
 // GENERAL flavour of K1, run on the workgroups nn_fast_kernel hands over (ovf_list[0 .. *ovf_count)): halos of any
 // shape (up to 128 rows), binary subdivision when a halo does not fit, global-memory scan as the last resort, in-loop
 // list compaction for dense neighbourhoods.  The source has already been moved by the fast kernel and the temporal
@@ -259,7 +260,9 @@ __global__ __launch_bounds__(BLOCK, (C >= 64 ? 2 : 3)) void nn_tile_cleanup_kern
     for (unsigned listed = blockIdx.x; listed < n_listed; listed += n_cleanup) {
     const int entry = ovf_list[listed];
     const int fast_slot = entry >> 2, half = entry & 3;
-    const int bid = fast_slot < n_extra ? split_list[fast_slot] : xcd_block(fast_slot - n_extra, (ns + BLOCK - 1) / BLOCK);
+    // (n_extra < 0: the fast kernel ran with SplitTable::all_halves)
+    const int bid = n_extra < 0 ? xcd_block(halves_slot(fast_slot), (ns + BLOCK - 1) / BLOCK)
+                                : (fast_slot < n_extra ? split_list[fast_slot] : xcd_block(fast_slot - n_extra, (ns + BLOCK - 1) / BLOCK));
     static_assert(C > M, "a compaction must leave room in the list");
     static_assert(CAP % 4 == 0 && CAP <= 65536 && C * 64 <= 3 * CAP && kTileRows <= 256, "the global fallback aliases the candidate buffer");
     static_assert((C & (C - 1)) == 0, "overflow_slot() masks");
@@ -915,7 +918,7 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
 #define PPCR_LIST_PERM 1
 #endif
 #ifndef PPCR_LIST_NOCLAMP
-#define PPCR_LIST_NOCLAMP 0
+#define PPCR_LIST_NOCLAMP 1
 #endif
 // candidate source of the fast flavour: list entries are byte offsets (4 * LDS index) into the SoA halo
 struct HaloList {
@@ -955,7 +958,14 @@ struct SplitTable {
     int n_extra;              // extra workgroups at the front of this launch's grid (0: no splitting in this launch)
     int presplit;             // a whole block whose halo exceeds this is registered for splitting BEFORE it overflows
                               // (halos grow a few per cent per iteration as the source drifts: 15/16 of the capacity)
+    int all_halves;           // small clouds: EVERY block is scanned as two half-blocks (grid = 2 * roundup8(blocks), no table):
+                              // a cloud of 100k points is 391 blocks on 1280 resident slots, and an iteration lasts as long
+                              // as one workgroup's dependent chain — two workgroups per block shorten the chain
 };
+// all_halves: which block and half workgroup g takes.  Workgroups g and g + 8 (same XCD: its L2 holds the halo both
+// stage) take the two halves of the block xcd_block() gives slot (g / 16) * 8 + g % 8; slots beyond the last block idle.
+__device__ __forceinline__ int halves_slot(int g) { return (g >> 4) * 8 + (g & 7); }
+__device__ __forceinline__ int halves_half(int g) { return 1 + ((g >> 3) & 1); }
 
 // the device-paced loop's state as the association kernel sees it (nullable): it only steps aside while abort is up
 struct LoopReset {
@@ -997,9 +1007,11 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     static_assert(CAP % 4 == 0 && CAP * 4 < 65536, "list entries are 16-bit byte offsets into the halo arrays");
     constexpr int BLOCK = 256, kWaves = 4, kRows = 128, kStageUnroll = 6;
 #if PPCR_LIST_NOCLAMP
-    // EXPERIMENT (tools/build_variant.py -DPPCR_LIST_NOCLAMP=1): ONE allocation with the list LAST, so that a store beyond
-    // the list's spare slot leaves the workgroup's LDS allocation — which the hardware drops (tools/micro/lds_oob.hip) —
-    // and the scan does not have to clamp its cursor.
+    // ONE allocation with the list LAST: a store beyond the list's spare slot then leaves the workgroup's LDS allocation,
+    // where the hardware drops it (gfx950, as the ISA documents; probed by tools/micro/lds_oob.hip, which
+    // tests/test_gpu_parity.py builds and runs) — the scan stores at its cursor without clamping it to the list's end:
+    // two v_min_u32 less on a 22-VALU trip (2508 -> 2427 VALU per wave, +1.6 % iterations/s; -DPPCR_LIST_NOCLAMP=0 is
+    // the clamped form with separate arrays).
     constexpr int kHaloBytes = (3 * CAP + CAP / 4) * 4, kListBytes = (C + 1) * BLOCK * 2;
     constexpr int kOffGbo = kHaloBytes, kOffBox = kOffGbo + kRows * 4, kOffBail = kOffBox + kWaves * 6 * 4, kOffList = (kOffBail + 4 + 15) & ~15;
     __shared__ __attribute__((aligned(16))) unsigned char s_all[kOffList + kListBytes];
@@ -1046,7 +1058,16 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
 
     // which block, and which of its waves' queries, this workgroup scans (uniform)
     int bid, half = 0;  // half: 0 whole block, 1 waves 0-1, 2 waves 2-3
-    if ((int)blockIdx.x < split.n_extra) {
+    if (split.all_halves) {
+        const int slot = halves_slot((int)blockIdx.x), nb = (ns + BLOCK - 1) / BLOCK;
+        if (slot >= nb) {  // (padding of the grid to a multiple of sixteen workgroups)
+            if constexpr (FTM != -2)
+                if (tid < kNSums) fm.partials[(size_t)tid * fm.nslots + blockIdx.x] = 0.0;
+            return;
+        }
+        bid = xcd_block(slot, nb);
+        half = halves_half((int)blockIdx.x);
+    } else if ((int)blockIdx.x < split.n_extra) {
         if (blockIdx.x >= min(*split.visible, (unsigned)kMaxSplit)) {
             if constexpr (FTM != -2)  // an idle slot of the partials still has to read as zero
                 if (tid < kNSums) fm.partials[(size_t)tid * fm.nslots + blockIdx.x] = 0.0;
@@ -1065,8 +1086,9 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     // ---- prologue: query, pending move, temporal cut-off ---------------------------------------------------------
     float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (aborted) return;
-    // the other counter of the ping-pong pair: idle during this launch  (the last workgroup is never an idle split slot)
-    if (tid == 0 && blockIdx.x == gridDim.x - 1) {
+    // the other counter of the ping-pong pair: idle during this launch  (the last workgroup is never an idle split slot;
+    // with all_halves the first one never idles)
+    if (tid == 0 && blockIdx.x == (split.all_halves ? 0u : gridDim.x - 1)) {
         *ovf_count_next = 0;
         if (un.next != nullptr) *un.next = 0;
     }

@@ -7,6 +7,8 @@ namespace ppcr {
 
 // Halo capacity of the steady-state (16-slot) variant: 31.3 KB of LDS, five workgroups per CU (1792: four).
 constexpr int kCapSteady = 1728;
+// workgroups (= partial-sum slots when K23 is folded in) of a steady-state K1 launch over nb blocks of 256 queries
+inline int steady_grid(int nb, bool all_halves) { return all_halves ? 2 * ((nb + 7) & ~7) : nb + dev::kMaxSplit; }
 
 struct TileLaunch {
     hipStream_t stream;
@@ -28,6 +30,7 @@ struct TileLaunch {
     unsigned *dm2;                // per query: float bits of its m-th neighbour's d2 (the temporal cut-off)
     int dm2_in;                   // dm2 of the previous association is usable
     int short_lists;              // option short_lists
+    int all_halves;               // steady-state variant: scan every block as two half-blocks (small clouds; see SplitTable)
     unsigned long long *stamps;   // diagnostic build only (nullptr otherwise)
     int *ovf_list;                // workgroups handed to the cleanup kernel by this launch ...
     unsigned *ovf_now, *ovf_next; // ... counted here; the other counter of the ping-pong pair

@@ -29,6 +29,10 @@ CONFIGS = {
     # the command line's own defaults (..._ex.cc:43-49: radius 3, 20 neighbours, inner loop to function_tolerance) at the
     # benchmark density: ~430 points in radius, a two-pass search (the 100k clouds of config 2)
     8: dict(n=200_000, max_neighbours=20, dof=5.0, radius=3.0, clouds=2, inner_steps=100),
+    # ... and on NON-UNIFORM clouds (the reference's inputs are PCD scans, not uniform cubes): a LiDAR-like scene and a slab
+    # with a density gradient and dense blobs (make_scene), same parameters
+    9: dict(n=200_000, max_neighbours=20, dof=5.0, radius=3.0, scene="lidar", inner_steps=100),
+    10: dict(n=200_000, max_neighbours=20, dof=5.0, radius=3.0, scene="slab", inner_steps=100),
 }
 
 
@@ -63,9 +67,61 @@ def make_pair(n, cfg=3, pair=0, stride=4):
     return np.ascontiguousarray(src), np.ascontiguousarray(tgt), R, t
 
 
+def lidar_like_scene(n, rng):
+    """Surfaces seen from a sensor at the origin — ground plane 1.8 m below, four walls — sampled uniformly in azimuth and
+    elevation, so the point density falls with the square of the range; 2 cm of range noise.  float32 [n, 3]."""
+    az = rng.uniform(0, 2 * np.pi, n)
+    el = np.radians(rng.uniform(-25, 3, n))
+    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], axis=1)
+    hit = np.full(n, 80.0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        hit = np.minimum(hit, np.where(d[:, 2] < 0, -1.8 / d[:, 2], np.inf))
+        for nx, ny, off in ((1, 0, 30.0), (-1, 0, 22.0), (0, 1, 14.0), (0, -1, 40.0)):
+            den = d[:, 0] * nx + d[:, 1] * ny
+            hit = np.minimum(hit, np.where(den > 1e-6, off / den, np.inf))
+    return (d * hit[:, None] + rng.normal(0, 0.02, size=(n, 3))).astype(np.float32)
+
+
+def slab_with_blobs(n, rng):
+    """A 160 x 80 x 12 slab whose density falls along x (beta(2, 5)) plus five dense Gaussian blobs (6000 points,
+    sigma 1.5) — densities that differ a hundredfold inside one cloud.  float32 [n, 3]."""
+    x = rng.beta(2.0, 5.0, size=n) * 160.0
+    base = np.stack([x, rng.uniform(0, 80, n), rng.uniform(0, 12, n)], axis=1)
+    blobs = np.concatenate([c + rng.normal(0, 1.5, size=(6000, 3))
+                            for c in rng.uniform([20, 10, 2], [140, 70, 10], size=(5, 3))])
+    return np.concatenate([base[: n - len(blobs)], blobs]).astype(np.float32)
+
+
+SCENES = {
+    # kind: (target generator, ground-truth axis, angle, translation): the source is the permuted target moved by the
+    # inverse of that motion plus N(0, 0.02^2) noise per coordinate
+    "lidar": (lidar_like_scene, (0.0, 0.05, 1.0), 0.01, (0.3, -0.2, 0.02)),
+    "slab": (slab_with_blobs, (0.1, 0.3, 1.0), 0.01, (0.3, -0.2, 0.1)),
+}
+
+
+def make_scene(kind, n=200_000, seed=33, stride=4):
+    """Pinned non-uniform pair -> (source, target, R_gt, t_gt), the layout of make_pair.  One generator per pair, drawn
+    in a fixed order (target, permutation, noise): seed 33 reproduces the clouds tests/test_gpu_configs.py has used
+    since round 3."""
+    gen, axis, angle, t = SCENES[kind]
+    rng = np.random.default_rng(seed)
+    tgt = gen(n, rng)
+    R = rodrigues(axis, angle)
+    t = np.asarray(t, np.float64)
+    src = ((tgt[rng.permutation(len(tgt))].astype(np.float64) - t) @ R + rng.normal(0, 0.02, size=(len(tgt), 3))).astype(np.float32)
+    if stride == 4:
+        src = np.concatenate([src, np.zeros((len(src), 1), np.float32)], axis=1)
+        tgt = np.concatenate([tgt, np.zeros((len(tgt), 1), np.float32)], axis=1)
+    return np.ascontiguousarray(src), np.ascontiguousarray(tgt), R, t
+
+
 def make_config(cfg, pair=0, n=None, stride=4):
+    """the pinned clouds of a configuration: uniform cubes (make_pair, seeds of `clouds` or of the config itself) or a scene"""
     c = CONFIGS[cfg]
-    return make_pair(n or c["n"], cfg=cfg, pair=pair, stride=stride)
+    if "scene" in c:
+        return make_scene(c["scene"], n or c["n"], seed=33 + 10 * pair, stride=stride)
+    return make_pair(n or c["n"], cfg=c.get("clouds", cfg), pair=pair, stride=stride)
 
 
 def rotation_angle(Ra, Rb):

@@ -311,6 +311,15 @@ def test_cli_batch_front_end_matches_single_runs(programs, tmp_path):
         a = np.array([float(v) for v in re.split(r"[,|R:T ]+", got[p][1]) if v])
         b = np.array([float(v) for v in re.split(r"[,|R:T ]+", last) if v])
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)      # six significant digits are printed
+    # one process per GPU: the same list as rank 0 of a world of one (this rank's share through ppcr_batch_run on its
+    # device, then the native RCCL all-gather of the transforms, ppcr_gather_transforms) prints the same lines
+    rk = subprocess.run([cli, "--batch", "pairs.txt", "--lanes", "2", "--rank", "0", "--world", "1", "--rendezvous", "rv.id"] + common,
+                        capture_output=True, text=True, cwd=tmp_path, timeout=600)
+    assert rk.returncode == 0, rk.stdout + rk.stderr
+    got_rk = re.findall(r"^pair (\d+) \(s\d\.pcd -> t\d\.pcd\), 4 iterations: (T: .*)$", rk.stdout, flags=re.M)
+    assert got_rk == got and not (tmp_path / "rv.id").exists()
+    bad = subprocess.run([cli, "--batch", "pairs.txt", "--rank", "1", "--world", "2"], capture_output=True, text=True, cwd=tmp_path)
+    assert bad.returncode != 0 and "--rendezvous" in bad.stderr
     # a list that names a missing cloud fails like the single-pair command
     (tmp_path / "bad.txt").write_text("s0.pcd nowhere.pcd\n")
     r = subprocess.run([cli, "--batch", "bad.txt"], capture_output=True, text=True, cwd=tmp_path)

@@ -1177,3 +1177,20 @@ def test_device_solve_handles_rank_deficient_clouds():
         assert cost[1] <= cost[0] * (1 + 1e-12) + 1e-12
         if name == "full":
             assert synth.rotation_angle(R, Rg) < 1e-6 and np.linalg.norm(t - tg) < 1e-5
+
+
+def test_lds_stores_beyond_the_allocation_are_dropped(tmp_path):
+    """What the unclamped list stores of nn_fast_kernel rely on (PPCR_LIST_NOCLAMP): an LDS store beyond the workgroup's
+    allocation is dropped by the hardware and an out-of-range load returns zero — probed on THIS device with sixteen
+    workgroups per CU hammering the space above their own 8 KB (tools/micro/lds_oob.hip: a leaking store would corrupt a
+    neighbour's pattern)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "lds_oob")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", os.path.join(root, "tools", "micro", "lds_oob.hip"), "-o", exe],
+                          stderr=subprocess.DEVNULL)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "corrupted words 0, non-zero out-of-range reads 0" in r.stdout, r.stdout

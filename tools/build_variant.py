@@ -23,8 +23,8 @@ vdir = os.path.join(build.PKG, "_variants")
 os.makedirs(vdir, exist_ok=True)
 obj = os.path.join(vdir, f"tile_m{width}_{name}.o")
 subprocess.check_call([build.hipcc()] + build.flags() + ["-c", f"-DPPCR_TILE_M={width}"] + args + [build.TILE_TU, "-o", obj])
-objs = [os.path.join(build.OBJ, "ppcr_hip.o")] + [
+objs = [os.path.join(build.OBJ, "ppcr_hip.o"), os.path.join(build.OBJ, "ppcr_comm.o")] + [
     obj if m == width else os.path.join(build.OBJ, f"ppcr_nn_tile_m{m}.o") for m in build.TILE_WIDTHS]
 out = os.path.join(vdir, f"libppcr_hip_{name}.so")
-subprocess.check_call([build.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+subprocess.check_call([build.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
 print(out)
