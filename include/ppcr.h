@@ -313,9 +313,13 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *   "brick_x"      x extent in cells of the 4x4 (y,z) bricks the source is ordered by: 1 (default), 2 or 4;
  *   "short_lists"  1 once the temporal cut-off is valid K1 runs with 16-slot lists, a 1728-candidate halo and five
  *                  workgroups per CU (default), 0 always 32 slots / three workgroups;
- *   "k1_halves"    the steady-state K1 scans every block of 256 queries as two half-blocks on two workgroups: -1 automatic
- *                  (default: clouds of up to 640 blocks, 164k points — small clouds leave most of the chip idle and an
- *                  iteration lasts as long as one workgroup's dependent chain), 0 never, 1 always;
+ *   "levels"       -1 / 1 the target is binned at several resolutions when its density varies widely or the radius holds far
+ *                  more than max_neighbours points, and every block of queries searches the finest level that covers its
+ *                  cut-off radii (default; uniform clouds searched with a radius of a few spacings keep one level),
+ *                  0 always one level (set before the first association);
+ *   "k1_halves"    the steady-state K1 scans every block of 256 queries as two half-blocks on two workgroups: 0 never
+ *                  (default: measured neutral at 100k points and slower from 160k on), 1 always, -1 clouds of up to 640
+ *                  blocks;
  *   "two_pass"     1 a bounded search whose radius holds far more than max_neighbours target points runs in two passes
  *                  (default): the grid and the tiled kernel work with radius / k, chosen from the target's density, and
  *                  only the rows that find fewer than max_neighbours there are searched again with the full radius;

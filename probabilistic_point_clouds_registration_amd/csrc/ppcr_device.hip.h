@@ -37,6 +37,21 @@ struct GridDesc {
     int xr_shift;  // log2(xr)
 };
 
+// One resolution of the target's grid.  A cloud whose density varies a hundredfold has no single good cell size: where
+// it is dense a radius-sized cell holds hundreds of points (no LDS tile holds a block's halo), where it is sparse the m-th
+// neighbour lies several cells away.  The target is therefore binned at a few resolutions (cell edges a factor two
+// apart, each with its own sorted copy) and every 256-query block of K1 picks, per launch, the FINEST level whose 27-cell
+// stencil still covers the largest cut-off radius among its rows (nn_fast_kernel<..., MULTI>).
+struct GridLevel {
+    GridDesc g;
+    const float4 *tgt;      // the target sorted by this level's cells
+    const int *cell_start;
+    const int *to_base;     // position in this level's order -> position in the base level's order (nullptr: this IS the base)
+    float r2_cap;           // largest search radius^2 this level's stencil covers, capped at the full radius^2
+    int pad;
+};
+constexpr int kMaxLevels = 6;
+
 struct Pose {  // y ~ R x + t ; c = fixed origin of the moments
     double R[9];
     double t[3];

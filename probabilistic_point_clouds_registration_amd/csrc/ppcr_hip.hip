@@ -132,6 +132,19 @@ struct ppcr_ctx {
     bool src_sorted = false;
     GridDesc grid{};
     DevBuf<int> cell_start;
+    // multi-level search (GridLevel): the levels OTHER than the base (whose grid / tgt_sorted / cell_start are the members
+    // above), the table nn_fast_kernel<..., MULTI> reads (ascending r2_cap) and which of its entries is the base
+    struct ExtraLevel {
+        GridDesc g{};
+        DevBuf<float4> tgt;
+        DevBuf<int> cell_start, to_base;
+        double radius = 0;
+    };
+    std::vector<ExtraLevel> extra_levels;
+    DevBuf<GridLevel> d_levels;
+    DevBuf<int> level_inv;
+    int n_levels = 1, base_level = 0, finest_extra = -1;  // finest_extra: index into extra_levels of the finest level (-1: the base is)
+    int opt_levels = -1;               // -1 automatic (non-uniform clouds / radii that hold far more than max_neighbours), 0 one level
     double origin[3] = {0, 0, 0};
     bool origin_valid = false;
 
@@ -218,7 +231,7 @@ struct ppcr_ctx {
     bool have_companion = false, have_ground_truth = false, have_previous = false;
     DevBuf<double> mse_part;
     int opt_short_lists = 1;
-    int opt_k1_halves = -1;      // steady-state K1 scans every block as two half-blocks: -1 automatic (small clouds), 0 never, 1 always
+    int opt_k1_halves = 0;       // steady-state K1 scans every block as two half-blocks: 0 never (default), 1 always, -1 small clouds
     int opt_fuse_k23 = 1;        // ppcr_align's one-step iterations fold K23 into the steady-state K1
     int opt_merge_fold = 1;      // ... and the fold-and-solve step rides in the cleanup launch
     bool assoc_folded = false;   // the last association's launches included the fold-and-solve step
@@ -363,21 +376,33 @@ int upload_cloud(ppcr_ctx *c, const void *ptr, bool on_device, int64_t n, int64_
 }
 
 // sort `n` points of `in` by grid cell into `out` (stable: ties keep ascending original index)
+// order: 0 the grid's cells (x fastest), 1 bricks (see brick_key_kernel), 2 the Hilbert curve over g's whole cells
 int sort_by_cell(ppcr_ctx *c, const GridDesc &g, const float4 *in, int n, float4 *out, DevBuf<int> *cell_start_out,
-                 bool brick_order = false)
+                 int order = 0)
 {
+    const bool brick_order = order == 1, hilbert = order == 2;
     const bool want_cell_start = cell_start_out != nullptr;
     HIP_TRY(c, c->keys_a.reserve((size_t)n + 1));
     HIP_TRY(c, c->keys_b.reserve((size_t)n + 1));
     HIP_TRY(c, c->vals_a.reserve((size_t)n + 1));
     HIP_TRY(c, c->vals_b.reserve((size_t)n + 1));
     if (n > 0) {
+        int end_bit_override = 0;
         {
             ProfScope ps(c, K_CELL_KEY);
-            if (brick_order)
+            int hbits = 1, hshift = 0;
+            if (hilbert) {
+                const int most = std::max(std::max(g.n[0] >> g.xr_shift, g.n[1]), g.n[2]);
+                while ((1 << hbits) < most) hbits++;
+                if (hbits > 10) hshift = hbits - 10, hbits = 10;  // 30-bit keys: coarser curve cells on very large grids
+            }
+            if (hilbert)
+                hilbert_key_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(in, n, g, c->keys_a.p, c->vals_a.p, hbits, hshift);
+            else if (brick_order)
                 brick_key_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(in, n, g, c->keys_a.p, c->vals_a.p, c->opt_brick_xshift);
             else
                 cell_key_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(in, n, g, c->keys_a.p, c->vals_a.p);
+            if (hilbert) end_bit_override = 3 * hbits;
         }
         PPCR_TRY(check_launch(c, "cell_key_kernel"));
         long long nkeys = g.ncells;
@@ -386,6 +411,7 @@ int sort_by_cell(ppcr_ctx *c, const GridDesc &g, const float4 *in, int n, float4
                     brick_count(g.n[1]) * brick_count(g.n[2]);
         int end_bit = 1;
         while (end_bit < 32 && (1ll << end_bit) < nkeys) end_bit++;
+        if (end_bit_override) end_bit = end_bit_override;
         size_t tmp_bytes = 0;
         HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, c->keys_a.p, c->keys_b.p, c->vals_a.p,
                                                      c->vals_b.p, n, 0, end_bit, c->stream));
@@ -500,9 +526,10 @@ void make_grid_desc(int n, const float lo[3], const float hi[3], double cell_rad
 
 // occupancy of the grid just built as the typical point sees it (cell_occupancy_kernel): the median over the points of
 // the count of the cell they live in, less one (a point of a uniform cloud of q per cell sits in a cell of q + 1)
-int grid_occupancy(ppcr_ctx *c, double *occ)
+int grid_occupancy(ppcr_ctx *c, double *occ, double *occ_p95 = nullptr)
 {
     *occ = 0;
+    if (occ_p95) *occ_p95 = 0;
     if (c->nt <= 0) return PPCR_OK;
     HIP_TRY(c, c->d_occupancy.reserve(kOccBins));
     HIP_TRY(c, hipMemsetAsync(c->d_occupancy.p, 0, kOccBins * sizeof(unsigned long long), c->stream));
@@ -513,13 +540,95 @@ int grid_occupancy(ppcr_ctx *c, double *occ)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     unsigned long long total = 0, run = 0;
     for (unsigned long long h : hist) total += h;
+    bool have_median = false;
     for (int b = 0; b < kOccBins; b++) {
         run += hist[b];
-        if (2 * run >= total) {
+        if (!have_median && 2 * run >= total) {
             *occ = std::max((double)b - 1.0, 0.0);
+            have_median = true;
+        }
+        if (20 * run >= 19 * total) {  // the cell 95 % of the points do not exceed (saturates at kOccBins - 1)
+            if (occ_p95) *occ_p95 = std::max((double)b - 1.0, 0.0);
             break;
         }
     }
+    return PPCR_OK;
+}
+
+// The levels of a multi-level search around the base grid just built (GridLevel): COARSER ones — cell edges doubling up
+// to the full radius — when the radius reaches beyond the base cells (rows of sparse regions, whose m-th neighbour lies
+// farther out than the first-pass radius, are then answered by the tiled kernel on a coarser level instead of one row per
+// wave), FINER ones — edges halving, at most two — when 5 % of the points sit in cells far fuller than the first pass
+// aims at (dense blobs, the near field of a scan: blocks there pick a level whose halo fits the LDS tile).  A uniform
+// cloud searched with a radius of a few points' spacing keeps its single level, and with it every kernel it ran before.
+void release_levels(ppcr_ctx *c)
+{
+    for (auto &lv : c->extra_levels) {
+        lv.tgt.release();
+        lv.cell_start.release();
+        lv.to_base.release();
+    }
+    c->extra_levels.clear();
+    c->n_levels = 1, c->base_level = 0, c->finest_extra = -1;
+}
+int build_levels(ppcr_ctx *c, bool bounded)
+{
+    release_levels(c);
+    const int n = (int)c->nt;
+    if (!bounded || c->opt_two_pass != 1 || c->opt_levels == 0 || n <= 0) return PPCR_OK;
+    std::vector<double> finer, coarser;
+    {
+        double occ = 0, occ95 = 0;
+        PPCR_TRY(grid_occupancy(c, &occ, &occ95));
+        const double cap = 0.1 * c->opt_first_pass_occ, q_want = std::max(target_occupancy(c->max_nb, cap, 0.1 * c->opt_first_pass_fill), 1.0);
+        // (halving the edge divides a cell's count by eight: one finer level from 4 x the aim, two from 32 x)
+        if (occ95 > 4.0 * q_want) finer.push_back(c->search_radius / 2);
+        if (occ95 > 32.0 * q_want) finer.push_back(c->search_radius / 4);
+    }
+    for (double s = c->search_radius; s < c->radius * (1.0 - 1e-9) && (int)coarser.size() < kMaxLevels - 3;) {
+        s = std::min(2.0 * s, c->radius);
+        coarser.push_back(s);
+    }
+    if (!coarser.empty()) coarser.back() = c->radius;  // the last level covers the full radius
+    if (finer.empty() && coarser.empty()) return PPCR_OK;
+    std::vector<double> radii;  // ascending, the base in between
+    for (auto it = finer.rbegin(); it != finer.rend(); ++it) radii.push_back(*it);
+    const int base_at = (int)radii.size();
+    radii.push_back(c->search_radius);
+    for (double s : coarser) radii.push_back(s);
+    const float r2_full = (float)(c->radius * c->radius);
+    HIP_TRY(c, c->level_inv.reserve((size_t)n));
+    level_inverse_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(c->tgt_sorted.p, n, c->level_inv.p);
+    PPCR_TRY(check_launch(c, "level_inverse_kernel"));
+    std::vector<GridLevel> table(radii.size());
+    c->extra_levels.resize(radii.size() - 1);
+    size_t e = 0;
+    for (size_t l = 0; l < radii.size(); l++) {
+        GridLevel &t = table[l];
+        std::memset(&t, 0, sizeof(t));
+        if ((int)l == base_at) {
+            t.g = c->grid, t.tgt = c->tgt_sorted.p, t.cell_start = c->cell_start.p, t.to_base = nullptr;
+            t.r2_cap = std::min((float)(c->search_radius * c->search_radius), r2_full);  // = the first-pass r2 of associate_impl
+            continue;
+        }
+        ppcr_ctx::ExtraLevel &lv = c->extra_levels[e];
+        lv.radius = radii[l];
+        make_grid_desc(n, c->tgt_lo, c->tgt_hi, lv.radius, c->opt_grid_xf, lv.g);
+        HIP_TRY(c, lv.tgt.reserve((size_t)n));
+        PPCR_TRY(sort_by_cell(c, lv.g, c->tgt_raw.p, n, lv.tgt.p, &lv.cell_start));
+        HIP_TRY(c, lv.to_base.reserve((size_t)n));
+        level_to_base_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(lv.tgt.p, n, c->level_inv.p, lv.to_base.p);
+        PPCR_TRY(check_launch(c, "level_to_base_kernel"));
+        t.g = lv.g, t.tgt = lv.tgt.p, t.cell_start = lv.cell_start.p, t.to_base = lv.to_base.p;
+        t.r2_cap = (l + 1 == radii.size()) ? r2_full : std::min((float)(lv.radius * lv.radius), r2_full);
+        if (l == 0 && base_at > 0) c->finest_extra = (int)e;
+        e++;
+    }
+    HIP_TRY(c, c->d_levels.reserve(table.size()));
+    HIP_TRY(c, hipMemcpyAsync(c->d_levels.p, table.data(), table.size() * sizeof(GridLevel), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // (`table` leaves scope)
+    c->n_levels = (int)radii.size();
+    c->base_level = base_at;
     return PPCR_OK;
 }
 
@@ -565,6 +674,7 @@ int ensure_grid(ppcr_ctx *c)
         // the points live in fuller cells than the bounding box suggested (a cloud that does not fill its box)
         search = std::max(search * std::cbrt(q_want / q_here), c->radius / kMaxReach);
     }
+    PPCR_TRY(build_levels(c, bounded));
     c->grid_valid = true;
     c->grid_radius = c->radius;
     c->grid_max_nb = c->max_nb;
@@ -578,7 +688,12 @@ int ensure_source_sorted(ppcr_ctx *c)
     if (c->src_sorted || !c->opt_sort_source || c->ns == 0) return PPCR_OK;
     invalidate_association(c);
     HIP_TRY(c, c->src_alt.reserve((size_t)c->ns));
-    PPCR_TRY(sort_by_cell(c, c->grid, c->src.p, (int)c->ns, c->src_alt.p, nullptr, c->opt_sort_source == 1));
+    // (multi-level searches: the Hilbert curve over the finest level's cells, see hilbert_key_kernel)
+    if (c->n_levels > 1 && c->opt_sort_source == 1)
+        PPCR_TRY(sort_by_cell(c, c->finest_extra >= 0 ? c->extra_levels[(size_t)c->finest_extra].g : c->grid, c->src.p, (int)c->ns,
+                              c->src_alt.p, nullptr, 2));
+    else
+        PPCR_TRY(sort_by_cell(c, c->grid, c->src.p, (int)c->ns, c->src_alt.p, nullptr, c->opt_sort_source == 1 ? 1 : 0));
     std::swap(c->src, c->src_alt);
     c->src_sorted = true;
     c->dm2_valid = false;  // row order changed
@@ -646,9 +761,10 @@ void dispatch_tile(TileLaunch &tl, int m)
 }
 
 // Small clouds leave most of the chip idle with one workgroup per 256 queries (100k points: 391 workgroups on 1280 resident
-// slots) and an iteration lasts as long as ONE workgroup's dependent chain: the steady-state K1 then scans every block as
-// two half-blocks (SplitTable::all_halves).  Automatic up to 640 blocks (164k points): beyond, the halves' duplicated
-// staging costs more than the shorter chain gives.
+// slots) and an iteration lasts as long as ONE workgroup's dependent chain.  Scanning every block as two half-blocks
+// (SplitTable::all_halves; option k1_halves) was built to shorten that chain and MEASURED NEUTRAL TO NEGATIVE: K1 26.3 us
+// with halves against 25.9 us whole at 100k, 23.3 / 22.7 at 50k, 47 / 38 at 250k (docs/experiments.md, round 4) — the
+// chain is the workgroup's dependent memory round trips and LDS latencies, not its scan work.  Off by default.
 bool k1_all_halves(const ppcr_ctx *c)
 {
     if (c->opt_k1_halves >= 0) return c->opt_k1_halves != 0;
@@ -732,7 +848,7 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             //  — dense parts whose halos outgrow the LDS tile — leaves those rows to nn_wide_kernel, which does not fold)
             const unsigned ovf_known = c->ovf_decide_pinned ? c->ovf_decide : c->ovf_last;
             const bool many_handed_over = ovf_known != ~0u && ovf_known > (unsigned)c->opt_fuse_max_handed_over;
-            if (fuse_R && c->opt_fuse_k23 && c->nt > 0 && c->reach == 1 && !many_handed_over) {
+            if (fuse_R && c->opt_fuse_k23 && c->nt > 0 && c->reach == 1 && c->n_levels <= 1 && !many_handed_over) {
                 const Model md = make_model(c);
                 const K23Form form = k23_form(c, md);
                 if (form.onepass && form.tm != -1) {  // the three forms compiled into K1: Gaussian, v + dim = 8, integer v + dim
@@ -768,13 +884,14 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             tl.src = c->src.p, tl.ns = (int)c->ns, tl.tgt = c->tgt_sorted.p, tl.cell_start = c->cell_start.p, tl.grid = c->grid;
             tl.r2 = r2, tl.m = m;
             tl.reach = c->reach, tl.r2_full = r2_full;
+            tl.levels = c->n_levels > 1 ? c->d_levels.p : nullptr, tl.n_levels = c->n_levels, tl.base_level = c->base_level;
             // who redoes the rows of handed-over workgroups: the cleanup role of the second launch when K23 is folded in (it
             // folds K23 for them as well, but walks a dense neighbourhood one candidate per lane at a time), nn_wide_kernel
             // otherwise — every launch that cannot fold, every two-pass search (an idle nn_wide_kernel costs what an idle
             // cleanup launch costs, and the choice does not depend on when a hand-over count reaches the host)
             // (K23 can only be folded in by the steady-state variant: widths up to 10, a valid cut-off, short lists)
             const bool may_fuse = fuse != nullptr && m <= 10 && c->opt_temporal && c->dm2_valid && c->opt_short_lists && !c->opt_stamps;
-            if (c->reach > 1 || !may_fuse) {
+            if (c->reach > 1 || c->n_levels > 1 || !may_fuse) {
                 if (c->d_short.cap < (size_t)ns + 3) {
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
                     HIP_TRY(c, c->d_short.reserve((size_t)ns + 3));
@@ -1503,6 +1620,9 @@ int ppcr_destroy(ppcr_ctx *c)
         (void)hipEventDestroy(r.stop);
     }
     for (auto ev : c->prof_pool) (void)hipEventDestroy(ev);
+    release_levels(c);
+    c->d_levels.release();
+    c->level_inv.release();
     c->staging.release();
     c->tgt_raw.release();
     c->tgt_sorted.release();
@@ -1614,6 +1734,12 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
     }
     if (std::strcmp(key, "short_lists") == 0) {
         c->opt_short_lists = value ? 1 : 0;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "levels") == 0) {
+        if (value < -1 || value > 1) return fail(c, PPCR_ERR_INVALID, "levels must be -1 (automatic), 0 (one level) or 1 (same as -1)");
+        c->opt_levels = value;
+        c->grid_valid = false;
         return PPCR_OK;
     }
     if (std::strcmp(key, "k1_halves") == 0) {

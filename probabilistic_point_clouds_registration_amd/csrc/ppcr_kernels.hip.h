@@ -109,6 +109,60 @@ __global__ void brick_key_kernel(const float4 *__restrict__ pts, int n, GridDesc
     vals[i] = i;
 }
 
+// Source ordering for MULTI-LEVEL searches: the Hilbert curve over the whole cells of the finest level.  Clouds whose
+// density varies a hundredfold have no brick size that suits them all; along a Hilbert curve ANY 256 consecutive points
+// form one connected, compact region at whatever the local density is — a few fine cells inside a dense blob, many in a
+// sparse stretch — so every block's halo is small at the level its cut-offs select.  (Skilling's transpose form of the
+// 3-D Hilbert index: `bits` bits per axis, 3 * bits <= 30.)
+__global__ void hilbert_key_kernel(const float4 *__restrict__ pts, int n, GridDesc g, unsigned *__restrict__ keys,
+                                   int *__restrict__ vals, int bits, int shift)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    unsigned X[3];
+    X[0] = (unsigned)(clampi(cell_coord(p.x, g.org[0], g.inv_hx, g.n[0]), 0, g.n[0] - 1) >> g.xr_shift) >> shift;
+    X[1] = (unsigned)clampi(cell_coord(p.y, g.org[1], g.inv_h, g.n[1]), 0, g.n[1] - 1) >> shift;
+    X[2] = (unsigned)clampi(cell_coord(p.z, g.org[2], g.inv_h, g.n[2]), 0, g.n[2] - 1) >> shift;
+    const unsigned M = 1u << (bits - 1);
+    for (unsigned Q = M; Q > 1; Q >>= 1) {  // inverse undo
+        const unsigned P = Q - 1;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            if (X[a] & Q) {
+                X[0] ^= P;
+            } else {
+                const unsigned t = (X[0] ^ X[a]) & P;
+                X[0] ^= t;
+                X[a] ^= t;
+            }
+        }
+    }
+    X[1] ^= X[0];  // Gray encode
+    X[2] ^= X[1];
+    unsigned t = 0;
+    for (unsigned Q = M; Q > 1; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1;
+    X[0] ^= t, X[1] ^= t, X[2] ^= t;
+    unsigned key = 0;  // interleave: bit b of X[0] is the most significant of its triple
+    for (int b = bits - 1; b >= 0; b--) key = (key << 3) | (((X[0] >> b) & 1u) << 2) | (((X[1] >> b) & 1u) << 1) | ((X[2] >> b) & 1u);
+    keys[i] = key;
+    vals[i] = i;
+}
+
+// multi-level search: inv[original index of the base level's p-th point] = p, then to_base[q] = inv[original index of
+// another level's q-th point] (the association is kept in base-level positions whichever level found the neighbour)
+__global__ void level_inverse_kernel(const float4 *__restrict__ base_sorted, int n, int *__restrict__ inv)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) inv[__float_as_int(base_sorted[p].w)] = p;
+}
+__global__ void level_to_base_kernel(const float4 *__restrict__ level_sorted, int n, const int *__restrict__ inv, int *__restrict__ to_base)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) to_base[q] = inv[__float_as_int(level_sorted[q].w)];
+}
+
 // K0c: permute points into sorted order (the w lane keeps the caller's original index)
 __global__ void gather_points_kernel(const float4 *__restrict__ in, const int *__restrict__ order, int n,
                                      float4 *__restrict__ out)

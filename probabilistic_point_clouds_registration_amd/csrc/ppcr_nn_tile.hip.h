@@ -981,17 +981,24 @@ struct UnansweredRows {
     int *list;
     unsigned *count, *next;
     int m_list;
+    // multi-level search (nn_fast_kernel<..., MULTI>): the levels in ascending order of r2_cap, which of them is the base
+    // (whose positions the association is written in, and on whose grid nn_wide_kernel searches), the full radius^2
+    const GridLevel *levels;
+    int n_levels, base_level;
+    float r2_full;
 };
 
 // FTM != -2 (0: Gaussian, k > 0: t model with v + dim = k, -3: t model with an integer v + dim read at run time) folds
 // K23 into this kernel: each lane finishes its row's
 // contribution to the 19 moments from the winners' coordinates while they are still in LDS (no neighbour gathers, no
 // second pass over the source, no K23 launch) and the workgroup folds them into fm.partials.  FTM = -2: plain K1.
-template <int M, int C, int CAP, bool STAMPS, int FTM = -2>
+// MULTI: the grid is chosen per workgroup from un.levels (GridLevel): tgt / cell_start / g / r2 of the arguments are the
+// base level's and only used by the first association (no cut-offs yet: every block searches the base level).
+template <int M, int C, int CAP, bool STAMPS, int FTM = -2, bool MULTI = false>
 __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 4) : (CAP * 13 + C * 512 <= 39000 ? 4 : 3))) void nn_fast_kernel(float4 *__restrict__ src, int ns,
-                                                         const float4 *__restrict__ tgt,
-                                                         const int *__restrict__ cell_start, GridDesc g,
-                                                         float r2, int m, int *__restrict__ nbr,
+                                                         const float4 *__restrict__ tgt0,
+                                                         const int *__restrict__ cell_start0, GridDesc g0,
+                                                         float r2_0, int m, int *__restrict__ nbr,
                                                          int *__restrict__ cnt, PendingMove pm,
                                                          unsigned *__restrict__ dm2, int dm2_valid,
                                                          int *__restrict__ ovf_list, unsigned *__restrict__ ovf_count,
@@ -1003,6 +1010,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     // then this one must touch nothing.  A uniform scalar load, tested below once the query load is in flight.
     const unsigned aborted = lr.st ? lr.st->abort : 0u;
     static_assert(C > M, "a re-scan must leave room in the list");
+    static_assert(!MULTI || FTM == -2, "a multi-level search leaves rows to nn_wide_kernel: K23 is its own kernel");
     static_assert(FTM == -2 || (3 * CAP + CAP / 4) * 4 >= kFoldScratchBytes, "the final fold borrows the halo buffer");
     static_assert(CAP % 4 == 0 && CAP * 4 < 65536, "list entries are 16-bit byte offsets into the halo arrays");
     constexpr int BLOCK = 256, kWaves = 4, kRows = 128, kStageUnroll = 6;
@@ -1013,12 +1021,14 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     // two v_min_u32 less on a 22-VALU trip (2508 -> 2427 VALU per wave, +1.6 % iterations/s; -DPPCR_LIST_NOCLAMP=0 is
     // the clamped form with separate arrays).
     constexpr int kHaloBytes = (3 * CAP + CAP / 4) * 4, kListBytes = (C + 1) * BLOCK * 2;
-    constexpr int kOffGbo = kHaloBytes, kOffBox = kOffGbo + kRows * 4, kOffBail = kOffBox + kWaves * 6 * 4, kOffList = (kOffBail + 4 + 15) & ~15;
+    constexpr int kOffGbo = kHaloBytes, kOffBox = kOffGbo + kRows * 4, kOffBail = kOffBox + kWaves * 6 * 4, kOffNeed = kOffBail + 4,
+                  kOffList = (kOffNeed + (MULTI ? kWaves * 4 : 0) + 15) & ~15;
     __shared__ __attribute__((aligned(16))) unsigned char s_all[kOffList + kListBytes];
     float *const s_halo = reinterpret_cast<float *>(s_all);
     int *const s_gbo = reinterpret_cast<int *>(s_all + kOffGbo);
     int(*const s_box)[6] = reinterpret_cast<int(*)[6]>(s_all + kOffBox);
     int &s_bail = *reinterpret_cast<int *>(s_all + kOffBail);
+    int *const s_need = reinterpret_cast<int *>(s_all + kOffNeed);  // (MULTI: the waves' largest cut-offs)
     unsigned short *const s_list = reinterpret_cast<unsigned short *>(s_all + kOffList);
     static_assert(sizeof(int2) * kRows <= kListBytes, "row table aliases the list area");
     int2 *const s_rowtab = reinterpret_cast<int2 *>(s_list);
@@ -1032,6 +1042,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     int2 *const s_rowtab = reinterpret_cast<int2 *>(s_list);
     __shared__ int s_box[kWaves][6];
     __shared__ int s_bail;
+    __shared__ int s_need[kWaves];
 #endif
     float *const s_x = s_halo, *const s_y = s_halo + CAP, *const s_z = s_halo + 2 * CAP;
     unsigned char *const s_rowid = reinterpret_cast<unsigned char *>(s_halo + 3 * CAP);
@@ -1111,9 +1122,42 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         if (prev != 0xFFFFFFFFu) {
             const float bound = __builtin_amdgcn_sqrtf(__uint_as_float(prev)) + moved;
             const float t2 = bound * bound * 1.00001f + 1e-30f;
-            thr0 = (t2 < r2) ? __float_as_uint(t2) : 0xFFFFFFFFu;
+            thr0 = (t2 < (MULTI ? un.r2_full : r2_0)) ? __float_as_uint(t2) : 0xFFFFFFFFu;
         }
     }
+    // ---- MULTI: which level of the grid this block searches ------------------------------------------------------
+    // The finest level whose stencil covers the block's largest cut-off radius (a row without a cut-off — it found fewer
+    // than m within the full radius last time, or there is no last time — needs the full radius).  The first association
+    // of a registration has no cut-offs at all: every block searches the base level with its first-pass radius, and the
+    // rows that come back short go to nn_wide_kernel, as in the single-level two-pass search.
+    GridDesc g_l;
+    const float4 *tgt_l = nullptr;
+    const int *cell_start_l = nullptr, *to_base = nullptr;
+    float r2_l = 0.f;
+    if constexpr (MULTI) {
+        int level = un.base_level;
+        if (dm2_valid) {
+            int need = valid ? (int)min(thr0, __float_as_uint(un.r2_full)) : 0;  // (bit patterns of positive floats order like ints)
+            need = wave_reduce(need, 0, OpMax());
+            if (lane == 0) s_need[wave] = need;
+            lds_barrier();
+            need = max(max(s_need[0], s_need[1]), max(s_need[2], s_need[3]));
+            const float need_f = __uint_as_float((unsigned)need);
+            level = un.n_levels - 1;
+            for (int l = un.n_levels - 2; l >= 0; l--)
+                if (un.levels[l].r2_cap >= need_f) level = l;
+        }
+        level = __builtin_amdgcn_readfirstlane(level);
+        const GridLevel *lv = un.levels + level;
+        g_l = lv->g;
+        tgt_l = lv->tgt, cell_start_l = lv->cell_start, to_base = lv->to_base;
+        // the first association searches the base level with the first-pass radius (r2_0 <= the level's cap)
+        r2_l = dm2_valid ? fminf(lv->r2_cap, un.r2_full) : r2_0;
+    }
+    const GridDesc &g = MULTI ? g_l : g0;
+    const float4 *__restrict__ const tgt = MULTI ? tgt_l : tgt0;
+    const int *__restrict__ const cell_start = MULTI ? cell_start_l : cell_start0;
+    const float r2 = MULTI ? r2_l : r2_0;
     const QueryCells qc = query_cells(q, g);
 
     // ---- the nine stencil runs [rb, re) in sorted-target positions, clipped in x --------------------------------
@@ -1384,6 +1428,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
                         // every candidate is written to the list's next free slot; only an accepted one moves the cursor
                         // (a rejected one is overwritten by whatever comes next): no branch, no exec juggling
 #if PPCR_LIST_NOCLAMP
+                        (void)list_last;
                         const unsigned slot_x = wp;
 #else
                         const unsigned slot_x = min(wp, list_last);
@@ -1478,14 +1523,20 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     if (valid) {
         int *out = nbr + i;
         for (int j = 0; j < n; j++) {
-            *out = L.pos_of(L.load(j));
+            int pos = L.pos_of(L.load(j));
+            if constexpr (MULTI)
+                if (to_base != nullptr) pos = to_base[pos];  // the association is kept in the base level's positions
+            *out = pos;
             out += ns;
         }
-        cnt[i] = unanswered ? -1 : n;
+        // MULTI: a row that found fewer than m inside a level's radius is final only when that radius is the full one;
+        // elsewhere it goes to nn_wide_kernel, marked unsearched (its count says nothing about the base level's radius)
+        const bool short_here = MULTI && n < un.m_list && r2 < un.r2_full && to_base != nullptr;
+        cnt[i] = (unanswered || short_here) ? -1 : n;
         dm2[i] = tm;
     }
     if constexpr (FTM == -2)
-        if (un.list != nullptr) list_rows(valid && (unanswered || n < un.m_list));
+        if (un.list != nullptr) list_rows(valid && (unanswered || (n < un.m_list && (!MULTI || r2 < un.r2_full))));
     stamp(5);
     if constexpr (FTM != -2) {
         // ---- K23 for this row, from LDS: weights at fm.P, the row's share of the 19 moments ----------------------

@@ -25,6 +25,8 @@ struct TileLaunch {
                                   //      launch then
     unsigned *short_next;         // the other counter of that list's ping-pong pair (nullable): every launch leaves it at zero
     unsigned *short_seen;         // diagnostic: the count nn_wide_kernel saw
+    const dev::GridLevel *levels; // multi-level search (n_levels > 1; needs short_count): the level table in device memory,
+    int n_levels, base_level;     //      ascending r2_cap; tgt / cell_start / grid above are the base level's
     int m;                        // max_neighbours (<= the M of the variant that is called)
     int *nbr, *cnt;               // the ELL association [m][ns], [ns]
     unsigned *dm2;                // per query: float bits of its m-th neighbour's d2 (the temporal cut-off)

@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 4, fourth GPU call: multi-level grids (tests that exercise two-pass / non-uniform paths first, then the whole suite,
+# then configs 8 / 9 / 10 with and without levels)
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r04d; rm -rf $OUT; mkdir -p $OUT; cd $R
+timeout 900 python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py -x -q -m gpu -k "cli_default_shape or two_pass or bit_identical or wave_kernel or row_per_wave or soak or dense" > $OUT/pytest_levels.log 2>&1; echo "pytest levels rc=$?" >> $OUT/summary.txt
+Q="python bench.py --no-extras --no-cpu-baseline"
+for cfg in 9 10 8; do
+  $Q --config $cfg > $OUT/cfg${cfg}_levels.json 2>> $OUT/bench.err
+  $Q --config $cfg --opt levels=0 > $OUT/cfg${cfg}_single.json 2>> $OUT/bench.err
+  $Q --config $cfg --inner-steps 1 > $OUT/cfg${cfg}_levels_inner1.json 2>> $OUT/bench.err
+done
+timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "pytest gpu rc=$?" >> $OUT/summary.txt
+for f in cfg9_levels cfg9_single cfg9_levels_inner1 cfg10_levels cfg10_single cfg10_levels_inner1 cfg8_levels cfg8_single cfg8_levels_inner1; do python - $OUT/$f.json <<'PY' >> $OUT/summary.txt
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d.get('roofline',{})
+    print(sys.argv[1].split('/')[-1], 'value', round(d['value'],1), 'ms/step', round(d['ms_per_step'],4), 'spread', round(d['windows']['spread'],4), {k: round(v*1e3,1) for k,v in d.get('kernels_ms_per_launch',{}).items()})
+except Exception as e: print(sys.argv[1], 'ERR', e)
+PY
+done
+cat $OUT/summary.txt; tail -15 $OUT/pytest_levels.log; tail -5 $OUT/pytest_gpu.log; tail -5 $OUT/bench.err
