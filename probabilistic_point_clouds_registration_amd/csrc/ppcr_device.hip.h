@@ -51,6 +51,7 @@ struct GridLevel {
     int pad;
 };
 constexpr int kMaxLevels = 6;
+constexpr int kLevelDbgWords = 6;  // diagnostic counters per level (UnansweredRows::level_dbg)
 
 struct Pose {  // y ~ R x + t ; c = fixed origin of the moments
     double R[9];

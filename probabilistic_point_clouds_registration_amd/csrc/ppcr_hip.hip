@@ -143,7 +143,12 @@ struct ppcr_ctx {
     std::vector<ExtraLevel> extra_levels;
     DevBuf<GridLevel> d_levels;
     DevBuf<int> level_inv;
+    DevBuf<unsigned> level_dbg;        // diagnostic counters of the multi-level search (option "level_stats")
+    int opt_level_stats = 0;
+    DevBuf<unsigned char> level_cap;   // per 256-query block of the (sorted) source: the coarsest level it may pick
+    bool level_cap_clean = false;      // ... all 0xFF for the current source order
     int n_levels = 1, base_level = 0, finest_extra = -1;  // finest_extra: index into extra_levels of the finest level (-1: the base is)
+    float level_r2_cap[kMaxLevels] = {0, 0, 0, 0, 0, 0};
     int opt_levels = -1;               // -1 automatic (non-uniform clouds / radii that hold far more than max_neighbours), 0 one level
     double origin[3] = {0, 0, 0};
     bool origin_valid = false;
@@ -526,10 +531,10 @@ void make_grid_desc(int n, const float lo[3], const float hi[3], double cell_rad
 
 // occupancy of the grid just built as the typical point sees it (cell_occupancy_kernel): the median over the points of
 // the count of the cell they live in, less one (a point of a uniform cloud of q per cell sits in a cell of q + 1)
-int grid_occupancy(ppcr_ctx *c, double *occ, double *occ_p95 = nullptr)
+int grid_occupancy(ppcr_ctx *c, double *occ, double *occ_p99 = nullptr)
 {
     *occ = 0;
-    if (occ_p95) *occ_p95 = 0;
+    if (occ_p99) *occ_p99 = 0;
     if (c->nt <= 0) return PPCR_OK;
     HIP_TRY(c, c->d_occupancy.reserve(kOccBins));
     HIP_TRY(c, hipMemsetAsync(c->d_occupancy.p, 0, kOccBins * sizeof(unsigned long long), c->stream));
@@ -547,8 +552,8 @@ int grid_occupancy(ppcr_ctx *c, double *occ, double *occ_p95 = nullptr)
             *occ = std::max((double)b - 1.0, 0.0);
             have_median = true;
         }
-        if (20 * run >= 19 * total) {  // the cell 95 % of the points do not exceed (saturates at kOccBins - 1)
-            if (occ_p95) *occ_p95 = std::max((double)b - 1.0, 0.0);
+        if (100 * run >= 99 * total) {  // the cell 99 % of the points do not exceed (saturates at kOccBins - 1)
+            if (occ_p99) *occ_p99 = std::max((double)b - 1.0, 0.0);
             break;
         }
     }
@@ -558,7 +563,7 @@ int grid_occupancy(ppcr_ctx *c, double *occ, double *occ_p95 = nullptr)
 // The levels of a multi-level search around the base grid just built (GridLevel): COARSER ones — cell edges doubling up
 // to the full radius — when the radius reaches beyond the base cells (rows of sparse regions, whose m-th neighbour lies
 // farther out than the first-pass radius, are then answered by the tiled kernel on a coarser level instead of one row per
-// wave), FINER ones — edges halving, at most two — when 5 % of the points sit in cells far fuller than the first pass
+// wave), FINER ones — edges halving, at most two — when 1 % of the points sit in cells far fuller than the first pass
 // aims at (dense blobs, the near field of a scan: blocks there pick a level whose halo fits the LDS tile).  A uniform
 // cloud searched with a radius of a few points' spacing keeps its single level, and with it every kernel it ran before.
 void release_levels(ppcr_ctx *c)
@@ -578,19 +583,24 @@ int build_levels(ppcr_ctx *c, bool bounded)
     if (!bounded || c->opt_two_pass != 1 || c->opt_levels == 0 || n <= 0) return PPCR_OK;
     std::vector<double> finer, coarser;
     {
-        double occ = 0, occ95 = 0;
-        PPCR_TRY(grid_occupancy(c, &occ, &occ95));
+        double occ = 0, occ99 = 0;
+        PPCR_TRY(grid_occupancy(c, &occ, &occ99));
         const double cap = 0.1 * c->opt_first_pass_occ, q_want = std::max(target_occupancy(c->max_nb, cap, 0.1 * c->opt_first_pass_fill), 1.0);
-        // (halving the edge divides a cell's count by eight: one finer level from 4 x the aim, two from 32 x)
-        if (occ95 > 4.0 * q_want) finer.push_back(c->search_radius / 2);
-        if (occ95 > 32.0 * q_want) finer.push_back(c->search_radius / 4);
+        // (halving the edge divides a cell's count by eight; the histogram saturates at kOccBins - 1 = 255 points per cell:
+        //  one finer level from 4 x the aim, two from 16 x)
+        if (occ99 > 4.0 * q_want) finer.push_back(c->search_radius / 2);
+        if (occ99 > 16.0 * q_want) finer.push_back(c->search_radius / 4);
     }
     for (double s = c->search_radius; s < c->radius * (1.0 - 1e-9) && (int)coarser.size() < kMaxLevels - 3;) {
         s = std::min(2.0 * s, c->radius);
         coarser.push_back(s);
     }
     if (!coarser.empty()) coarser.back() = c->radius;  // the last level covers the full radius
-    if (finer.empty() && coarser.empty()) return PPCR_OK;
+    // Several levels only for clouds WITH a dense tail.  A uniform cloud whose radius reaches beyond the first-pass cells
+    // leaves a fraction of a per cent of its rows (the cloud's edge) to nn_wide_kernel, and the multi-level kernel's
+    // longer prologue (feedback byte, level table, a barrier) costs it more than those rows do: measured 7.6 k against
+    // 9.7 k it/s at the command line's defaults on the uniform 200k cloud.
+    if (finer.empty()) return PPCR_OK;
     std::vector<double> radii;  // ascending, the base in between
     for (auto it = finer.rbegin(); it != finer.rend(); ++it) radii.push_back(*it);
     const int base_at = (int)radii.size();
@@ -629,6 +639,7 @@ int build_levels(ppcr_ctx *c, bool bounded)
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // (`table` leaves scope)
     c->n_levels = (int)radii.size();
     c->base_level = base_at;
+    for (size_t l = 0; l < table.size(); l++) c->level_r2_cap[l] = table[l].r2_cap;
     return PPCR_OK;
 }
 
@@ -689,15 +700,17 @@ int ensure_source_sorted(ppcr_ctx *c)
     invalidate_association(c);
     HIP_TRY(c, c->src_alt.reserve((size_t)c->ns));
     // (multi-level searches: the Hilbert curve over the finest level's cells, see hilbert_key_kernel)
-    if (c->n_levels > 1 && c->opt_sort_source == 1)
-        PPCR_TRY(sort_by_cell(c, c->finest_extra >= 0 ? c->extra_levels[(size_t)c->finest_extra].g : c->grid, c->src.p, (int)c->ns,
-                              c->src_alt.p, nullptr, 2));
+    // — only when there ARE finer levels (dense parts, whose blocks must be compact at a fine scale): the curve's blocks have
+    // larger bounding boxes than bricks (K1 58 against 51 us on a uniform cloud), which coarser levels alone do not need
+    if (c->n_levels > 1 && c->finest_extra >= 0 && c->opt_sort_source == 1)
+        PPCR_TRY(sort_by_cell(c, c->extra_levels[(size_t)c->finest_extra].g, c->src.p, (int)c->ns, c->src_alt.p, nullptr, 2));
     else
         PPCR_TRY(sort_by_cell(c, c->grid, c->src.p, (int)c->ns, c->src_alt.p, nullptr, c->opt_sort_source == 1 ? 1 : 0));
     std::swap(c->src, c->src_alt);
     c->src_sorted = true;
     c->dm2_valid = false;  // row order changed
     c->split_clean = false;
+    c->level_cap_clean = false;
     return PPCR_OK;
 }
 
@@ -821,7 +834,7 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
         HIP_TRY(c, c->nbr.reserve((size_t)m * (size_t)std::max(ns, 1)));
         HIP_TRY(c, c->cnt.reserve((size_t)std::max(ns, 1)));
         HIP_TRY(c, c->dm2.reserve((size_t)std::max(ns, 1)));
-        HIP_TRY(c, c->ovf_list.reserve((size_t)std::max(nblocks(std::max(ns, 1), 256) + kMaxSplit, k1_steady_slots(c))));
+        HIP_TRY(c, c->ovf_list.reserve((size_t)std::max(nblocks(std::max(ns, 1), 256) + kMaxSplit, steady_grid(nblocks(std::max(ns, 1), 256), true))));
         if (!c->split_clean) {
             const size_t nbk = (size_t)nblocks(std::max(ns, 1), 256);
             HIP_TRY(c, c->split_flag.reserve(nbk));
@@ -885,6 +898,17 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             tl.r2 = r2, tl.m = m;
             tl.reach = c->reach, tl.r2_full = r2_full;
             tl.levels = c->n_levels > 1 ? c->d_levels.p : nullptr, tl.n_levels = c->n_levels, tl.base_level = c->base_level;
+            if (c->n_levels > 1) {
+                const size_t nbk = (size_t)nblocks(std::max(ns, 1), 256);
+                if (!c->level_cap_clean || c->level_cap.cap < nbk) {
+                    HIP_TRY(c, c->level_cap.reserve(nbk));
+                    HIP_TRY(c, hipMemsetAsync(c->level_cap.p, 0x0F, nbk, c->stream));  // cap 15, floor 0
+                    c->level_cap_clean = true;
+                }
+                tl.level_cap = c->level_cap.p;
+                for (int l = 0; l < kMaxLevels; l++) tl.r2_cap[l] = c->level_r2_cap[l];
+                tl.level_dbg = (c->opt_level_stats && c->level_dbg.p) ? c->level_dbg.p : nullptr;
+            }
             // who redoes the rows of handed-over workgroups: the cleanup role of the second launch when K23 is folded in (it
             // folds K23 for them as well, but walks a dense neighbourhood one candidate per lane at a time), nn_wide_kernel
             // otherwise — every launch that cannot fold, every two-pass search (an idle nn_wide_kernel costs what an idle
@@ -1623,6 +1647,7 @@ int ppcr_destroy(ppcr_ctx *c)
     release_levels(c);
     c->d_levels.release();
     c->level_inv.release();
+    c->level_cap.release();
     c->staging.release();
     c->tgt_raw.release();
     c->tgt_sorted.release();
@@ -1736,6 +1761,12 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
         c->opt_short_lists = value ? 1 : 0;
         return PPCR_OK;
     }
+    if (std::strcmp(key, "level_stats") == 0) {  // diagnostic: cumulative per-level counters (ppcr_debug_get_levels); setting it clears them
+        HIP_TRY(c, c->level_dbg.reserve((size_t)kMaxLevels * kLevelDbgWords));
+        HIP_TRY(c, hipMemsetAsync(c->level_dbg.p, 0, (size_t)kMaxLevels * kLevelDbgWords * sizeof(unsigned), c->stream));
+        c->opt_level_stats = value ? 1 : 0;
+        return PPCR_OK;
+    }
     if (std::strcmp(key, "levels") == 0) {
         if (value < -1 || value > 1) return fail(c, PPCR_ERR_INVALID, "levels must be -1 (automatic), 0 (one level) or 1 (same as -1)");
         c->opt_levels = value;
@@ -1835,6 +1866,7 @@ static int set_source_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, in
     if (c->mbox_seq > (1u << 30)) PPCR_TRY(restart_sequence_numbers(c));
     c->ovf_last = ~0u;
     c->split_clean = false;
+    c->level_cap_clean = false;
     c->move_pending = false;  // a deferred move of the previous source dies with it
     c->move_on_device = false;
     c->dm2_valid = false;
@@ -2646,6 +2678,30 @@ int ppcr_debug_get_search(ppcr_ctx *c, double out[2])
     CTX_ENTER(c);
     out[0] = c->grid_valid ? (double)c->reach : 0.0;
     out[1] = c->grid_valid ? c->search_radius : 0.0;
+    return PPCR_OK;
+}
+
+// diagnostic: the multi-level search's cumulative counters since option "level_stats" was set — out[0] = levels, out[1] = base
+// level, then per level: cell radius * 1000, and kLevelDbgWords counters {blocks, handed over (shape), handed over (size), short
+// rows listed, staged candidates, rows}
+int ppcr_debug_get_levels(ppcr_ctx *c, unsigned *out, int capacity)
+{
+    CTX_ENTER(c);
+    if (!out || capacity < 2 + kMaxLevels * (1 + kLevelDbgWords)) return fail(c, PPCR_ERR_INVALID, "ppcr_debug_get_levels: buffer too small");
+    std::memset(out, 0, (size_t)capacity * sizeof(unsigned));
+    out[0] = (unsigned)c->n_levels, out[1] = (unsigned)c->base_level;
+    std::vector<unsigned> raw((size_t)kMaxLevels * kLevelDbgWords, 0u);
+    if (c->level_dbg.p) {
+        HIP_TRY(c, hipMemcpyAsync(raw.data(), c->level_dbg.p, raw.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    size_t e = 0;
+    for (int l = 0; l < c->n_levels && l < kMaxLevels; l++) {
+        const double radius = (l == c->base_level) ? c->search_radius : c->extra_levels[e++].radius;
+        unsigned *row = out + 2 + (size_t)l * (1 + kLevelDbgWords);
+        row[0] = (unsigned)std::lround(radius * 1000.0);
+        for (int k = 0; k < kLevelDbgWords; k++) row[1 + k] = raw[(size_t)l * kLevelDbgWords + (size_t)k];
+    }
     return PPCR_OK;
 }
 

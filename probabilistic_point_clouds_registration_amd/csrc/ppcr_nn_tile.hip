@@ -56,8 +56,11 @@ void launch_tile(TileLaunch &t)
     const LoopReset lr{t.loop_st};
     // (one-pass search: only rows marked unsearched are listed, its short rows are final)
     const bool multi = t.n_levels > 1 && t.levels != nullptr && t.short_count != nullptr;
-    const UnansweredRows un{(t.short_count ? t.short_list : nullptr), t.short_count, t.short_next, ((t.reach > 1 || multi) ? t.m : 0),
-                            (multi ? t.levels : nullptr), (multi ? t.n_levels : 0), t.base_level, t.r2_full};
+    UnansweredRows un{(t.short_count ? t.short_list : nullptr), t.short_count, t.short_next, ((t.reach > 1 || multi) ? t.m : 0),
+                      (multi ? t.levels : nullptr), (multi ? t.n_levels : 0), t.base_level, t.r2_full, {0, 0, 0, 0, 0, 0},
+                      (multi ? t.level_cap : nullptr), (multi ? t.level_dbg : nullptr)};
+    static_assert(kMaxLevels == 6, "initialiser above");
+    for (int l = 0; l < kMaxLevels; l++) un.r2_cap[l] = (multi && l < t.n_levels) ? t.r2_cap[l] : 0.f;
     // the steady-state (16-slot) variant runs with a halo capacity that gives FIVE workgroups per CU (31.3 KB of LDS)
     // and splits the few blocks that outgrow it; the first association (32 slots, three per CU) keeps the large one
 #define PPCR_FAST(Cc, STAMPc, FTMc, FMc)                                                                               \
@@ -70,22 +73,22 @@ void launch_tile(TileLaunch &t)
     if (multi) {
         // multi-level search: every block picks its level of the grid in the kernel; no split table (a block whose halo
         // does not fit at its level leaves its rows to nn_wide_kernel), nothing folded in
-        const SplitTable no_table{nullptr, nullptr, nullptr, nullptr, 0, INT_MAX, halves ? 1 : 0};
+        // (the two-workgroups-per-block grid: the second workgroup only works for blocks marked split, see the kernel)
+        const SplitTable two_per_block{nullptr, nullptr, nullptr, nullptr, 0, INT_MAX, 1};
+        const int grid_multi = steady_grid(nb, true);
         bool done = false;
         if constexpr (M <= 12) {
             if (t.dm2_in && t.short_lists) {
-                nn_fast_kernel<M, 16, kCapSteady, false, -2, true><<<(halves ? steady_grid(nb, true) : nb), 256, 0, t.stream>>>(
+                nn_fast_kernel<M, 16, kCapSteady, false, -2, true><<<grid_multi, 256, 0, t.stream>>>(
                     t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
-                    no_table, nullptr, fm_none, lr, un);
+                    two_per_block, nullptr, fm_none, lr, un);
                 done = true;
             }
         }
-        if (!done) {
-            const SplitTable whole{nullptr, nullptr, nullptr, nullptr, 0, INT_MAX, 0};
-            nn_fast_kernel<M, C, CAP, false, -2, true><<<nb, 256, 0, t.stream>>>(t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt,
-                                                                                 t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next, whole,
-                                                                                 nullptr, fm_none, lr, un);
-        }
+        if (!done)
+            nn_fast_kernel<M, C, CAP, false, -2, true><<<grid_multi, 256, 0, t.stream>>>(t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr,
+                                                                                         t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,
+                                                                                         t.ovf_next, two_per_block, nullptr, fm_none, lr, un);
         steady = true;  // (skips the single-level launches below)
     } else
     if constexpr (M <= 12) {

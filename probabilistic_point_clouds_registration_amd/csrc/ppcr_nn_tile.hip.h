@@ -986,6 +986,10 @@ struct UnansweredRows {
     const GridLevel *levels;
     int n_levels, base_level;
     float r2_full;
+    float r2_cap[kMaxLevels];  // the levels' r2_cap, by value (the level choice then needs no memory round trip of its own)
+    unsigned char *level_cap;  // per 256-query block: coarsest level it may pick | finest << 4 | split << 7 (feedback of halos that did not fit)
+    unsigned *level_dbg;       // diagnostic (nullable): per level {blocks, handed over for the halo's shape, ... for its size,
+                               //   short rows listed, staged candidates, rows}, cumulative (ppcr_debug_get_levels)
 };
 
 // FTM != -2 (0: Gaussian, k > 0: t model with v + dim = k, -3: t model with an integer v + dim read at run time) folds
@@ -1010,10 +1014,13 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     // then this one must touch nothing.  A uniform scalar load, tested below once the query load is in flight.
     const unsigned aborted = lr.st ? lr.st->abort : 0u;
     static_assert(C > M, "a re-scan must leave room in the list");
+    static_assert(kMaxLevels <= 8, "s_need holds eight counts per wave");
     static_assert(!MULTI || FTM == -2, "a multi-level search leaves rows to nn_wide_kernel: K23 is its own kernel");
     static_assert(FTM == -2 || (3 * CAP + CAP / 4) * 4 >= kFoldScratchBytes, "the final fold borrows the halo buffer");
     static_assert(CAP % 4 == 0 && CAP * 4 < 65536, "list entries are 16-bit byte offsets into the halo arrays");
-    constexpr int BLOCK = 256, kWaves = 4, kRows = 128, kStageUnroll = 6;
+    // (MULTI, three workgroups per CU: the curve-ordered blocks of a multi-level search have up to 128 short rows, and
+    //  registers to keep twelve of them in flight)
+    constexpr int BLOCK = 256, kWaves = 4, kRows = 128, kStageUnroll = (MULTI && C > 16) ? 12 : 6;
 #if PPCR_LIST_NOCLAMP
     // ONE allocation with the list LAST: a store beyond the list's spare slot then leaves the workgroup's LDS allocation,
     // where the hardware drops it (gfx950, as the ISA documents; probed by tools/micro/lds_oob.hip, which
@@ -1022,7 +1029,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     // the clamped form with separate arrays).
     constexpr int kHaloBytes = (3 * CAP + CAP / 4) * 4, kListBytes = (C + 1) * BLOCK * 2;
     constexpr int kOffGbo = kHaloBytes, kOffBox = kOffGbo + kRows * 4, kOffBail = kOffBox + kWaves * 6 * 4, kOffNeed = kOffBail + 4,
-                  kOffList = (kOffNeed + (MULTI ? kWaves * 4 : 0) + 15) & ~15;
+                  kOffList = (kOffNeed + (MULTI ? kWaves * 8 * 4 : 0) + 15) & ~15;
     __shared__ __attribute__((aligned(16))) unsigned char s_all[kOffList + kListBytes];
     float *const s_halo = reinterpret_cast<float *>(s_all);
     int *const s_gbo = reinterpret_cast<int *>(s_all + kOffGbo);
@@ -1042,7 +1049,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     int2 *const s_rowtab = reinterpret_cast<int2 *>(s_list);
     __shared__ int s_box[kWaves][6];
     __shared__ int s_bail;
-    __shared__ int s_need[kWaves];
+    __shared__ int s_need[kWaves * 8];
 #endif
     float *const s_x = s_halo, *const s_y = s_halo + CAP, *const s_z = s_halo + 2 * CAP;
     unsigned char *const s_rowid = reinterpret_cast<unsigned char *>(s_halo + 3 * CAP);
@@ -1069,6 +1076,8 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
 
     // which block, and which of its waves' queries, this workgroup scans (uniform)
     int bid, half = 0;  // half: 0 whole block, 1 waves 0-1, 2 waves 2-3
+    unsigned level_fb = 0x0Fu;  // MULTI: the block's feedback byte (UnansweredRows::level_cap)
+    float4 q_early = make_float4(0.f, 0.f, 0.f, 0.f);
     if (split.all_halves) {
         const int slot = halves_slot((int)blockIdx.x), nb = (ns + BLOCK - 1) / BLOCK;
         if (slot >= nb) {  // (padding of the grid to a multiple of sixteen workgroups)
@@ -1078,6 +1087,18 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         }
         bid = xcd_block(slot, nb);
         half = halves_half((int)blockIdx.x);
+        if constexpr (MULTI) {
+            // multi-level searches launch the two-workgroups-per-block grid and use the second workgroup only for the
+            // blocks marked split (bit 7 of level_cap: their halo outgrew the tile at the level their cut-offs ask for;
+            // half a block's halo is ~60 % of the block's): everybody else's second workgroup leaves at once
+            level_fb = un.level_cap != nullptr ? (unsigned)un.level_cap[bid] : 0x0Fu;
+            // (the query is asked for in the same breath: which lanes are valid depends on the byte, the load need not wait for it)
+            q_early = src[min(bid * BLOCK + tid, ns - 1)];
+            if (!(level_fb & 0x80u)) {
+                if (half == 2) return;
+                half = 0;
+            }
+        }
     } else if ((int)blockIdx.x < split.n_extra) {
         if (blockIdx.x >= min(*split.visible, (unsigned)kMaxSplit)) {
             if constexpr (FTM != -2)  // an idle slot of the partials still has to read as zero
@@ -1095,7 +1116,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     if (tid == 0) s_bail = 0;
 
     // ---- prologue: query, pending move, temporal cut-off ---------------------------------------------------------
-    float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 q = valid ? ((MULTI && split.all_halves) ? q_early : src[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (aborted) return;
     // the other counter of the ping-pong pair: idle during this launch  (the last workgroup is never an idle split slot;
     // with all_halves the first one never idles)
@@ -1134,18 +1155,36 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     const float4 *tgt_l = nullptr;
     const int *cell_start_l = nullptr, *to_base = nullptr;
     float r2_l = 0.f;
+    int level = 0;
     if constexpr (MULTI) {
-        int level = un.base_level;
+        level = un.base_level;
         if (dm2_valid) {
-            int need = valid ? (int)min(thr0, __float_as_uint(un.r2_full)) : 0;  // (bit patterns of positive floats order like ints)
-            need = wave_reduce(need, 0, OpMax());
-            if (lane == 0) s_need[wave] = need;
+            // The finest level that covers the cut-offs of at least 7/8 of the block's rows (a row whose cut-off reaches
+            // beyond the level searches the level's radius all the same: it is exact when it finds m there, and goes to
+            // nn_wide_kernel when it does not).  Going by the block's LARGEST cut-off was measured first: one row at the
+            // cloud's edge then drags its whole block to a level whose halo no tile holds (uniform 200k cloud at radius 3:
+            // 22 % of the rows sit in such blocks).  Each lane finds the finest level that covers its own cut-off, the
+            // waves count their lanes per level, the block adds the counts up.
+            const float need_f = __uint_as_float(min(thr0, __float_as_uint(un.r2_full)));  // no cut-off: the full radius
+            int mine = un.n_levels - 1;
+#pragma unroll
+            for (int l = kMaxLevels - 2; l >= 0; l--)
+                if (l < un.n_levels - 1 && un.r2_cap[l] >= need_f) mine = l;
+            int below[kMaxLevels];  // lanes of this wave whose cut-off level l covers
+#pragma unroll
+            for (int l = 0; l < kMaxLevels; l++) below[l] = __popcll(__ballot(valid && mine <= l));
+            if (lane == 0) {
+#pragma unroll
+                for (int l = 0; l < kMaxLevels; l++) s_need[wave * 8 + l] = below[l];
+            }
             lds_barrier();
-            need = max(max(s_need[0], s_need[1]), max(s_need[2], s_need[3]));
-            const float need_f = __uint_as_float((unsigned)need);
+            const int n_rows = s_need[un.n_levels - 1] + s_need[8 + un.n_levels - 1] + s_need[16 + un.n_levels - 1] + s_need[24 + un.n_levels - 1];
             level = un.n_levels - 1;
             for (int l = un.n_levels - 2; l >= 0; l--)
-                if (un.levels[l].r2_cap >= need_f) level = l;
+                if (8 * (s_need[l] + s_need[8 + l] + s_need[16 + l] + s_need[24 + l]) >= 7 * n_rows) level = l;
+            // ... but never a level at which this block's halo has outgrown the tile before (level_cap, see below)
+            // cap | floor << 4 | split << 7 (a block that met both keeps the floor)
+            level = max(min(level, (int)(level_fb & 15u)), (int)((level_fb >> 4) & 7u));
         }
         level = __builtin_amdgcn_readfirstlane(level);
         const GridLevel *lv = un.levels + level;
@@ -1247,13 +1286,23 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     const int ny_h = hy1 - hy0 + 1, nz_h = hz1 - hz0 + 1;
     // row slot = rz << ys | ry: 8 (y) x 16 (z) slots, or 16 x 8 for the blocks that straddle two columns of the source
     // order in y (a block that straddles in z as well, one in a few hundred, goes to the cleanup kernel)
+    // MULTI: any box of at most 128 rows, slot = rz * ny_h + ry (the blocks of surfaces — a wall's 9 x 9 rows, a ground
+    // plane's 18 x 3 — fit neither power-of-two shape): the lane -> (ry, rz) split is a multiplication by a reciprocal
+    // that is exact for slots below 128 (slot * ny_h < 2^16), the run bases a multiplication by the uniform ny_h.
     const int ys = (ny_h <= 8) ? 3 : 4;
-    const bool shape_ok = hx0 <= hx1 && ny_h >= 1 && nz_h >= 1 && ny_h <= 16 && nz_h <= (kRows >> ys);
+    const int yw = MULTI ? max(ny_h, 1) : (1 << ys);  // slots per z step
+    const bool shape_ok = MULTI ? (hx0 <= hx1 && ny_h >= 1 && nz_h >= 1 && ny_h <= kRows && ny_h * nz_h <= kRows)
+                                : (hx0 <= hx1 && ny_h >= 1 && nz_h >= 1 && ny_h <= 16 && nz_h <= (kRows >> ys));
     // lane l owns halo row slots l (A) and l + 64 (B): global begin, length; LDS offsets from a scan of A + B
     int gbA, lenA, gbB, lenB;
     {
         const int ymask = (1 << ys) - 1;
-        const int ryA = lane & ymask, rzA = lane >> ys, ryB = (lane + 64) & ymask, rzB = (lane + 64) >> ys;
+        int ryA = lane & ymask, rzA = lane >> ys, ryB = (lane + 64) & ymask, rzB = (lane + 64) >> ys;
+        if constexpr (MULTI) {
+            const unsigned magic = 65536u / (unsigned)yw + 1u;  // floor(s / yw) = (s * magic) >> 16 for s < 128, yw <= 128
+            rzA = (int)(((unsigned)lane * magic) >> 16), rzB = (int)(((unsigned)(lane + 64) * magic) >> 16);
+            ryA = lane - rzA * yw, ryB = lane + 64 - rzB * yw;
+        }
         const bool hasA = shape_ok && ryA < ny_h && rzA < nz_h, hasB = shape_ok && ryB < ny_h && rzB < nz_h;
         const int baseA = ((hz0 + rzA) * g.n[1] + hy0 + ryA) * g.n[0], baseB = ((hz0 + rzB) * g.n[1] + hy0 + ryB) * g.n[0];
         gbA = cell_start[(unsigned)(hasA ? baseA + hx0 : 0)];
@@ -1291,6 +1340,22 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         // the cleanup kernel redoes this workgroup's queries (this launch): entry = grid index * 4 + half — or, when the
         // unanswered rows are listed, nn_wide_kernel searches them (marked unsearched)
         if (tid == 0) ovf_list[atomicAdd(ovf_count, 1u)] = (int)blockIdx.x * 4 + half;
+        if constexpr (MULTI) {  // from the next launch on this block searches a finer level (more short rows, but a halo that fits)
+            // (level_cap[bid] = cap | floor << 4.  A halo too LARGE for the tile: a finer level next time, i.e. more short
+            //  rows but a halo that fits; a halo of too many ROWS — a surface seen at too fine a level — a coarser one)
+            if (tid == 0 && un.level_cap != nullptr) {
+                const unsigned cf = level_fb;
+                unsigned cap = cf & 15u, floor_ = (cf >> 4) & 7u, split_ = cf & 0x80u;
+                if (!shape_ok) floor_ = (unsigned)min(level + 1, un.n_levels - 1);
+                else if (!split_ && split.all_halves) split_ = 0x80u;  // first: the same level on two workgroups
+                else cap = (unsigned)max(level - 1, 0);                // a half still does not fit: a finer level
+                un.level_cap[bid] = (unsigned char)(cap | (floor_ << 4) | split_);
+            }
+            if (tid == 0 && un.level_dbg != nullptr) {
+                atomicAdd(un.level_dbg + level * kLevelDbgWords + 0, 1u);
+                atomicAdd(un.level_dbg + level * kLevelDbgWords + (shape_ok ? 2 : 1), 1u);
+            }
+        }
         if (valid) cnt[i] = -1;
         if constexpr (FTM == -2)  // (a launch that folds K23 in never lists: the cleanup role redoes its hand-overs)
             if (un.list != nullptr) list_rows(valid);
@@ -1336,13 +1401,26 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
                     s_z[d] = cz[u];
                     s_rowid[d] = (unsigned char)sr[u];
                 }
-                for (int k = lane + 64; k < sl[u]; k += 64) {  // rows longer than a wave (dense data)
-                    const float4 t = tgt[sg[u] + k];
-                    const int d = so[u] + k;
-                    s_x[d] = t.x;
-                    s_y[d] = t.y;
-                    s_z[d] = t.z;
-                    s_rowid[d] = (unsigned char)sr[u];
+                // rows longer than a wave (dense data): four more loads in flight per trip (one at a time each 64 points
+                // cost a memory round trip of their own)
+                for (int k0 = 64; k0 < sl[u]; k0 += 256) {
+                    float tx[4], ty[4], tz[4];
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const float *gp = reinterpret_cast<const float *>(tgt + sg[u] + min(k0 + 64 * v + lane, sl[u] - 1));
+                        tx[v] = gp[0], ty[v] = gp[1], tz[v] = gp[2];
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const int k = k0 + 64 * v + lane;
+                        if (k < sl[u]) {
+                            const int d = so[u] + k;
+                            s_x[d] = tx[v];
+                            s_y[d] = ty[v];
+                            s_z[d] = tz[v];
+                            s_rowid[d] = (unsigned char)sr[u];
+                        }
+                    }
                 }
             }
         }
@@ -1369,11 +1447,11 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         // arbitrary runs.  25-comparator network (0/1 principle), a comparator is a v_max_u32 / v_min_u32 pair.
         unsigned key[9];
         {
-            const char *gbo_c = reinterpret_cast<const char *>(s_gbo) + 4 * ((qc.cz - hz0) * (1 << ys) + (qc.cy - hy0));
+            const char *gbo_c = reinterpret_cast<const char *>(s_gbo) + 4 * ((qc.cz - hz0) * yw + (qc.cy - hy0));
 #pragma unroll
             for (int k = 0; k < 9; k++) {
                 const int rl = re[k] - rb[k];
-                const int start = rb[k] - *reinterpret_cast<const int *>(gbo_c + 4 * ((k / 3 - 1) * (1 << ys) + (k % 3 - 1)));
+                const int start = rb[k] - *reinterpret_cast<const int *>(gbo_c + 4 * ((k / 3 - 1) * yw + (k % 3 - 1)));
                 key[k] = rl > 0 ? ((unsigned)rl << 16) | (unsigned)(start << 2) : 0u;
             }
             constexpr int net[25][2] = {{0, 3}, {1, 7}, {2, 5}, {4, 8}, {0, 7}, {2, 4}, {3, 8}, {5, 6}, {0, 2},
@@ -1537,6 +1615,20 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     }
     if constexpr (FTM == -2)
         if (un.list != nullptr) list_rows(valid && (unanswered || (n < un.m_list && (!MULTI || r2 < un.r2_full))));
+    if constexpr (MULTI) {
+        if (un.level_dbg != nullptr) {
+            const int n_short = __popcll(__ballot(valid && (unanswered || (n < un.m_list && r2 < un.r2_full))));
+            const int n_valid = __popcll(__ballot(valid));
+            if (lane == 0) {
+                atomicAdd(un.level_dbg + level * kLevelDbgWords + 3, (unsigned)n_short);
+                atomicAdd(un.level_dbg + level * kLevelDbgWords + 5, (unsigned)n_valid);
+                if (wave == 0) {
+                    atomicAdd(un.level_dbg + level * kLevelDbgWords + 0, 1u);
+                    atomicAdd(un.level_dbg + level * kLevelDbgWords + 4, (unsigned)total);
+                }
+            }
+        }
+    }
     stamp(5);
     if constexpr (FTM != -2) {
         // ---- K23 for this row, from LDS: weights at fm.P, the row's share of the 19 moments ----------------------
