@@ -85,8 +85,13 @@ void launch_tile(TileLaunch &t)
                 done = true;
             }
         }
+        // (32-slot lists with the steady-state halo capacity — 39.4 KB, four workgroups per CU, one residency round for a
+        //  200k-point cloud instead of two — were measured: K1 145 -> 128 us on the LiDAR-like scene, 118 -> 92 us on the
+        //  slab, but 30-80 % more rows in nn_wide_kernel (more blocks outgrow the smaller tile and cascade): 4.09 k against
+        //  3.99 k and 4.17 k against 4.47 k it/s.  The large tile stays.)
+        constexpr int CAPM = CAP;
         if (!done)
-            nn_fast_kernel<M, C, CAP, false, -2, true><<<grid_multi, 256, 0, t.stream>>>(t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr,
+            nn_fast_kernel<M, C, CAPM, false, -2, true><<<grid_multi, 256, 0, t.stream>>>(t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr,
                                                                                          t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,
                                                                                          t.ovf_next, two_per_block, nullptr, fm_none, lr, un);
         steady = true;  // (skips the single-level launches below)

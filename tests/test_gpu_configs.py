@@ -274,6 +274,22 @@ def test_cli_default_shape_through_align(scene):
         c.set_target(tgt)
         c.set_source(src)
         res = c.align(4, cost_drop_thresh=0.0, inner_steps=100, f_tol=10e-6)
+        # both scenes have a dense tail: the target is binned at several resolutions and the blocks pick their level
+        lv = c.debug_levels()
+        assert lv["levels"] >= 3 and 0 < lv["base"] < lv["levels"] - 1, lv
+        rp, col, _ = c.get_association(want_d2=False)
+    # the association the multi-level search left equals the single-level one's, neighbour for neighbour
+    with _lib.Context(0) as c1:
+        c1.set_option("levels", 0)
+        c1.set_params(3.0, 20, 5.0, 3)
+        c1.set_target(tgt)
+        c1.set_source(src)
+        res1 = c1.align(4, cost_drop_thresh=0.0, inner_steps=100, f_tol=10e-6)
+        assert c1.debug_levels()["levels"] == 1
+        rp1, col1, _ = c1.get_association(want_d2=False)
+    np.testing.assert_array_equal(rp, rp1)
+    np.testing.assert_array_equal(col, col1)
+    np.testing.assert_allclose(res["history"], res1["history"], rtol=0, atol=1e-9)
     ora = po.align(src, tgt, 3.0, 20, 5.0, 4, cost_drop_thresh=0.0, inner_max_steps=100, f_tol=10e-6)
     assert res["n_iter"] == ora["n_iter"] == 4
     np.testing.assert_array_equal(res["inner_steps"], ora["inner_steps"])
