@@ -145,7 +145,8 @@ def k1_instantiation(cfg, inner_steps, two_pass, fused=True):
         elif vpd == int(vpd) and 1 <= vpd <= 64:
             ftm = -3
     c, cap = (16, 1728) if steady else ((32, 2240) if width <= 24 else (48, 2048))
-    return f"nn_fast_kernel<{width}, {c}, {cap}, false, {ftm}>"
+    multi = "scene" in cfg   # (clouds with a dense tail: the multi-level instantiation)
+    return f"nn_fast_kernel<{width}, {c}, {cap}, false, {ftm}, {'true' if multi else 'false'}>"
 
 
 def effective_cores():
@@ -566,7 +567,7 @@ def run_rank(a):
                            "kernel": kname + (": first pass of a two-pass radius search (rows that come back short go to "
                                               "nn_wide_kernel; K23 is its own kernel)" if two_pass else
                                               ": K1 with the previous iteration's source move in its prologue" +
-                                              (" and K23 (weights + 19 moments) folded in" if not kname.endswith("-2>") else "")),
+                                              (" and K23 (weights + 19 moments) folded in" if ", -2, " not in kname else "")),
                            "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": traffic_source,

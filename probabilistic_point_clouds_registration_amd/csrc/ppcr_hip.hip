@@ -576,15 +576,15 @@ void release_levels(ppcr_ctx *c)
     c->extra_levels.clear();
     c->n_levels = 1, c->base_level = 0, c->finest_extra = -1;
 }
-int build_levels(ppcr_ctx *c, bool bounded)
+int build_levels(ppcr_ctx *c, bool bounded, const double *known_p99 = nullptr)
 {
     release_levels(c);
     const int n = (int)c->nt;
     if (!bounded || c->opt_two_pass != 1 || c->opt_levels == 0 || n <= 0) return PPCR_OK;
     std::vector<double> finer, coarser;
     {
-        double occ = 0, occ99 = 0;
-        PPCR_TRY(grid_occupancy(c, &occ, &occ99));
+        double occ = 0, occ99 = known_p99 ? *known_p99 : 0.0;
+        if (!known_p99) PPCR_TRY(grid_occupancy(c, &occ, &occ99));
         const double cap = 0.1 * c->opt_first_pass_occ, q_want = std::max(target_occupancy(c->max_nb, cap, 0.1 * c->opt_first_pass_fill), 1.0);
         // (halving the edge divides a cell's count by eight; the histogram saturates at kOccBins - 1 = 255 points per cell:
         //  one finer level from 4 x the aim, two from 16 x)
@@ -672,20 +672,24 @@ int ensure_grid(ppcr_ctx *c)
         const double per_cell = (double)n * c->radius * c->radius * c->radius / vol;
         search = c->opt_two_pass >= 2 ? c->radius / c->opt_two_pass : choose_search_radius(c->radius, per_cell, c->max_nb, 0.1 * c->opt_first_pass_occ, 0.1 * c->opt_first_pass_fill);
     }
+    bool have_occ = false;
+    double occ_p99 = 0;
     for (int attempt = 0;; attempt++) {
         c->search_radius = search;
         c->reach = search < c->radius ? std::min(kMaxReach, (int)std::ceil(c->radius / search - 1e-9)) : 1;
         make_grid_desc(n, c->tgt_lo, c->tgt_hi, c->search_radius, c->opt_grid_xf, c->grid);
         PPCR_TRY(sort_by_cell(c, c->grid, c->tgt_raw.p, n, c->tgt_sorted.p, &c->cell_start));
+        have_occ = false;
         if (!(bounded && c->opt_two_pass == 1) || attempt == 2 || search <= c->radius / kMaxReach) break;
         double q_here = 0;  // points per cell (edge ~search) where the dense part of the cloud lives
-        PPCR_TRY(grid_occupancy(c, &q_here));
+        PPCR_TRY(grid_occupancy(c, &q_here, &occ_p99));
+        have_occ = true;  // (of the grid as it stands: build_levels need not measure it again)
         const double cap = 0.1 * c->opt_first_pass_occ, q_want = target_occupancy(c->max_nb, cap, 0.1 * c->opt_first_pass_fill);
         if (q_here <= 1.5 * std::max(q_want, cap)) break;  // close enough: keep this grid
         // the points live in fuller cells than the bounding box suggested (a cloud that does not fill its box)
         search = std::max(search * std::cbrt(q_want / q_here), c->radius / kMaxReach);
     }
-    PPCR_TRY(build_levels(c, bounded));
+    PPCR_TRY(build_levels(c, bounded, have_occ ? &occ_p99 : nullptr));
     c->grid_valid = true;
     c->grid_radius = c->radius;
     c->grid_max_nb = c->max_nb;
@@ -1759,6 +1763,12 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
     }
     if (std::strcmp(key, "short_lists") == 0) {
         c->opt_short_lists = value ? 1 : 0;
+        return PPCR_OK;
+    }
+    if (std::strcmp(key, "debug_mbox_seq") == 0) {  // TEST HOOK: continue the handle's sequence numbers from `value` (nothing in flight)
+        if (value < 0) return fail(c, PPCR_ERR_INVALID, "debug_mbox_seq must be >= 0");
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->mbox_seq = (unsigned)value;
         return PPCR_OK;
     }
     if (std::strcmp(key, "level_stats") == 0) {  // diagnostic: cumulative per-level counters (ppcr_debug_get_levels); setting it clears them

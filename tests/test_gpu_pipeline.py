@@ -255,3 +255,25 @@ def test_align_many_paces_inner_loops_on_the_device():
         finally:
             for c in ctxs:
                 c.close()
+
+
+def test_sequence_numbers_far_into_a_handles_life():
+    """A pooled handle's sequence numbers grow by one per fold for days.  (i) Past 2^29 the product seq * kMaxDevSteps that
+    orders the device-paced IRLS steps no longer fits 32 bits (it is a 64-bit word now: with the 32-bit one a later step
+    could start before the previous one had solved); (ii) past 2^30 the next source upload restarts everything stamped
+    with sequence numbers from zero.  Both must leave a registration with an inner loop exactly what a fresh handle gives."""
+    src, tgt, _, _ = synth.make_pair(30_000, cfg=2)
+    kw = dict(cost_drop_thresh=0.0, inner_steps=30, f_tol=1e-7)
+    with _lib.Context(0) as c:
+        c.set_params(1.0, 10, 5.0, 3)
+        c.set_target(tgt)
+        c.set_source(src)
+        fresh = c.align(6, **kw)
+        assert max(fresh["inner_steps"]) >= 3          # (the device walks several steps per iteration)
+        for start in ((1 << 29) + 11, (1 << 30) + 7, 0x7FFFFF00):
+            c.set_option("debug_mbox_seq", start)
+            c.set_source(src)                          # (past 2^30: restarts the sequence numbers)
+            again = c.align(6, **kw)
+            np.testing.assert_array_equal(again["inner_steps"], fresh["inner_steps"])
+            np.testing.assert_array_equal(again["history"], fresh["history"])
+            np.testing.assert_array_equal(again["costs"], fresh["costs"])

@@ -11,7 +11,7 @@ def short(name):
     name = re.sub(r"\(.*", "", name).replace("void ", "").replace("ppcr::dev::", "")
     if "rocprim" in name:
         return "rocprim"
-    return name[:40]
+    return name[:64]
 
 
 def main(dirs):
