@@ -1194,3 +1194,61 @@ def test_lds_stores_beyond_the_allocation_are_dropped(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "corrupted words 0, non-zero out-of-range reads 0" in r.stdout, r.stdout
+
+
+def test_randomised_multi_level_soak():
+    """Seeded random sweep aimed at the multi-level search (GridLevel, nn_fast_kernel<..., MULTI>): targets whose density
+    varies a hundredfold and more — a sparse box with a density gradient, dense Gaussian blobs, a thin plane — searched with
+    radii that hold many times max_neighbours points; the source moves between associations and keeps its cut-offs
+    (defer_moves), so from the second association on every block picks its level, blocks split, go finer and coarser.
+    Neighbour sets and float d2 equal the oracle's, bit for bit, at every step; the counters prove that blocks did search
+    levels other than the base."""
+    rng = np.random.default_rng(int(os.environ.get("PPCR_SOAK_SEED", "31337")))
+    off_base_rows, multi_trials = 0, 0
+    trials = int(os.environ.get("PPCR_SOAK_TRIALS", "8"))
+    for trial in range(trials):
+        nt = int(rng.integers(30000, 90000))
+        ext = np.array([rng.uniform(20, 60), rng.uniform(15, 40), rng.uniform(4, 20)])
+        u = rng.beta(2.0, float(rng.uniform(2.0, 6.0)), size=nt)            # density gradient along x
+        tgt = np.stack([u * ext[0], rng.uniform(0, ext[1], nt), rng.uniform(0, ext[2], nt)], axis=1)
+        for _ in range(int(rng.integers(1, 5))):                             # blobs far denser than the rest
+            k = int(rng.integers(1500, 8000))
+            tgt[rng.integers(0, nt, size=k)] = rng.uniform(0.1, 0.9, size=3) * ext + rng.normal(0, rng.uniform(0.1, 0.8), size=(k, 3))
+        if trial % 2 == 0:                                                   # a thin, densely sampled plane (a wall)
+            k = int(rng.integers(3000, 12000))
+            wall = np.stack([np.full(k, rng.uniform(0.2, 0.8) * ext[0]), rng.uniform(0, ext[1], k) * 0.5, rng.uniform(0, ext[2], k)], axis=1)
+            tgt[rng.integers(0, nt, size=k)] = wall + rng.normal(0, 0.01, size=(k, 3))
+        tgt = (tgt + rng.uniform(-100, 100, size=3) * rng.choice([0.0, 1.0])).astype(np.float32)
+        if trial % 4 == 3:
+            tgt = (np.round(tgt * 16) / 16).astype(np.float32)               # exact ties
+        ns = int(rng.integers(8000, 30000))
+        src = (tgt[rng.integers(0, nt, size=ns)] + rng.normal(0, rng.choice([0.005, 0.05]), size=(ns, 3))).astype(np.float32)
+        radius = float(rng.uniform(1.0, 3.5))
+        m = int(rng.choice([5, 10, 10, 16, 20, 20, 32]))
+        with _lib.Context(0) as c:
+            c.set_option("defer_moves", 1)
+            c.set_params(radius, m, 5.0, 3)
+            c.set_target(tgt)
+            c.set_source(src)
+            cur = src.copy()
+            for step in range(6):
+                if step == 1:
+                    c.set_option("level_stats", 1)
+                c.associate()
+                rp, col, d2 = c.get_association()
+                orp, ocol, od2 = po.radius_search(cur, tgt, radius, m, method=1)
+                tag = f"trial {trial} step {step} (nt {nt} ns {ns} r {radius:.3f} m {m})"
+                np.testing.assert_array_equal(rp, orp, err_msg=tag)
+                np.testing.assert_array_equal(col, ocol, err_msg=tag)
+                np.testing.assert_array_equal(d2, od2, err_msg=tag)
+                T = np.eye(4)
+                T[:3, :3] = synth.rodrigues(rng.normal(size=3), float(rng.choice([0.0, 0.002, 0.01])))
+                T[:3, 3] = rng.normal(0, float(rng.choice([0.0, 0.005, 0.05])), size=3)
+                c.apply_transform(T)
+                po.transform_cloud(cur, T)
+            lv = c.debug_levels()
+            if lv["levels"] > 1:
+                multi_trials += 1
+                off_base_rows += sum(p["rows"] for k, p in enumerate(lv["per_level"]) if k != lv["base"])
+    assert multi_trials >= trials // 2, multi_trials
+    assert off_base_rows > 10000, off_base_rows
