@@ -937,7 +937,8 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
             if (c->opt_stamps) {
                 // sized from the grid this launch really has (the steady-state variant adds kMaxSplit workgroups in front):
                 // 8 words per wave, then one word per lane (its sorted run lengths)
-                const size_t nwg = (size_t)std::max(nblocks(ns, 256) + kMaxSplit, k1_steady_slots(c));
+                // (a multi-level search launches two workgroups per block; the reader sums the records of exactly this grid)
+                const size_t nwg = c->n_levels > 1 ? (size_t)steady_grid(nblocks(ns, 256), true) : (size_t)std::max(nblocks(ns, 256) + kMaxSplit, k1_steady_slots(c));
                 const size_t nst = (nwg * (kBlock / 64) + 64) * 8 + nwg * 256;
                 if (c->d_stamps.cap < nst) {
                     HIP_TRY(c, hipStreamSynchronize(c->stream));

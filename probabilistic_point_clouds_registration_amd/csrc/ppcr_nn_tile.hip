@@ -77,8 +77,24 @@ void launch_tile(TileLaunch &t)
         const SplitTable two_per_block{nullptr, nullptr, nullptr, nullptr, 0, INT_MAX, 1};
         const int grid_multi = steady_grid(nb, true);
         bool done = false;
+        if constexpr (M == 10) {  // diagnostic builds (option stamps): per-phase cycle counts of the multi-level kernel
+            if (st && t.dm2_in && t.short_lists) {
+                nn_fast_kernel<M, 16, kCapSteady, true, -2, true><<<grid_multi, 256, 0, t.stream>>>(
+                    t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
+                    two_per_block, st, fm_none, lr, un);
+                done = true;
+            }
+        }
+        if constexpr (M == 10 || M == 20) {
+            if (st && !done) {
+                nn_fast_kernel<M, C, CAP, true, -2, true><<<grid_multi, 256, 0, t.stream>>>(
+                    t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
+                    two_per_block, st, fm_none, lr, un);
+                done = true;
+            }
+        }
         if constexpr (M <= 12) {
-            if (t.dm2_in && t.short_lists) {
+            if (!done && t.dm2_in && t.short_lists) {
                 nn_fast_kernel<M, 16, kCapSteady, false, -2, true><<<grid_multi, 256, 0, t.stream>>>(
                     t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
                     two_per_block, nullptr, fm_none, lr, un);

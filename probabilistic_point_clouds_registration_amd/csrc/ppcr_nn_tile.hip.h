@@ -996,47 +996,6 @@ struct UnansweredRows {
 // K23 into this kernel: each lane finishes its row's
 // contribution to the 19 moments from the winners' coordinates while they are still in LDS (no neighbour gathers, no
 // second pass over the source, no K23 launch) and the workgroup folds them into fm.partials.  FTM = -2: plain K1.
-// The kernel's argument block as the ABI lays it out (same members, same order): late_args() reads arguments that are
-// only needed at the kernel's END — the output arrays, the folded-in moments' pose and model — from the kernarg segment
-// at that point.  As plain parameters the compiler loads them at the kernel's top and, out of scalar registers (106 in
-// use), parks them in VGPR lanes: 24 v_writelane + 51 v_readlane per wave in the folded instantiation.
-#ifndef PPCR_LATE_ARGS
-#define PPCR_LATE_ARGS 1
-#endif
-struct FastKernelArgs {
-    float4 *src;
-    int ns;
-    const float4 *tgt0;
-    const int *cell_start0;
-    GridDesc g0;
-    float r2_0;
-    int m;
-    int *nbr;
-    int *cnt;
-    PendingMove pm;
-    unsigned *dm2;
-    int dm2_valid;
-    int *ovf_list;
-    unsigned *ovf_count;
-    unsigned *ovf_count_next;
-    SplitTable split;
-    unsigned long long *stamps;
-    FusedMoments fm;
-    LoopReset lr;
-    UnansweredRows un;
-};
-__device__ __forceinline__ const FastKernelArgs *late_args()
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    // (the segment pointer lives in the constant address space; as an integer and back it is an ordinary pointer)
-    const FastKernelArgs *ka = (const FastKernelArgs *)(__UINTPTR_TYPE__)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka));  // (opaque from here on: loads through it cannot be hoisted above this point)
-    return ka;
-#else
-    return nullptr;  // (host pass: never called)
-#endif
-}
-
 // MULTI: the grid is chosen per workgroup from un.levels (GridLevel): tgt / cell_start / g / r2 of the arguments are the
 // base level's and only used by the first association (no cut-offs yet: every block searches the base level).
 template <int M, int C, int CAP, bool STAMPS, int FTM = -2, bool MULTI = false>
@@ -1639,14 +1598,8 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         if (lane == 0 && atomicExch(&s_bail, 1) == 0) ovf_list[atomicAdd(ovf_count, 1u)] = (int)blockIdx.x * 4 + half;
         n = max(n, 0);
     }
-#if PPCR_LATE_ARGS
-    const FastKernelArgs *const ka = late_args();
-    int *const nbr_l = ka->nbr, *const cnt_l = ka->cnt;
-#else
-    int *const nbr_l = nbr, *const cnt_l = cnt;
-#endif
     if (valid) {
-        int *out = nbr_l + i;
+        int *out = nbr + i;
         for (int j = 0; j < n; j++) {
             int pos = L.pos_of(L.load(j));
             if constexpr (MULTI)
@@ -1657,7 +1610,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         // MULTI: a row that found fewer than m inside a level's radius is final only when that radius is the full one;
         // elsewhere it goes to nn_wide_kernel, marked unsearched (its count says nothing about the base level's radius)
         const bool short_here = MULTI && n < un.m_list && r2 < un.r2_full && to_base != nullptr;
-        cnt_l[i] = (unanswered || short_here) ? -1 : n;
+        cnt[i] = (unanswered || short_here) ? -1 : n;
         dm2[i] = tm;
     }
     if constexpr (FTM == -2)
@@ -1682,29 +1635,24 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         RowAcc acc;
 #pragma unroll
         for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
-#if PPCR_LATE_ARGS
-        const FusedMoments &fml = ka->fm;
-#else
-        const FusedMoments &fml = fm;
-#endif
         if (valid && n > 0) {
             double xr[3];
-            rotated_point(fml.P, q, xr);
+            rotated_point(fm.P, q, xr);
             RowMoments<FTM> row;
-            row.begin(fml.md);
+            row.begin(fm.md);
 #pragma unroll
             for (int j = 0; j < M; j++) {
                 if (j < n) {  // nearly every row is full: the branch is uniform for most waves
                     const float4 y = L.get(L.load(j));
-                    row.add_pair(fml.md, xr, y.x, y.y, y.z);
+                    row.add_pair(fm.md, xr, y.x, y.y, y.z);
                 }
             }
-            row.finish(acc, fml.P, q, xr);
+            row.finish(acc, fm.P, q, xr);
         }
         __syncthreads();  // every wave is through with the halo: the fold borrows its memory
         double *const scratch = reinterpret_cast<double *>(s_halo);
         // a block that was handed to the cleanup kernel (s_bail) leaves its slot to that kernel
-        block_reduce_scratch(acc, scratch, scratch + 10 * 257, fml.partials + blockIdx.x, (size_t)fml.nslots, s_bail == 0);
+        block_reduce_scratch(acc, scratch, scratch + 10 * 257, fm.partials + blockIdx.x, (size_t)fm.nslots, s_bail == 0);
         stamp(6);
     }
     flush_stamps();
