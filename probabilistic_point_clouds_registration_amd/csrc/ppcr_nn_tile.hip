@@ -6,6 +6,8 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "ppcr_nn_tile.hip.h"
@@ -31,9 +33,43 @@ using namespace ppcr::dev;
 // whether it was — the partials then have one slot per fast-kernel workgroup (nb + kMaxSplit).
 // t.fold (with fuse, steady-state variant only): when given, the fold-and-solve step rides in the cleanup launch and
 // t.merged tells whether it did.
+// PPCR_LIST_NOCLAMP: every instantiation of nn_fast_kernel this unit can launch must own exactly FastLds::kBytes of LDS
+// (see FastLds).  Checked once per process and list width; a mismatch is a build defect, not a run-time condition: abort.
+template <int M, int C, int CAP, bool STAMPS, int FTM, bool MULTI>
+bool fast_kernel_lds_ok()
+{
+#if PPCR_LIST_NOCLAMP
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&nn_fast_kernel<M, C, CAP, STAMPS, FTM, MULTI>)) != hipSuccess) return false;
+    return (int)attr.sharedSizeBytes == FastLds<C, CAP, MULTI>::kBytes;
+#else
+    return true;
+#endif
+}
+template <int M>
+void check_fast_kernel_lds()
+{
+    static const bool ok = [] {
+        constexpr int C = (M <= 24) ? 32 : 48;
+        constexpr int CAP = (M <= 24) ? 2240 : 2048;
+        bool good = fast_kernel_lds_ok<M, C, CAP, false, -2, false>() && fast_kernel_lds_ok<M, C, CAP, false, -2, true>();
+        if constexpr (M <= 12)
+            good = good && fast_kernel_lds_ok<M, 16, kCapSteady, false, -2, false>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, 8, false>() &&
+                   fast_kernel_lds_ok<M, 16, kCapSteady, false, 0, false>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, -3, false>() &&
+                   fast_kernel_lds_ok<M, 16, kCapSteady, false, -2, true>();
+        return good;
+    }();
+    if (!ok) {
+        std::fprintf(stderr, "libppcr_hip: nn_fast_kernel<%d, ...> owns LDS besides its FastLds allocation: the unclamped list stores "
+                             "would overwrite it (build defect)\n", M);
+        std::abort();
+    }
+}
+
 template <int M>
 void launch_tile(TileLaunch &t)
 {
+    check_fast_kernel_lds<M>();
     unsigned long long *const st = t.stamps;
     constexpr int C = (M <= 24) ? 32 : 48;
     constexpr int CAP = (M <= 24) ? 2240 : 2048;

@@ -996,6 +996,18 @@ struct UnansweredRows {
 // K23 into this kernel: each lane finishes its row's
 // contribution to the 19 moments from the winners' coordinates while they are still in LDS (no neighbour gathers, no
 // second pass over the source, no K23 launch) and the workgroup folds them into fm.partials.  FTM = -2: plain K1.
+// The ONE LDS allocation of nn_fast_kernel (PPCR_LIST_NOCLAMP): halo (x[], y[], z[], row bytes), row table, boxes, flags, and
+// LAST the lists — the unclamped stores of the scan rely on nothing of the workgroup's lying behind them.  The host checks
+// the compiled kernels' static LDS size against kBytes before the first launch (check_fast_kernel_lds): a __shared__
+// variable that slipped into the kernel some other way would sit behind the list and be overwritten silently.
+template <int C, int CAP, bool MULTI>
+struct FastLds {
+    static constexpr int kHaloBytes = (3 * CAP + CAP / 4) * 4, kListBytes = (C + 1) * 256 * 2;
+    static constexpr int kOffGbo = kHaloBytes, kOffBox = kOffGbo + 128 * 4, kOffBail = kOffBox + 4 * 6 * 4, kOffNeed = kOffBail + 4,
+                         kOffList = (kOffNeed + (MULTI ? 4 * 8 * 4 : 0) + 15) & ~15;
+    static constexpr int kBytes = kOffList + kListBytes;
+};
+
 // MULTI: the grid is chosen per workgroup from un.levels (GridLevel): tgt / cell_start / g / r2 of the arguments are the
 // base level's and only used by the first association (no cut-offs yet: every block searches the base level).
 template <int M, int C, int CAP, bool STAMPS, int FTM = -2, bool MULTI = false>
@@ -1027,10 +1039,11 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     // tests/test_gpu_parity.py builds and runs) — the scan stores at its cursor without clamping it to the list's end:
     // two v_min_u32 less on a 22-VALU trip (2508 -> 2427 VALU per wave, +1.6 % iterations/s; -DPPCR_LIST_NOCLAMP=0 is
     // the clamped form with separate arrays).
-    constexpr int kHaloBytes = (3 * CAP + CAP / 4) * 4, kListBytes = (C + 1) * BLOCK * 2;
-    constexpr int kOffGbo = kHaloBytes, kOffBox = kOffGbo + kRows * 4, kOffBail = kOffBox + kWaves * 6 * 4, kOffNeed = kOffBail + 4,
-                  kOffList = (kOffNeed + (MULTI ? kWaves * 8 * 4 : 0) + 15) & ~15;
-    __shared__ __attribute__((aligned(16))) unsigned char s_all[kOffList + kListBytes];
+    using Lds = FastLds<C, CAP, MULTI>;
+    constexpr int kListBytes = Lds::kListBytes, kOffGbo = Lds::kOffGbo, kOffBox = Lds::kOffBox, kOffBail = Lds::kOffBail,
+                  kOffNeed = Lds::kOffNeed, kOffList = Lds::kOffList;
+    static_assert(BLOCK == 256 && kWaves == 4 && kRows == 128, "FastLds mirrors these");
+    __shared__ __attribute__((aligned(16))) unsigned char s_all[Lds::kBytes];
     float *const s_halo = reinterpret_cast<float *>(s_all);
     int *const s_gbo = reinterpret_cast<int *>(s_all + kOffGbo);
     int(*const s_box)[6] = reinterpret_cast<int(*)[6]>(s_all + kOffBox);
