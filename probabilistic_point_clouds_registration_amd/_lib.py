@@ -380,11 +380,11 @@ class Context:
     def debug_levels(self):
         """ppcr_debug_get_levels (diagnostic; option level_stats): per level of a multi-level search
         {radius, blocks, handed_over_shape, handed_over_size, short_rows, staged, rows}, cumulative."""
-        buf = (C.c_uint * 64)()
+        buf = (C.c_uint * 128)()
         f = self._L.ppcr_debug_get_levels
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         f.restype = C.c_int
-        self._ck(f(self._h, buf, 64))
+        self._ck(f(self._h, buf, 128))
         n, base = int(buf[0]), int(buf[1])
         keys = ("blocks", "handed_over_shape", "handed_over_size", "short_rows", "staged", "rows")
         return dict(levels=n, base=base, per_level=[dict(radius=buf[2 + 7 * l] / 1000.0, **{k: int(buf[3 + 7 * l + j]) for j, k in enumerate(keys)})

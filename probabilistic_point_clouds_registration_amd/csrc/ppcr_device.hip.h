@@ -39,7 +39,7 @@ struct GridDesc {
 
 // One resolution of the target's grid.  A cloud whose density varies a hundredfold has no single good cell size: where
 // it is dense a radius-sized cell holds hundreds of points (no LDS tile holds a block's halo), where it is sparse the m-th
-// neighbour lies several cells away.  The target is therefore binned at a few resolutions (cell edges a factor two
+// neighbour lies several cells away.  The target is therefore binned at several resolutions (cell edges a factor sqrt(2)
 // apart, each with its own sorted copy) and every 256-query block of K1 picks, per launch, the FINEST level whose 27-cell
 // stencil still covers the largest cut-off radius among its rows (nn_fast_kernel<..., MULTI>).
 struct GridLevel {
@@ -50,7 +50,7 @@ struct GridLevel {
     float r2_cap;           // largest search radius^2 this level's stencil covers, capped at the full radius^2
     int pad;
 };
-constexpr int kMaxLevels = 6;
+constexpr int kMaxLevels = 12;  // cell edges a factor sqrt(2) apart: a 45-fold range of cut-off radii
 constexpr int kLevelDbgWords = 6;  // diagnostic counters per level (UnansweredRows::level_dbg)
 
 struct Pose {  // y ~ R x + t ; c = fixed origin of the moments

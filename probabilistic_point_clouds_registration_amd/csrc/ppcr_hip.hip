@@ -145,10 +145,10 @@ struct ppcr_ctx {
     DevBuf<int> level_inv;
     DevBuf<unsigned> level_dbg;        // diagnostic counters of the multi-level search (option "level_stats")
     int opt_level_stats = 0;
-    DevBuf<unsigned char> level_cap;   // per 256-query block of the (sorted) source: the coarsest level it may pick
+    DevBuf<unsigned short> level_cap;  // per 256-query block of the (sorted) source: cap | floor << 4 | split << 8 (UnansweredRows::level_cap)
     bool level_cap_clean = false;      // ... all 0xFF for the current source order
     int n_levels = 1, base_level = 0, finest_extra = -1;  // finest_extra: index into extra_levels of the finest level (-1: the base is)
-    float level_r2_cap[kMaxLevels] = {0, 0, 0, 0, 0, 0};
+    float level_r2_cap[kMaxLevels] = {};
     int opt_levels = -1;               // -1 automatic (non-uniform clouds / radii that hold far more than max_neighbours), 0 one level
     double origin[3] = {0, 0, 0};
     bool origin_valid = false;
@@ -549,11 +549,11 @@ int grid_occupancy(ppcr_ctx *c, double *occ, double *occ_p99 = nullptr)
     for (int b = 0; b < kOccBins; b++) {
         run += hist[b];
         if (!have_median && 2 * run >= total) {
-            *occ = std::max((double)b - 1.0, 0.0);
+            *occ = std::max(occ_bin_value(b) - 1.0, 0.0);
             have_median = true;
         }
-        if (100 * run >= 99 * total) {  // the cell 99 % of the points do not exceed (saturates at kOccBins - 1)
-            if (occ_p99) *occ_p99 = std::max((double)b - 1.0, 0.0);
+        if (100 * run >= 99 * total) {  // the cell 99 % of the points do not exceed (bins of 16 above 255, saturating at ~4300)
+            if (occ_p99) *occ_p99 = std::max(occ_bin_value(b) - 1.0, 0.0);
             break;
         }
     }
@@ -563,7 +563,7 @@ int grid_occupancy(ppcr_ctx *c, double *occ, double *occ_p99 = nullptr)
 // The levels of a multi-level search around the base grid just built (GridLevel): COARSER ones — cell edges doubling up
 // to the full radius — when the radius reaches beyond the base cells (rows of sparse regions, whose m-th neighbour lies
 // farther out than the first-pass radius, are then answered by the tiled kernel on a coarser level instead of one row per
-// wave), FINER ones — edges halving, at most two — when 1 % of the points sit in cells far fuller than the first pass
+// wave), FINER ones — edges shrinking by sqrt(2), at most six — when 1 % of the points sit in cells far fuller than the first pass
 // aims at (dense blobs, the near field of a scan: blocks there pick a level whose halo fits the LDS tile).  A uniform
 // cloud searched with a radius of a few points' spacing keeps its single level, and with it every kernel it ran before.
 void release_levels(ppcr_ctx *c)
@@ -586,12 +586,14 @@ int build_levels(ppcr_ctx *c, bool bounded, const double *known_p99 = nullptr)
         double occ = 0, occ99 = known_p99 ? *known_p99 : 0.0;
         if (!known_p99) PPCR_TRY(grid_occupancy(c, &occ, &occ99));
         const double cap = 0.1 * c->opt_first_pass_occ, q_want = std::max(target_occupancy(c->max_nb, cap, 0.1 * c->opt_first_pass_fill), 1.0);
-        // (halving the edge divides a cell's count by eight; the histogram saturates at kOccBins - 1 = 255 points per cell:
-        //  one finer level from 4 x the aim, two from 16 x)
-        if (occ99 > 4.0 * q_want) finer.push_back(c->search_radius / 2);
-        if (occ99 > 16.0 * q_want) finer.push_back(c->search_radius / 4);
+        // (an edge shorter by sqrt(2) divides a cell's count by 2.83 in a volume but only by 2 on a SURFACE — and scans are
+        //  surfaces: one finer level per factor 2 of the 99th percentile above the aim, at most six.  That is where the
+        //  blocks of a scan's near field are, and a query there tests 9 h^2 rho candidates for the pi R^2 rho it needs; the
+        //  coarser levels, thinly populated, stay a factor two apart)
+        if (occ99 > 4.0 * q_want)  // (the dense tail that switches the levels on at all)
+            for (int k = 1; k <= 6 && occ99 > std::pow(2.0, k) * q_want; k++) finer.push_back(c->search_radius / std::pow(1.41421356, k));
     }
-    for (double s = c->search_radius; s < c->radius * (1.0 - 1e-9) && (int)coarser.size() < kMaxLevels - 3;) {
+    for (double s = c->search_radius; s < c->radius * (1.0 - 1e-9) && (int)(finer.size() + coarser.size()) < kMaxLevels - 1;) {
         s = std::min(2.0 * s, c->radius);
         coarser.push_back(s);
     }
@@ -906,7 +908,7 @@ int associate_impl(ppcr_ctx *c, const Mat3 *fuse_R = nullptr, const double *fuse
                 const size_t nbk = (size_t)nblocks(std::max(ns, 1), 256);
                 if (!c->level_cap_clean || c->level_cap.cap < nbk) {
                     HIP_TRY(c, c->level_cap.reserve(nbk));
-                    HIP_TRY(c, hipMemsetAsync(c->level_cap.p, 0x0F, nbk, c->stream));  // cap 15, floor 0
+                    HIP_TRY(c, hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(c->level_cap.p), 0x000F, nbk, c->stream));  // cap 15, floor 0, whole
                     c->level_cap_clean = true;
                 }
                 tl.level_cap = c->level_cap.p;

@@ -183,12 +183,14 @@ __global__ void cell_start_kernel(const unsigned *__restrict__ keys_sorted, int 
     for (int c = prev + 1; c <= cur; c++) cell_start[c] = i;
 }
 
-// Occupancy of the grid's WHOLE cells (x slices folded back) as the POINTS see it: hist[min(count, kOccBins - 1)] += count
+// Occupancy of the grid's WHOLE cells (x slices folded back) as the POINTS see it: hist[occ_bin(count)] += count
 // for every cell, i.e. how many points live in a cell of that many.  The host takes the median over the points — the
 // cell the typical row finds itself in (q + 1 for a uniform cloud of q points per cell; unmoved by a few blobs a hundred
 // times denser than the rest, which weighted means follow) — and sizes the first-pass search radius for THAT row: rows of
 // much sparser and much denser neighbourhoods are what the second pass is for.
-constexpr int kOccBins = 256;
+constexpr int kOccBins = 512;  // counts below 256 one per bin, above in steps of 16 (up to 4336 points per cell)
+__host__ __device__ inline int occ_bin(int cnt) { return cnt < 256 ? cnt : min(256 + (cnt - 256) / 16, kOccBins - 1); }
+__host__ inline double occ_bin_value(int b) { return b < 256 ? (double)b : 256.0 + 16.0 * (b - 256) + 8.0; }
 __global__ __launch_bounds__(kBlock) void cell_occupancy_kernel(const int *__restrict__ cell_start, GridDesc g, unsigned long long *__restrict__ hist)
 {
     __shared__ unsigned s_hist[kOccBins];
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void cell_occupancy_kernel(const int *__res
         const int cx = (int)(w - row * ncx);
         const long long base = row * g.n[0] + ((long long)cx << g.xr_shift);
         const int cnt = cell_start[base + g.xr] - cell_start[base];
-        if (cnt > 0) atomicAdd(&s_hist[min(cnt, kOccBins - 1)], (unsigned)cnt);
+        if (cnt > 0) atomicAdd(&s_hist[occ_bin(cnt)], (unsigned)cnt);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < kOccBins; b += kBlock)

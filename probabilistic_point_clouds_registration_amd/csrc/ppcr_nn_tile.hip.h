@@ -987,7 +987,7 @@ struct UnansweredRows {
     int n_levels, base_level;
     float r2_full;
     float r2_cap[kMaxLevels];  // the levels' r2_cap, by value (the level choice then needs no memory round trip of its own)
-    unsigned char *level_cap;  // per 256-query block: coarsest level it may pick | finest << 4 | split << 7 (feedback of halos that did not fit)
+    unsigned short *level_cap;  // per 256-query block: coarsest level it may pick | finest << 4 | split << 8 (feedback of halos that did not fit)
     unsigned *level_dbg;       // diagnostic (nullable): per level {blocks, handed over for the halo's shape, ... for its size,
                                //   short rows listed, staged candidates, rows}, cumulative (ppcr_debug_get_levels)
 };
@@ -1004,7 +1004,7 @@ template <int C, int CAP, bool MULTI>
 struct FastLds {
     static constexpr int kHaloBytes = (3 * CAP + CAP / 4) * 4, kListBytes = (C + 1) * 256 * 2;
     static constexpr int kOffGbo = kHaloBytes, kOffBox = kOffGbo + 128 * 4, kOffBail = kOffBox + 4 * 6 * 4, kOffNeed = kOffBail + 4,
-                         kOffList = (kOffNeed + (MULTI ? 4 * 8 * 4 : 0) + 15) & ~15;
+                         kOffList = (kOffNeed + (MULTI ? 4 * 16 * 4 : 0) + 15) & ~15;
     static constexpr int kBytes = kOffList + kListBytes;
 };
 
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     // then this one must touch nothing.  A uniform scalar load, tested below once the query load is in flight.
     const unsigned aborted = lr.st ? lr.st->abort : 0u;
     static_assert(C > M, "a re-scan must leave room in the list");
-    static_assert(kMaxLevels <= 8, "s_need holds eight counts per wave");
+    static_assert(kMaxLevels <= 16, "s_need holds sixteen counts per wave; the feedback word four bits per level index");
     static_assert(!MULTI || FTM == -2, "a multi-level search leaves rows to nn_wide_kernel: K23 is its own kernel");
     static_assert(FTM == -2 || (3 * CAP + CAP / 4) * 4 >= kFoldScratchBytes, "the final fold borrows the halo buffer");
     static_assert(CAP % 4 == 0 && CAP * 4 < 65536, "list entries are 16-bit byte offsets into the halo arrays");
@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     int2 *const s_rowtab = reinterpret_cast<int2 *>(s_list);
     __shared__ int s_box[kWaves][6];
     __shared__ int s_bail;
-    __shared__ int s_need[kWaves * 8];
+    __shared__ int s_need[kWaves * 16];
 #endif
     float *const s_x = s_halo, *const s_y = s_halo + CAP, *const s_z = s_halo + 2 * CAP;
     unsigned char *const s_rowid = reinterpret_cast<unsigned char *>(s_halo + 3 * CAP);
@@ -1102,12 +1102,12 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         half = halves_half((int)blockIdx.x);
         if constexpr (MULTI) {
             // multi-level searches launch the two-workgroups-per-block grid and use the second workgroup only for the
-            // blocks marked split (bit 7 of level_cap: their halo outgrew the tile at the level their cut-offs ask for;
+            // blocks marked split (bit 8 of level_cap: their halo outgrew the tile at the level their cut-offs ask for;
             // half a block's halo is ~60 % of the block's): everybody else's second workgroup leaves at once
             level_fb = un.level_cap != nullptr ? (unsigned)un.level_cap[bid] : 0x0Fu;
             // (the query is asked for in the same breath: which lanes are valid depends on the byte, the load need not wait for it)
             q_early = src[min(bid * BLOCK + tid, ns - 1)];
-            if (!(level_fb & 0x80u)) {
+            if (!(level_fb & 0x100u)) {
                 if (half == 2) return;
                 half = 0;
             }
@@ -1188,16 +1188,16 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
             for (int l = 0; l < kMaxLevels; l++) below[l] = __popcll(__ballot(valid && mine <= l));
             if (lane == 0) {
 #pragma unroll
-                for (int l = 0; l < kMaxLevels; l++) s_need[wave * 8 + l] = below[l];
+                for (int l = 0; l < kMaxLevels; l++) s_need[wave * 16 + l] = below[l];
             }
             lds_barrier();
-            const int n_rows = s_need[un.n_levels - 1] + s_need[8 + un.n_levels - 1] + s_need[16 + un.n_levels - 1] + s_need[24 + un.n_levels - 1];
+            const int n_rows = s_need[un.n_levels - 1] + s_need[16 + un.n_levels - 1] + s_need[32 + un.n_levels - 1] + s_need[48 + un.n_levels - 1];
             level = un.n_levels - 1;
             for (int l = un.n_levels - 2; l >= 0; l--)
-                if (8 * (s_need[l] + s_need[8 + l] + s_need[16 + l] + s_need[24 + l]) >= 7 * n_rows) level = l;
+                if (8 * (s_need[l] + s_need[16 + l] + s_need[32 + l] + s_need[48 + l]) >= 7 * n_rows) level = l;
             // ... but never a level at which this block's halo has outgrown the tile before (level_cap, see below)
-            // cap | floor << 4 | split << 7 (a block that met both keeps the floor)
-            level = max(min(level, (int)(level_fb & 15u)), (int)((level_fb >> 4) & 7u));
+            // cap | floor << 4 | split << 8 (a block that met both keeps the floor)
+            level = max(min(level, (int)(level_fb & 15u)), (int)((level_fb >> 4) & 15u));
         }
         level = __builtin_amdgcn_readfirstlane(level);
         const GridLevel *lv = un.levels + level;
@@ -1358,11 +1358,11 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
             //  rows but a halo that fits; a halo of too many ROWS — a surface seen at too fine a level — a coarser one)
             if (tid == 0 && un.level_cap != nullptr) {
                 const unsigned cf = level_fb;
-                unsigned cap = cf & 15u, floor_ = (cf >> 4) & 7u, split_ = cf & 0x80u;
+                unsigned cap = cf & 15u, floor_ = (cf >> 4) & 15u, split_ = cf & 0x100u;
                 if (!shape_ok) floor_ = (unsigned)min(level + 1, un.n_levels - 1);
-                else if (!split_ && split.all_halves) split_ = 0x80u;  // first: the same level on two workgroups
+                else if (!split_ && split.all_halves) split_ = 0x100u;  // first: the same level on two workgroups
                 else cap = (unsigned)max(level - 1, 0);                // a half still does not fit: a finer level
-                un.level_cap[bid] = (unsigned char)(cap | (floor_ << 4) | split_);
+                un.level_cap[bid] = (unsigned short)(cap | (floor_ << 4) | split_);
             }
             if (tid == 0 && un.level_dbg != nullptr) {
                 atomicAdd(un.level_dbg + level * kLevelDbgWords + 0, 1u);
