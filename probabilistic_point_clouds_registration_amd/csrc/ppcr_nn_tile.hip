@@ -53,6 +53,8 @@ void check_fast_kernel_lds()
         constexpr int C = (M <= 24) ? 32 : 48;
         constexpr int CAP = (M <= 24) ? 2240 : 2048;
         bool good = fast_kernel_lds_ok<M, C, CAP, false, -2, false>() && fast_kernel_lds_ok<M, C, CAP, false, -2, true>();
+        if constexpr (M > 12 && M <= 24)
+            good = good && fast_kernel_lds_ok<M, (M <= 16 ? 24 : 28), (M <= 16 ? 2048 : 1920), false, -2, false>();
         if constexpr (M <= 12)
             good = good && fast_kernel_lds_ok<M, 16, kCapSteady, false, -2, false>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, 8, false>() &&
                    fast_kernel_lds_ok<M, 16, kCapSteady, false, 0, false>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, -3, false>() &&
@@ -73,6 +75,12 @@ void launch_tile(TileLaunch &t)
     unsigned long long *const st = t.stamps;
     constexpr int C = (M <= 24) ? 32 : 48;
     constexpr int CAP = (M <= 24) ? 2240 : 2048;
+    // Mid-width lists (12 < M <= 24: the command line's 20 neighbours) have a steady-state variant of their own: with the
+    // temporal cut-off the lists end near m entries, so 24 / 28 slots do (an overflowing lane tightens its threshold and
+    // scans again), and with a 2048- / 1920-candidate halo the kernel takes ~40 KB of LDS: FOUR workgroups per CU instead
+    // of three.  200k points are 782 blocks: three per CU run them in two residency rounds (768 slots), four in one.
+    constexpr bool kMid = (M > 12 && M <= 24);
+    constexpr int C2 = (M <= 16) ? 24 : 28, CAP2 = (M <= 16) ? 2048 : 1920;
     // the cleanup flavour and the second pass of a two-pass search meet neighbourhoods of 50+ in-radius candidates without
     // a cut-off: lists of 64 (one scan and one selection where 32 slots need two or three rescans); 62 KB of LDS: two
     // workgroups per CU for kernels that run on a few workgroups
@@ -84,8 +92,9 @@ void launch_tile(TileLaunch &t)
     const bool halves = t.all_halves != 0;
     const SplitTable split_on = halves ? SplitTable{nullptr, nullptr, nullptr, nullptr, 0, INT_MAX, 1}
                                        : SplitTable{t.split_flag, t.split_list, t.split_state, t.split_state + 1, kMaxSplit, kCapSteady * 15 / 16, 0};
-    const SplitTable split_off = (M <= 12 && !halves) ? SplitTable{t.split_flag, t.split_list, t.split_state, t.split_state + 1, 0, kCapSteady * 15 / 16, 0}
-                                                      : SplitTable{nullptr, nullptr, nullptr, nullptr, 0, INT_MAX, 0};  // no steady-state variant to split for
+    const SplitTable split_off = ((M <= 12 || kMid) && !halves)
+                                     ? SplitTable{t.split_flag, t.split_list, t.split_state, t.split_state + 1, 0, (kMid ? CAP2 : kCapSteady) * 15 / 16, 0}
+                                     : SplitTable{nullptr, nullptr, nullptr, nullptr, 0, INT_MAX, 0};  // no steady-state variant to split for
     const int grid_steady = steady_grid(nb, halves);
     FusedMoments fm_none;
     std::memset(&fm_none, 0, sizeof(fm_none));
@@ -128,6 +137,9 @@ void launch_tile(TileLaunch &t)
                 done = true;
             }
         }
+        // (the mid-width steady-state variant — 28 slots, four workgroups per CU — was measured here as well: rows that search
+        //  a level's whole radius accept more than 28 candidates more often, overflow twice and go to nn_wide_kernel: 3.92 k
+        //  against 4.07 k it/s on the LiDAR-like scene, 4.13 k against 4.44 k on the slab.  Multi-level searches keep 32 slots.)
         if constexpr (M <= 12) {
             if (!done && t.dm2_in && t.short_lists) {
                 nn_fast_kernel<M, 16, kCapSteady, false, -2, true><<<grid_multi, 256, 0, t.stream>>>(
@@ -166,6 +178,14 @@ void launch_tile(TileLaunch &t)
                 else PPCR_FAST(16, false, -2, fm_none);
             }
             t.fused = ftm != -2;
+        }
+    } else if constexpr (kMid) {
+        if (t.dm2_in && t.short_lists && !halves && t.short_count != nullptr) {
+            steady = true;
+            const SplitTable split_mid{t.split_flag, t.split_list, t.split_state, t.split_state + 1, kMaxSplit, CAP2 * 15 / 16, 0};
+            nn_fast_kernel<M, C2, CAP2, false, -2, false><<<nb + kMaxSplit, 256, 0, t.stream>>>(
+                t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
+                split_mid, nullptr, fm_none, lr, un);
         }
     }
     if (!steady && !multi) {

@@ -1011,7 +1011,7 @@ struct FastLds {
 // MULTI: the grid is chosen per workgroup from un.levels (GridLevel): tgt / cell_start / g / r2 of the arguments are the
 // base level's and only used by the first association (no cut-offs yet: every block searches the base level).
 template <int M, int C, int CAP, bool STAMPS, int FTM = -2, bool MULTI = false>
-__global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 4) : (CAP * 13 + C * 512 <= 39000 ? 4 : 3))) void nn_fast_kernel(float4 *__restrict__ src, int ns,
+__global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 4) : (CAP * 13 + C * 512 <= 39400 ? 4 : 3))) void nn_fast_kernel(float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt0,
                                                          const int *__restrict__ cell_start0, GridDesc g0,
                                                          float r2_0, int m, int *__restrict__ nbr,
