@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <cfloat>
@@ -417,14 +418,18 @@ int sort_by_cell(ppcr_ctx *c, const GridDesc &g, const float4 *in, int n, float4
         int end_bit = 1;
         while (end_bit < 32 && (1ll << end_bit) < nkeys) end_bit++;
         if (end_bit_override) end_bit = end_bit_override;
+        // rocPRIM's radix sort with the merge-sort limit lowered from its default of 2^20 items: a cloud of a million points
+        // otherwise takes the block-sort + ten-merge-passes route (~100 us) where three onesweep passes over 20-odd key bits
+        // do; both are stable (ties keep ascending original index)
+        using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 98304>;
         size_t tmp_bytes = 0;
-        HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, c->keys_a.p, c->keys_b.p, c->vals_a.p,
-                                                     c->vals_b.p, n, 0, end_bit, c->stream));
+        HIP_TRY(c, rocprim::radix_sort_pairs<SortConfig>(nullptr, tmp_bytes, c->keys_a.p, c->keys_b.p, c->vals_a.p, c->vals_b.p, (size_t)n, 0u,
+                                                         (unsigned)end_bit, c->stream));
         HIP_TRY(c, c->cub_tmp.reserve(tmp_bytes + 16));
         {
             ProfScope ps(c, K_RADIX_SORT);
-            HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp_bytes, c->keys_a.p, c->keys_b.p,
-                                                         c->vals_a.p, c->vals_b.p, n, 0, end_bit, c->stream));
+            HIP_TRY(c, rocprim::radix_sort_pairs<SortConfig>(c->cub_tmp.p, tmp_bytes, c->keys_a.p, c->keys_b.p, c->vals_a.p, c->vals_b.p,
+                                                             (size_t)n, 0u, (unsigned)end_bit, c->stream));
         }
         {
             ProfScope ps(c, K_GATHER);
