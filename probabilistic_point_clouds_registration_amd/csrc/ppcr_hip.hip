@@ -121,6 +121,20 @@ struct ppcr_ctx {
     bool grid_valid = false;
     double grid_radius = -1;
     int grid_max_nb = -1;
+    // the grid build in two halves (grid_begin / grid_finish): with a host buffer coming in, the first half is enqueued on
+    // aux_stream at the end of ppcr_set_target and runs while the caller's ppcr_set_source copies over PCIe
+    hipStream_t aux_stream = nullptr;
+    int opt_eager_grid = 1;
+    bool params_set = false;         // ppcr_set_params has been called (the early build does not start on the defaults)
+    bool grid_pending = false;       // grid_begin ran on aux_stream for (pending_radius, pending_max_nb); grid_finish has not yet
+    double pending_radius = -1;
+    int pending_max_nb = -1;
+    double grid_search = 1.0;        // the build in progress: its search radius, which attempt it is, whether its occupancy
+    int grid_attempt = 0;            // histogram is on its way to h_occupancy
+    bool grid_bounded = false, grid_occ_inflight = false;
+    unsigned long long *h_occupancy = nullptr;  // pinned, kOccBins words
+    float *h_bbox = nullptr;                    // pinned, kBboxBlocks partial boxes of the target (bbox_launch / bbox_fold)
+    int bbox_blocks = 0;
     // two-pass radius search (see nn_wide_kernel): the grid is built for search_radius = radius / reach <= radius
     double search_radius = 1.0;
     int reach = 1;
@@ -356,12 +370,15 @@ Pose make_pose(const ppcr_ctx *c, const Mat3 &R, const double t[3])
 }
 
 // upload (host or device pointer) + repack into float4 {x,y,z,original index}
-int upload_cloud(ppcr_ctx *c, const void *ptr, bool on_device, int64_t n, int64_t stride, DevBuf<float4> &dst)
+int bbox_launch(ppcr_ctx *c, const float4 *pts, int n);
+// with_bbox: the cloud's bounding box rides along (bbox_launch: folded by the caller after return, the stream is idle then)
+int upload_cloud(ppcr_ctx *c, const void *ptr, bool on_device, int64_t n, int64_t stride, DevBuf<float4> &dst, bool with_bbox = false)
 {
     if (n < 0 || n > (int64_t)INT32_MAX - 1024) return fail(c, PPCR_ERR_INVALID, "cloud size out of range");
     if (stride < 12 || (stride % 4) != 0) return fail(c, PPCR_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
     if (n > 0 && ptr == nullptr) return fail(c, PPCR_ERR_INVALID, "null cloud pointer");
     HIP_TRY(c, dst.reserve((size_t)std::max<int64_t>(n, 1)));
+    if (with_bbox) c->bbox_blocks = 0;
     if (n == 0) return PPCR_OK;
     const unsigned char *raw = static_cast<const unsigned char *>(ptr);
     if (!on_device) {
@@ -376,6 +393,7 @@ int upload_cloud(ppcr_ctx *c, const void *ptr, bool on_device, int64_t n, int64_
         repack_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(raw, n, stride, dst.p);
     }
     PPCR_TRY(check_launch(c, "repack_kernel"));
+    if (with_bbox) PPCR_TRY(bbox_launch(c, dst.p, (int)n));
     // the caller's host buffer may be freed after return
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return PPCR_OK;
@@ -418,10 +436,11 @@ int sort_by_cell(ppcr_ctx *c, const GridDesc &g, const float4 *in, int n, float4
         int end_bit = 1;
         while (end_bit < 32 && (1ll << end_bit) < nkeys) end_bit++;
         if (end_bit_override) end_bit = end_bit_override;
-        // rocPRIM's radix sort with the merge-sort limit lowered from its default of 2^20 items: a cloud of a million points
-        // otherwise takes the block-sort + ten-merge-passes route (~100 us) where three onesweep passes over 20-odd key bits
-        // do; both are stable (ties keep ascending original index)
-        using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 98304>;
+        // rocPRIM's radix sort with the merge-sort limit lowered from its default of 2^20 items to 320k: a cloud of a million
+        // points otherwise takes the block-sort + merge-passes route (161 us for 20 key bits) where three onesweep passes do
+        // (102 us); below ~350k items the merge route is the faster one (200k: 60 against 91 us) — tools/micro/sort_bench.hip.
+        // Both are stable (ties keep ascending original index).
+        using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 327680>;
         size_t tmp_bytes = 0;
         HIP_TRY(c, rocprim::radix_sort_pairs<SortConfig>(nullptr, tmp_bytes, c->keys_a.p, c->keys_b.p, c->vals_a.p, c->vals_b.p, (size_t)n, 0u,
                                                          (unsigned)end_bit, c->stream));
@@ -448,33 +467,37 @@ int sort_by_cell(ppcr_ctx *c, const GridDesc &g, const float4 *in, int n, float4
     return PPCR_OK;
 }
 
-// bounding box of the finite points of a float4 cloud (device) -> host
-int cloud_bbox(ppcr_ctx *c, const float4 *pts, int n, float lo[3], float hi[3])
+// bounding box of the finite points of a float4 cloud: per-block partial boxes on their way to pinned host memory
+// (bbox_launch), folded once the stream has been synchronised (bbox_fold)
+constexpr int kBboxBlocks = 1024;
+int bbox_launch(ppcr_ctx *c, const float4 *pts, int n)
 {
-    for (int a = 0; a < 3; a++) lo[a] = hi[a] = 0;
+    c->bbox_blocks = 0;
     if (n <= 0) return PPCR_OK;
-    const int nb = std::min(1024, nblocks(n));
-    HIP_TRY(c, c->bbox_part.reserve((size_t)nb * 6));
+    const int nb = std::min(kBboxBlocks, nblocks(n));
+    HIP_TRY(c, c->bbox_part.reserve((size_t)kBboxBlocks * 6));
     {
         ProfScope ps(c, K_BBOX);
         bbox_kernel<<<nb, kBlock, 0, c->stream>>>(pts, n, c->bbox_part.p);
     }
     PPCR_TRY(check_launch(c, "bbox_kernel"));
-    std::vector<float> part((size_t)nb * 6);
-    HIP_TRY(c, hipMemcpyAsync(part.data(), c->bbox_part.p, part.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_bbox, c->bbox_part.p, (size_t)nb * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    c->bbox_blocks = nb;
+    return PPCR_OK;
+}
+void bbox_fold(const ppcr_ctx *c, float lo[3], float hi[3])
+{
     for (int a = 0; a < 3; a++) {
         lo[a] = INFINITY;
         hi[a] = -INFINITY;
     }
-    for (int b = 0; b < nb; b++)
+    for (int b = 0; b < c->bbox_blocks; b++)
         for (int a = 0; a < 3; a++) {
-            lo[a] = std::min(lo[a], part[(size_t)b * 6 + a]);
-            hi[a] = std::max(hi[a], part[(size_t)b * 6 + 3 + a]);
+            lo[a] = std::min(lo[a], c->h_bbox[(size_t)b * 6 + a]);
+            hi[a] = std::max(hi[a], c->h_bbox[(size_t)b * 6 + 3 + a]);
         }
     for (int a = 0; a < 3; a++)
-        if (!(lo[a] <= hi[a])) lo[a] = hi[a] = 0;  // no finite coordinate at all
-    return PPCR_OK;
+        if (!(lo[a] <= hi[a])) lo[a] = hi[a] = 0;  // no finite coordinate at all (or no point)
 }
 
 constexpr int kMaxReach = 8;  // the second pass's stencil is (2 reach + 1)^2 rows
@@ -536,20 +559,25 @@ void make_grid_desc(int n, const float lo[3], const float hi[3], double cell_rad
 
 // occupancy of the grid just built as the typical point sees it (cell_occupancy_kernel): the median over the points of
 // the count of the cell they live in, less one (a point of a uniform cloud of q per cell sits in a cell of q + 1)
-int grid_occupancy(ppcr_ctx *c, double *occ, double *occ_p99 = nullptr)
+int grid_occupancy_launch(ppcr_ctx *c)
 {
-    *occ = 0;
-    if (occ_p99) *occ_p99 = 0;
     if (c->nt <= 0) return PPCR_OK;
     HIP_TRY(c, c->d_occupancy.reserve(kOccBins));
     HIP_TRY(c, hipMemsetAsync(c->d_occupancy.p, 0, kOccBins * sizeof(unsigned long long), c->stream));
     cell_occupancy_kernel<<<std::min(1024, nblocks(c->grid.ncells)), kBlock, 0, c->stream>>>(c->cell_start.p, c->grid, c->d_occupancy.p);
     PPCR_TRY(check_launch(c, "cell_occupancy_kernel"));
-    std::vector<unsigned long long> hist(kOccBins, 0ull);
-    HIP_TRY(c, hipMemcpyAsync(hist.data(), c->d_occupancy.p, kOccBins * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_occupancy, c->d_occupancy.p, kOccBins * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    return PPCR_OK;
+}
+// (the stream grid_occupancy_launch ran on has been synchronised)
+void grid_occupancy_read(const ppcr_ctx *c, double *occ, double *occ_p99)
+{
+    *occ = 0;
+    if (occ_p99) *occ_p99 = 0;
+    if (c->nt <= 0) return;
+    const unsigned long long *hist = c->h_occupancy;
     unsigned long long total = 0, run = 0;
-    for (unsigned long long h : hist) total += h;
+    for (int b = 0; b < kOccBins; b++) total += hist[b];
     bool have_median = false;
     for (int b = 0; b < kOccBins; b++) {
         run += hist[b];
@@ -562,6 +590,12 @@ int grid_occupancy(ppcr_ctx *c, double *occ, double *occ_p99 = nullptr)
             break;
         }
     }
+}
+int grid_occupancy(ppcr_ctx *c, double *occ, double *occ_p99 = nullptr)
+{
+    PPCR_TRY(grid_occupancy_launch(c));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    grid_occupancy_read(c, occ, occ_p99);
     return PPCR_OK;
 }
 
@@ -581,9 +615,12 @@ void release_levels(ppcr_ctx *c)
     c->extra_levels.clear();
     c->n_levels = 1, c->base_level = 0, c->finest_extra = -1;
 }
+// (a new target or radius: the levels' buffers stay with the handle — freeing and allocating three per level cost a scan
+//  of 200k points 5-7 ms per pair, most of its set-up; they are released with the handle)
+void reset_levels(ppcr_ctx *c) { c->n_levels = 1, c->base_level = 0, c->finest_extra = -1; }
 int build_levels(ppcr_ctx *c, bool bounded, const double *known_p99 = nullptr)
 {
-    release_levels(c);
+    reset_levels(c);
     const int n = (int)c->nt;
     if (!bounded || c->opt_two_pass != 1 || c->opt_levels == 0 || n <= 0) return PPCR_OK;
     std::vector<double> finer, coarser;
@@ -618,7 +655,7 @@ int build_levels(ppcr_ctx *c, bool bounded, const double *known_p99 = nullptr)
     level_inverse_kernel<<<nblocks(n), kBlock, 0, c->stream>>>(c->tgt_sorted.p, n, c->level_inv.p);
     PPCR_TRY(check_launch(c, "level_inverse_kernel"));
     std::vector<GridLevel> table(radii.size());
-    c->extra_levels.resize(radii.size() - 1);
+    if (c->extra_levels.size() < radii.size() - 1) c->extra_levels.resize(radii.size() - 1);
     size_t e = 0;
     for (size_t l = 0; l < radii.size(); l++) {
         GridLevel &t = table[l];
@@ -658,17 +695,28 @@ int build_levels(ppcr_ctx *c, bool bounded, const double *known_p99 = nullptr)
 // where it can.  The estimate starts from the bounding box and
 // is corrected with the occupancy measured on the grid it produced (dense blobs in a sparse box): at most three builds,
 // once per (target, radius, max_neighbours).
-int ensure_grid(ppcr_ctx *c)
+// one build of the base grid for c->grid_search; unless it is the last one allowed, its occupancy histogram is sent on its
+// way to the host behind it.  Nothing here waits for the device.
+int grid_build_attempt(ppcr_ctx *c)
 {
-    if (!c->have_tgt) return fail(c, PPCR_ERR_STATE, "target cloud not set");
-    if (c->grid_valid && c->grid_radius == c->radius && c->grid_max_nb == c->max_nb) return PPCR_OK;
-    if (!(c->radius > 0) || !std::isfinite(c->radius)) return fail(c, PPCR_ERR_INVALID, "radius must be positive and finite");
+    const int n = (int)c->nt;
+    c->search_radius = c->grid_search;
+    c->reach = c->grid_search < c->radius ? std::min(kMaxReach, (int)std::ceil(c->radius / c->grid_search - 1e-9)) : 1;
+    make_grid_desc(n, c->tgt_lo, c->tgt_hi, c->search_radius, c->opt_grid_xf, c->grid);
+    PPCR_TRY(sort_by_cell(c, c->grid, c->tgt_raw.p, n, c->tgt_sorted.p, &c->cell_start));
+    c->grid_occ_inflight = false;
+    if (!(c->grid_bounded && c->opt_two_pass == 1) || c->grid_attempt == 2 || c->grid_search <= c->radius / kMaxReach) return PPCR_OK;
+    PPCR_TRY(grid_occupancy_launch(c));
+    c->grid_occ_inflight = true;
+    return PPCR_OK;
+}
+
+// first half: the estimate of the first-pass radius from the bounding box, the first build enqueued on c->stream
+int grid_begin(ppcr_ctx *c)
+{
     invalidate_association(c);
     c->dm2_valid = false;
-    const int n = (int)c->nt;
-    PPCR_TRY(cloud_bbox(c, c->tgt_raw.p, n, c->tgt_lo, c->tgt_hi));
-    for (int a = 0; a < 3; a++) c->origin[a] = 0.5 * ((double)c->tgt_lo[a] + (double)c->tgt_hi[a]);
-    c->origin_valid = true;
+    const int n = (int)c->nt;  // (tgt_lo / tgt_hi: folded by ppcr_set_target, the box came with the upload)
     HIP_TRY(c, c->tgt_sorted.reserve((size_t)std::max(n, 1)));
     const bool bounded = c->max_nb > 0 && (int64_t)c->max_nb < c->nt && c->max_nb <= kEllMaxWidth;
     double search = c->radius;
@@ -679,28 +727,86 @@ int ensure_grid(ppcr_ctx *c)
         const double per_cell = (double)n * c->radius * c->radius * c->radius / vol;
         search = c->opt_two_pass >= 2 ? c->radius / c->opt_two_pass : choose_search_radius(c->radius, per_cell, c->max_nb, 0.1 * c->opt_first_pass_occ, 0.1 * c->opt_first_pass_fill);
     }
+    c->grid_bounded = bounded;
+    c->grid_search = search;
+    c->grid_attempt = 0;
+    return grid_build_attempt(c);
+}
+
+// second half: read the occupancy the build produced, rebuild while it is far from the aim, then the levels
+int grid_finish(ppcr_ctx *c)
+{
+    for (int a = 0; a < 3; a++) c->origin[a] = 0.5 * ((double)c->tgt_lo[a] + (double)c->tgt_hi[a]);
+    c->origin_valid = true;
     bool have_occ = false;
     double occ_p99 = 0;
-    for (int attempt = 0;; attempt++) {
-        c->search_radius = search;
-        c->reach = search < c->radius ? std::min(kMaxReach, (int)std::ceil(c->radius / search - 1e-9)) : 1;
-        make_grid_desc(n, c->tgt_lo, c->tgt_hi, c->search_radius, c->opt_grid_xf, c->grid);
-        PPCR_TRY(sort_by_cell(c, c->grid, c->tgt_raw.p, n, c->tgt_sorted.p, &c->cell_start));
-        have_occ = false;
-        if (!(bounded && c->opt_two_pass == 1) || attempt == 2 || search <= c->radius / kMaxReach) break;
+    while (c->grid_occ_inflight) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
         double q_here = 0;  // points per cell (edge ~search) where the dense part of the cloud lives
-        PPCR_TRY(grid_occupancy(c, &q_here, &occ_p99));
+        grid_occupancy_read(c, &q_here, &occ_p99);
+        c->grid_occ_inflight = false;
         have_occ = true;  // (of the grid as it stands: build_levels need not measure it again)
         const double cap = 0.1 * c->opt_first_pass_occ, q_want = target_occupancy(c->max_nb, cap, 0.1 * c->opt_first_pass_fill);
         if (q_here <= 1.5 * std::max(q_want, cap)) break;  // close enough: keep this grid
         // the points live in fuller cells than the bounding box suggested (a cloud that does not fill its box)
-        search = std::max(search * std::cbrt(q_want / q_here), c->radius / kMaxReach);
+        c->grid_search = std::max(c->grid_search * std::cbrt(q_want / q_here), c->radius / kMaxReach);
+        c->grid_attempt++;
+        have_occ = false;
+        PPCR_TRY(grid_build_attempt(c));
     }
-    PPCR_TRY(build_levels(c, bounded, have_occ ? &occ_p99 : nullptr));
+    PPCR_TRY(build_levels(c, c->grid_bounded, have_occ ? &occ_p99 : nullptr));
     c->grid_valid = true;
     c->grid_radius = c->radius;
     c->grid_max_nb = c->max_nb;
     c->src_sorted = false;  // re-sort against the new grid at the next associate()
+    return PPCR_OK;
+}
+
+// a first half in flight on aux_stream: wait for it (ppcr_set_target again, an option that changes the build, destroy)
+int grid_settle(ppcr_ctx *c)
+{
+    if (!c->grid_pending) return PPCR_OK;
+    c->grid_pending = false;
+    c->grid_occ_inflight = false;
+    HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
+    return PPCR_OK;
+}
+
+int ensure_grid(ppcr_ctx *c)
+{
+    if (!c->have_tgt) return fail(c, PPCR_ERR_STATE, "target cloud not set");
+    if (c->grid_valid && c->grid_radius == c->radius && c->grid_max_nb == c->max_nb) return PPCR_OK;
+    if (!(c->radius > 0) || !std::isfinite(c->radius)) return fail(c, PPCR_ERR_INVALID, "radius must be positive and finite");
+    if (c->grid_pending) {
+        const bool usable = c->pending_radius == c->radius && c->pending_max_nb == c->max_nb;
+        const bool occ = c->grid_occ_inflight;
+        PPCR_TRY(grid_settle(c));
+        if (usable) {
+            c->grid_occ_inflight = occ;
+            return grid_finish(c);
+        }
+    }
+    PPCR_TRY(grid_begin(c));
+    return grid_finish(c);
+}
+
+// ppcr_set_target's tail: the first half of the grid build, on aux_stream, when the search is already configured
+int grid_begin_early(ppcr_ctx *c)
+{
+    // (max_neighbours 0: the handle of an exact-association caller — ppcr_set_association, the weight updater — which never searches)
+    if (!c->opt_eager_grid || !c->params_set || c->nt <= 0 || c->max_nb <= 0 || !(c->radius > 0) || !std::isfinite(c->radius)) return PPCR_OK;
+    hipStream_t main_stream = c->stream;
+    c->stream = c->aux_stream;
+    const int rc = grid_begin(c);
+    c->stream = main_stream;
+    if (rc != PPCR_OK) {
+        (void)hipStreamSynchronize(c->aux_stream);
+        c->grid_occ_inflight = false;
+        return rc;
+    }
+    c->grid_pending = true;
+    c->pending_radius = c->radius;
+    c->pending_max_nb = c->max_nb;
     return PPCR_OK;
 }
 
@@ -1625,6 +1731,9 @@ int ppcr_create(int device_id, ppcr_ctx **out)
     if (!c) return fail(nullptr, PPCR_ERR_NOMEM, "out of host memory");
     c->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_occupancy), sizeof(unsigned long long) * kOccBins, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_bbox), sizeof(float) * 6 * kBboxBlocks, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_sums), sizeof(double) * kNSums, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_total), sizeof(unsigned long long), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_mbox), sizeof(HostMailbox) * kMailboxRing, hipHostMallocMapped | hipHostMallocCoherent);
@@ -1651,6 +1760,7 @@ int ppcr_destroy(ppcr_ctx *c)
     if (!c) return PPCR_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     for (auto &r : c->prof_recs) {
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
@@ -1707,9 +1817,12 @@ int ppcr_destroy(ppcr_ctx *c)
     c->track_ticket.release();
     if (c->h_sums) (void)hipHostFree(c->h_sums);
     if (c->h_total) (void)hipHostFree(c->h_total);
+    if (c->h_occupancy) (void)hipHostFree(c->h_occupancy);
+    if (c->h_bbox) (void)hipHostFree(c->h_bbox);
     if (c->h_mbox) (void)hipHostFree(c->h_mbox);
     if (c->h_report) (void)hipHostFree(c->h_report);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     delete c;
     return PPCR_OK;
 }
@@ -1732,6 +1845,7 @@ int ppcr_set_params(ppcr_ctx *c, double radius, int max_neighbours, double dof, 
     c->max_nb = max_neighbours;
     c->dof = dof;
     c->dim = dim;
+    c->params_set = true;
     return PPCR_OK;
 }
 
@@ -1739,6 +1853,11 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
 {
     CTX_ENTER(c);
     if (!key) return fail(c, PPCR_ERR_INVALID, "null option key");
+    PPCR_TRY(grid_settle(c));  // an early grid build was begun under the options as they were: it is dropped
+    if (std::strcmp(key, "eager_grid") == 0) {  // ppcr_set_target starts the grid build (on a second stream) when the search is configured
+        c->opt_eager_grid = value ? 1 : 0;
+        return PPCR_OK;
+    }
     if (std::strcmp(key, "sort_source") == 0) {
         if (c->have_src && c->src_sorted && !value)
             return fail(c, PPCR_ERR_STATE, "sort_source can only be switched off before the source has been sorted");
@@ -1851,7 +1970,9 @@ int ppcr_set_option(ppcr_ctx *c, const char *key, int value)
 
 static int set_target_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, int64_t stride)
 {
-    PPCR_TRY(upload_cloud(c, p, dev, n, stride, c->tgt_raw));
+    PPCR_TRY(grid_settle(c));  // (a build of the previous target still reading tgt_raw)
+    PPCR_TRY(upload_cloud(c, p, dev, n, stride, c->tgt_raw, true));
+    bbox_fold(c, c->tgt_lo, c->tgt_hi);
     c->nt = n;
     c->have_tgt = true;
     c->grid_valid = false;
@@ -1859,7 +1980,8 @@ static int set_target_common(ppcr_ctx *c, const void *p, bool dev, int64_t n, in
     c->dm2_valid = false;
     c->assoc_space = 0;
     invalidate_association(c);
-    return PPCR_OK;
+    // (upload_cloud left the main stream idle: nothing earlier still reads the buffers the build writes)
+    return grid_begin_early(c);
 }
 
 // Sequence numbers (mailbox slots, completion flags, LoopState::finished, the report ring) grow by one per fold for the
@@ -2739,6 +2861,7 @@ int ppcr_synchronize(ppcr_ctx *c)
 {
     CTX_ENTER(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->grid_pending) HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
     return PPCR_OK;
 }
 
@@ -2746,6 +2869,7 @@ int ppcr_profile_enable(ppcr_ctx *c, int enable)
 {
     CTX_ENTER(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->grid_pending) HIP_TRY(c, hipStreamSynchronize(c->aux_stream));  // (events of an early grid build)
     for (auto &r : c->prof_recs) {
         c->prof_pool.push_back(r.start);
         c->prof_pool.push_back(r.stop);
@@ -2763,6 +2887,7 @@ int ppcr_profile_get(ppcr_ctx *c, ppcr_kernel_stat *out, int capacity, int *n_ou
 {
     CTX_ENTER(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->grid_pending) HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
     for (auto &r : c->prof_recs) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
@@ -2972,12 +3097,12 @@ int ppcr_nearest_sq_distances(int device_id, const float *queries, int64_t nq, i
     ppcr_ctx *c = nullptr;
     PPCR_TRY(ppcr_create(device_id, &c));
     auto body = [&]() -> int {
+        c->opt_eager_grid = 0;  // (the cell edge is chosen below, from the box that comes with the upload)
         PPCR_TRY(set_target_common(c, targets, false, nt, t_stride_bytes));
         PPCR_TRY(set_source_common(c, queries, false, nq, q_stride_bytes));
         if (nq == 0) return PPCR_OK;
         // a cubic grid with a few points per cell: the nearest neighbour is then usually in the first shell or two
-        float lo[3], hi[3];
-        PPCR_TRY(cloud_bbox(c, c->tgt_raw.p, (int)nt, lo, hi));
+        const float *lo = c->tgt_lo, *hi = c->tgt_hi;
         double vol = 1, emax = 0;
         for (int a = 0; a < 3; a++) {
             const double e = (double)hi[a] - (double)lo[a];

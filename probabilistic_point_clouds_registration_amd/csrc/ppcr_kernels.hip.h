@@ -173,14 +173,34 @@ __global__ void gather_points_kernel(const float4 *__restrict__ in, const int *_
 }
 
 // K0d: cell_start[c] = first sorted position with key >= c  (cell_start has ncells+1 entries)
-__global__ void cell_start_kernel(const unsigned *__restrict__ keys_sorted, int n, int ncells,
-                                  int *__restrict__ cell_start)
+// Lane i owns the cells between two consecutive sorted keys.  A few empty cells it fills itself; a long run of them — the
+// empty space between the parts of a scan, 10^5 cells and more on the finer levels of a multi-level search — is filled by
+// the whole workgroup, 256 cells per step (one lane walking it alone made this kernel 0.43 ms per level on a 200k-point
+// scan, nine tenths of the target's set-up).
+constexpr int kCellRunLong = 32;
+__global__ __launch_bounds__(kBlock) void cell_start_kernel(const unsigned *__restrict__ keys_sorted, int n, int ncells,
+                                                            int *__restrict__ cell_start)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n) return;
-    int prev = (i == 0) ? -1 : (int)keys_sorted[i - 1];
-    int cur = (i == n) ? ncells : (int)keys_sorted[i];
-    for (int c = prev + 1; c <= cur; c++) cell_start[c] = i;
+    __shared__ int s_runs, s_first[kBlock], s_last[kBlock], s_value[kBlock];
+    if (threadIdx.x == 0) s_runs = 0;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) {
+        const int prev = (i == 0) ? -1 : (int)keys_sorted[i - 1];
+        const int cur = (i == n) ? ncells : (int)keys_sorted[i];
+        if (cur - prev <= kCellRunLong) {
+            for (int c = prev + 1; c <= cur; c++) cell_start[c] = i;
+        } else {
+            const int k = atomicAdd(&s_runs, 1);
+            s_first[k] = prev + 1, s_last[k] = cur, s_value[k] = i;
+        }
+    }
+    __syncthreads();
+    const int runs = s_runs;
+    for (int k = 0; k < runs; k++) {
+        const int last = s_last[k], v = s_value[k];
+        for (int c = s_first[k] + (int)threadIdx.x; c <= last; c += kBlock) cell_start[c] = v;
+    }
 }
 
 // Occupancy of the grid's WHOLE cells (x slices folded back) as the POINTS see it: hist[occ_bin(count)] += count

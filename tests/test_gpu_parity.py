@@ -140,6 +140,63 @@ def test_nn_sorted_and_unsorted_source_agree(ctx):
     np.testing.assert_array_equal(ctx.get_source(), g["src"])   # export undoes the spatial sort
 
 
+def test_early_grid_build_changes_nothing():
+    """ppcr_set_target starts the grid build on a second stream when the search is configured (option eager_grid, on by
+    default); the association is the one a handle without it makes — also when the parameters, an option or the target
+    itself change between the upload and the association (the early build is then dropped)."""
+    src, tgt, _, _ = synth.make_pair(30_000, cfg=41)
+    scene_s, scene_t, _, _ = synth.make_scene("slab", 30_000, seed=5)
+    for s_, t_, radius, m in ((src, tgt, 1.0, 10), (scene_s, scene_t, 3.0, 20)):
+        with _lib.Context(0) as plain:
+            plain.set_option("eager_grid", 0)
+            want = _assoc(plain, s_, t_, radius, m)
+            want_small = _assoc(plain, s_, t_, 0.5 * radius, 5)
+        with _lib.Context(0) as c:
+            for x, y in zip(_assoc(c, s_, t_, radius, m), want):          # the early build is used
+                np.testing.assert_array_equal(x, y)
+            c.set_params(radius, m, 5.0, 3)
+            c.set_target(t_)
+            c.set_params(0.5 * radius, 5, 5.0, 3)                         # ... dropped: another radius
+            c.set_source(s_)
+            c.associate()
+            for x, y in zip(c.get_association(), want_small):
+                np.testing.assert_array_equal(x, y)
+            c.set_params(radius, m, 5.0, 3)
+            c.set_target(s_)                                              # ... dropped: the target is replaced at once
+            c.set_target(t_)
+            c.set_option("two_pass", 1)                                   # ... dropped: an option is set
+            c.set_source(s_)
+            c.synchronize()
+            c.associate()
+            for x, y in zip(c.get_association(), want):
+                np.testing.assert_array_equal(x, y)
+        T = []
+        for eager in (1, 0):                                              # the same calls on two fresh handles
+            with _lib.Context(0) as h:
+                h.set_option("eager_grid", eager)
+                h.set_params(radius, m, 5.0, 3)
+                h.set_target(t_)
+                h.set_source(s_)
+                T.append(h.align(3, inner_steps=1)["history"][-1])
+        np.testing.assert_array_equal(T[0], T[1])
+
+
+def test_nn_parts_far_apart_vs_oracle(ctx):
+    """two parts of a cloud 4000 radii apart: the cell table between them is one long run of empty cells
+    (cell_start_kernel fills such runs with the whole workgroup)"""
+    rng = np.random.Generator(np.random.PCG64(77))
+    a = (rng.random((3000, 3)) * 12.0).astype(np.float32)
+    b = (rng.random((3000, 3)) * 12.0 + np.array([4000.0, 0.0, 0.0])).astype(np.float32)
+    tgt = np.concatenate([a, b])
+    src = (tgt[rng.permutation(tgt.shape[0])] + rng.normal(0, 0.01, tgt.shape)).astype(np.float32)
+    for m in (10, 0):
+        rp, col, d2 = _assoc(ctx, src, tgt, 1.0, m)
+        orp, ocol, od2 = po.radius_search(src, tgt, 1.0, m, method=1)
+        np.testing.assert_array_equal(rp, orp)
+        np.testing.assert_array_equal(col, ocol)
+        np.testing.assert_array_equal(d2, od2)
+
+
 def test_nn_100k_vs_oracle(ctx):
     src, tgt, _, _ = synth.make_config(2)                    # BASELINE configs[1]
     rp, col, d2 = _assoc(ctx, src, tgt, 1.0, 10)

@@ -1,6 +1,7 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/setup; rm -rf $OUT; mkdir -p $OUT; cd $R
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "nn_random or grid_ties or sorted_and_unsorted or 100k or transform_bit or voxel" > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/summary.txt
+timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/summary.txt
+for k in 3 9 10; do echo "config $k" >> $OUT/summary.txt; python tools/exp_setup.py $k >> $OUT/summary.txt 2>&1; done
 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpp-api > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 python - $OUT/bench_n1.json <<'PY' >> $OUT/summary.txt
 import json,sys
