@@ -64,7 +64,11 @@ int ppcr_set_params(ppcr_ctx *ctx, double radius, int max_neighbours, double dof
 /* Upload clouds (host pointers).  Replaces the cloud members the reference keeps
  * (prob_point_cloud_registration.h:50-55) and, for the target, the per-iteration kd-tree
  * build (src/prob_point_cloud_registration.cc:66-67): the uniform grid over the target is
- * built once, lazily, at the first ppcr_associate() for the current radius. */
+ * built once per (target, radius, max_neighbours).  When ppcr_set_params has configured a bounded
+ * search, ppcr_set_target starts that build on a second stream before it returns, so that it runs
+ * while the caller's ppcr_set_source copies over PCIe (option "eager_grid"); otherwise, and
+ * whenever the parameters or a grid option change afterwards, it is built at the first
+ * ppcr_associate() / ppcr_align().  Both uploads return once the caller's buffer has been read. */
 int ppcr_set_target(ppcr_ctx *ctx, const float *xyz, int64_t n, int64_t stride_bytes);
 int ppcr_set_source(ppcr_ctx *ctx, const float *xyz, int64_t n, int64_t stride_bytes);
 /* Same, from device memory already resident on the handle's GPU (e.g. a torch tensor). */
@@ -332,6 +336,7 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *                  point lives (default 110); fuller cells: fewer short rows, more workgroups whose halo outgrows the LDS tile;
  *   "first_pass_fill"  tenths: the first-pass sphere of a two-pass search should hold this many times max_neighbours points
  *                  where the density allows (default 22: ~2.2 m candidates answer nearly every row in the first pass);
+ *   "eager_grid"   1 ppcr_set_target starts the grid build (default, see there), 0 the first association builds it;
  *   "stamps"       1 collect per-phase cycle counts and per-lane run lengths of K1 (diagnostic build of the kernel). */
 int ppcr_set_option(ppcr_ctx *ctx, const char *key, int value);
 
