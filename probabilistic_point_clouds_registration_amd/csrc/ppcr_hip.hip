@@ -123,7 +123,8 @@ struct ppcr_ctx {
     int grid_max_nb = -1;
     // the grid build in two halves (grid_begin / grid_finish): with a host buffer coming in, the first half is enqueued on
     // aux_stream at the end of ppcr_set_target and runs while the caller's ppcr_set_source copies over PCIe
-    hipStream_t aux_stream = nullptr;
+    hipStream_t aux_stream = nullptr;   // the device's shared second stream (device_aux_stream), not owned
+    hipEvent_t aux_done = nullptr;      // recorded behind this handle's early build
     int opt_eager_grid = 1;
     bool params_set = false;         // ppcr_set_params has been called (the early build does not start on the defaults)
     bool grid_pending = false;       // grid_begin ran on aux_stream for (pending_radius, pending_max_nb); grid_finish has not yet
@@ -768,7 +769,7 @@ int grid_settle(ppcr_ctx *c)
     if (!c->grid_pending) return PPCR_OK;
     c->grid_pending = false;
     c->grid_occ_inflight = false;
-    HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
+    HIP_TRY(c, hipEventSynchronize(c->aux_done));
     return PPCR_OK;
 }
 
@@ -790,19 +791,37 @@ int ensure_grid(ppcr_ctx *c)
     return grid_finish(c);
 }
 
+// One second stream per DEVICE, shared by its handles and kept for the life of the process: a second stream per handle
+// cost a batch a quarter of its rate (64 handles x 250k points on one GPU: 31.6 k it/s against 42.0 k, the extra streams
+// idle) — the runtime spreads streams over a few hardware queues.
+int device_aux_stream(ppcr_ctx *c, hipStream_t *out)
+{
+    static std::mutex mu;
+    static std::vector<hipStream_t> streams;
+    std::lock_guard<std::mutex> lock(mu);
+    if ((int)streams.size() <= c->device) streams.resize((size_t)c->device + 1, nullptr);
+    if (!streams[(size_t)c->device]) HIP_TRY(c, hipStreamCreateWithFlags(&streams[(size_t)c->device], hipStreamNonBlocking));
+    *out = streams[(size_t)c->device];
+    return PPCR_OK;
+}
+
 // ppcr_set_target's tail: the first half of the grid build, on aux_stream, when the search is already configured
 int grid_begin_early(ppcr_ctx *c)
 {
     // (max_neighbours 0: the handle of an exact-association caller — ppcr_set_association, the weight updater — which never searches)
     if (!c->opt_eager_grid || !c->params_set || c->nt <= 0 || c->max_nb <= 0 || !(c->radius > 0) || !std::isfinite(c->radius)) return PPCR_OK;
+    if (!c->aux_stream) PPCR_TRY(device_aux_stream(c, &c->aux_stream));
+    if (!c->aux_done) HIP_TRY(c, hipEventCreateWithFlags(&c->aux_done, hipEventDisableTiming));
     hipStream_t main_stream = c->stream;
     c->stream = c->aux_stream;
     const int rc = grid_begin(c);
     c->stream = main_stream;
-    if (rc != PPCR_OK) {
+    const hipError_t e = hipEventRecord(c->aux_done, c->aux_stream);
+    if (rc != PPCR_OK || e != hipSuccess) {
         (void)hipStreamSynchronize(c->aux_stream);
         c->grid_occ_inflight = false;
-        return rc;
+        if (rc != PPCR_OK) return rc;
+        HIP_TRY(c, e);
     }
     c->grid_pending = true;
     c->pending_radius = c->radius;
@@ -1731,7 +1750,6 @@ int ppcr_create(int device_id, ppcr_ctx **out)
     if (!c) return fail(nullptr, PPCR_ERR_NOMEM, "out of host memory");
     c->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_occupancy), sizeof(unsigned long long) * kOccBins, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_bbox), sizeof(float) * 6 * kBboxBlocks, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_sums), sizeof(double) * kNSums, hipHostMallocDefault);
@@ -1760,7 +1778,8 @@ int ppcr_destroy(ppcr_ctx *c)
     if (!c) return PPCR_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    if (c->grid_pending) (void)hipEventSynchronize(c->aux_done);
+    if (c->aux_done) (void)hipEventDestroy(c->aux_done);
     for (auto &r : c->prof_recs) {
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
@@ -1822,7 +1841,6 @@ int ppcr_destroy(ppcr_ctx *c)
     if (c->h_mbox) (void)hipHostFree(c->h_mbox);
     if (c->h_report) (void)hipHostFree(c->h_report);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     delete c;
     return PPCR_OK;
 }
@@ -2861,7 +2879,7 @@ int ppcr_synchronize(ppcr_ctx *c)
 {
     CTX_ENTER(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->grid_pending) HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
+    if (c->grid_pending) HIP_TRY(c, hipEventSynchronize(c->aux_done));
     return PPCR_OK;
 }
 
@@ -2869,7 +2887,7 @@ int ppcr_profile_enable(ppcr_ctx *c, int enable)
 {
     CTX_ENTER(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->grid_pending) HIP_TRY(c, hipStreamSynchronize(c->aux_stream));  // (events of an early grid build)
+    if (c->grid_pending) HIP_TRY(c, hipEventSynchronize(c->aux_done));  // (events of an early grid build)
     for (auto &r : c->prof_recs) {
         c->prof_pool.push_back(r.start);
         c->prof_pool.push_back(r.stop);
@@ -2887,7 +2905,7 @@ int ppcr_profile_get(ppcr_ctx *c, ppcr_kernel_stat *out, int capacity, int *n_ou
 {
     CTX_ENTER(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->grid_pending) HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
+    if (c->grid_pending) HIP_TRY(c, hipEventSynchronize(c->aux_done));
     for (auto &r : c->prof_recs) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
