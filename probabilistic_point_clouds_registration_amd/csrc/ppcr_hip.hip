@@ -437,11 +437,15 @@ int sort_by_cell(ppcr_ctx *c, const GridDesc &g, const float4 *in, int n, float4
         int end_bit = 1;
         while (end_bit < 32 && (1ll << end_bit) < nkeys) end_bit++;
         if (end_bit_override) end_bit = end_bit_override;
-        // rocPRIM's radix sort with the merge-sort limit lowered from its default of 2^20 items to 320k: a cloud of a million
-        // points otherwise takes the block-sort + merge-passes route (161 us for 20 key bits) where three onesweep passes do
-        // (102 us); below ~350k items the merge route is the faster one (200k: 60 against 91 us) — tools/micro/sort_bench.hip.
-        // Both are stable (ties keep ascending original index).
-        using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 327680>;
+        // rocPRIM's radix sort, configured for clouds of 10^5..10^6 points (tools/micro/sort_bench.hip; (u32, i32) pairs, 21
+        // key bits).  By default it merge-sorts up to 2^20 items — 159 us for a million, 60 us for 200k — and its onesweep
+        // passes work in blocks of 6144 items (102 / 91 us).  Onesweep from 96k items on, in blocks of 2048 (a pass is bound
+        // by the chain of its blocks' look-backs and by how few blocks 200k items are): 98 us for a million, 66 for 500k,
+        // 49 for 200k, 43 for 100k.  Stable either way (ties keep ascending original index).
+        using SortConfig = rocprim::radix_sort_config<
+            rocprim::default_config, rocprim::default_config,
+            rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 4>, rocprim::kernel_config<512, 4>, 8, rocprim::block_radix_rank_algorithm::match>,
+            98304>;
         size_t tmp_bytes = 0;
         HIP_TRY(c, rocprim::radix_sort_pairs<SortConfig>(nullptr, tmp_bytes, c->keys_a.p, c->keys_b.p, c->vals_a.p, c->vals_b.p, (size_t)n, 0u,
                                                          (unsigned)end_bit, c->stream));

@@ -33,11 +33,17 @@ int main()
 {
     hipStream_t st;
     hipStreamCreate(&st);
-    using Low = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 98304>;
-    using Low32 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 32768>;
-    std::printf("%10s %5s %14s %14s %14s\n", "n", "bits", "default us", "limit 98304 us", "limit 32768 us");
-    for (size_t n : {20000ul, 50000ul, 100000ul, 200000ul, 500000ul, 1000000ul, 2000000ul})
-        for (unsigned bits : {16u, 20u, 24u, 30u}) {
+    using Low = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 32768>;
+    using rocprim::kernel_config;
+    constexpr auto kMatch = rocprim::block_radix_rank_algorithm::match;
+    // onesweep with smaller blocks (more of them: a million items are 163 blocks of 512 x 12) and other digit widths
+    using A = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::radix_sort_onesweep_config<kernel_config<256, 12>, kernel_config<256, 12>, 8, kMatch>, 32768>;
+    using B = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::radix_sort_onesweep_config<kernel_config<256, 8>, kernel_config<256, 8>, 8, kMatch>, 32768>;
+    using C = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::radix_sort_onesweep_config<kernel_config<256, 6>, kernel_config<256, 6>, 7, kMatch>, 32768>;
+    using D = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::radix_sort_onesweep_config<kernel_config<512, 4>, kernel_config<512, 4>, 8, kMatch>, 32768>;
+    std::printf("%10s %5s %12s %12s %12s %12s %12s %12s\n", "n", "bits", "default us", "onesweep", "256x12", "256x8", "256x6 r7", "512x4");
+    for (size_t n : {100000ul, 200000ul, 500000ul, 1000000ul})
+        for (unsigned bits : {16u, 21u, 24u}) {
             std::vector<unsigned> h(n);
             std::mt19937 rng(7);
             for (auto &k : h) k = rng() & ((1u << bits) - 1u);
@@ -47,8 +53,11 @@ int main()
             hipMemcpy(ka, h.data(), n * 4, hipMemcpyHostToDevice);
             const float a = run<rocprim::default_config>(ka, kb, va, vb, n, bits, st);
             const float b = run<Low>(ka, kb, va, vb, n, bits, st);
-            const float c = run<Low32>(ka, kb, va, vb, n, bits, st);
-            std::printf("%10zu %5u %14.1f %14.1f %14.1f\n", n, bits, a, b, c);
+            const float c = run<A>(ka, kb, va, vb, n, bits, st);
+            const float d = run<B>(ka, kb, va, vb, n, bits, st);
+            const float e = run<C>(ka, kb, va, vb, n, bits, st);
+            const float f = run<D>(ka, kb, va, vb, n, bits, st);
+            std::printf("%10zu %5u %12.1f %12.1f %12.1f %12.1f %12.1f %12.1f\n", n, bits, a, b, c, d, e, f);
             hipFree(ka), hipFree(kb), hipFree(va), hipFree(vb);
         }
     return 0;
