@@ -18,6 +18,9 @@
 #include <string>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -3236,6 +3239,61 @@ HandlePool &batch_pool()
 }
 }  // namespace
 
+namespace {
+
+// hand-over point between the two threads a device's share of a batch runs on (ppcr_batch_run)
+template <class T>
+struct HandOver {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<T> items;
+    bool closed = false;
+    void push(const T &v)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            items.push_back(v);
+        }
+        cv.notify_one();
+    }
+    void close()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            closed = true;
+        }
+        cv.notify_all();
+    }
+    // 1: *out taken; 0: nothing there now (wait = false only); -1: closed and empty
+    int pop(T *out, bool wait)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (wait) cv.wait(lk, [&] { return closed || !items.empty(); });
+        if (items.empty()) return closed ? -1 : 0;
+        *out = items.front();
+        items.pop_front();
+        return 1;
+    }
+};
+
+struct PreparedPair {
+    ppcr_ctx *c;
+    int64_t pair;
+};
+
+// everything the first association of a registration would wait for, done where waiting costs nothing (the preparing
+// thread of ppcr_batch_run): the second half of the grid build, the levels, the source's spatial sort
+int prepare_first_association(ppcr_ctx *c)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    PPCR_TRY(ensure_grid(c));
+    PPCR_TRY(ensure_source_sorted(c));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PPCR_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int ppcr_align_many(ppcr_ctx *const *ctxs, int n, int lanes, int n_iter, double cost_drop_thresh,
@@ -3347,10 +3405,114 @@ int ppcr_batch_run(const ppcr_pair *pairs, int64_t n_pairs, const ppcr_batch_opt
     for (int d = 0; d < n_devices; d++)
         if (device_ids[d] < 0 || device_ids[d] >= visible) return report(PPCR_ERR_INVALID, "ppcr_batch_run: device id out of range");
 
-    // one work list per device (pair p -> device p % n_devices), drained by that device's lanes
+    // pair p -> device p % n_devices
+    FirstError first;
+    // Bounded searches with the device-paced loop (every pair of every batch the command line or batch.py builds): TWO
+    // threads per device.  One PREPARES pairs — uploads (synchronous PCIe copies), grid build, levels, source sort: all the
+    // waiting of a registration — on handles nobody is iterating on; the other only enqueues and polls, up to
+    // `lanes_per_device` registrations in flight on their own streams, as ppcr_align_many does.  A thread per lane
+    // (what this was: each doing its own uploads between its iterations) reached 1.07 k pairs/s at two lanes and LESS at
+    // four (0.96 k; 64 x 250k on one GPU): every copy held up the other lanes' launches.
+    bool two_threads = opt->max_neighbours > 0 && opt->max_neighbours <= kEllMaxWidth;
+    for (int64_t p = 0; p < n_pairs && two_threads; p++)
+        two_threads = pairs[p].n_source > 0 && (int64_t)opt->max_neighbours < pairs[p].n_target;
+    auto device_share = [&](int d) {
+        const int dev = device_ids[d];
+        const int64_t mine = (n_pairs - d + n_devices - 1) / n_devices;
+        const int lanes = (int)std::max<int64_t>(1, std::min<int64_t>(lanes_per_device, mine));
+        std::vector<ppcr_ctx *> handles;  // in flight, being prepared, or waiting on either side
+        HandOver<ppcr_ctx *> idle;
+        HandOver<PreparedPair> ready;
+        for (int64_t h = 0; h < std::min<int64_t>(mine, (int64_t)lanes + 2); h++) {
+            ppcr_ctx *c = batch_pool().take(dev);
+            const int rc = c ? PPCR_OK : ppcr_create(dev, &c);
+            if (rc != PPCR_OK) {
+                first.set(rc, ppcr_last_error(nullptr));
+                break;
+            }
+            handles.push_back(c);
+            idle.push(c);
+        }
+        if (!first.failed()) {
+            std::thread preparing([&]() {
+                for (int64_t k = 0; k < mine && !first.failed(); k++) {
+                    ppcr_ctx *c = nullptr;
+                    if (idle.pop(&c, true) != 1) break;  // (closed: the other thread met an error)
+                    const int64_t p = (int64_t)d + k * n_devices;
+                    const ppcr_pair &pr = pairs[p];
+                    int rc = ppcr_set_params(c, opt->radius, opt->max_neighbours, opt->dof, opt->dim);
+                    if (rc == PPCR_OK) rc = ppcr_set_target(c, pr.target, pr.n_target, pr.target_stride_bytes);
+                    if (rc == PPCR_OK) rc = ppcr_set_source(c, pr.source, pr.n_source, pr.source_stride_bytes);
+                    if (rc == PPCR_OK) rc = prepare_first_association(c);
+                    if (rc != PPCR_OK) {
+                        first.set(rc, "pair " + std::to_string(p) + ": " + ppcr_last_error(c));
+                        break;
+                    }
+                    ready.push(PreparedPair{c, p});
+                }
+                ready.close();
+            });
+            struct Running {
+                AlignJob job;
+                int64_t pair;
+            };
+            std::vector<std::unique_ptr<Running>> window;
+            bool more = true;
+            while ((more || !window.empty()) && !first.failed()) {
+                while (more && (int)window.size() < lanes) {
+                    PreparedPair pp{nullptr, 0};
+                    const int got = ready.pop(&pp, window.empty());
+                    if (got < 0) more = false;
+                    if (got <= 0) break;
+                    std::unique_ptr<Running> r(new Running{make_job(pp.c, opt->n_iter, opt->cost_drop_thresh, opt->n_cost_drop_it, opt->q0, opt->t0,
+                                                                    opt->inner_steps, opt->f_tol, nullptr, nullptr, nullptr),
+                                                           pp.pair});
+                    int rc = r->job.validate();
+                    if (rc == PPCR_OK && !r->job.pipelined) rc = r->job.run();  // (a handle with the mailbox switched off: here and now)
+                    if (rc != PPCR_OK) {
+                        first.set(rc, "pair " + std::to_string(pp.pair) + ": " + ppcr_last_error(pp.c));
+                        break;
+                    }
+                    window.push_back(std::move(r));
+                }
+                bool any = false;
+                for (size_t w = 0; w < window.size() && !first.failed();) {
+                    Running &r = *window[w];
+                    bool progressed = false;
+                    const int rc = r.job.advance(false, &progressed);
+                    if (rc != PPCR_OK) {
+                        first.set(rc, "pair " + std::to_string(r.pair) + ": " + ppcr_last_error(r.job.c));
+                        break;
+                    }
+                    any = any || progressed;
+                    if (r.job.finished) {
+                        // the totals are on the host; what is still queued on the handle's stream (its last move is a
+                        // host-side pending one) the next upload waits for
+                        std::memcpy(T_all + (size_t)r.pair * 12, r.job.Tcum, sizeof(r.job.Tcum));
+                        if (n_iter_done) n_iter_done[r.pair] = r.job.rule.iteration;
+                        idle.push(r.job.c);
+                        window.erase(window.begin() + (long)w);
+                    } else {
+                        w++;
+                    }
+                }
+                if (!any && !window.empty()) std::this_thread::yield();
+            }
+            if (first.failed())
+                for (auto &r : window) r->job.abandon();
+            idle.close();
+            preparing.join();
+        }
+        // handles that worked go back to the pool (their buffers stay allocated for the next batch); after a failure none
+        // of them is trusted again
+        for (ppcr_ctx *c : handles) {
+            (void)hipSetDevice(dev);
+            if (first.failed() || hipStreamSynchronize(c->stream) != hipSuccess || !batch_pool().give(dev, c)) ppcr_destroy(c);
+        }
+    };
+    // everything else (unbounded or very wide searches: the host-paced loop): a thread per lane, each with its own handle
     std::vector<std::atomic<int64_t>> next(n_devices);
     for (auto &a : next) a.store(0);
-    FirstError first;
     auto worker = [&](int d) {
         ppcr_ctx *c = batch_pool().take(device_ids[d]);
         int rc = c ? PPCR_OK : ppcr_create(device_ids[d], &c);
@@ -3375,12 +3537,14 @@ int ppcr_batch_run(const ppcr_pair *pairs, int64_t n_pairs, const ppcr_batch_opt
                 break;
             }
         }
-        // a handle that worked goes back to the pool (its buffers stay allocated for the next batch); one that failed is
-        // not trusted again
         if (rc != PPCR_OK || hipStreamSynchronize(c->stream) != hipSuccess || !batch_pool().give(device_ids[d], c)) ppcr_destroy(c);
     };
     std::vector<std::thread> pool;
     for (int d = 0; d < n_devices; d++) {
+        if (two_threads) {
+            pool.emplace_back(device_share, d);
+            continue;
+        }
         const int64_t mine = (n_pairs - d + n_devices - 1) / n_devices;
         const int lanes = (int)std::max<int64_t>(1, std::min<int64_t>(lanes_per_device, mine));
         for (int l = 0; l < lanes; l++) pool.emplace_back(worker, d);
