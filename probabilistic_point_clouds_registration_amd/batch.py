@@ -28,8 +28,8 @@ def register_pair_hip(src, tgt, params, device_id=0, n_iter=20, inner_steps=1, c
 
 def register_local_pairs_hip(make_pair, n_pairs, world_size, rank, device_id=0, lanes=2, n_iter=20, inner_steps=1,
                              cost_drop_thresh=0.0, n_cost_drop_it=5):
-    """This rank's share through ppcr_batch_run: `lanes` pairs in flight on the rank's GPU (their uploads and
-    3x3 host solves overlap each other's kernels). All pairs must share one parameter set. -> {pair: 3x4}"""
+    """This rank's share through ppcr_batch_run: `lanes` pairs in flight on the rank's GPU, the next pairs' uploads,
+    grid builds and source sorts prepared on a second thread meanwhile. All pairs must share one parameter set. -> {pair: 3x4}"""
     from . import _lib
     mine = shard_pairs(n_pairs, world_size, rank)
     if not mine:
