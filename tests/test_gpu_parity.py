@@ -607,7 +607,7 @@ def test_companion_and_reports_follow_the_source(ctx):
 
 
 def test_batch_run_and_align_many(ctx):
-    """ppcr_batch_run (host buffers in, worker lanes inside) and ppcr_align_many (resident handles): every pair's
+    """ppcr_batch_run (host buffers in, its threads inside) and ppcr_align_many (resident handles): every pair's
     final transform equals the same pair registered alone, and the oracle's, whatever the lane count."""
     prm = dict(radius=1.0, max_neighbours=10, dof=5.0)
     pairs = [synth.make_pair(3000 + 500 * p, cfg=5, pair=p, stride=3 + (p % 2))[:2] for p in range(5)]
@@ -664,6 +664,27 @@ def test_batch_run_and_align_many(ctx):
         _lib.batch_run(pairs[:1], n_iter=1, device_ids=(99,), **prm)
     with pytest.raises(_lib.PpcrError, match="pair [01]: radius"):
         _lib.batch_run(pairs[:2], n_iter=1, radius=-1.0, max_neighbours=10)
+    # after a failed batch (its handles are not trusted again) the next one runs on fresh handles
+    Td, _ = _lib.batch_run(pairs[:2], n_iter=5, device_ids=(0,), lanes_per_device=2, **prm)
+    np.testing.assert_array_equal(Td[0], solo[0])
+    # many short registrations through the two threads of a device's share (one preparing pairs, one keeping the window
+    # full), the reference's inner schedule: every transform the one the pair gets alone
+    many = [synth.make_pair(1500 + 37 * p, cfg=6, pair=p, stride=3)[:2] for p in range(48)]
+    Tm, dm = _lib.batch_run(many, n_iter=6, inner_steps=100, device_ids=(0,), lanes_per_device=6, **prm)
+    assert list(dm) == [6] * 48
+    for p in (0, 1, 17, 46, 47):
+        with _lib.Context(0) as c:
+            c.set_params(1.0, 10, 5.0, 3)
+            c.set_target(many[p][1])
+            c.set_source(many[p][0])
+            np.testing.assert_array_equal(c.align(6, cost_drop_thresh=0.0, inner_steps=100)["history"][-1], Tm[p])
+    # an unbounded search (max_neighbours 0: the host-paced loop) keeps a thread per lane
+    Tu, du = _lib.batch_run(many[:4], n_iter=2, radius=1.0, max_neighbours=0, dof=5.0, device_ids=(0,), lanes_per_device=2)
+    with _lib.Context(0) as c:
+        c.set_params(1.0, 0, 5.0, 3)
+        c.set_target(many[3][1])
+        c.set_source(many[3][0])
+        np.testing.assert_array_equal(c.align(2, cost_drop_thresh=0.0, inner_steps=1)["history"][-1], Tu[3])
 
 
 def test_temporal_cutoff_and_deferred_move_change_nothing(ctx):
