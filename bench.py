@@ -128,7 +128,7 @@ def spawn_ranks(a):
 
 def k1_instantiation(cfg, inner_steps, two_pass, fused=True):
     """Template string of the nn_fast_kernel instantiation a config's steady-state iterations launch (mirrors
-    launch_tile<M> in csrc/ppcr_nn_tile.hip and k23_form in csrc/ppcr_hip.hip): list width M = the narrowest compiled
+    launch_tile<M> in csrc/ppcr_nn_tile.hip and k23_form in csrc/ppcr_hip_iteration.inc): list width M = the narrowest compiled
     width holding max_neighbours; widths <= 10 have the steady-state variant (16-slot lists, 1728-candidate halo), wider
     ones keep 32 slots and the 2240-candidate halo; FTM = the K23 form folded in (8: t with v + dim = 8, 0: Gaussian,
     -3: another integer v + dim, -2: none — two-pass searches, wide lists, non-integer v + dim, fuse_k23 = 0)."""

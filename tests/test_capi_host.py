@@ -52,7 +52,7 @@ def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "probabilistic_point_clouds_registration_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".cc")):
+            if f.endswith((".py", ".hip", ".inc", ".h", ".hpp", ".cpp", ".cc")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 for needle in ("import oracle", "from oracle", "libppcr_oracle", "ppcr_oracle.c", "po_radius_search"):
                     assert needle not in txt, (f, needle)
