@@ -221,9 +221,9 @@ typedef struct ppcr_batch_options {
 
 /* T_all: n_pairs*12 doubles (final cumulative [R|t] of each pair, identity when no iteration ran);
  * n_iter_done: n_pairs ints or NULL.  On failure the first error text is copied to err (may be NULL).
- * Pair p runs on device_ids[p % n_devices].  Threads: two per device for bounded searches (one prepares pairs on idle
- * handles — uploads, grid build, source sort —, the other keeps up to lanes_per_device registrations in flight and
- * only enqueues and polls); one per lane for unbounded / very wide searches (host-paced loop). */
+ * Pair p runs on device_ids[p % n_devices].  Threads: two or three per device for bounded searches (one — two from three lanes on —
+ * prepares pairs on idle handles: uploads, grid build, source sort; one keeps up to lanes_per_device registrations in
+ * flight and only enqueues and polls); one per lane for unbounded / very wide searches (host-paced loop). */
 int ppcr_batch_run(const ppcr_pair *pairs, int64_t n_pairs, const ppcr_batch_options *opt,
                    const int *device_ids, int n_devices, int lanes_per_device, double *T_all,
                    int32_t *n_iter_done, char *err, int64_t err_capacity);
