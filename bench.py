@@ -679,20 +679,23 @@ def run_rank(a):
         if batch_cfg and world == 1 and not a.no_extras:
             # pairs per second END TO END: host buffers in (upload, grid build, source sort, K iterations), several
             # pairs in flight per GPU so that one pair's uploads overlap another pair's iterations (ppcr_batch_run)
-            host_pairs = [synth.make_config(a.config, pair=p, n=n)[:2] for p in range(min(n_pairs, 16))]
+            host_pairs = [synth.make_config(a.config, pair=p, n=n)[:2] for p in range(min(n_pairs, 64))]   # (64 x 250k: 0.5 GB of host memory)
             for _ in range(2):   # warm-up: ppcr_batch_run keeps its handles, four of them have grown their buffers after this
                 _lib.batch_run(host_pairs[:8], cfg["radius"], cfg["max_neighbours"], cfg["dof"], n_iter=a.steps + a.warmup,
                                inner_steps=a.inner_steps, device_ids=(local_rank,), lanes_per_device=4)
             e2e = {}
-            for lanes in (1, 2, 4):
-                t0 = time.perf_counter()
-                _lib.batch_run(host_pairs, cfg["radius"], cfg["max_neighbours"], cfg["dof"], n_iter=a.steps + a.warmup,
-                               inner_steps=a.inner_steps, device_ids=(local_rank,), lanes_per_device=lanes)
-                e2e[f"lanes_{lanes}"] = len(host_pairs) / (time.perf_counter() - t0)
+            for lanes in (1, 2, 4, 6):
+                best = 0.0
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    _lib.batch_run(host_pairs, cfg["radius"], cfg["max_neighbours"], cfg["dof"], n_iter=a.steps + a.warmup,
+                                   inner_steps=a.inner_steps, device_ids=(local_rank,), lanes_per_device=lanes)
+                    best = max(best, len(host_pairs) / (time.perf_counter() - t0))
+                e2e[f"lanes_{lanes}"] = best
             out["pairs_per_s_end_to_end"] = dict(e2e, pairs=len(host_pairs), iterations_per_pair=a.steps + a.warmup,
                                                  note="ppcr_batch_run on one GPU, host buffers in: upload + grid build + "
-                                                      "source sort + iterations per pair, `lanes` pairs in flight; its "
-                                                      "pooled handles are warm (two untimed batches before)")
+                                                      "source sort + iterations per pair, `lanes` pairs in flight (best of two "
+                                                      "calls each); its pooled handles are warm (two untimed batches before)")
         if batch_cfg and not a.no_verify:
             # every gathered transform against a single-rank, single-stream run of the same pair and schedule
             worst = 0.0
