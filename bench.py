@@ -205,6 +205,28 @@ def cpu_baseline_refshape(src, tgt, cfg, iters=3):
                 seconds=dt, mean_inner_steps=float(np.mean(res["inner_steps"])))
 
 
+def trace_phases(stderr_text, skip=0):
+    """Median over the PPCR_TRACE lines (one per align(); the first `skip` are warm-up objects) of the first time each mark
+    was passed, microseconds from the call's entry: validated (loop state ready), grid (the early grid build waited for),
+    sorted (source sort enqueued), reserved (the association's buffers there), k1 (first association launched), enqueued
+    (first train complete), consumed (first iteration's result on the host), ran / finished (loop over, stream idle)."""
+    rows = []
+    for ln in stderr_text.splitlines():
+        if not ln.startswith("PPCR_TRACE "):
+            continue
+        first = {}
+        for tok in ln.split()[1:]:
+            k, _, v = tok.partition("=")
+            if k not in first:
+                first[k] = float(v)
+        rows.append(first)
+    rows = rows[skip:]
+    if not rows:
+        return None
+    keys = [k for k in ("validated", "grid", "sorted", "reserved", "k1", "enqueued", "consumed", "ran", "finished") if all(k in r for r in rows)]
+    return {k: round(float(np.median([r[k] for r in rows])), 1) for k in keys}
+
+
 def cpp_api_block(src, tgt, cfg, a):
     """ppcr_cpp_api_test --bench: the built C++ classes over libppcr_hip.so, in their own process."""
     import tempfile
@@ -223,10 +245,14 @@ def cpp_api_block(src, tgt, cfg, a):
             cmd = [exe, "--bench", sp, tp, repr(float(cfg["radius"])), str(cfg["max_neighbours"]), dof, str(a.warmup),
                    str(a.steps), str(inner), "7"]
             try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                # PPCR_TRACE: the library marks the host wall clock through every align() (stderr, one line per call);
+                # the marks of the fresh objects say WHERE a box spends align_fixed_overhead_ms
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, PPCR_TRACE="1"))
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 block[key] = json.loads(line[-1]) if (r.returncode == 0 and line) else {
                     "error": f"exit {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+                if "error" not in block[key]:
+                    block[key]["fresh_align_phases_us"] = trace_phases(r.stderr, skip=3)
             except (OSError, subprocess.TimeoutExpired, ValueError) as e:
                 block[key] = {"error": str(e)}
     return block

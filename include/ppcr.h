@@ -232,6 +232,17 @@ int ppcr_batch_run(const ppcr_pair *pairs, int64_t n_pairs, const ppcr_batch_opt
  * unloading the library or to give the memory back; never required for correctness. */
 int ppcr_batch_release(void);
 
+/* Device memory of the handles (no counterpart in the reference: its clouds live in host memory owned by PCL).
+ * Every handle's buffers are blocks of a per-device pool: the library takes memory from the driver in a few large
+ * slabs, sub-allocates them on the host side, and keeps what ppcr_destroy gives back for the next handle (at most
+ * PPCR_POOL_KEEP_MB of wholly unused slabs, default 4096; the environment variable is read once) — a fresh handle's
+ * first registration then makes no driver call at all.
+ * ppcr_memory_stats: bytes held from the driver, bytes in use by live buffers, hipMalloc calls made so far (any pointer
+ * may be NULL).  ppcr_memory_trim: hand every unused slab (and the pinned blocks of destroyed handles) back to the
+ * driver now — synchronises the device; call it when other users of the GPU need the memory. */
+int ppcr_memory_stats(int device_id, uint64_t *reserved_bytes, uint64_t *in_use_bytes, uint64_t *driver_allocs);
+int ppcr_memory_trim(int device_id);
+
 /* The same loop over handles whose clouds are already resident (set_source/set_target done by the caller):
  * ppcr_align on each of the n handles, `lanes` of them in flight at a time on their own streams.
  * T_final: n*12 doubles; n_done: n ints or NULL.  Handles may live on different devices.

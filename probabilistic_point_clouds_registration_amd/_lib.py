@@ -24,6 +24,7 @@ SYMBOLS = [
     "ppcr_profile_get", "ppcr_set_option", "ppcr_batch_run", "ppcr_align_many", "ppcr_set_companion",
     "ppcr_get_companion", "ppcr_set_ground_truth", "ppcr_mse_ground_truth", "ppcr_mse_previous", "ppcr_voxel_filter",
     "ppcr_nearest_sq_distances", "ppcr_stop_rule_check", "ppcr_align_report", "ppcr_batch_release",
+    "ppcr_memory_stats", "ppcr_memory_trim",
     "ppcr_comm_get_id", "ppcr_comm_create", "ppcr_comm_destroy", "ppcr_gather_transforms", "ppcr_comm_last_error",
 ]
 
@@ -125,6 +126,8 @@ def load():
     L.ppcr_batch_run.argtypes = [C.POINTER(Pair), i64, C.POINTER(BatchOptions), C.POINTER(i32), i32, i32, vp, vp,
                                  C.c_char_p, i64]
     L.ppcr_align_many.argtypes = [C.POINTER(vp), i32, i32, i32, dbl, dbl, vp, vp, i32, dbl, vp, vp]
+    L.ppcr_memory_stats.argtypes = [i32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.ppcr_memory_trim.argtypes = [i32]
     L.ppcr_comm_get_id.argtypes = [vp]
     L.ppcr_comm_create.argtypes = [i32, i32, i32, vp, C.POINTER(vp)]
     L.ppcr_comm_destroy.argtypes = [vp]
@@ -467,6 +470,23 @@ def batch_run(pairs, radius, max_neighbours, dof=5.0, n_iter=20, cost_drop_thres
     if rc != 0:
         raise PpcrError(rc, err.value.decode())
     return T, done
+
+
+def memory_stats(device_id=0):
+    """ppcr_memory_stats: the device pool the handles' buffers are cut from — bytes held from the driver, bytes in use,
+    hipMalloc calls made so far."""
+    r, u, n = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    rc = load().ppcr_memory_stats(int(device_id), C.byref(r), C.byref(u), C.byref(n))
+    if rc != 0:
+        raise PpcrError(rc, load().ppcr_last_error(None).decode())
+    return {"reserved_bytes": r.value, "in_use_bytes": u.value, "driver_allocs": n.value}
+
+
+def memory_trim(device_id=0):
+    """ppcr_memory_trim: unused slabs (and the pinned blocks of destroyed handles) back to the driver."""
+    rc = load().ppcr_memory_trim(int(device_id))
+    if rc != 0:
+        raise PpcrError(rc, load().ppcr_last_error(None).decode())
 
 
 def batch_release():

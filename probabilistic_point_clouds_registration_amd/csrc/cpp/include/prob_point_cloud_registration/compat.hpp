@@ -179,6 +179,7 @@ public:
     template <class It>
     void setFromTriplets(It first, It last);
     void makeCompressed() {}
+    bool isCompressed() const { return true; }  // (this stand-in only has the compressed form)
     T coeff(long r, long c) const
     {
         for (int k = outer_[r]; k < outer_[r + 1]; k++)

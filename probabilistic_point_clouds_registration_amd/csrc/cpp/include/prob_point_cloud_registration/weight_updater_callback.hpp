@@ -41,6 +41,15 @@ public:
     ceres::CallbackReturnType operator()(const ceres::IterationSummary &) override
     {
         const std::size_t n_terms = error_terms_->size();
+        // The reference re-reads *error_terms_ and *data_association_ on every call.  The device route holds a snapshot of
+        // both (the terms' points, the rows): it is only taken again while the caller's objects are the ones snapshotted —
+        // same ErrorTerm objects in the same order (their points never change after construction, error_term.hpp:13-20),
+        // same compressed row structure — and rebuilt from scratch otherwise.
+        if (route_ == kDevice && !snapshot_is_current()) {
+            device_.reset();
+            route_ = kUndecided;
+        }
+        if (route_ == kHostResiduals && n_terms != host_route_terms_) route_ = kUndecided;  // (other terms: decide again)
         if (route_ == kUndecided) prepare_device_route();
         if (route_ == kDevice) {
             weights_.resize(n_terms);
@@ -68,13 +77,31 @@ public:
 private:
     enum Route { kUndecided, kDevice, kHostResiduals };
 
+    bool snapshot_is_current() const
+    {
+        const long rows = data_association_->rows();
+        if (!data_association_->isCompressed() || static_cast<std::size_t>(rows) + 1 != outer_snapshot_.size()) return false;
+        if (error_terms_->size() != terms_snapshot_.size() || static_cast<std::size_t>(data_association_->nonZeros()) != terms_snapshot_.size())
+            return false;
+        const int *outer = data_association_->outerIndexPtr();
+        for (std::size_t i = 0; i < outer_snapshot_.size(); ++i)
+            if (outer[i] != outer_snapshot_[i]) return false;
+        for (std::size_t k = 0; k < terms_snapshot_.size(); ++k)
+            if ((*error_terms_)[k] != terms_snapshot_[k]) return false;
+        return true;
+    }
+
     void prepare_device_route()
     {
         route_ = kHostResiduals;
+        host_route_terms_ = error_terms_->size();
         const long rows = data_association_->rows();
         const long nnz = data_association_->nonZeros();
         if (rows <= 0 || nnz <= 0 || static_cast<std::size_t>(nnz) != error_terms_->size()) return;
+        // (outerIndexPtr()[i + 1] ends row i only in compressed storage; an uncompressed matrix keeps the host route)
+        if (!data_association_->isCompressed()) return;
         const int *outer = data_association_->outerIndexPtr();
+        if (outer[0] != 0 || outer[rows] != nnz) return;
         std::vector<float> src(static_cast<std::size_t>(rows) * 3, 0.f), tgt(static_cast<std::size_t>(nnz) * 3);
         std::vector<int> col(static_cast<std::size_t>(nnz));
         for (long i = 0; i < rows; ++i)
@@ -100,6 +127,8 @@ private:
             dev->check(ppcr_set_source(c, src.data(), rows, 12), "ppcr_set_source");
             dev->check(ppcr_set_association(c, outer, col.data(), rows), "ppcr_set_association");
             device_ = std::move(dev);
+            outer_snapshot_.assign(outer, outer + rows + 1);
+            terms_snapshot_.assign(error_terms_->begin(), error_terms_->end());
             route_ = kDevice;
         } catch (const DeviceError &) {
             // no handle: the host-residual route reports through updateWeights
@@ -115,6 +144,9 @@ private:
     Route route_ = kUndecided;
     std::unique_ptr<DeviceContext> device_;
     std::vector<double> weights_;
+    std::size_t host_route_terms_ = 0;               // the term count the host route was chosen for
+    std::vector<int> outer_snapshot_;                // what the handle holds: the rows ...
+    std::vector<const ErrorTerm *> terms_snapshot_;  // ... and the terms whose points were uploaded, in order
 };
 
 }  // namespace prob_point_cloud_registration

@@ -7,7 +7,10 @@
 // where every non-empty line of pairs.txt names "<source.pcd> <target.pcd>": the pairs are registered by ppcr_batch_run
 // over every visible GPU (pair p on device p % n, L pairs in flight per device) and one line per pair is printed.
 // The program is organised as a small pipeline of its own: parse -> load -> register -> publish.
+#include <cstdint>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <filesystem>
 #include <fstream>
 #include <iostream>
@@ -38,6 +41,7 @@ struct Job {
     // on its device and takes part in the final RCCL all-gather of the transforms; rank 0 prints them
     int rank = 0, world = 1;
     std::string rendezvous;                            // --rendezvous: a file rank 0 leaves the communicator id in
+    std::string run_id;                                // --run-id: a token of THIS launch; ranks only accept a rendezvous file that carries it
     bool device_given = false;                         // --device on the command line (rank mode: default rank % devices)
     bool gaussian = false;
 };
@@ -53,7 +57,7 @@ struct BadArgument {
                  "         [-r <float>] [-d <float>] [-i <int>] [-m <int>] [-t <float>] [-s <float>] [--device <int>]\n"
                  "         [--inner-steps <int>] <source_file_name> <target_file_name>\n"
                  "   or: probabilistic_point_cloud_registration --batch <pair_list_file> [--lanes <int>] [options as above]\n"
-                 "         [--rank <int> --world <int> --rendezvous <file>]   (one process per GPU, RCCL gather of the transforms)"
+                 "         [--rank <int> --world <int> --rendezvous <file> [--run-id <string>]]   (one process per GPU, RCCL gather of the transforms)"
               << std::endl;
     std::exit(EXIT_FAILURE);
 }
@@ -137,6 +141,7 @@ Job parseCommandLine(int argc, char **argv)
         else if (a == "--rank") job.rank = cur.integer(a);
         else if (a == "--world") job.world = cur.integer(a);
         else if (a == "--rendezvous") job.rendezvous = cur.valueOf(a);
+        else if (a == "--run-id") job.run_id = cur.valueOf(a);
         else if (is("-h", "--help")) throw BadArgument{"help requested", a};
         else if (looksLikeFlag(a)) throw BadArgument{"Couldn't find match for argument", a};
         else files.push_back(a);
@@ -225,41 +230,66 @@ void writeSummary(const Job &job, const std::string &table)
     out << table;
 }
 
-// one-process-per-GPU mode of --batch: the communicator of the final gather.  Rank 0 draws the RCCL id and leaves its
-// 128 bytes in the rendezvous file (written under another name and renamed, so a reader never sees half of it); the
-// other ranks wait for the file.  ppcr_comm_create is collective.
-ppcr_comm *joinRanks(const Job &job, int device)
-{
+// one-process-per-GPU mode of --batch: the communicator of the final gather, made BEFORE any cloud is read (every rank
+// is then at the same point of its life, and a rank that fails later still takes part in the collectives: runBatch).
+// Rank 0 removes whatever an earlier launch left under the rendezvous name, draws the RCCL id and leaves a record
+// {magic, time written, --run-id token, id} there (written under another name and renamed, so a reader never sees half
+// of it).  The other ranks wait for a record of THIS launch: one that carries their --run-id token when a token was
+// given, else one written no earlier than a minute before they started (a file left by a crashed launch is older, or
+// carries another token).  ppcr_comm_create is collective.
+struct RendezvousRecord {
+    char magic[8];
+    std::int64_t written_unix_ms;
+    char run_id[64];
     unsigned char id[PPCR_COMM_ID_BYTES];
+};
+constexpr char kRendezvousMagic[8] = {'P', 'P', 'C', 'R', 'r', 'v', '0', '2'};
+
+std::int64_t unixMillis()
+{
+    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
+
+ppcr_comm *joinRanks(const Job &job, int device, std::int64_t started_unix_ms)
+{
+    RendezvousRecord rec;
+    std::memset(&rec, 0, sizeof rec);
     if (job.rank == 0) {
-        if (ppcr_comm_get_id(id) != PPCR_OK) return nullptr;
+        std::error_code ec;
+        fs::remove(job.rendezvous, ec);  // (a crashed launch's record: nobody of this launch may take it for ours)
+        if (ppcr_comm_get_id(rec.id) != PPCR_OK) return nullptr;
+        std::memcpy(rec.magic, kRendezvousMagic, sizeof rec.magic);
+        rec.written_unix_ms = unixMillis();
+        std::snprintf(rec.run_id, sizeof rec.run_id, "%s", job.run_id.c_str());
         const std::string tmp = job.rendezvous + ".tmp";
         {
             std::ofstream out(tmp, std::ios::binary);
-            out.write(reinterpret_cast<const char *>(id), sizeof id);
+            out.write(reinterpret_cast<const char *>(&rec), sizeof rec);
             if (!out) return nullptr;
         }
-        std::error_code ec;
         fs::rename(tmp, job.rendezvous, ec);
         if (ec) return nullptr;
     } else {
         bool have = false;
-        for (int tries = 0; tries < 1200 && !have; tries++) {  // two minutes
+        for (int tries = 0; tries < 1200 && !have; tries++) {  // two minutes from this rank's start
             std::error_code ec;
-            if (fs::exists(job.rendezvous, ec) && fs::file_size(job.rendezvous, ec) == sizeof id) {
+            if (fs::exists(job.rendezvous, ec) && fs::file_size(job.rendezvous, ec) == sizeof rec) {
                 std::ifstream in(job.rendezvous, std::ios::binary);
-                in.read(reinterpret_cast<char *>(id), sizeof id);
-                have = in.gcount() == static_cast<std::streamsize>(sizeof id);
+                in.read(reinterpret_cast<char *>(&rec), sizeof rec);
+                have = in.gcount() == static_cast<std::streamsize>(sizeof rec) && std::memcmp(rec.magic, kRendezvousMagic, sizeof rec.magic) == 0;
+                rec.run_id[sizeof rec.run_id - 1] = 0;
+                if (have && !job.run_id.empty()) have = job.run_id.compare(0, sizeof rec.run_id - 1, rec.run_id) == 0;
+                else if (have) have = rec.written_unix_ms >= started_unix_ms - 60000;
             }
             if (!have) std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }
         if (!have) {
-            std::cerr << "rank " << job.rank << ": no communicator id appeared in " << job.rendezvous << std::endl;
+            std::cerr << "rank " << job.rank << ": no communicator id of this launch appeared in " << job.rendezvous << std::endl;
             return nullptr;
         }
     }
     ppcr_comm *comm = nullptr;
-    if (ppcr_comm_create(device, job.rank, job.world, id, &comm) != PPCR_OK) return nullptr;
+    if (ppcr_comm_create(device, job.rank, job.world, rec.id, &comm) != PPCR_OK) return nullptr;
     return comm;
 }
 
@@ -267,6 +297,7 @@ ppcr_comm *joinRanks(const Job &job, int device)
 // --world / --rendezvous: one process per GPU) this rank's share on its device, then the RCCL gather of the transforms
 int runBatch(const Job &job)
 {
+    const std::int64_t started = unixMillis();
     std::ifstream list(job.batch_path);
     if (!list) {
         std::cout << "Could not read the pair list " << job.batch_path << ", closing" << std::endl;
@@ -287,39 +318,7 @@ int runBatch(const Job &job)
         files.emplace_back(src_name, tgt_name);
     }
     const std::size_t n_pairs = files.size();
-    // the pairs THIS process registers: all of them, or p % world == rank (the deal of ppcr_batch_run and batch.py)
-    std::vector<std::size_t> mine;
-    for (std::size_t p = 0; p < n_pairs; p++)
-        if (!ranked || static_cast<int>(p % static_cast<std::size_t>(job.world)) == job.rank) mine.push_back(p);
-    std::vector<Cloud::Ptr> clouds;  // source, target, source, target, ... of `mine`
-    for (std::size_t p : mine)
-        for (const std::string *name : {&files[p].first, &files[p].second}) {
-            Cloud::Ptr cloud = readCloud(*name);
-            if (!cloud) {
-                std::cout << "Could not load " << *name << ", closing" << std::endl;
-                return EXIT_FAILURE;
-            }
-            clouds.push_back(cloud);
-        }
-    std::vector<ppcr_pair> pairs(mine.size());
-    for (std::size_t k = 0; k < mine.size(); k++) {
-        const Cloud &s = *clouds[2 * k], &t = *clouds[2 * k + 1];
-        pairs[k] = ppcr_pair{s.empty() ? nullptr : &s[0].x, static_cast<int64_t>(s.size()), sizeof(pcl::PointXYZ),
-                             t.empty() ? nullptr : &t[0].x, static_cast<int64_t>(t.size()), sizeof(pcl::PointXYZ)};
-    }
     const auto &p = job.params;
-    ppcr_batch_options opt{};
-    opt.radius = p.radius;
-    opt.dof = p.dof;
-    opt.cost_drop_thresh = p.cost_drop_thresh;
-    opt.n_cost_drop_it = p.n_cost_drop_it;
-    opt.f_tol = 10e-6;  // the reference's function_tolerance
-    for (int k = 0; k < 4; k++) opt.q0[k] = p.initial_rotation[k];
-    for (int k = 0; k < 3; k++) opt.t0[k] = p.initial_translation[k];
-    opt.max_neighbours = p.max_neighbours;
-    opt.dim = 3;
-    opt.n_iter = p.n_iter;
-    opt.inner_steps = p.inner_max_steps;
     int n_devices = 0;
     ppcr_device_count(&n_devices);
     if (n_devices < 1) {
@@ -330,35 +329,96 @@ int runBatch(const Job &job)
     if (ranked) devices.push_back(job.device_given ? p.device_id : job.rank % n_devices);
     else
         for (int d = 0; d < n_devices; d++) devices.push_back(d);
-    std::vector<double> T_mine(12 * mine.size());
-    std::vector<int32_t> it_mine(mine.size());
-    char err[512] = {0};
-    if (job.params.verbose)
-        std::cout << "Registering " << mine.size() << " of " << n_pairs << " pairs on " << devices.size() << " device(s), " << job.lanes
-                  << " in flight each" << (ranked ? " (rank " + std::to_string(job.rank) + " of " + std::to_string(job.world) + ")" : std::string())
-                  << std::endl;
-    const int rc = ppcr_batch_run(pairs.data(), static_cast<int64_t>(pairs.size()), &opt, devices.data(), static_cast<int>(devices.size()),
-                                  job.lanes, T_mine.data(), it_mine.data(), err, sizeof err);
-    if (rc != PPCR_OK) {
-        std::cerr << "registration failed: " << err << std::endl;
-        return EXIT_FAILURE;
+    // Ranked: the communicator FIRST.  Every rank reads the same list and arrives here within its start-up time; from here
+    // on a rank that fails (a cloud it cannot read, a registration error) keeps its place in the collectives and reports
+    // the failure through them, so that no rank is left waiting inside one.
+    ppcr_comm *comm = nullptr;
+    if (ranked) {
+        comm = joinRanks(job, devices[0], started);
+        if (!comm) {
+            std::cerr << "rank " << job.rank << ": could not join the ranks: " << ppcr_comm_last_error() << std::endl;
+            return EXIT_FAILURE;
+        }
+    }
+    // the pairs THIS process registers: all of them, or p % world == rank (the deal of ppcr_batch_run and batch.py)
+    std::vector<std::size_t> mine;
+    for (std::size_t k = 0; k < n_pairs; k++)
+        if (!ranked || static_cast<int>(k % static_cast<std::size_t>(job.world)) == job.rank) mine.push_back(k);
+    bool local_ok = true;
+    std::vector<Cloud::Ptr> clouds;  // source, target, source, target, ... of `mine`
+    for (std::size_t k : mine) {
+        for (const std::string *name : {&files[k].first, &files[k].second}) {
+            Cloud::Ptr cloud = readCloud(*name);
+            if (!cloud) {
+                std::cout << "Could not load " << *name << ", closing" << std::endl;
+                local_ok = false;
+                break;
+            }
+            clouds.push_back(cloud);
+        }
+        if (!local_ok) break;
+    }
+    std::vector<double> T_mine(12 * mine.size(), std::numeric_limits<double>::quiet_NaN());
+    std::vector<int32_t> it_mine(mine.size(), 0);
+    if (local_ok) {
+        std::vector<ppcr_pair> pairs(mine.size());
+        for (std::size_t k = 0; k < mine.size(); k++) {
+            const Cloud &s = *clouds[2 * k], &t = *clouds[2 * k + 1];
+            pairs[k] = ppcr_pair{s.empty() ? nullptr : &s[0].x, static_cast<int64_t>(s.size()), sizeof(pcl::PointXYZ),
+                                 t.empty() ? nullptr : &t[0].x, static_cast<int64_t>(t.size()), sizeof(pcl::PointXYZ)};
+        }
+        ppcr_batch_options opt{};
+        opt.radius = p.radius;
+        opt.dof = p.dof;
+        opt.cost_drop_thresh = p.cost_drop_thresh;
+        opt.n_cost_drop_it = p.n_cost_drop_it;
+        opt.f_tol = 10e-6;  // the reference's function_tolerance
+        for (int k = 0; k < 4; k++) opt.q0[k] = p.initial_rotation[k];
+        for (int k = 0; k < 3; k++) opt.t0[k] = p.initial_translation[k];
+        opt.max_neighbours = p.max_neighbours;
+        opt.dim = 3;
+        opt.n_iter = p.n_iter;
+        opt.inner_steps = p.inner_max_steps;
+        char err[512] = {0};
+        if (job.params.verbose)
+            std::cout << "Registering " << mine.size() << " of " << n_pairs << " pairs on " << devices.size() << " device(s), " << job.lanes
+                      << " in flight each" << (ranked ? " (rank " + std::to_string(job.rank) + " of " + std::to_string(job.world) + ")" : std::string())
+                      << std::endl;
+        const int rc = ppcr_batch_run(pairs.data(), static_cast<int64_t>(pairs.size()), &opt, devices.data(), static_cast<int>(devices.size()),
+                                      job.lanes, T_mine.data(), it_mine.data(), err, sizeof err);
+        if (rc != PPCR_OK) {
+            std::cerr << "registration failed: " << err << std::endl;
+            local_ok = false;
+        }
+    }
+    if (!ranked) {
+        if (!local_ok) return EXIT_FAILURE;
     }
     std::vector<double> T(12 * n_pairs);
     std::vector<int32_t> iterations(n_pairs);
     if (ranked) {
-        // the job's ONE collective: every rank ends up with every transform (and, in a second record, iteration count)
-        ppcr_comm *comm = joinRanks(job, devices[0]);
+        // the job's collectives: every rank ends up with every transform, (a second record) every iteration count and (a
+        // third, one slot per rank) every rank's verdict — a failed rank sends NaN transforms and says so
         std::vector<double> counts_mine(12 * mine.size(), 0.0), counts(12 * n_pairs, 0.0);
         for (std::size_t k = 0; k < mine.size(); k++) counts_mine[12 * k] = it_mine[k];
-        const bool ok = comm != nullptr &&
-                        ppcr_gather_transforms(comm, T_mine.data(), static_cast<int64_t>(n_pairs), T.data()) == PPCR_OK &&
-                        ppcr_gather_transforms(comm, counts_mine.data(), static_cast<int64_t>(n_pairs), counts.data()) == PPCR_OK;
+        const std::size_t world = static_cast<std::size_t>(job.world);
+        std::vector<double> verdict_mine(12, 0.0), verdicts(12 * world, 0.0);
+        verdict_mine[0] = local_ok ? 1.0 : 0.0;
+        bool ok = ppcr_gather_transforms(comm, verdict_mine.data(), static_cast<int64_t>(world), verdicts.data()) == PPCR_OK &&
+                  ppcr_gather_transforms(comm, T_mine.data(), static_cast<int64_t>(n_pairs), T.data()) == PPCR_OK &&
+                  ppcr_gather_transforms(comm, counts_mine.data(), static_cast<int64_t>(n_pairs), counts.data()) == PPCR_OK;
         if (!ok) std::cerr << "gather of the transforms failed: " << ppcr_comm_last_error() << std::endl;
         ppcr_comm_destroy(comm);
         if (job.rank == 0) {
             std::error_code ec;
             fs::remove(job.rendezvous, ec);
         }
+        if (!ok) return EXIT_FAILURE;
+        for (std::size_t r = 0; r < world; r++)
+            if (!(verdicts[12 * r] == 1.0)) {
+                if (job.rank == 0 || static_cast<int>(r) == job.rank) std::cerr << "rank " << r << " failed: no result is reported" << std::endl;
+                ok = false;
+            }
         if (!ok) return EXIT_FAILURE;
         for (std::size_t k = 0; k < n_pairs; k++) iterations[k] = static_cast<int32_t>(counts[12 * k]);
         if (job.rank != 0) return EXIT_SUCCESS;  // rank 0 reports

@@ -12,6 +12,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -26,6 +27,7 @@
 #include <vector>
 
 #include "ppcr_host_math.hpp"
+#include "ppcr_pool.hpp"
 #include "ppcr_kernels.hip.h"
 #include "ppcr_nn_tile_launch.hip.h"
 
@@ -71,24 +73,42 @@ constexpr int kMaxAhead = 3;       // outer iterations ppcr_align may have enque
 constexpr int kEllMaxWidth = 32;   // widest register-list NN variant / widest ELL association
 constexpr int kAccumMaxBlocks = 1024;
 
+// A device buffer of a handle: a block of the device's pool (ppcr_pool.hpp), grown on demand, never shrunk.
 template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;
+    int dev = 0;  // the device whose pool the block came from
     hipError_t reserve(size_t n)
     {
         if (n <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
+        if (p) {
+            // growing: launches in flight may still read the old block (what hipFree used to wait for by itself)
+            (void)hipDeviceSynchronize();
+            device_pool(dev).free(p);
+        }
         p = nullptr;
         cap = 0;
         size_t want = n + n / 8 + 64;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T));
-        if (e == hipSuccess) cap = want;
+        hipError_t e = hipGetDevice(&dev);
+        void *block = nullptr;
+        if (e == hipSuccess) e = device_pool(dev).alloc(want * sizeof(T), &block);
+        if (e == hipSuccess) {
+            p = static_cast<T *>(block);
+            cap = want;
+        }
         return e;
     }
+    // the block back to the pool once nothing in flight can touch it
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) (void)hipDeviceSynchronize();
+        release_idle();
+    }
+    // (the caller has made sure of that itself: ppcr_destroy, after synchronising the handle's streams)
+    void release_idle()
+    {
+        if (p) device_pool(dev).free(p);
         p = nullptr;
         cap = 0;
     }
@@ -136,6 +156,7 @@ struct ppcr_ctx {
     double grid_search = 1.0;        // the build in progress: its search radius, which attempt it is, whether its occupancy
     int grid_attempt = 0;            // histogram is on its way to h_occupancy
     bool grid_bounded = false, grid_occ_inflight = false;
+    char *h_pinned = nullptr;                   // the handle's one pinned, device-mapped block; the h_* / d_mbox / d_report pointers are cuts of it
     unsigned long long *h_occupancy = nullptr;  // pinned, kOccBins words
     float *h_bbox = nullptr;                    // pinned, kBboxBlocks partial boxes of the target (bbox_launch / bbox_fold)
     int bbox_blocks = 0;
@@ -248,6 +269,9 @@ struct ppcr_ctx {
     int64_t prof_n[K_NUM] = {0};
 
     double dbg_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics of the last ppcr_align (ppcr_debug_get_host_times)
+    // PPCR_TRACE=1 in the environment: host wall-clock marks of one ppcr_align (where a call's fixed cost goes), printed
+    // to stderr when the call returns
+    std::vector<std::pair<const char *, double>> trace;
     // reporting clouds (the step after each iteration: cc:110-129): a full-resolution companion that follows every
     // move of the source, the ground truth and the previous-iteration snapshot, all in the caller's index order
     DevBuf<float4> companion, ground_truth, previous;
@@ -272,6 +296,28 @@ struct ppcr_ctx {
     const float4 *tgt_cur() const { return tgt_space(assoc_space); }
 };
 
+
+namespace {
+const bool g_trace = [] { const char *e = std::getenv("PPCR_TRACE"); return e && *e && *e != '0'; }();
+// (per-iteration marks only while the trace is short — the first dozen iterations; closing marks always)
+inline void trace_mark(ppcr_ctx *c, const char *what, bool closing = false)
+{
+    if (g_trace && (closing || c->trace.size() < 96))
+        c->trace.emplace_back(what, std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count());
+}
+void trace_print(ppcr_ctx *c)
+{
+    if (!g_trace || c->trace.empty()) return;
+    std::string line = "PPCR_TRACE";
+    char buf[96];
+    for (size_t k = 0; k < c->trace.size(); k++) {
+        std::snprintf(buf, sizeof(buf), " %s=%.1f", c->trace[k].first, (c->trace[k].second - c->trace[0].second) * 1e6);
+        line += buf;
+    }
+    std::fprintf(stderr, "%s\n", line.c_str());
+    c->trace.clear();
+}
+}  // namespace
 
 // The rest of this translation unit, in reading order:
 #include "ppcr_hip_setup.inc"      // errors, uploads, K0: grid build in two halves, levels, source sort

@@ -59,6 +59,11 @@ void check_fast_kernel_lds()
             good = good && fast_kernel_lds_ok<M, 16, kCapSteady, false, -2, false>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, 8, false>() &&
                    fast_kernel_lds_ok<M, 16, kCapSteady, false, 0, false>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, -3, false>() &&
                    fast_kernel_lds_ok<M, 16, kCapSteady, false, -2, true>();
+        // the diagnostic (option "stamps") instantiations launch_tile can reach
+        if constexpr (M == 10)
+            good = good && fast_kernel_lds_ok<M, 16, kCapSteady, true, -2, true>() && fast_kernel_lds_ok<M, 16, kCapSteady, true, -2, false>() &&
+                   fast_kernel_lds_ok<M, C, CAP, true, -2, false>();
+        if constexpr (M == 10 || M == 20) good = good && fast_kernel_lds_ok<M, C, CAP, true, -2, true>();
         return good;
     }();
     if (!ok) {
@@ -98,6 +103,8 @@ void launch_tile(TileLaunch &t)
     const int grid_steady = steady_grid(nb, halves);
     FusedMoments fm_none;
     std::memset(&fm_none, 0, sizeof(fm_none));
+    VerletLists vv_none;
+    std::memset(&vv_none, 0, sizeof(vv_none));
     const LoopReset lr{t.loop_st};
     // (one-pass search: only rows marked unsearched are listed, its short rows are final)
     const bool multi = t.n_levels > 1 && t.levels != nullptr && t.short_count != nullptr;
@@ -110,7 +117,15 @@ void launch_tile(TileLaunch &t)
 #define PPCR_FAST(Cc, STAMPc, FTMc, FMc)                                                                               \
     nn_fast_kernel<M, Cc, (Cc <= 16 ? kCapSteady : CAP), STAMPc, FTMc><<<(Cc <= 16 ? grid_steady : nb), 256, 0, t.stream>>>( \
         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,  \
-        t.ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc, lr, un)
+        t.ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc, lr, un, vv_none)
+    // steady state with Verlet lists: [nn_verify_kernel, when lists exist] + nn_fast_kernel<..., VERLET> over the same grid
+#define PPCR_VERIFY(FTMc, FMc)                                                                                          \
+    nn_verify_kernel<M, FTMc><<<grid_steady, 256, 0, t.stream>>>(t.src, t.ns, t.tgt, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2,   \
+                                                                 split_on, FMc, lr, vv)
+#define PPCR_FAST_V(FTMc, FMc)                                                                                          \
+    nn_fast_kernel<M, 16, kCapSteady, false, FTMc, false, true><<<grid_steady, 256, 0, t.stream>>>(                      \
+        t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, pm_b, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,    \
+        t.ovf_next, split_on, nullptr, FMc, lr, un, vv)
     t.fused = false;
     int ftm = -2;  // model folded into this launch (-2: none)
     bool steady = false;
@@ -125,7 +140,7 @@ void launch_tile(TileLaunch &t)
             if (st && t.dm2_in && t.short_lists) {
                 nn_fast_kernel<M, 16, kCapSteady, true, -2, true><<<grid_multi, 256, 0, t.stream>>>(
                     t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
-                    two_per_block, st, fm_none, lr, un);
+                    two_per_block, st, fm_none, lr, un, vv_none);
                 done = true;
             }
         }
@@ -133,7 +148,7 @@ void launch_tile(TileLaunch &t)
             if (st && !done) {
                 nn_fast_kernel<M, C, CAP, true, -2, true><<<grid_multi, 256, 0, t.stream>>>(
                     t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
-                    two_per_block, st, fm_none, lr, un);
+                    two_per_block, st, fm_none, lr, un, vv_none);
                 done = true;
             }
         }
@@ -144,7 +159,7 @@ void launch_tile(TileLaunch &t)
             if (!done && t.dm2_in && t.short_lists) {
                 nn_fast_kernel<M, 16, kCapSteady, false, -2, true><<<grid_multi, 256, 0, t.stream>>>(
                     t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
-                    two_per_block, nullptr, fm_none, lr, un);
+                    two_per_block, nullptr, fm_none, lr, un, vv_none);
                 done = true;
             }
         }
@@ -156,7 +171,7 @@ void launch_tile(TileLaunch &t)
         if (!done)
             nn_fast_kernel<M, C, CAPM, false, -2, true><<<grid_multi, 256, 0, t.stream>>>(t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr,
                                                                                          t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,
-                                                                                         t.ovf_next, two_per_block, nullptr, fm_none, lr, un);
+                                                                                         t.ovf_next, two_per_block, nullptr, fm_none, lr, un, vv_none);
         steady = true;  // (skips the single-level launches below)
     } else
     if constexpr (M <= 12) {
@@ -165,6 +180,25 @@ void launch_tile(TileLaunch &t)
         if (t.dm2_in && t.short_lists) {
             steady = true;
             if (t.fuse && !st) ftm = t.fuse_tm;
+            // Verlet lists (t.verlet_mode: 1 build them in this launch, 2 verify first and rebuild where needed)
+            if (t.verlet_mode != 0 && !st && !halves) {
+                VerletLists vv = t.verlet;
+                PendingMove pm_b = t.pm;
+                vv.build_all = t.verlet_mode == 2 ? 0 : 1;
+                if (t.verlet_mode == 2) {
+                    if (ftm == 0) PPCR_VERIFY(0, *t.fuse);
+                    else if (ftm == 8) PPCR_VERIFY(8, *t.fuse);
+                    else if (ftm == -3) PPCR_VERIFY(-3, *t.fuse);
+                    else PPCR_VERIFY(-2, fm_none);
+                    pm_b.enabled = 0;  // (the verification launch has moved the source)
+                    if (t.between0) t.between0(t.between_arg);
+                }
+                if (ftm == 0) PPCR_FAST_V(0, *t.fuse);
+                else if (ftm == 8) PPCR_FAST_V(8, *t.fuse);
+                else if (ftm == -3) PPCR_FAST_V(-3, *t.fuse);
+                else PPCR_FAST_V(-2, fm_none);
+                t.verlet_built = true;
+            } else
             if constexpr (M == 10) {
                 if (st) PPCR_FAST(16, true, -2, fm_none);
                 else if (ftm == 0) PPCR_FAST(16, false, 0, *t.fuse);
@@ -185,7 +219,7 @@ void launch_tile(TileLaunch &t)
             const SplitTable split_mid{t.split_flag, t.split_list, t.split_state, t.split_state + 1, kMaxSplit, CAP2 * 15 / 16, 0};
             nn_fast_kernel<M, C2, CAP2, false, -2, false><<<nb + kMaxSplit, 256, 0, t.stream>>>(
                 t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
-                split_mid, nullptr, fm_none, lr, un);
+                split_mid, nullptr, fm_none, lr, un, vv_none);
         }
     }
     if (!steady && !multi) {
@@ -197,6 +231,8 @@ void launch_tile(TileLaunch &t)
         }
     }
 #undef PPCR_FAST
+#undef PPCR_FAST_V
+#undef PPCR_VERIFY
     if (t.short_count == nullptr && t.between) t.between(t.between_arg);
     if (t.short_count != nullptr) {
         if (t.between2) t.between2(t.between_arg);

@@ -917,8 +917,15 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
 #ifndef PPCR_LIST_PERM
 #define PPCR_LIST_PERM 1
 #endif
+// (the unclamped list stores lean on gfx950 dropping DS stores beyond the workgroup's allocation — probed by
+//  tools/micro/lds_oob.hip and tests/test_gpu_parity.py — so any other device target gets the clamped form; the host
+//  pass sees the same value as the gfx950 device pass this library is built for)
 #ifndef PPCR_LIST_NOCLAMP
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#define PPCR_LIST_NOCLAMP 0
+#else
 #define PPCR_LIST_NOCLAMP 1
+#endif
 #endif
 // candidate source of the fast flavour: list entries are byte offsets (4 * LDS index) into the SoA halo
 struct HaloList {
@@ -1010,7 +1017,9 @@ struct FastLds {
 
 // MULTI: the grid is chosen per workgroup from un.levels (GridLevel): tgt / cell_start / g / r2 of the arguments are the
 // base level's and only used by the first association (no cut-offs yet: every block searches the base level).
-template <int M, int C, int CAP, bool STAMPS, int FTM = -2, bool MULTI = false>
+// VERLET (steady-state variant only): the launch also builds the rows' Verlet lists (see VerletLists) — for every
+// workgroup (vv.build_all) or for those nn_verify_kernel flagged in vv.need; the others leave at once.
+template <int M, int C, int CAP, bool STAMPS, int FTM = -2, bool MULTI = false, bool VERLET = false>
 __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 4) : (CAP * 13 + C * 512 <= 39400 ? 4 : 3))) void nn_fast_kernel(float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt0,
                                                          const int *__restrict__ cell_start0, GridDesc g0,
@@ -1020,12 +1029,15 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
                                                          int *__restrict__ ovf_list, unsigned *__restrict__ ovf_count,
                                                          unsigned *__restrict__ ovf_count_next, SplitTable split,
                                                          unsigned long long *__restrict__ stamps, FusedMoments fm,
-                                                         LoopReset lr, UnansweredRows un)
+                                                         LoopReset lr, UnansweredRows un, VerletLists vv)
 {
     // an earlier launch may have handed the iteration to the host (LoopState::abort, set before this kernel started):
     // then this one must touch nothing.  A uniform scalar load, tested below once the query load is in flight.
     const unsigned aborted = lr.st ? lr.st->abort : 0u;
     static_assert(C > M, "a re-scan must leave room in the list");
+    static_assert(!VERLET || (C <= kVerletSlots && !MULTI && !STAMPS), "Verlet lists are built by the steady-state variant: a list is the scan's LDS list");
+    // VERLET, after a verification launch: only the workgroups it flagged have anything to do (uniform scalar load)
+    const bool verlet_skip = VERLET && !vv.build_all && vv.need[blockIdx.x] == 0;
     static_assert(kMaxLevels <= 16, "s_need holds sixteen counts per wave; the feedback word four bits per level index");
     static_assert(!MULTI || FTM == -2, "a multi-level search leaves rows to nn_wide_kernel: K23 is its own kernel");
     static_assert(FTM == -2 || (3 * CAP + CAP / 4) * 4 >= kFoldScratchBytes, "the final fold borrows the halo buffer");
@@ -1137,6 +1149,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         *ovf_count_next = 0;
         if (un.next != nullptr) *un.next = 0;
     }
+    if (verlet_skip) return;  // (its rows were answered from their lists; its slot of the partial sums is written)
     float moved = 0.f;  // how far this query travelled since the association that produced dm2
     if (pm.enabled && valid) {
         const float4 q0 = q;
@@ -1158,6 +1171,13 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
             const float t2 = bound * bound * 1.00001f + 1e-30f;
             thr0 = (t2 < (MULTI ? un.r2_full : r2_0)) ? __float_as_uint(t2) : 0xFFFFFFFFu;
         }
+    }
+    // VERLET: the scan collects every target within G = bound + 2 skin (the bound on the m-th distance, or the radius for a
+    // row that has none); the grid was built with cells of at least radius + 2 skin, so the stencil covers G
+    unsigned thr_v = 0;
+    if constexpr (VERLET) {
+        const float bnd = __builtin_amdgcn_sqrtf(thr0 != 0xFFFFFFFFu ? __uint_as_float(thr0) : r2_0) + vv.skin2;
+        thr_v = __float_as_uint(bnd * bnd);
     }
     // ---- MULTI: which level of the grid this block searches ------------------------------------------------------
     // The finest level whose stencil covers the block's largest cut-off radius (a row without a cut-off — it found fewer
@@ -1227,7 +1247,7 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     // little way into a cell does not need the row beyond it.
     int xlo = INT_MAX, xhi = INT_MIN, ylo = INT_MAX, yhi = INT_MIN, zlo = INT_MAX, zhi = INT_MIN;
     {
-        const float R2 = __uint_as_float(min(thr0, __float_as_uint(r2))) * 1.000004f;
+        const float R2 = __uint_as_float(VERLET ? thr_v : min(thr0, __float_as_uint(r2))) * 1.000004f;
         const float ux = (q.x - g.org[0]) * g.inv_hx;
         const float fy = q.y - g.org[1], fz = q.z - g.org[2];
         const float gy0 = fmaxf(fy - (float)qc.cy * g.h - g.eps, 0.f), gy2 = fmaxf((float)(qc.cy + 1) * g.h - fy - g.eps, 0.f);
@@ -1353,6 +1373,8 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         // the cleanup kernel redoes this workgroup's queries (this launch): entry = grid index * 4 + half — or, when the
         // unanswered rows are listed, nn_wide_kernel searches them (marked unsearched)
         if (tid == 0) ovf_list[atomicAdd(ovf_count, 1u)] = (int)blockIdx.x * 4 + half;
+        if constexpr (VERLET)
+            if (valid) vv.vg2[i] = 0.f;  // (whoever redoes these rows builds no lists: they come back here next time)
         if constexpr (MULTI) {  // from the next launch on this block searches a finer level (more short rows, but a halo that fits)
             // (level_cap[bid] = cap | floor << 4.  A halo too LARGE for the tile: a finer level next time, i.e. more short
             //  rows but a halo that fits; a halo of too many ROWS — a surface seen at too fine a level — a coarser one)
@@ -1488,7 +1510,8 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         }
         // d2 >= +0 and r2 > 0, so "d2 < r2" is "bits(d2) <= bits(r2) - 1" (a NaN d2 has larger bits and fails): the
         // radius test and the running cut-off are ONE unsigned compare per candidate
-        unsigned thr = min(thr0, __float_as_uint(r2) - 1u);
+        const unsigned thr_a = min(thr0, __float_as_uint(r2) - 1u);  // the association's own threshold
+        unsigned thr = VERLET ? thr_v : thr_a;                       // what the scan accepts
         typedef float v2f __attribute__((ext_vector_type(2)));
         const v2f qx2 = {q.x, q.x}, qy2 = {q.y, q.y}, qz2 = {q.z, q.z};
         // LDS addresses as plain 32-bit integers (address space 3): the write cursor and the candidate cursor are
@@ -1545,6 +1568,31 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
             // list overflow (dense neighbourhood, or no usable cut-off yet): the C entries that were kept are genuine
             // in-radius candidates, so the m-th smallest of them bounds the final m-th distance: scan again
             (void)select_top_m<M>(L, tgt, q, C, m, thr);
+            if constexpr (VERLET) thr = min(thr, thr_a);  // (the list of such a row ends at its cut-off: no margin, rebuilt next time)
+        }
+        if constexpr (VERLET) {
+            // the list as scanned — every target whose d2 bits are <= thr — is the row's Verlet list ...
+            if (n >= 0) {
+                int *out = vv.vl + i;
+                for (int j = 0; j < n; j++) {
+                    *out = L.pos_of(L.load(j));
+                    out += ns;
+                }
+                vv.vn[i] = (unsigned char)n;
+                vv.vacc[i] = 0.f;
+            }
+            vv.vg2[i] = n >= 0 ? __uint_as_float(thr) : 0.f;
+            // ... and what lies beyond the association's own threshold (radius, temporal cut-off) leaves the list now
+            if (n > 0 && thr > thr_a) {
+                int w = 0;
+                for_each_entry(L, q, n, [&](int, int e, unsigned b) {
+                    if (b <= thr_a) {
+                        L.store(w, e);
+                        w++;
+                    }
+                });
+                n = w;
+            }
         }
         stamp(3);
         // ---- selection: the list -> its m smallest by (d2, original index); tm = d2 bits of the m-th -----------------
@@ -1669,6 +1717,165 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         stamp(6);
     }
     flush_stamps();
+}
+
+// The verification launch of a steady-state association (see VerletLists): same grid, same workgroup -> (block, half)
+// map and same slots of the partial sums as the steady-state nn_fast_kernel that follows it in the stream.  A workgroup
+// whose rows all pass the completeness test answers them from their lists — kVerletSlots gathers of 16 bytes, the same
+// float d2 as everywhere, the m smallest by (d2, original index), K23 folded in from the winners still in registers —
+// and one that holds a failing row raises its need flag and leaves everything to nn_fast_kernel (which then sees the
+// queries already moved: the cut-off it starts from is stored here as the bound at the NEW position).
+template <int M, int FTM>
+__global__ __launch_bounds__(256, 4) void nn_verify_kernel(float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt, float r2, int m,
+                                                           int *__restrict__ nbr, int *__restrict__ cnt, PendingMove pm,
+                                                           unsigned *__restrict__ dm2, SplitTable split, FusedMoments fm, LoopReset lr,
+                                                           VerletLists vv)
+{
+    constexpr int BLOCK = 256, CV = kVerletSlots;
+    static_assert(M <= CV, "a list holds at least the m winners");
+    const unsigned aborted = lr.st ? lr.st->abort : 0u;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid, half = 0;
+    if ((int)blockIdx.x < split.n_extra) {
+        if (blockIdx.x >= min(*split.visible, (unsigned)kMaxSplit)) {  // an idle split slot: zero sums, nothing to rebuild
+            if constexpr (FTM != -2)
+                if (tid < kNSums) fm.partials[(size_t)tid * fm.nslots + blockIdx.x] = 0.0;
+            if (tid == 0 && !aborted) vv.need[blockIdx.x] = 0;
+            return;
+        }
+        bid = split.list[blockIdx.x];
+        half = 2;
+    } else {
+        bid = xcd_block((int)blockIdx.x - split.n_extra, (ns + BLOCK - 1) / BLOCK);
+        if (split.n_extra > 0 && split.flag[bid] == 2) half = 1;
+    }
+    const int i = bid * BLOCK + tid;
+    const bool valid = i < ns && (half == 0 || (wave >> 1) == half - 1);
+    float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (aborted) return;
+    // the pending move, as in nn_fast_kernel's prologue (which runs without one after this launch)
+    float moved = 0.f;
+    if (pm.enabled && valid) {
+        const float4 q0 = q;
+        q = move_point(q, pm.enabled == 2 ? *pm.dev : pm.P);
+        src[i] = q;
+        const float ex = q.x - q0.x, ey = q.y - q0.y, ez = q.z - q0.z;
+        moved = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez);
+    }
+    unsigned prev = 0xFFFFFFFFu;
+    float g2 = 0.f, acc = 0.f;
+    if (valid) {
+        prev = dm2[i];
+        g2 = vv.vg2[i];
+        acc = vv.vacc[i] + moved;
+    }
+    // ---- is the list still complete?  needs every target within n = min(m-th distance bound, radius) of the query ----
+    const bool has_prev = prev != 0xFFFFFFFFu;
+    const float dm_new = __builtin_amdgcn_sqrtf(__uint_as_float(has_prev ? prev : 0u)) + moved;  // bound on the m-th distance here
+    const float radius = __builtin_amdgcn_sqrtf(r2);
+    const float reach = ((has_prev ? fminf(dm_new, radius) : radius) + acc) * 1.0001f;
+    const bool ok = !valid || reach * reach < g2;  // (no list: g2 = 0)
+    if (!__syncthreads_and(ok)) {
+        if (tid == 0) vv.need[blockIdx.x] = 1;
+        if (valid && has_prev && moved > 0.f) dm2[i] = __float_as_uint(dm_new * dm_new * 1.00001f);
+        return;
+    }
+    if (tid == 0) vv.need[blockIdx.x] = 0;
+    // ---- thresholds exactly as nn_fast_kernel takes them -----------------------------------------------------------
+    unsigned thr0 = 0xFFFFFFFFu;
+    if (valid && has_prev) {
+        const float t2 = dm_new * dm_new * 1.00001f + 1e-30f;
+        thr0 = t2 < r2 ? __float_as_uint(t2) : 0xFFFFFFFFu;
+    }
+    const unsigned thr = min(thr0, __float_as_uint(r2) - 1u);
+    int nl = 0;
+    if (valid) {
+        vv.vacc[i] = acc;
+        nl = vv.vn[i];
+    }
+    // ---- re-measure the list: all index loads, then all gathers, in flight together --------------------------------
+    int pos[CV];
+    float cx[CV], cy[CV], cz[CV];
+    unsigned d2b[CV];
+    {
+        const int *col = vv.vl + (valid ? i : 0);
+#pragma unroll
+        for (int k = 0; k < CV; k++) pos[k] = (k < nl) ? col[(size_t)k * ns] : 0;  // (position 0 always exists)
+#pragma unroll
+        for (int k = 0; k < CV; k++) {
+            const float *g = reinterpret_cast<const float *>(tgt + pos[k]);
+            cx[k] = g[0], cy[k] = g[1], cz[k] = g[2];
+        }
+    }
+    unsigned in = 0;  // bit k: list entry k is (still) among the answer
+#pragma unroll
+    for (int k = 0; k < CV; k++) {
+        d2b[k] = (k < nl) ? __float_as_uint(dist2_flann(q, make_float4(cx[k], cy[k], cz[k], 0.f))) : 0xFFFFFFFFu;
+        in |= (d2b[k] <= thr) ? (1u << k) : 0u;
+    }
+    int n = __popc(in);
+    // ---- more than m within the threshold: the largest by (d2, original index) leave, one per round ------------------
+    int surplus = n - m;
+    while (__ballot(surplus > 0) != 0ull) {
+        if (surplus > 0) {
+            unsigned best = 0;
+#pragma unroll
+            for (int k = 0; k < CV; k++) best = max(best, ((in >> k) & 1u) ? d2b[k] : 0u);
+            int bk = 0, ties = 0;
+#pragma unroll
+            for (int k = 0; k < CV; k++) {
+                const bool hit = ((in >> k) & 1u) && d2b[k] == best;
+                bk = hit ? k : bk;
+                ties += hit ? 1 : 0;
+            }
+            if (ties > 1) {  // equal distances at the boundary: the larger original index leaves (the oracle's order)
+                unsigned worst = 0;
+#pragma unroll
+                for (int k = 0; k < CV; k++)
+                    if (((in >> k) & 1u) && d2b[k] == best) {
+                        const unsigned o = (unsigned)__float_as_int(tgt[pos[k]].w);
+                        if (o >= worst) worst = o, bk = k;
+                    }
+            }
+            in &= ~(1u << bk);
+            surplus--;
+        }
+    }
+    n = min(n, m);
+    unsigned tm = 0xFFFFFFFFu;  // d2 bits of the m-th neighbour (all-ones: fewer than m)
+    if (n == m) {
+        tm = 0;
+#pragma unroll
+        for (int k = 0; k < CV; k++) tm = max(tm, ((in >> k) & 1u) ? d2b[k] : 0u);
+    }
+    if (valid) {
+        int *out = nbr + i;
+#pragma unroll
+        for (int k = 0; k < CV; k++)
+            if ((in >> k) & 1u) {
+                *out = pos[k];
+                out += ns;
+            }
+        cnt[i] = n;
+        dm2[i] = tm;
+    }
+    if constexpr (FTM != -2) {
+        RowAcc sums;
+#pragma unroll
+        for (int j = 0; j < kNSums; j++) sums.a[j] = 0.0;
+        if (valid && n > 0) {
+            double xr[3];
+            rotated_point(fm.P, q, xr);
+            RowMoments<FTM> row;
+            row.begin(fm.md);
+#pragma unroll
+            for (int k = 0; k < CV; k++)
+                if ((in >> k) & 1u) row.add_pair(fm.md, xr, cx[k], cy[k], cz[k]);
+            row.finish(sums, fm.P, q, xr);
+        }
+        block_reduce_store<BLOCK, true>(sums, fm.partials, fm.nslots, (int)blockIdx.x);
+    }
 }
 
 }  // namespace dev

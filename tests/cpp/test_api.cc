@@ -268,6 +268,39 @@ static void weightUpdaterCallbackTest(double dof)
         for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(terms[k]->weight()->scale(), mixed.valuePtr()[k], 1e-15);
         terms[1] = keep;
     }
+    {
+        WeightUpdaterCallback callback(&assoc, &params, &terms, &weight_updater, rotation, translation);
+        callback(ceres::IterationSummary());
+        EXPECT_TRUE(callback.onDevice());
+        // The caller rebuilds its association and terms between two calls (fewer rows, fewer terms), as the reference's
+        // callback — which re-reads both at every call — allows: the device snapshot must be dropped, not written past.
+        Eigen::SparseMatrix<double, Eigen::RowMajor> smaller(rows / 2, (long)target.size());
+        std::vector<Eigen::Triplet<double>> tl2;
+        for (int i = 0; i < rows / 2; ++i)
+            for (int d = 0; d < 1 + (i + 1) % 2; ++d) tl2.push_back(Eigen::Triplet<double>(i, (i * 3 + d * 17) % (int)target.size(), 1));
+        smaller.setFromTriplets(tl2.begin(), tl2.end());
+        smaller.makeCompressed();
+        std::vector<std::unique_ptr<ErrorTerm>> owned2;
+        const std::vector<ErrorTerm *> before = terms;
+        terms.clear();
+        for (long i = 0; i < smaller.outerSize(); ++i)
+            for (Eigen::SparseMatrix<double, Eigen::RowMajor>::InnerIterator it(smaller, i); it; ++it) {
+                owned2.emplace_back(new ErrorTerm(source[(std::size_t)it.row()], target[(std::size_t)it.col()]));
+                terms.push_back(owned2.back().get());
+            }
+        EXPECT_TRUE(terms.size() < before.size());
+        assoc = smaller;
+        callback(ceres::IterationSummary());
+        EXPECT_TRUE(callback.onDevice());
+        sq.clear();
+        for (ErrorTerm *e : terms) {
+            double r[3];
+            (*e)(rotation, translation, r);
+            sq.push_back(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        }
+        const auto rebuilt = weight_updater.updateWeights(assoc, sq);
+        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(terms[k]->weight()->scale(), rebuilt.valuePtr()[k], 1e-12);
+    }
 }
 
 // utilities.hpp:28-234: closest-point metrics against a brute-force nearest neighbour computed right here
@@ -445,9 +478,13 @@ static int benchMain(int argc, char **argv)
     params.cost_drop_thresh = 0;  // -c 0: exactly n_iter iterations
     // every object is constructed (clouds uploaded) before anything is timed, and the align() calls then run back to
     // back: the device does not idle (and clock down) through uploads between two measurements
+    std::vector<double> construct_s;
     auto make = [&](int n_iter) {
         params.n_iter = n_iter;
-        return std::make_unique<ProbPointCloudRegistration>(source, target, params);
+        const auto t0 = std::chrono::steady_clock::now();
+        auto reg = std::make_unique<ProbPointCloudRegistration>(source, target, params);
+        construct_s.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        return reg;
     };
     auto timed = [&](ProbPointCloudRegistration &reg, std::size_t *n_done) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -467,9 +504,10 @@ static int benchMain(int argc, char **argv)
     }
     std::size_t done = 0;
     for (auto &w : warmups) (void)timed(*w, &done);  // code objects, allocations, clocks
-    std::vector<double> steady, whole;
+    std::vector<double> steady, whole, short_s;
     for (int r = 0; r < repeats; r++) {
         const double ta = timed(*shorts[(std::size_t)r], nullptr);
+        short_s.push_back(ta);
         const double tb = timed(*longs[(std::size_t)r], &done);
         if (done != (std::size_t)(warm + steady_steps)) {
             std::fprintf(stderr, "early stop: %zu iterations\n", done);
@@ -480,10 +518,17 @@ static int benchMain(int argc, char **argv)
     }
     std::sort(steady.begin(), steady.end());
     std::sort(whole.begin(), whole.end());
+    std::sort(short_s.begin(), short_s.end());
+    std::sort(construct_s.begin(), construct_s.end());
+    // what a fresh object's align() costs beyond its iterations at the steady rate (grid build, source sort, first
+    // associations without cut-offs, allocations), and what constructing the object costs (uploads, early grid build)
+    const double steady_med = steady[steady.size() / 2];
+    const double fixed_ms = (short_s[short_s.size() / 2] - warm / steady_med) * 1e3;
     std::printf("{\"steady_it_per_s\": %.3f, \"steady_min\": %.3f, \"steady_max\": %.3f, \"whole_align_it_per_s\": %.3f, "
+                "\"align_fixed_overhead_ms\": %.4f, \"construct_ms\": %.4f, "
                 "\"warm\": %d, \"steps\": %d, \"inner_max_steps\": %d, \"repeats\": %d, \"points\": [%zu, %zu]}\n",
-                steady[steady.size() / 2], steady.front(), steady.back(), whole[whole.size() / 2], warm, steady_steps, params.inner_max_steps,
-                repeats, source->size(), target->size());
+                steady_med, steady.front(), steady.back(), whole[whole.size() / 2], fixed_ms, construct_s[construct_s.size() / 2] * 1e3,
+                warm, steady_steps, params.inner_max_steps, repeats, source->size(), target->size());
     return 0;
 }
 

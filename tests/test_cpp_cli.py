@@ -318,6 +318,20 @@ def test_cli_batch_front_end_matches_single_runs(programs, tmp_path):
     assert rk.returncode == 0, rk.stdout + rk.stderr
     got_rk = re.findall(r"^pair (\d+) \(s\d\.pcd -> t\d\.pcd\), 4 iterations: (T: .*)$", rk.stdout, flags=re.M)
     assert got_rk == got and not (tmp_path / "rv.id").exists()
+    # a record left behind by a crashed launch (any 128 bytes, or a well-formed one of another launch) is never taken for
+    # this launch's: rank 0 replaces it before anybody joins; the ranks compare the --run-id token
+    (tmp_path / "rv.id").write_bytes(b"\x7f" * 128)
+    rk2 = subprocess.run([cli, "--batch", "pairs.txt", "--lanes", "2", "--rank", "0", "--world", "1", "--rendezvous", "rv.id",
+                          "--run-id", "launch-42"] + common, capture_output=True, text=True, cwd=tmp_path, timeout=600)
+    assert rk2.returncode == 0, rk2.stdout + rk2.stderr
+    assert re.findall(r"^pair (\d+) \(s\d\.pcd -> t\d\.pcd\), 4 iterations: (T: .*)$", rk2.stdout, flags=re.M) == got
+    # a rank that fails AFTER the communicator exists still takes part in the gathers (no rank may be left inside a
+    # collective) and the launch as a whole reports the failure
+    (tmp_path / "bad_ranked.txt").write_text("s0.pcd t0.pcd\ns1.pcd nowhere.pcd\n")
+    rk3 = subprocess.run([cli, "--batch", "bad_ranked.txt", "--rank", "0", "--world", "1", "--rendezvous", "rv.id"] + common,
+                         capture_output=True, text=True, cwd=tmp_path, timeout=120)
+    assert rk3.returncode == 1 and "Could not load nowhere.pcd" in rk3.stdout and "rank 0 failed" in rk3.stderr
+    assert "pair 0" not in rk3.stdout and not (tmp_path / "rv.id").exists()
     bad = subprocess.run([cli, "--batch", "pairs.txt", "--rank", "1", "--world", "2"], capture_output=True, text=True, cwd=tmp_path)
     assert bad.returncode != 0 and "--rendezvous" in bad.stderr
     # a list that names a missing cloud fails like the single-pair command

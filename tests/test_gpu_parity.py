@@ -687,6 +687,61 @@ def test_batch_run_and_align_many(ctx):
         np.testing.assert_array_equal(c.align(2, cost_drop_thresh=0.0, inner_steps=1)["history"][-1], Tu[3])
 
 
+def test_device_memory_pool_serves_fresh_handles_without_driver_calls(ctx):
+    """The handles' buffers are blocks of a per-device pool (csrc/ppcr_pool.hpp, ppcr_memory_stats / ppcr_memory_trim): a
+    second fresh handle registering a pair of the same size makes NO hipMalloc call, recycled memory changes no result,
+    and trimming hands the slabs back."""
+    src, tgt, _, _ = synth.make_pair(40000, cfg=2, stride=3)
+
+    def one():
+        with _lib.Context(0) as c:
+            c.set_params(1.0, 10, 5.0, 3)
+            c.set_target(tgt)
+            c.set_source(src)
+            busy = _lib.memory_stats(0)
+            return c.align(6, cost_drop_thresh=0.0, inner_steps=3)["history"], busy
+
+    first, _ = one()
+    before = _lib.memory_stats(0)
+    assert before["reserved_bytes"] > 0 and before["driver_allocs"] >= 1
+    for _ in range(3):
+        again, busy = one()
+        np.testing.assert_array_equal(again, first)               # recycled blocks, same bits
+        assert busy["in_use_bytes"] > 0
+    after = _lib.memory_stats(0)
+    assert after["driver_allocs"] == before["driver_allocs"]     # three fresh handles, not one driver allocation
+    assert after["reserved_bytes"] == before["reserved_bytes"]
+    _lib.batch_release()
+    held = _lib.memory_stats(0)["in_use_bytes"]                   # (other live handles of the session, e.g. the fixture's)
+    _lib.memory_trim(0)
+    trimmed = _lib.memory_stats(0)
+    assert trimmed["in_use_bytes"] == held and trimmed["reserved_bytes"] <= after["reserved_bytes"]
+    again, _ = one()                                              # and the pool grows again on demand
+    np.testing.assert_array_equal(again, first)
+    with pytest.raises(_lib.PpcrError):
+        _lib.memory_stats(99)
+
+
+@pytest.mark.timeout(120)
+def test_batch_run_with_empty_device_shares(ctx):
+    """Fewer pairs than devices / a device listed more than once: some shares of ppcr_batch_run are empty.  The two-thread
+    runner of round 4 deadlocked there (no handle to pass between its two sides); an empty share must start nothing."""
+    prm = dict(radius=1.0, max_neighbours=10, dof=5.0)
+    pairs = [synth.make_pair(2500 + 300 * p, cfg=5, pair=p, stride=3)[:2] for p in range(3)]
+    ref, _ = _lib.batch_run(pairs, n_iter=4, device_ids=(0,), lanes_per_device=1, **prm)
+    for ids, sel in (((0, 0), 1), ((0, 0, 0, 0, 0, 0, 0, 0), 2), ((0, 0), 3), ((0, 0, 0, 0), 3)):
+        T, done = _lib.batch_run(pairs[:sel], n_iter=4, device_ids=ids, lanes_per_device=2, **prm)
+        assert list(done) == [4] * sel
+        np.testing.assert_array_equal(T, ref[:sel])
+    # the thread-per-lane runner (unbounded search) with an empty share
+    Tu, du = _lib.batch_run(pairs[:1], n_iter=2, radius=1.0, max_neighbours=0, dof=5.0, device_ids=(0, 0, 0), lanes_per_device=2)
+    assert list(du) == [2]
+    n_dev = _lib.device_count()
+    if n_dev > 1:                                                  # more devices than pairs, for real
+        T, done = _lib.batch_run(pairs[:1], n_iter=4, device_ids=tuple(range(n_dev)), lanes_per_device=2, **prm)
+        np.testing.assert_array_equal(T, ref[:1])
+
+
 def test_temporal_cutoff_and_deferred_move_change_nothing(ctx):
     """The steady-state shortcuts (cut-off started from the previous m-th distance + own displacement; source move
     folded into the next K1 prologue) must not change a single neighbour: compare against a context with the

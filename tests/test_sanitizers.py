@@ -151,3 +151,29 @@ def test_pcd_reader_under_asan_and_ubsan(tmp_path):
     assert got[os.path.join(d, "crlf.pcd")] == (0, 5)
     refused = sum(1 for rc, _ in got.values() if rc != 0)
     assert refused > 100   # most truncations and many flips must be refused, none may crash
+
+
+def _tsan_ok():
+    return shutil.which("g++") is not None and _gcc_lib("libtsan.so") is not None
+
+
+@needs_asan
+def test_device_pool_suballocator_under_asan_ubsan_and_tsan(tmp_path):
+    """csrc/ppcr_pool.hpp — the sub-allocator every handle's device buffers are cut from — with a host stand-in for the
+    driver: randomised alloc / free traffic (overlap shows as a wrong byte, a block outside its slab as a sanitizer
+    report), coalescing back to whole slabs, trimming, a full device; then four threads on one pool under TSan (the
+    preparing threads of ppcr_batch_run share the pool with their callers)."""
+    src = os.path.join(ROOT, "tests", "cpp", "test_pool.cc")
+    common = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include",
+              "-I", os.path.join(ROOT, "probabilistic_point_clouds_registration_amd", "csrc"), src, "-pthread"]
+    if not os.path.exists("/opt/rocm/include/hip/hip_runtime.h"):
+        pytest.skip("HIP headers not installed")
+    exe = str(tmp_path / "pool_asan")
+    subprocess.check_call(common + ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, **SAN_ENV), timeout=600)
+    assert r.returncode == 0 and "pool test: 0 failed" in r.stdout, (r.stdout + r.stderr)[-3000:]
+    if _tsan_ok():
+        exe = str(tmp_path / "pool_tsan")
+        subprocess.check_call(common + ["-fsanitize=thread", "-DPOOL_TEST_SMALL_SLABS", "-o", exe])
+        r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"), timeout=600)
+        assert r.returncode == 0 and "pool test: 0 failed" in r.stdout and "ThreadSanitizer" not in r.stderr, (r.stdout + r.stderr)[-3000:]

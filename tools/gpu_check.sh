@@ -1,6 +1,6 @@
 #!/bin/bash
 # the round's closing check: whole GPU suite, C++ API test, smoke, the driver's bench command
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/check; rm -rf $OUT; mkdir -p $OUT; cd $R
+set -u; R=${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}; OUT=$R/gpurun_out/check; rm -rf $OUT; mkdir -p $OUT; cd $R
 timeout 1800 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "pytest gpu rc=$?" >> $OUT/summary.txt
 ./probabilistic_point_clouds_registration_amd/ppcr_cpp_api_test > $OUT/cpp_api_test.log 2>&1; echo "cpp_api_test rc=$?" >> $OUT/summary.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/summary.txt

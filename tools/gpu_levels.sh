@@ -1,6 +1,6 @@
 #!/bin/bash
 # multi-level search: the scene tests and soaks, then configs 9 / 10 / 8, per-level counters
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/levels; rm -rf $OUT; mkdir -p $OUT; cd $R
+set -u; R=${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}; OUT=$R/gpurun_out/levels; rm -rf $OUT; mkdir -p $OUT; cd $R
 timeout 1200 python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py -x -q -m gpu -k "cli_default_shape or two_pass or bit_identical or wave_kernel or row_per_wave or soak or dense or multi_level" > $OUT/pytest_levels.log 2>&1; echo "pytest levels rc=$?" >> $OUT/summary.txt
 Q="python bench.py --no-extras --no-cpu-baseline"
 for cfg in 9 10 8; do

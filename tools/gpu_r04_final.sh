@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, final evidence: rocprofv3 kernel stats + PMC passes (tools/profile_round.sh), the driver's bench command, the
 # other configs' bench lines, the host-budget runs, the whole GPU suite
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r04_final; rm -rf $OUT; mkdir -p $OUT; cd $R
+set -u; R=${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}; OUT=$R/gpurun_out/r04_final; rm -rf $OUT; mkdir -p $OUT; cd $R
 bash tools/profile_round.sh r04_final > $OUT/profile_round.log 2>&1
 cp $R/gpurun_out/prof_r04_final/*.csv $R/gpurun_out/prof_r04_final/*.txt $R/gpurun_out/prof_r04_final/*.json $OUT/ 2>/dev/null
 cd $R

@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/setup; rm -rf $OUT; mkdir -p $OUT; cd $R
+set -u; R=${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}; OUT=$R/gpurun_out/setup; rm -rf $OUT; mkdir -p $OUT; cd $R
 timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/summary.txt
 for k in 3 9 10; do echo "config $k" >> $OUT/summary.txt; python tools/exp_setup.py $k >> $OUT/summary.txt 2>&1; done
 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpp-api > $OUT/bench_n1.json 2> $OUT/bench_n1.err

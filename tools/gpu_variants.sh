@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of K1 translation-unit variants (tools/build_variant.py): the driver's bench command without the extras, two rounds
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/variants; rm -rf $OUT; mkdir -p $OUT; cd $R
+set -u; R=${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}; OUT=$R/gpurun_out/variants; rm -rf $OUT; mkdir -p $OUT; cd $R
 V=$R/probabilistic_point_clouds_registration_amd/_variants
 B="python bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-cpp-api"
 for round in 1 2; do

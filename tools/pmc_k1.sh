@@ -1,7 +1,7 @@
 #!/bin/bash
 # K1/K23 instruction-mix counters: separate --pmc passes, kernel-trace only (dev tool, run under gpurun)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+set -u; R=${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}
 OUT=$R/gpurun_out/pmc_k1
 rm -rf $OUT; mkdir -p $OUT
 i=0

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel stats of tools/exp_iter.py (dev tool, run under gpurun): usage: bash tools/prof_iter.sh <tag> [exp_iter args]
 TAG=${1:-x}; shift
-R=$GRAFT_REPO_ROOT
+set -u; R=${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

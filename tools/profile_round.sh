@@ -5,7 +5,7 @@
 # into K1) and, behind them, the stand-alone forms.
 # usage: bash tools/profile_round.sh <tag> [nopmcmix] [dof]    outputs under gpurun_out/prof_<tag>/   (dof: exp_align.py's model, default 5)
 TAG=${1:-rXX}
-R=$GRAFT_REPO_ROOT
+set -u; R=${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -17,7 +17,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --kernel-trace --output-format csv --pmc $set -d $OUT/pmc_$set -o pmc -- python3 $R/tools/exp_align.py 1000000 dof=${3:-5} > $OUT/log_$set.txt 2>&1
 done
 python3 $R/tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/pmc_hbm_traffic.txt 2>&1
-if [ "$2" != "nopmcmix" ]; then
+if [ "${2:-}" != "nopmcmix" ]; then
   i=0
   for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
              "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
