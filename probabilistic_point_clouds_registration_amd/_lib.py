@@ -402,6 +402,25 @@ class Context:
         self._ck(f(self._h, C.byref(out)))
         return int(out.value)
 
+    def debug_verlet(self):
+        """ppcr_debug_get_verlet (diagnostic): the steady-state Verlet lists as the last association left them."""
+        buf = (C.c_longlong * 6)()
+        f = self._L.ppcr_debug_get_verlet
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        f.restype = C.c_int
+        self._ck(f(self._h, buf))
+        return dict(workgroups=int(buf[0]), rebuilt=int(buf[1]), rows=int(buf[2]), rows_without_list=int(buf[3]),
+                    mean_list=(buf[4] / max(1, buf[2] - buf[3])), trusted=bool(buf[5]))
+
+    def debug_read(self, name, dtype, count):
+        """ppcr_debug_read_buffer (diagnostic): a raw copy of a device buffer of the handle."""
+        out = np.zeros(count, dtype=dtype)
+        f = self._L.ppcr_debug_read_buffer
+        f.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+        f.restype = C.c_int
+        self._ck(f(self._h, name.encode(), out.ctypes.data, out.nbytes))
+        return out
+
     def synchronize(self):
         self._ck(self._L.ppcr_synchronize(self._h))
 

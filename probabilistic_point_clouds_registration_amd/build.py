@@ -20,7 +20,7 @@ TILE_TU = os.path.join(CSRC, "ppcr_nn_tile.hip")
 TILE_WIDTHS = (10, 4, 5, 8, 16, 20, 32)   # K1's compiled-in list widths, one object each (the default first)
 SOURCES = [MAIN_TU, TILE_TU, COMM_TU]
 DEPS = SOURCES + [os.path.join(CSRC, h) for h in ("ppcr_device.hip.h", "ppcr_kernels.hip.h", "ppcr_nn_tile.hip.h",
-                                                  "ppcr_nn_tile_launch.hip.h", "ppcr_host_math.hpp",
+                                                  "ppcr_nn_tile_launch.hip.h", "ppcr_host_math.hpp", "ppcr_pool.hpp",
                                                   # the C-ABI unit ppcr_hip.hip in reading order
                                                   "ppcr_hip_setup.inc", "ppcr_hip_iteration.inc", "ppcr_hip_api.inc",
                                                   "ppcr_hip_align.inc", "ppcr_hip_extras.inc", "ppcr_hip_batch.inc")] + [

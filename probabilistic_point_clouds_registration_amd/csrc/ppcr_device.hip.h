@@ -575,15 +575,14 @@ struct PendingMove {
 // Verlet lists: the steady state of a registration.  Once the source barely moves between two associations, searching the
 // grid again finds the same neighbours again.  Instead, an association made by nn_fast_kernel also leaves, per query, the
 // list of EVERY target within G = (bound on its m-th distance, or the radius) + 2 * skin of the query's position, and the
-// next associations only re-measure that list (nn_verify_kernel: ~12 gathers per query instead of a 43-candidate scan)
+// next associations only re-measure that list (verlet_answer_rows: ~12 gathers per query instead of a 43-candidate scan)
 // for as long as it provably still holds every target the exact search could return:
 //   at the build position p0 the list holds all y with |y - p0| <= G;  later, at p, with a = path length travelled since
 //   (>= |p - p0|), the query needs all y within n = min(r_m(p), radius) of p, and r_m(p) <= r_m(previous) + |last move|;
 //   such a y has |y - p0| <= n + a, so the list is complete while  n + a < G  (float slack: the test inflates by 1e-4).
 // The m nearest of the list by (d2, original index) are then the m nearest of the cloud, ties included (a target tying at
-// the m-th distance is within n as well).  The test is per row, the decision per workgroup: one row that fails sends its
-// workgroup's rows back to nn_fast_kernel in the same launch pair (need flag), which rebuilds their lists around the new
-// positions.  Rigid moves shrink as a registration converges, so lists built with skin ~ the last move's length outlive
+// the m-th distance is within n as well).  The test is per row, the decision per workgroup: one row that fails makes its
+// workgroup search the grid as before, which rebuilds its rows' lists around their new positions.  Rigid moves shrink as a registration converges, so lists built with skin ~ the last move's length outlive
 // the rest of it; the first iterations of a registration rebuild every time and cost what they cost before plus the
 // list's 64 bytes per query.
 struct VerletLists {
@@ -591,9 +590,10 @@ struct VerletLists {
     unsigned char *vn;    // [ns] how many
     float *vg2;           // [ns] the list holds every target whose float d2 at the BUILD position is <= this; 0: no list
     float *vacc;          // [ns] path length the query has travelled since the build (bounds its displacement)
-    unsigned char *need;  // [workgroups of the steady-state grid] 1: nn_fast_kernel (re)builds this workgroup's rows now
+    unsigned *rebuilt;    // diagnostic (nullable): workgroups that failed the test and searched again, cumulative
+    unsigned tgt_bytes;   // size of the sorted target in bytes (the gathers go through a buffer descriptor)
     float skin2;          // 2 * skin: how far beyond the cut-off bound a list is built
-    int build_all;        // nn_fast_kernel: no verification ran before this launch, every workgroup builds
+    int build_all;        // no lists exist yet (or they are not trusted): every workgroup searches and builds
 };
 constexpr int kVerletSlots = 16;
 

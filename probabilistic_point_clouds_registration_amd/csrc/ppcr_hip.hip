@@ -219,6 +219,15 @@ struct ppcr_ctx {
     DevBuf<unsigned> dm2;    // per (sorted) source row: float d2 bits of its m-th neighbour in the last tiled K1
     bool dm2_valid = false;  // dm2 matches the current source order / target / radius / max_neighbours
     int opt_temporal = 1;
+    // Verlet lists (steady state, ppcr_device.hip.h: VerletLists): option "verlet" 1 (default) / 0, "verlet_skin" in 1e-4 of
+    // the radius (default 100: lists reach 2 x 0.01 radius beyond the cut-off bound; the grid's cells are that much larger)
+    int opt_verlet = 1, opt_verlet_skin = 100;
+    double grid_skin2 = 0;       // 2 x skin the grid in use was built for (0: its cells do not cover a list's reach)
+    bool verlet_ok = false;      // the rows' lists were (re)built or verified by the previous association and nothing moved the source since but K1's own prologue
+    DevBuf<int> vl;
+    DevBuf<unsigned char> vn;
+    DevBuf<unsigned> vcount;
+    DevBuf<float> vg2, vacc;
     DevBuf<int> gen_counts, gen_row_ptr, gen_pos;
     DevBuf<unsigned long long> gen_keys;
     DevBuf<unsigned long long> d_total;

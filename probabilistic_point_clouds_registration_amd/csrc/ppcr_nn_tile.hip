@@ -35,13 +35,13 @@ using namespace ppcr::dev;
 // t.merged tells whether it did.
 // PPCR_LIST_NOCLAMP: every instantiation of nn_fast_kernel this unit can launch must own exactly FastLds::kBytes of LDS
 // (see FastLds).  Checked once per process and list width; a mismatch is a build defect, not a run-time condition: abort.
-template <int M, int C, int CAP, bool STAMPS, int FTM, bool MULTI>
+template <int M, int C, int CAP, bool STAMPS, int FTM, bool MULTI, bool VERLET = false>
 bool fast_kernel_lds_ok()
 {
 #if PPCR_LIST_NOCLAMP
     hipFuncAttributes attr;
-    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&nn_fast_kernel<M, C, CAP, STAMPS, FTM, MULTI>)) != hipSuccess) return false;
-    return (int)attr.sharedSizeBytes == FastLds<C, CAP, MULTI>::kBytes;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&nn_fast_kernel<M, C, CAP, STAMPS, FTM, MULTI, VERLET>)) != hipSuccess) return false;
+    return (int)attr.sharedSizeBytes == FastLds<C, CAP, MULTI, (VERLET ? M : 0)>::kAllocBytes;
 #else
     return true;
 #endif
@@ -58,7 +58,10 @@ void check_fast_kernel_lds()
         if constexpr (M <= 12)
             good = good && fast_kernel_lds_ok<M, 16, kCapSteady, false, -2, false>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, 8, false>() &&
                    fast_kernel_lds_ok<M, 16, kCapSteady, false, 0, false>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, -3, false>() &&
-                   fast_kernel_lds_ok<M, 16, kCapSteady, false, -2, true>();
+                   fast_kernel_lds_ok<M, 16, kCapSteady, false, -2, true>() &&
+                   // (the Verlet variants: their allocation is the larger of the search's and the list path's)
+                   fast_kernel_lds_ok<M, 16, kCapSteady, false, -2, false, true>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, 8, false, true>() &&
+                   fast_kernel_lds_ok<M, 16, kCapSteady, false, 0, false, true>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, -3, false, true>();
         // the diagnostic (option "stamps") instantiations launch_tile can reach
         if constexpr (M == 10)
             good = good && fast_kernel_lds_ok<M, 16, kCapSteady, true, -2, true>() && fast_kernel_lds_ok<M, 16, kCapSteady, true, -2, false>() &&
@@ -118,13 +121,10 @@ void launch_tile(TileLaunch &t)
     nn_fast_kernel<M, Cc, (Cc <= 16 ? kCapSteady : CAP), STAMPc, FTMc><<<(Cc <= 16 ? grid_steady : nb), 256, 0, t.stream>>>( \
         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,  \
         t.ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc, lr, un, vv_none)
-    // steady state with Verlet lists: [nn_verify_kernel, when lists exist] + nn_fast_kernel<..., VERLET> over the same grid
-#define PPCR_VERIFY(FTMc, FMc)                                                                                          \
-    nn_verify_kernel<M, FTMc><<<grid_steady, 256, 0, t.stream>>>(t.src, t.ns, t.tgt, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2,   \
-                                                                 split_on, FMc, lr, vv)
+    // steady state with Verlet lists: nn_fast_kernel<..., VERLET> answers from the lists where they still hold
 #define PPCR_FAST_V(FTMc, FMc)                                                                                          \
     nn_fast_kernel<M, 16, kCapSteady, false, FTMc, false, true><<<grid_steady, 256, 0, t.stream>>>(                      \
-        t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, pm_b, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,    \
+        t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,    \
         t.ovf_next, split_on, nullptr, FMc, lr, un, vv)
     t.fused = false;
     int ftm = -2;  // model folded into this launch (-2: none)
@@ -183,16 +183,7 @@ void launch_tile(TileLaunch &t)
             // Verlet lists (t.verlet_mode: 1 build them in this launch, 2 verify first and rebuild where needed)
             if (t.verlet_mode != 0 && !st && !halves) {
                 VerletLists vv = t.verlet;
-                PendingMove pm_b = t.pm;
                 vv.build_all = t.verlet_mode == 2 ? 0 : 1;
-                if (t.verlet_mode == 2) {
-                    if (ftm == 0) PPCR_VERIFY(0, *t.fuse);
-                    else if (ftm == 8) PPCR_VERIFY(8, *t.fuse);
-                    else if (ftm == -3) PPCR_VERIFY(-3, *t.fuse);
-                    else PPCR_VERIFY(-2, fm_none);
-                    pm_b.enabled = 0;  // (the verification launch has moved the source)
-                    if (t.between0) t.between0(t.between_arg);
-                }
                 if (ftm == 0) PPCR_FAST_V(0, *t.fuse);
                 else if (ftm == 8) PPCR_FAST_V(8, *t.fuse);
                 else if (ftm == -3) PPCR_FAST_V(-3, *t.fuse);
@@ -232,7 +223,6 @@ void launch_tile(TileLaunch &t)
     }
 #undef PPCR_FAST
 #undef PPCR_FAST_V
-#undef PPCR_VERIFY
     if (t.short_count == nullptr && t.between) t.between(t.between_arg);
     if (t.short_count != nullptr) {
         if (t.between2) t.between2(t.between_arg);

@@ -917,6 +917,13 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
 #ifndef PPCR_LIST_PERM
 #define PPCR_LIST_PERM 1
 #endif
+#ifndef PPCR_VERLET_ROW_ORDER
+#define PPCR_VERLET_ROW_ORDER 0
+#endif
+#ifndef PPCR_VERLET_RETRY
+#define PPCR_VERLET_RETRY 1
+#endif
+
 // (the unclamped list stores lean on gfx950 dropping DS stores beyond the workgroup's allocation — probed by
 //  tools/micro/lds_oob.hip and tests/test_gpu_parity.py — so any other device target gets the clamped form; the host
 //  pass sees the same value as the gfx950 device pass this library is built for)
@@ -999,6 +1006,141 @@ struct UnansweredRows {
                                //   short rows listed, staged candidates, rows}, cumulative (ppcr_debug_get_levels)
 };
 
+// Answer a workgroup's rows from their Verlet lists (see VerletLists; called by nn_fast_kernel<..., VERLET> once every row
+// of the workgroup has passed the completeness test): kVerletSlots gathers of 16 bytes per row, the same float d2 as
+// everywhere, the m smallest by (d2, original index), the association's row written in list order, K23 folded in from the
+// winners (compacted through LDS so that the f64 phase runs without the 48 coordinate registers).
+// thr: the association's threshold (radius and temporal cut-off in one, as the scan uses it); s_mem: at least
+// VerletLds<M>::kBytes of LDS nobody else is using.
+template <int M>
+struct VerletLds {
+    static constexpr int kWinBytes = 3 * (M + 1) * 256 * 4;  // x[], y[], z[] of up to M winners per lane + one spare slot
+    static constexpr int kBytes = kWinBytes > kFoldScratchBytes ? kWinBytes : kFoldScratchBytes;
+};
+template <int M, int FTM>
+__device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, const bool valid, const float4 q, const int ns,
+                                                   const float4 *__restrict__ tgt, const unsigned thr, const int m,
+                                                   int *__restrict__ nbr, int *__restrict__ cnt, unsigned *__restrict__ dm2,
+                                                   const FusedMoments &fm, const VerletLists &vv, unsigned char *s_mem)
+{
+    constexpr int BLOCK = 256, CV = kVerletSlots;
+    static_assert(M <= CV, "a list holds at least the m winners");
+    const int nl = valid ? (int)vv.vn[i] : 0;
+    // ---- re-measure the list: all index loads, then all gathers, in flight together --------------------------------
+    float cx[CV], cy[CV], cz[CV];
+    unsigned d2b[CV];
+    // Buffer loads (uniform descriptor + ONE 32-bit offset register per address): the sixteen list slots of a row share
+    // the lane's row offset (the slot is the scalar offset), a gather's address is the position * 16 — no 64-bit address
+    // pairs, so that all sixteen gathers are in flight together inside the register budget of four workgroups per CU.
+    // (host: ns < 2^26 and nt < 2^28 in this mode, so both byte ranges fit 32 bits)
+    const unsigned row4 = (unsigned)(valid ? i : 0) * 4u;
+    const auto rs_vl = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(vv.vl), 0, (int)((unsigned)ns * (unsigned)(CV * 4)), 0x00020000);
+    const auto rs_tgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(tgt), 0, (int)vv.tgt_bytes, 0x00020000);
+    // list entry k of this row (a coalesced, cached load: the positions are not kept in registers between the gathers and the output)
+    auto list_pos = [&](int k) { return (int)__builtin_amdgcn_raw_buffer_load_b32(rs_vl, (int)row4, (int)((unsigned)k * (unsigned)ns * 4u), 0); };
+    {
+        // every slot of a list is a valid position (nn_fast_kernel pads with 0), so nothing here is predicated
+        int pos[CV];
+#pragma unroll
+        for (int k = 0; k < CV; k++) {
+            const int p = list_pos(k);
+            pos[k] = valid ? p : 0;  // (a lane without a query read row 0's slots: whatever they hold is not a position to gather from)
+        }
+#pragma unroll
+        for (int k = 0; k < CV; k++) {
+            typedef unsigned v3u __attribute__((ext_vector_type(3)));
+            const v3u g = __builtin_amdgcn_raw_buffer_load_b96(rs_tgt, (int)((unsigned)pos[k] << 4), 0, 0);
+            cx[k] = __uint_as_float(g.x), cy[k] = __uint_as_float(g.y), cz[k] = __uint_as_float(g.z);
+        }
+    }
+    unsigned in = 0;  // bit k: list entry k is (still) among the answer
+#pragma unroll
+    for (int k = 0; k < CV; k++) {
+        d2b[k] = (k < nl) ? __float_as_uint(dist2_flann(q, make_float4(cx[k], cy[k], cz[k], 0.f))) : 0xFFFFFFFFu;
+        in |= (d2b[k] <= thr) ? (1u << k) : 0u;
+    }
+    int n = __popc(in);
+    // ---- more than m within the threshold: the largest by (d2, original index) leave, one per round ------------------
+    int surplus = n - m;
+    while (__ballot(surplus > 0) != 0ull) {
+        if (surplus > 0) {
+            unsigned best = 0;
+#pragma unroll
+            for (int k = 0; k < CV; k++) best = max(best, ((in >> k) & 1u) ? d2b[k] : 0u);
+            int bk = 0, ties = 0;
+#pragma unroll
+            for (int k = 0; k < CV; k++) {
+                const bool hit = ((in >> k) & 1u) && d2b[k] == best;
+                bk = hit ? k : bk;
+                ties += hit ? 1 : 0;
+            }
+            if (ties > 1) {  // equal distances at the boundary: the larger original index leaves (the oracle's order)
+                unsigned worst = 0;
+#pragma unroll
+                for (int k = 0; k < CV; k++)
+                    if (((in >> k) & 1u) && d2b[k] == best) {
+                        const unsigned o = __builtin_amdgcn_raw_buffer_load_b32(rs_tgt, (int)(((unsigned)list_pos(k) << 4) + 12u), 0, 0);
+                        if (o >= worst) worst = o, bk = k;
+                    }
+            }
+            in &= ~(1u << bk);
+            surplus--;
+        }
+    }
+    n = min(n, m);
+    unsigned tm = 0xFFFFFFFFu;  // d2 bits of the m-th neighbour (all-ones: fewer than m)
+    if (n == m) {
+        tm = 0;
+#pragma unroll
+        for (int k = 0; k < CV; k++) tm = max(tm, ((in >> k) & 1u) ? d2b[k] : 0u);
+    }
+    if (valid) {
+        int *out = nbr + i;
+#pragma unroll
+        for (int k = 0; k < CV; k++)
+            if ((in >> k) & 1u) {
+                *out = list_pos(k);
+                out += ns;
+            }
+        cnt[i] = n;
+        dm2[i] = tm;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FTM != -2) {
+        // ---- K23 for this row at fm.P.  The winners' coordinates are compacted into LDS first — every list entry is
+        // stored at the lane's cursor, only a winner moves it, as in nn_fast_kernel's scan — so that the 48 coordinate
+        // registers are free while the f64 moments are formed, and the loop below runs over n pairs, not 16 predicated ones
+        float *const s_wx = reinterpret_cast<float *>(s_mem), *const s_wy = s_wx + (M + 1) * BLOCK, *const s_wz = s_wy + (M + 1) * BLOCK;
+        {
+            int w = tid;
+#pragma unroll
+            for (int k = 0; k < CV; k++) {
+                s_wx[w] = cx[k];
+                s_wy[w] = cy[k];
+                s_wz[w] = cz[k];
+                w += ((in >> k) & 1u) ? BLOCK : 0;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (nothing of the f64 phase is to be hoisted above the stores that free the registers)
+        RowAcc sums;
+#pragma unroll
+        for (int j = 0; j < kNSums; j++) sums.a[j] = 0.0;
+        if (valid && n > 0) {
+            double xr[3];
+            rotated_point(fm.P, q, xr);
+            RowMoments<FTM> row;
+            row.begin(fm.md);
+#pragma unroll
+            for (int j = 0; j < M; j++)
+                if (j < n) row.add_pair(fm.md, xr, s_wx[j * BLOCK + tid], s_wy[j * BLOCK + tid], s_wz[j * BLOCK + tid]);  // (a lane reads what it wrote)
+            row.finish(sums, fm.P, q, xr);
+        }
+        __syncthreads();  // every lane is through with its winners: the fold borrows the memory
+        double *const scratch = reinterpret_cast<double *>(s_mem);
+        block_reduce_scratch(sums, scratch, scratch + 10 * 257, fm.partials + blockIdx.x, (size_t)fm.nslots, true);
+    }
+}
+
 // FTM != -2 (0: Gaussian, k > 0: t model with v + dim = k, -3: t model with an integer v + dim read at run time) folds
 // K23 into this kernel: each lane finishes its row's
 // contribution to the 19 moments from the winners' coordinates while they are still in LDS (no neighbour gathers, no
@@ -1007,20 +1149,28 @@ struct UnansweredRows {
 // LAST the lists — the unclamped stores of the scan rely on nothing of the workgroup's lying behind them.  The host checks
 // the compiled kernels' static LDS size against kBytes before the first launch (check_fast_kernel_lds): a __shared__
 // variable that slipped into the kernel some other way would sit behind the list and be overwritten silently.
-template <int C, int CAP, bool MULTI>
+// (kAllocBytes: what the kernel allocates — the Verlet variant answers rows from their lists in the same memory and needs a
+//  little more than the search does; the padding behind the list is nobody's)
+template <int C, int CAP, bool MULTI, int VERLET_M = 0>
 struct FastLds {
     static constexpr int kHaloBytes = (3 * CAP + CAP / 4) * 4, kListBytes = (C + 1) * 256 * 2;
     static constexpr int kOffGbo = kHaloBytes, kOffBox = kOffGbo + 128 * 4, kOffBail = kOffBox + 4 * 6 * 4, kOffNeed = kOffBail + 4,
                          kOffList = (kOffNeed + (MULTI ? 4 * 16 * 4 : 0) + 15) & ~15;
     static constexpr int kBytes = kOffList + kListBytes;
+    static constexpr int kVerletBytes = VERLET_M > 0 ? VerletLds<(VERLET_M > 0 ? VERLET_M : 1)>::kBytes : 0;
+    static constexpr int kAllocBytes = kBytes > kVerletBytes ? kBytes : kVerletBytes;
 };
 
 // MULTI: the grid is chosen per workgroup from un.levels (GridLevel): tgt / cell_start / g / r2 of the arguments are the
 // base level's and only used by the first association (no cut-offs yet: every block searches the base level).
-// VERLET (steady-state variant only): the launch also builds the rows' Verlet lists (see VerletLists) — for every
-// workgroup (vv.build_all) or for those nn_verify_kernel flagged in vv.need; the others leave at once.
+// VERLET (steady-state variant only): the rows keep Verlet lists (see VerletLists).  A workgroup whose rows all pass the
+// completeness test answers them from their lists (verlet_answer_rows) and is done; one that holds a failing row — or any
+// workgroup when vv.build_all says that no lists exist yet — searches as usual and leaves fresh lists behind.  One kernel
+// for both: a rebuild is one workgroup's chain of dependent round trips (~25 us), which a launch of its own would add to
+// every iteration in which a single row of the cloud fails — inside the launch it hides behind the other workgroups' work.
+// Four workgroups per CU (the list path holds 48 coordinates in registers).
 template <int M, int C, int CAP, bool STAMPS, int FTM = -2, bool MULTI = false, bool VERLET = false>
-__global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 4) : (CAP * 13 + C * 512 <= 39400 ? 4 : 3))) void nn_fast_kernel(float4 *__restrict__ src, int ns,
+__global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 4) : (CAP * 13 + C * 512 <= 39400 ? 4 : 3))) void nn_fast_kernel(float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt0,
                                                          const int *__restrict__ cell_start0, GridDesc g0,
                                                          float r2_0, int m, int *__restrict__ nbr,
@@ -1036,9 +1186,6 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     const unsigned aborted = lr.st ? lr.st->abort : 0u;
     static_assert(C > M, "a re-scan must leave room in the list");
     static_assert(!VERLET || (C <= kVerletSlots && !MULTI && !STAMPS), "Verlet lists are built by the steady-state variant: a list is the scan's LDS list");
-    // VERLET, after a verification launch: only the workgroups it flagged have anything to do (uniform scalar load)
-    const bool verlet_skip = VERLET && !vv.build_all && vv.need[blockIdx.x] == 0;
-    static_assert(kMaxLevels <= 16, "s_need holds sixteen counts per wave; the feedback word four bits per level index");
     static_assert(!MULTI || FTM == -2, "a multi-level search leaves rows to nn_wide_kernel: K23 is its own kernel");
     static_assert(FTM == -2 || (3 * CAP + CAP / 4) * 4 >= kFoldScratchBytes, "the final fold borrows the halo buffer");
     static_assert(CAP % 4 == 0 && CAP * 4 < 65536, "list entries are 16-bit byte offsets into the halo arrays");
@@ -1051,11 +1198,11 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     // tests/test_gpu_parity.py builds and runs) — the scan stores at its cursor without clamping it to the list's end:
     // two v_min_u32 less on a 22-VALU trip (2508 -> 2427 VALU per wave, +1.6 % iterations/s; -DPPCR_LIST_NOCLAMP=0 is
     // the clamped form with separate arrays).
-    using Lds = FastLds<C, CAP, MULTI>;
+    using Lds = FastLds<C, CAP, MULTI, (VERLET ? M : 0)>;
     constexpr int kListBytes = Lds::kListBytes, kOffGbo = Lds::kOffGbo, kOffBox = Lds::kOffBox, kOffBail = Lds::kOffBail,
                   kOffNeed = Lds::kOffNeed, kOffList = Lds::kOffList;
     static_assert(BLOCK == 256 && kWaves == 4 && kRows == 128, "FastLds mirrors these");
-    __shared__ __attribute__((aligned(16))) unsigned char s_all[Lds::kBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char s_all[Lds::kAllocBytes];
     float *const s_halo = reinterpret_cast<float *>(s_all);
     int *const s_gbo = reinterpret_cast<int *>(s_all + kOffGbo);
     int(*const s_box)[6] = reinterpret_cast<int(*)[6]>(s_all + kOffBox);
@@ -1149,7 +1296,6 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
         *ovf_count_next = 0;
         if (un.next != nullptr) *un.next = 0;
     }
-    if (verlet_skip) return;  // (its rows were answered from their lists; its slot of the partial sums is written)
     float moved = 0.f;  // how far this query travelled since the association that produced dm2
     if (pm.enabled && valid) {
         const float4 q0 = q;
@@ -1175,9 +1321,34 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     // VERLET: the scan collects every target within G = bound + 2 skin (the bound on the m-th distance, or the radius for a
     // row that has none); the grid was built with cells of at least radius + 2 skin, so the stencil covers G
     unsigned thr_v = 0;
+    float need = 0.f;
     if constexpr (VERLET) {
-        const float bnd = __builtin_amdgcn_sqrtf(thr0 != 0xFFFFFFFFu ? __uint_as_float(thr0) : r2_0) + vv.skin2;
+        // how far the m-th neighbour (or, without a cut-off, the radius) can be from the query where it is now
+        need = __builtin_amdgcn_sqrtf(thr0 != 0xFFFFFFFFu ? __uint_as_float(thr0) : r2_0);
+        const float bnd = need + vv.skin2;
         thr_v = __float_as_uint(bnd * bnd);
+        if (!vv.build_all) {
+            // ---- are the lists still complete?  (VerletLists: need + path travelled < the list's reach, with float slack) ----
+            float g2 = 0.f, acc = 0.f;
+            if (valid) {
+                g2 = vv.vg2[i];
+                acc = vv.vacc[i] + moved;
+            }
+            const float reach = (need + acc) * 1.0001f;
+            const bool ok = !valid || reach * reach < g2;  // (no list: g2 = 0; a NaN anywhere fails)
+            // the workgroup's verdict through four words of s_gbo (idle until the row table is built, two barriers from here)
+            const bool wave_ok = __ballot(!ok) == 0ull;  // (every lane votes: NOT inside the one-lane store below)
+            if (lane == 0) s_gbo[wave] = wave_ok ? 1 : 0;
+            lds_barrier();
+            const int all_ok = s_gbo[0] & s_gbo[1] & s_gbo[2] & s_gbo[3];
+            lds_barrier();  // (everybody has read the verdict: the list path writes its winners over these words)
+            if (all_ok) {
+                if (valid) vv.vacc[i] = acc;
+                verlet_answer_rows<M, FTM>(tid, i, valid, q, ns, tgt0, min(thr0, __float_as_uint(r2_0) - 1u), m, nbr, cnt, dm2, fm, vv, s_all);
+                return;
+            }
+            if (tid == 0 && vv.rebuilt != nullptr) atomicAdd(vv.rebuilt, 1u);  // (diagnostic: workgroups that searched again)
+        }
     }
     // ---- MULTI: which level of the grid this block searches ------------------------------------------------------
     // The finest level whose stencil covers the block's largest cut-off radius (a row without a cut-off — it found fewer
@@ -1492,12 +1663,17 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
             constexpr int net[25][2] = {{0, 3}, {1, 7}, {2, 5}, {4, 8}, {0, 7}, {2, 4}, {3, 8}, {5, 6}, {0, 2},
                                         {1, 3}, {4, 5}, {7, 8}, {1, 4}, {3, 6}, {5, 7}, {0, 1}, {2, 4}, {3, 5},
                                         {6, 8}, {2, 3}, {4, 5}, {6, 7}, {1, 2}, {3, 4}, {5, 6}};
+            // (VERLET: the runs stay in row order — ascending positions in the sorted target — so that every row's list, and
+            //  with it the association, is sorted by position: lanes next to each other then gather their k-th entries from
+            //  the same few cache lines in nn_verify_kernel and K23.  Only (re)building launches pay the less even walk.)
+            if constexpr (!PPCR_VERLET_ROW_ORDER || !VERLET) {
 #pragma unroll
-            for (int c = 0; c < 25; c++) {
-                const int a = net[c][0], b = net[c][1];
-                const unsigned kh = max(key[a], key[b]), kl = min(key[a], key[b]);  // descending
-                key[a] = kh;
-                key[b] = kl;
+                for (int c = 0; c < 25; c++) {
+                    const int a = net[c][0], b = net[c][1];
+                    const unsigned kh = max(key[a], key[b]), kl = min(key[a], key[b]);  // descending
+                    key[a] = kh;
+                    key[b] = kl;
+                }
             }
         }
         if constexpr (STAMPS) {  // diagnostic: this lane's nine sorted run lengths, 7 bits each, behind the wave records
@@ -1561,7 +1737,17 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
             }
             n = (int)((wp - list0) >> 9);
             if (n <= C) break;
-            if (attempt == 1) {  // more than C candidates tie at the threshold: leave the block to the general flavour
+            if constexpr (VERLET) {
+                // more than C targets within the list's reach (one row in 10^5 at the benchmark's density): a quarter of the
+                // skin first — a list with less room, rebuilt sooner, but not one without any room, which would send its
+                // workgroup through the search in every iteration
+                if (PPCR_VERLET_RETRY && attempt == 0) {
+                    const float b = need + 0.25f * vv.skin2;
+                    thr = __float_as_uint(b * b);
+                    continue;
+                }
+            }
+            if (attempt == ((VERLET && PPCR_VERLET_RETRY) ? 2 : 1)) {  // more than C candidates tie at the threshold: leave the block to the general flavour
                 n = -1;
                 break;
             }
@@ -1576,6 +1762,10 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
                 int *out = vv.vl + i;
                 for (int j = 0; j < n; j++) {
                     *out = L.pos_of(L.load(j));
+                    out += ns;
+                }
+                for (int j = n; j < kVerletSlots; j++) {  // (every slot a valid position: the verification loads all of them)
+                    *out = 0;
                     out += ns;
                 }
                 vv.vn[i] = (unsigned char)n;
@@ -1719,164 +1909,6 @@ __global__ __launch_bounds__(256, (C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 
     flush_stamps();
 }
 
-// The verification launch of a steady-state association (see VerletLists): same grid, same workgroup -> (block, half)
-// map and same slots of the partial sums as the steady-state nn_fast_kernel that follows it in the stream.  A workgroup
-// whose rows all pass the completeness test answers them from their lists — kVerletSlots gathers of 16 bytes, the same
-// float d2 as everywhere, the m smallest by (d2, original index), K23 folded in from the winners still in registers —
-// and one that holds a failing row raises its need flag and leaves everything to nn_fast_kernel (which then sees the
-// queries already moved: the cut-off it starts from is stored here as the bound at the NEW position).
-template <int M, int FTM>
-__global__ __launch_bounds__(256, 4) void nn_verify_kernel(float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt, float r2, int m,
-                                                           int *__restrict__ nbr, int *__restrict__ cnt, PendingMove pm,
-                                                           unsigned *__restrict__ dm2, SplitTable split, FusedMoments fm, LoopReset lr,
-                                                           VerletLists vv)
-{
-    constexpr int BLOCK = 256, CV = kVerletSlots;
-    static_assert(M <= CV, "a list holds at least the m winners");
-    const unsigned aborted = lr.st ? lr.st->abort : 0u;
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bid, half = 0;
-    if ((int)blockIdx.x < split.n_extra) {
-        if (blockIdx.x >= min(*split.visible, (unsigned)kMaxSplit)) {  // an idle split slot: zero sums, nothing to rebuild
-            if constexpr (FTM != -2)
-                if (tid < kNSums) fm.partials[(size_t)tid * fm.nslots + blockIdx.x] = 0.0;
-            if (tid == 0 && !aborted) vv.need[blockIdx.x] = 0;
-            return;
-        }
-        bid = split.list[blockIdx.x];
-        half = 2;
-    } else {
-        bid = xcd_block((int)blockIdx.x - split.n_extra, (ns + BLOCK - 1) / BLOCK);
-        if (split.n_extra > 0 && split.flag[bid] == 2) half = 1;
-    }
-    const int i = bid * BLOCK + tid;
-    const bool valid = i < ns && (half == 0 || (wave >> 1) == half - 1);
-    float4 q = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (aborted) return;
-    // the pending move, as in nn_fast_kernel's prologue (which runs without one after this launch)
-    float moved = 0.f;
-    if (pm.enabled && valid) {
-        const float4 q0 = q;
-        q = move_point(q, pm.enabled == 2 ? *pm.dev : pm.P);
-        src[i] = q;
-        const float ex = q.x - q0.x, ey = q.y - q0.y, ez = q.z - q0.z;
-        moved = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez);
-    }
-    unsigned prev = 0xFFFFFFFFu;
-    float g2 = 0.f, acc = 0.f;
-    if (valid) {
-        prev = dm2[i];
-        g2 = vv.vg2[i];
-        acc = vv.vacc[i] + moved;
-    }
-    // ---- is the list still complete?  needs every target within n = min(m-th distance bound, radius) of the query ----
-    const bool has_prev = prev != 0xFFFFFFFFu;
-    const float dm_new = __builtin_amdgcn_sqrtf(__uint_as_float(has_prev ? prev : 0u)) + moved;  // bound on the m-th distance here
-    const float radius = __builtin_amdgcn_sqrtf(r2);
-    const float reach = ((has_prev ? fminf(dm_new, radius) : radius) + acc) * 1.0001f;
-    const bool ok = !valid || reach * reach < g2;  // (no list: g2 = 0)
-    if (!__syncthreads_and(ok)) {
-        if (tid == 0) vv.need[blockIdx.x] = 1;
-        if (valid && has_prev && moved > 0.f) dm2[i] = __float_as_uint(dm_new * dm_new * 1.00001f);
-        return;
-    }
-    if (tid == 0) vv.need[blockIdx.x] = 0;
-    // ---- thresholds exactly as nn_fast_kernel takes them -----------------------------------------------------------
-    unsigned thr0 = 0xFFFFFFFFu;
-    if (valid && has_prev) {
-        const float t2 = dm_new * dm_new * 1.00001f + 1e-30f;
-        thr0 = t2 < r2 ? __float_as_uint(t2) : 0xFFFFFFFFu;
-    }
-    const unsigned thr = min(thr0, __float_as_uint(r2) - 1u);
-    int nl = 0;
-    if (valid) {
-        vv.vacc[i] = acc;
-        nl = vv.vn[i];
-    }
-    // ---- re-measure the list: all index loads, then all gathers, in flight together --------------------------------
-    int pos[CV];
-    float cx[CV], cy[CV], cz[CV];
-    unsigned d2b[CV];
-    {
-        const int *col = vv.vl + (valid ? i : 0);
-#pragma unroll
-        for (int k = 0; k < CV; k++) pos[k] = (k < nl) ? col[(size_t)k * ns] : 0;  // (position 0 always exists)
-#pragma unroll
-        for (int k = 0; k < CV; k++) {
-            const float *g = reinterpret_cast<const float *>(tgt + pos[k]);
-            cx[k] = g[0], cy[k] = g[1], cz[k] = g[2];
-        }
-    }
-    unsigned in = 0;  // bit k: list entry k is (still) among the answer
-#pragma unroll
-    for (int k = 0; k < CV; k++) {
-        d2b[k] = (k < nl) ? __float_as_uint(dist2_flann(q, make_float4(cx[k], cy[k], cz[k], 0.f))) : 0xFFFFFFFFu;
-        in |= (d2b[k] <= thr) ? (1u << k) : 0u;
-    }
-    int n = __popc(in);
-    // ---- more than m within the threshold: the largest by (d2, original index) leave, one per round ------------------
-    int surplus = n - m;
-    while (__ballot(surplus > 0) != 0ull) {
-        if (surplus > 0) {
-            unsigned best = 0;
-#pragma unroll
-            for (int k = 0; k < CV; k++) best = max(best, ((in >> k) & 1u) ? d2b[k] : 0u);
-            int bk = 0, ties = 0;
-#pragma unroll
-            for (int k = 0; k < CV; k++) {
-                const bool hit = ((in >> k) & 1u) && d2b[k] == best;
-                bk = hit ? k : bk;
-                ties += hit ? 1 : 0;
-            }
-            if (ties > 1) {  // equal distances at the boundary: the larger original index leaves (the oracle's order)
-                unsigned worst = 0;
-#pragma unroll
-                for (int k = 0; k < CV; k++)
-                    if (((in >> k) & 1u) && d2b[k] == best) {
-                        const unsigned o = (unsigned)__float_as_int(tgt[pos[k]].w);
-                        if (o >= worst) worst = o, bk = k;
-                    }
-            }
-            in &= ~(1u << bk);
-            surplus--;
-        }
-    }
-    n = min(n, m);
-    unsigned tm = 0xFFFFFFFFu;  // d2 bits of the m-th neighbour (all-ones: fewer than m)
-    if (n == m) {
-        tm = 0;
-#pragma unroll
-        for (int k = 0; k < CV; k++) tm = max(tm, ((in >> k) & 1u) ? d2b[k] : 0u);
-    }
-    if (valid) {
-        int *out = nbr + i;
-#pragma unroll
-        for (int k = 0; k < CV; k++)
-            if ((in >> k) & 1u) {
-                *out = pos[k];
-                out += ns;
-            }
-        cnt[i] = n;
-        dm2[i] = tm;
-    }
-    if constexpr (FTM != -2) {
-        RowAcc sums;
-#pragma unroll
-        for (int j = 0; j < kNSums; j++) sums.a[j] = 0.0;
-        if (valid && n > 0) {
-            double xr[3];
-            rotated_point(fm.P, q, xr);
-            RowMoments<FTM> row;
-            row.begin(fm.md);
-#pragma unroll
-            for (int k = 0; k < CV; k++)
-                if ((in >> k) & 1u) row.add_pair(fm.md, xr, cx[k], cy[k], cz[k]);
-            row.finish(sums, fm.P, q, xr);
-        }
-        block_reduce_store<BLOCK, true>(sums, fm.partials, fm.nslots, (int)blockIdx.x);
-    }
-}
 
 }  // namespace dev
 }  // namespace ppcr

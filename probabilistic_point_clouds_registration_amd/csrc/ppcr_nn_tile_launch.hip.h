@@ -45,13 +45,12 @@ struct TileLaunch {
     unsigned *split_state;        // {registrations, registrations visible to extra workgroups}
     dev::PendingMove pm;
     dev::VerletLists verlet;        // steady-state Verlet lists (buffers of [16][ns] + per-row state), used when verlet_mode != 0:
-    int verlet_mode;                //   0 off; 1 this association builds every row's list; 2 the lists are verified first
-                                    //   (nn_verify_kernel) and only the workgroups that fail are searched and rebuilt
+    int verlet_mode;                //   0 off; 1 this association builds every row's list; 2 workgroups whose rows' lists still
+                                    //   hold answer from them, the others search and rebuild
     const dev::FusedMoments *fuse;  // fold K23 into K1 at this pose / model when the steady-state variant runs
     int fuse_tm;                    // ... in this compiled form: 0 Gaussian, 8 t with v + dim = 8, -3 t with another integer v + dim
     const dev::FoldSolve *fold;     // ... and the fold-and-solve step into the cleanup launch
     dev::LoopState *loop_st;        // device-paced loop: every launch steps aside while its abort flag is up (nullable)
-    void (*between0)(void *);       // called between the verification launch and the search (profiling scopes), may be null
     void (*between)(void *);        // called between the two launches (profiling scopes), may be null
     void (*between2)(void *);       // ... and before the second pass of a two-pass search
     void *between_arg;
