@@ -126,7 +126,7 @@ def spawn_ranks(a):
     return subprocess.run(cmd, env=env).returncode
 
 
-def k1_instantiation(cfg, inner_steps, two_pass, fused=True):
+def k1_instantiation(cfg, inner_steps, two_pass, fused=True, verlet=True):
     """Template string of the nn_fast_kernel instantiation a config's steady-state iterations launch (mirrors
     launch_tile<M> in csrc/ppcr_nn_tile.hip and k23_form in csrc/ppcr_hip_iteration.inc): list width M = the narrowest compiled
     width holding max_neighbours; widths <= 10 have the steady-state variant (16-slot lists, 1728-candidate halo), wider
@@ -146,6 +146,10 @@ def k1_instantiation(cfg, inner_steps, two_pass, fused=True):
             ftm = -3
     c, cap = (16, 1728) if steady else ((32, 2240) if width <= 24 else (48, 2048))
     multi = "scene" in cfg   # (clouds with a dense tail: the multi-level instantiation)
+    if steady and not two_pass and not multi and verlet:
+        # the Verlet variant (csrc/ppcr_device.hip.h: VerletLists): 24-slot scan lists, 1920-candidate halo, four workgroups
+        # per CU; rows answered from their lists where the lists still hold
+        return f"nn_fast_kernel<{width}, 24, 1920, false, {ftm}, false, true>"
     return f"nn_fast_kernel<{width}, {c}, {cap}, false, {ftm}, {'true' if multi else 'false'}>"
 
 
@@ -584,8 +588,9 @@ def run_rank(a):
         # instantiation these windows ran (entries are keyed by the kernel's template string)
         two_pass = "nn_wide_kernel" in prof
         fused_on = not any(kv.split("=")[0] == "fuse_k23" and int(kv.split("=")[1]) == 0 for kv in a.opt)
-        kname = k1_instantiation(cfg, a.inner_steps, two_pass, fused_on)
-        kname_alone = k1_instantiation(cfg, a.inner_steps, two_pass, False)
+        verlet_on = not any(kv.split("=")[0] == "verlet" and int(kv.split("=")[1]) != 1 for kv in a.opt)
+        kname = k1_instantiation(cfg, a.inner_steps, two_pass, fused_on, verlet_on)
+        kname_alone = k1_instantiation(cfg, a.inner_steps, two_pass, False, verlet_on)
         traffic, traffic_source, traffic_alone, pmc = None, None, None, {}
         tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
         if os.path.exists(tpath) and ns == nt == 1000000 and not two_pass:
@@ -600,7 +605,10 @@ def run_rank(a):
                            "kernel": kname + (": first pass of a two-pass radius search (rows that come back short go to "
                                               "nn_wide_kernel; K23 is its own kernel)" if two_pass else
                                               ": K1 with the previous iteration's source move in its prologue" +
-                                              (" and K23 (weights + 19 moments) folded in" if ", -2, " not in kname else "")),
+                                              (" and K23 (weights + 19 moments) folded in" if ", -2, " not in kname else "") +
+                                              ("; Verlet variant: a workgroup whose rows' lists still provably hold every possible "
+                                               "neighbour re-measures the lists (16 gathers per row), the others search the grid and "
+                                               "rebuild" if kname.endswith("true>") else "")),
                            "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": traffic_source,
@@ -674,6 +682,41 @@ def run_rank(a):
                                   "mean_inner_steps": inner_mean,
                                   "schedule": f"<=100 IRLS steps per association, f_tol={REF_F_TOL:g} "
                                               "(the C++ layer's and the reference's default); device-paced inner loop"}
+        # Where the timed windows sit on the registration's way to its fixed point, and what the same kernels do once it is
+        # there.  The windows time iterations warmup+1 .. warmup+steps after a fresh upload: the source still moves by
+        # ~1e-2 .. 1e-3 radii per iteration there, so part of the workgroups search the grid again every iteration (their
+        # rows' Verlet lists no longer provably hold every possible neighbour); `searched_share` is that part, counted by
+        # the kernel itself.  `converged`: 3 x steps further iterations of the SAME registration after 60 more (moves
+        # < 1e-4 radii): every row is answered from its list.
+        try:
+            ctx.set_source(src)
+            if a.warmup > 0:
+                ctx.align(a.warmup, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
+            v0 = ctx.debug_verlet()
+            ctx.align(a.steps, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
+            v1 = ctx.debug_verlet()
+            ctx.align(60, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
+            ctx.synchronize()
+            v2 = ctx.debug_verlet()
+            crates = []
+            for _ in range(3):
+                tc0 = time.perf_counter()
+                ctx.align(3 * a.steps, cost_drop_thresh=0.0, inner_steps=a.inner_steps, want_history=False)
+                ctx.synchronize()
+                crates.append(3 * a.steps / (time.perf_counter() - tc0))
+            v3 = ctx.debug_verlet()
+            real = max(1, v1["workgroups"] - 128)
+            out["steady_state"] = {
+                "verlet_lists": bool(v1["rows"] > 0 and v1["trusted"]),
+                "window": {"searched_share": (v1["rebuilt"] - v0["rebuilt"]) / (a.steps * real) if v1["rows"] else None,
+                           "mean_list_length": v1["mean_list"] if v1["rows"] else None},
+                "converged": {"it_per_s": float(np.median(crates)), "min_it_per_s": min(crates), "max_it_per_s": max(crates),
+                              "searched_share": (v3["rebuilt"] - v2["rebuilt"]) / (9 * a.steps * real) if v3["rows"] else None,
+                              "after_iterations": a.warmup + a.steps + 60},
+                "note": "value (the headline) is the median window; converged.it_per_s is the same registration, same "
+                        "kernels and schedule, once the source has stopped moving — never part of value"}
+        except Exception as e:   # (a diagnostic block must not cost the line)
+            out["steady_state"] = {"error": str(e)}
         # one whole registration the way the command line runs it by default, HOST BUFFERS IN: uploads, grid build,
         # source sort, first association and the loop until hasConverged() stops it (-c 0.01 -n 5, inner loop to
         # function_tolerance) — what a caller of align() waits for; the handle is warm (its buffers exist)

@@ -545,10 +545,21 @@ __device__ __forceinline__ void block_reduce_store(const RowAcc &acc, double *__
 // XCD's L2 instead of being fetched once per XCD.  A bijection on [0, nb): the first 8 * (nb / 8) ids are permuted,
 // the remainder keeps its place.  K23 uses the same map for its tiles of rows: a tile's gathers touch the target points
 // around its rows, and with every eighth tile per XCD each XCD's 4 MB L2 saw the whole 16 MB target.
+// (Chunks of kXcdChunk blocks, dealt to the XCDs in turn, rather than one contiguous eighth of the blocks per XCD: work
+//  that depends on WHERE a block lies — Verlet lists expire first where the cloud moves most, dense regions hand blocks
+//  over — then spreads over all eight XCDs instead of queueing on one, while a chunk, two columns of the source order,
+//  still shares its halo in one L2.)
+constexpr int kXcdChunk = 32;
 __device__ __forceinline__ int xcd_block(int g, int nb)
 {
-    const int per = nb >> 3;
-    return g < 8 * per ? (g & 7) * per + (g >> 3) : g;
+    const int full = nb / (8 * kXcdChunk) * (8 * kXcdChunk);  // the part of the range that is whole super-chunks
+    if (g >= full) {
+        // the rest: one contiguous eighth per XCD, as far as it divides
+        const int r = g - full, per = (nb - full) >> 3;
+        return full + (r < 8 * per ? (r & 7) * per + (r >> 3) : r);
+    }
+    const int xcd = g & 7, idx = g >> 3;  // the idx-th workgroup this XCD receives
+    return ((idx / kXcdChunk) * 8 + xcd) * kXcdChunk + idx % kXcdChunk;
 }
 
 // rigid move of one point: f64 arithmetic summed left to right, f32 store (pcl::transformPointCloud
@@ -574,7 +585,8 @@ struct PendingMove {
 // ---------------------------------------------------------------------------------------------
 // Verlet lists: the steady state of a registration.  Once the source barely moves between two associations, searching the
 // grid again finds the same neighbours again.  Instead, an association made by nn_fast_kernel also leaves, per query, the
-// list of EVERY target within G = (bound on its m-th distance, or the radius) + 2 * skin of the query's position, and the
+// list of EVERY target within G of the query's position — G = (bound on its m-th distance, or the radius) + 2 * skin, or the
+// distance of the 16th nearest target when more than sixteen lie that close — and the
 // next associations only re-measure that list (verlet_answer_rows: ~12 gathers per query instead of a 43-candidate scan)
 // for as long as it provably still holds every target the exact search could return:
 //   at the build position p0 the list holds all y with |y - p0| <= G;  later, at p, with a = path length travelled since
@@ -591,11 +603,19 @@ struct VerletLists {
     float *vg2;           // [ns] the list holds every target whose float d2 at the BUILD position is <= this; 0: no list
     float *vacc;          // [ns] path length the query has travelled since the build (bounds its displacement)
     unsigned *rebuilt;    // diagnostic (nullable): workgroups that failed the test and searched again, cumulative
+    // dispatch order (ppcr_nn_tile.hip.h: verlet_slot): per XCD class c the slots filed "front" then those filed "back",
+    // [2][8][ceil(grid / 8)] ints, with their counts [8][2]; order_now == nullptr: slot = workgroup index
+    const int *order_now;
+    const unsigned *count_now;
+    int *order_next;       // where this launch's workgroups file their slots for the next one (nullable)
+    unsigned *count_next;
+    unsigned *count_clear; // the counters of the launch after next: zeroed by this launch (nullable)
     unsigned tgt_bytes;   // size of the sorted target in bytes (the gathers go through a buffer descriptor)
     float skin2;          // 2 * skin: how far beyond the cut-off bound a list is built
     int build_all;        // no lists exist yet (or they are not trusted): every workgroup searches and builds
 };
 constexpr int kVerletSlots = 16;
+constexpr int kVerletScanSlots = 24;  // list slots of the search that builds them: the nearest kVerletSlots of up to 24 accepted
 
 // ---------------------------------------------------------------------------------------------
 // The closed-form weighted rigid solve for ONE lane (it sits on the iteration's critical path right behind the moment

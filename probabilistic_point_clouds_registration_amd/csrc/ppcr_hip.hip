@@ -220,13 +220,18 @@ struct ppcr_ctx {
     bool dm2_valid = false;  // dm2 matches the current source order / target / radius / max_neighbours
     int opt_temporal = 1;
     // Verlet lists (steady state, ppcr_device.hip.h: VerletLists): option "verlet" 1 (default) / 0, "verlet_skin" in 1e-4 of
-    // the radius (default 100: lists reach 2 x 0.01 radius beyond the cut-off bound; the grid's cells are that much larger)
-    int opt_verlet = 1, opt_verlet_skin = 100;
+    // the radius (default 500: lists reach up to 2 x 0.05 radius beyond the cut-off bound — less where more than sixteen targets lie
+    // that close; the grid's cells are that much larger)
+    int opt_verlet = 1, opt_verlet_skin = 500;
+    int opt_verlet_order = 1;    // option "verlet_order": workgroups forecast to search again are dispatched first (default 1)
     double grid_skin2 = 0;       // 2 x skin the grid in use was built for (0: its cells do not cover a list's reach)
     bool verlet_ok = false;      // the rows' lists were (re)built or verified by the previous association and nothing moved the source since but K1's own prologue
     DevBuf<int> vl;
     DevBuf<unsigned char> vn;
-    DevBuf<unsigned> vcount;
+    DevBuf<unsigned> vcount;     // [0]: diagnostic rebuild counter; [16 .. 64): three sets of dispatch-order counters
+    DevBuf<int> vorder;          // two dispatch orders (this launch's, the next one's), 2 x 8 x ceil(grid / 8) slots each
+    unsigned verlet_launches = 0;  // Verlet launches enqueued on this handle (the rotation of the order buffers and counters)
+    bool verlet_order_ok = false;  // the previous association filed a dispatch order for this one
     DevBuf<float> vg2, vacc;
     DevBuf<int> gen_counts, gen_row_ptr, gen_pos;
     DevBuf<unsigned long long> gen_keys;

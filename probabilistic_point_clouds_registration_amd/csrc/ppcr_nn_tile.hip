@@ -60,8 +60,10 @@ void check_fast_kernel_lds()
                    fast_kernel_lds_ok<M, 16, kCapSteady, false, 0, false>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, -3, false>() &&
                    fast_kernel_lds_ok<M, 16, kCapSteady, false, -2, true>() &&
                    // (the Verlet variants: their allocation is the larger of the search's and the list path's)
-                   fast_kernel_lds_ok<M, 16, kCapSteady, false, -2, false, true>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, 8, false, true>() &&
-                   fast_kernel_lds_ok<M, 16, kCapSteady, false, 0, false, true>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, -3, false, true>();
+                   fast_kernel_lds_ok<M, kVerletScanSlots, kCapVerlet, false, -2, false, true>() &&
+                   fast_kernel_lds_ok<M, kVerletScanSlots, kCapVerlet, false, 8, false, true>() &&
+                   fast_kernel_lds_ok<M, kVerletScanSlots, kCapVerlet, false, 0, false, true>() &&
+                   fast_kernel_lds_ok<M, kVerletScanSlots, kCapVerlet, false, -3, false, true>();
         // the diagnostic (option "stamps") instantiations launch_tile can reach
         if constexpr (M == 10)
             good = good && fast_kernel_lds_ok<M, 16, kCapSteady, true, -2, true>() && fast_kernel_lds_ok<M, 16, kCapSteady, true, -2, false>() &&
@@ -123,9 +125,9 @@ void launch_tile(TileLaunch &t)
         t.ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc, lr, un, vv_none)
     // steady state with Verlet lists: nn_fast_kernel<..., VERLET> answers from the lists where they still hold
 #define PPCR_FAST_V(FTMc, FMc)                                                                                          \
-    nn_fast_kernel<M, 16, kCapSteady, false, FTMc, false, true><<<grid_steady, 256, 0, t.stream>>>(                      \
+    nn_fast_kernel<M, kVerletScanSlots, kCapVerlet, false, FTMc, false, true><<<grid_steady, 256, 0, t.stream>>>(                      \
         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,    \
-        t.ovf_next, split_on, nullptr, FMc, lr, un, vv)
+        t.ovf_next, split_on_v, nullptr, FMc, lr, un, vv)
     t.fused = false;
     int ftm = -2;  // model folded into this launch (-2: none)
     bool steady = false;
@@ -184,6 +186,7 @@ void launch_tile(TileLaunch &t)
             if (t.verlet_mode != 0 && !st && !halves) {
                 VerletLists vv = t.verlet;
                 vv.build_all = t.verlet_mode == 2 ? 0 : 1;
+                const SplitTable split_on_v{t.split_flag, t.split_list, t.split_state, t.split_state + 1, kMaxSplit, kCapVerlet * 15 / 16, 0};
                 if (ftm == 0) PPCR_FAST_V(0, *t.fuse);
                 else if (ftm == 8) PPCR_FAST_V(8, *t.fuse);
                 else if (ftm == -3) PPCR_FAST_V(-3, *t.fuse);

@@ -1006,6 +1006,39 @@ struct UnansweredRows {
                                //   short rows listed, staged candidates, rows}, cumulative (ppcr_debug_get_levels)
 };
 
+// Dispatch order of the Verlet variant's workgroups (VerletLists::order_*).  A workgroup that has to search again runs
+// ~3 times as long as one that answers from its lists; dispatched late, it IS the launch's tail (493 of 4035 workgroups
+// searching: 100 us where their share of the work is 69).  So every workgroup, when it is done, files its slot for the
+// NEXT launch under "will probably search" (front) or "will probably not" (back) — a forecast from the rows' remaining
+// room and their last move; being wrong costs time, never correctness: what a workgroup does is decided by the test on
+// the spot — and the next launch's g-th workgroup takes the g-th slot of front + back.  Per XCD class (slot % 8 ==
+// workgroup % 8): a slot's block keeps the XCD whose L2 its neighbours' halos are in.
+__device__ __forceinline__ unsigned verlet_slot(const VerletLists &vv)
+{
+    if (vv.order_now == nullptr) return blockIdx.x;
+    const unsigned c = blockIdx.x & 7u, j = blockIdx.x >> 3, per = (gridDim.x + 7u) >> 3;
+    const unsigned nf = vv.count_now[2 * c];
+    return j < nf ? (unsigned)vv.order_now[c * per + j] : (unsigned)vv.order_now[8 * per + c * per + (j - nf)];
+}
+__device__ __forceinline__ void verlet_file_slot(const VerletLists &vv, unsigned wg, bool front)
+{
+    if (vv.order_next == nullptr) return;
+    const unsigned c = wg & 7u, per = (gridDim.x + 7u) >> 3;
+    const unsigned pos = atomicAdd(vv.count_next + 2 * c + (front ? 0u : 1u), 1u);
+    vv.order_next[(front ? 0u : 8 * per) + c * per + pos] = (int)wg;
+}
+// the workgroup's forecast: any lane's `mine` -> one verdict, through the LDS word s_word (two barriers; every thread calls)
+__device__ __forceinline__ void verlet_forecast(const VerletLists &vv, unsigned wg, bool mine, int *s_word)
+{
+    if (vv.order_next == nullptr) return;  // (uniform)
+    if (threadIdx.x == 0) *s_word = 0;
+    lds_barrier();
+    const bool any = __ballot(mine) != 0ull;
+    if ((threadIdx.x & 63) == 0 && any) *s_word = 1;
+    lds_barrier();
+    if (threadIdx.x == 0) verlet_file_slot(vv, wg, *s_word != 0);
+}
+
 // Answer a workgroup's rows from their Verlet lists (see VerletLists; called by nn_fast_kernel<..., VERLET> once every row
 // of the workgroup has passed the completeness test): kVerletSlots gathers of 16 bytes per row, the same float d2 as
 // everywhere, the m smallest by (d2, original index), the association's row written in list order, K23 folded in from the
@@ -1021,7 +1054,8 @@ template <int M, int FTM>
 __device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, const bool valid, const float4 q, const int ns,
                                                    const float4 *__restrict__ tgt, const unsigned thr, const int m,
                                                    int *__restrict__ nbr, int *__restrict__ cnt, unsigned *__restrict__ dm2,
-                                                   const FusedMoments &fm, const VerletLists &vv, unsigned char *s_mem)
+                                                   const FusedMoments &fm, const VerletLists &vv, unsigned char *s_mem,
+                                                   const unsigned wg, const float g2, const float acc, const float moved, const float radius)
 {
     constexpr int BLOCK = 256, CV = kVerletSlots;
     static_assert(M <= CV, "a list holds at least the m winners");
@@ -1137,8 +1171,13 @@ __device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, c
         }
         __syncthreads();  // every lane is through with its winners: the fold borrows the memory
         double *const scratch = reinterpret_cast<double *>(s_mem);
-        block_reduce_scratch(sums, scratch, scratch + 10 * 257, fm.partials + blockIdx.x, (size_t)fm.nslots, true);
+        block_reduce_scratch(sums, scratch, scratch + 10 * 257, fm.partials + wg, (size_t)fm.nslots, true);
+        __syncthreads();  // (the forecast below borrows a word of the same memory)
     }
+    // will this row's list still do after one more move like the last one?  (VerletLists' test with the new m-th distance)
+    const float need_next = (tm != 0xFFFFFFFFu ? __builtin_amdgcn_sqrtf(__uint_as_float(tm)) : radius) + moved;
+    const float reach_next = (need_next + acc + moved) * 1.0001f;
+    verlet_forecast(vv, wg, valid && !(reach_next * reach_next < g2), reinterpret_cast<int *>(s_mem));
 }
 
 // FTM != -2 (0: Gaussian, k > 0: t model with v + dim = k, -3: t model with an integer v + dim read at run time) folds
@@ -1155,7 +1194,7 @@ template <int C, int CAP, bool MULTI, int VERLET_M = 0>
 struct FastLds {
     static constexpr int kHaloBytes = (3 * CAP + CAP / 4) * 4, kListBytes = (C + 1) * 256 * 2;
     static constexpr int kOffGbo = kHaloBytes, kOffBox = kOffGbo + 128 * 4, kOffBail = kOffBox + 4 * 6 * 4, kOffNeed = kOffBail + 4,
-                         kOffList = (kOffNeed + (MULTI ? 4 * 16 * 4 : 0) + 15) & ~15;
+                         kOffList = (kOffNeed + (MULTI ? 4 * 16 * 4 : 4) + 15) & ~15;  // (one word at kOffNeed also without MULTI: the Verlet forecast's)
     static constexpr int kBytes = kOffList + kListBytes;
     static constexpr int kVerletBytes = VERLET_M > 0 ? VerletLds<(VERLET_M > 0 ? VERLET_M : 1)>::kBytes : 0;
     static constexpr int kAllocBytes = kBytes > kVerletBytes ? kBytes : kVerletBytes;
@@ -1185,7 +1224,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
     // then this one must touch nothing.  A uniform scalar load, tested below once the query load is in flight.
     const unsigned aborted = lr.st ? lr.st->abort : 0u;
     static_assert(C > M, "a re-scan must leave room in the list");
-    static_assert(!VERLET || (C <= kVerletSlots && !MULTI && !STAMPS), "Verlet lists are built by the steady-state variant: a list is the scan's LDS list");
+    static_assert(!VERLET || (C >= kVerletSlots && !MULTI && !STAMPS), "Verlet lists are built by the steady-state variant: a list is the nearest part of the scan's LDS list");
     static_assert(!MULTI || FTM == -2, "a multi-level search leaves rows to nn_wide_kernel: K23 is its own kernel");
     static_assert(FTM == -2 || (3 * CAP + CAP / 4) * 4 >= kFoldScratchBytes, "the final fold borrows the halo buffer");
     static_assert(CAP % 4 == 0 && CAP * 4 < 65536, "list entries are 16-bit byte offsets into the halo arrays");
@@ -1245,20 +1284,26 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the workgroup's SLOT: its index in the launch, or (Verlet variant) the slot the previous launch filed for this place
+    // in the dispatch order (verlet_slot).  The slot names the block, the partial sums' column, the hand-over entry.
+    unsigned wg = blockIdx.x;
+    // (a launch that steps aside does not look at the order: the launch that should have filed it may have stepped aside too)
+    if constexpr (VERLET)
+        if (!aborted) wg = (unsigned)__builtin_amdgcn_readfirstlane((int)verlet_slot(vv));
 
     // which block, and which of its waves' queries, this workgroup scans (uniform)
     int bid, half = 0;  // half: 0 whole block, 1 waves 0-1, 2 waves 2-3
     unsigned level_fb = 0x0Fu;  // MULTI: the block's feedback byte (UnansweredRows::level_cap)
     float4 q_early = make_float4(0.f, 0.f, 0.f, 0.f);
     if (split.all_halves) {
-        const int slot = halves_slot((int)blockIdx.x), nb = (ns + BLOCK - 1) / BLOCK;
+        const int slot = halves_slot((int)wg), nb = (ns + BLOCK - 1) / BLOCK;
         if (slot >= nb) {  // (padding of the grid to a multiple of sixteen workgroups)
             if constexpr (FTM != -2)
-                if (tid < kNSums) fm.partials[(size_t)tid * fm.nslots + blockIdx.x] = 0.0;
+                if (tid < kNSums) fm.partials[(size_t)tid * fm.nslots + wg] = 0.0;
             return;
         }
         bid = xcd_block(slot, nb);
-        half = halves_half((int)blockIdx.x);
+        half = halves_half((int)wg);
         if constexpr (MULTI) {
             // multi-level searches launch the two-workgroups-per-block grid and use the second workgroup only for the
             // blocks marked split (bit 8 of level_cap: their halo outgrew the tile at the level their cut-offs ask for;
@@ -1271,16 +1316,18 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
                 half = 0;
             }
         }
-    } else if ((int)blockIdx.x < split.n_extra) {
-        if (blockIdx.x >= min(*split.visible, (unsigned)kMaxSplit)) {
+    } else if ((int)wg < split.n_extra) {
+        if (wg >= min(*split.visible, (unsigned)kMaxSplit)) {
             if constexpr (FTM != -2)  // an idle slot of the partials still has to read as zero
-                if (tid < kNSums) fm.partials[(size_t)tid * fm.nslots + blockIdx.x] = 0.0;
+                if (tid < kNSums) fm.partials[(size_t)tid * fm.nslots + wg] = 0.0;
+            if constexpr (VERLET)
+                if (tid == 0 && !aborted) verlet_file_slot(vv, wg, false);
             return;
         }
-        bid = split.list[blockIdx.x];
+        bid = split.list[wg];
         half = 2;
     } else {
-        bid = xcd_block((int)blockIdx.x - split.n_extra, (ns + BLOCK - 1) / BLOCK);
+        bid = xcd_block((int)wg - split.n_extra, (ns + BLOCK - 1) / BLOCK);
         if (split.n_extra > 0 && split.flag[bid] == 2) half = 1;
     }
     const int i = bid * BLOCK + tid;
@@ -1292,9 +1339,12 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
     if (aborted) return;
     // the other counter of the ping-pong pair: idle during this launch  (the last workgroup is never an idle split slot;
     // with all_halves the first one never idles)
-    if (tid == 0 && blockIdx.x == (split.all_halves ? 0u : gridDim.x - 1)) {
+    if (tid == 0 && wg == (split.all_halves ? 0u : gridDim.x - 1)) {
         *ovf_count_next = 0;
         if (un.next != nullptr) *un.next = 0;
+        if constexpr (VERLET)
+            if (vv.count_clear != nullptr)
+                for (int k = 0; k < 16; k++) vv.count_clear[k] = 0;  // (the dispatch-order counters of the launch after next)
     }
     float moved = 0.f;  // how far this query travelled since the association that produced dm2
     if (pm.enabled && valid) {
@@ -1344,7 +1394,8 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
             lds_barrier();  // (everybody has read the verdict: the list path writes its winners over these words)
             if (all_ok) {
                 if (valid) vv.vacc[i] = acc;
-                verlet_answer_rows<M, FTM>(tid, i, valid, q, ns, tgt0, min(thr0, __float_as_uint(r2_0) - 1u), m, nbr, cnt, dm2, fm, vv, s_all);
+                verlet_answer_rows<M, FTM>(tid, i, valid, q, ns, tgt0, min(thr0, __float_as_uint(r2_0) - 1u), m, nbr, cnt, dm2, fm, vv, s_all,
+                                           wg, g2, acc, moved, __builtin_amdgcn_sqrtf(r2_0));
                 return;
             }
             if (tid == 0 && vv.rebuilt != nullptr) atomicAdd(vv.rebuilt, 1u);  // (diagnostic: workgroups that searched again)
@@ -1543,9 +1594,11 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
     if (handed_over) {
         // the cleanup kernel redoes this workgroup's queries (this launch): entry = grid index * 4 + half — or, when the
         // unanswered rows are listed, nn_wide_kernel searches them (marked unsearched)
-        if (tid == 0) ovf_list[atomicAdd(ovf_count, 1u)] = (int)blockIdx.x * 4 + half;
-        if constexpr (VERLET)
+        if (tid == 0) ovf_list[atomicAdd(ovf_count, 1u)] = (int)wg * 4 + half;
+        if constexpr (VERLET) {
             if (valid) vv.vg2[i] = 0.f;  // (whoever redoes these rows builds no lists: they come back here next time)
+            if (tid == 0) verlet_file_slot(vv, wg, true);
+        }
         if constexpr (MULTI) {  // from the next launch on this block searches a finer level (more short rows, but a halo that fits)
             // (level_cap[bid] = cap | floor << 4.  A halo too LARGE for the tile: a finer level next time, i.e. more short
             //  rows but a halo that fits; a halo of too many ROWS — a surface seen at too fine a level — a coarser one)
@@ -1636,6 +1689,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
 
     int n = 0;
     unsigned tm = 0xFFFFFFFFu;  // d2 bits of the m-th neighbour (all-ones: fewer than m found)
+    float vg_new = 0.f;         // VERLET: the reach (as d2) of the list this launch built for the row
     // A lane's column of the list.  With column = tid the lanes 2k and 2k + 1 of a wave share a 32-bit LDS word, and in
     // the scan every lane writes at its own cursor (another slot = another address in the same bank): the two u16 stores
     // of the pair collide whenever their cursors differ.  The columns of a wave are therefore dealt so that a word is
@@ -1681,7 +1735,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
                 unsigned long long pk = 0;
 #pragma unroll
                 for (int k = 0; k < 9; k++) pk |= (unsigned long long)min(key[k] >> 16, 127u) << (7 * k);
-                stamps[((size_t)gridDim.x * kWaves + 64) * 8 + (size_t)blockIdx.x * BLOCK + tid] = pk;
+                stamps[((size_t)gridDim.x * kWaves + 64) * 8 + (size_t)wg * BLOCK + tid] = pk;
             }
         }
         // d2 >= +0 and r2 > 0, so "d2 < r2" is "bits(d2) <= bits(r2) - 1" (a NaN d2 has larger bits and fails): the
@@ -1757,7 +1811,15 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
             if constexpr (VERLET) thr = min(thr, thr_a);  // (the list of such a row ends at its cut-off: no margin, rebuilt next time)
         }
         if constexpr (VERLET) {
-            // the list as scanned — every target whose d2 bits are <= thr — is the row's Verlet list ...
+            // The row's Verlet list: the kVerletSlots NEAREST of what the scan accepted (every target whose d2 bits are <= thr;
+            // the scan's lists are half as long again).  A list cut to its nearest sixteen is complete below its farthest
+            // member — for the typical row that is the 16th neighbour's distance against the 10th's: 0.14 radii of room at
+            // the benchmark's density, however little a fixed skin would have allowed.
+            if (n > kVerletSlots) {
+                unsigned t_far = 0;
+                n = select_top_m<kVerletSlots>(L, tgt, q, n, kVerletSlots, t_far);
+                thr = t_far > 0u ? t_far - 1u : 0u;  // (strictly below the farthest kept: equal distances beyond it were dropped)
+            }
             if (n >= 0) {
                 int *out = vv.vl + i;
                 for (int j = 0; j < n; j++) {
@@ -1771,7 +1833,8 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
                 vv.vn[i] = (unsigned char)n;
                 vv.vacc[i] = 0.f;
             }
-            vv.vg2[i] = n >= 0 ? __uint_as_float(thr) : 0.f;
+            vg_new = n >= 0 ? __uint_as_float(thr) : 0.f;  // (0: no list — also the degenerate row whose sixteen nearest are all at distance 0)
+            vv.vg2[i] = vg_new;
             // ... and what lies beyond the association's own threshold (radius, temporal cut-off) leaves the list now
             if (n > 0 && thr > thr_a) {
                 int w = 0;
@@ -1846,7 +1909,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
     // simply overwritten there with identical values
     const bool unanswered = n < 0;  // (marked unsearched, like the rows of a workgroup that bailed: see nn_wide_kernel)
     if (__ballot(unanswered) != 0ull) {
-        if (lane == 0 && atomicExch(&s_bail, 1) == 0) ovf_list[atomicAdd(ovf_count, 1u)] = (int)blockIdx.x * 4 + half;
+        if (lane == 0 && atomicExch(&s_bail, 1) == 0) ovf_list[atomicAdd(ovf_count, 1u)] = (int)wg * 4 + half;
         n = max(n, 0);
     }
     if (valid) {
@@ -1903,8 +1966,15 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
         __syncthreads();  // every wave is through with the halo: the fold borrows its memory
         double *const scratch = reinterpret_cast<double *>(s_halo);
         // a block that was handed to the cleanup kernel (s_bail) leaves its slot to that kernel
-        block_reduce_scratch(acc, scratch, scratch + 10 * 257, fm.partials + blockIdx.x, (size_t)fm.nslots, s_bail == 0);
+        block_reduce_scratch(acc, scratch, scratch + 10 * 257, fm.partials + wg, (size_t)fm.nslots, s_bail == 0);
         stamp(6);
+    }
+    if constexpr (VERLET) {
+        // the forecast for the next launch's dispatch order (verlet_forecast): will the fresh list still do after one more
+        // move like this one?  (a row without a list, or a block the cleanup kernel redoes: no)
+        const float need_next = (tm != 0xFFFFFFFFu ? __builtin_amdgcn_sqrtf(__uint_as_float(tm)) : __builtin_amdgcn_sqrtf(r2_0)) + moved;
+        const float reach_next = (need_next + moved) * 1.0001f;
+        verlet_forecast(vv, wg, valid && !(reach_next * reach_next < vg_new), s_need);
     }
     flush_stamps();
 }

@@ -7,6 +7,9 @@ namespace ppcr {
 
 // Halo capacity of the steady-state (16-slot) variant: 31.3 KB of LDS, five workgroups per CU (1792: four).
 constexpr int kCapSteady = 1728;
+// ... of the Verlet variant (four workgroups per CU either way: its list path holds 48 coordinates in registers), whose
+// lists reach further than the plain search's cut-off: larger cells, larger halos
+constexpr int kCapVerlet = 1920;
 // workgroups (= partial-sum slots when K23 is folded in) of a steady-state K1 launch over nb blocks of 256 queries
 inline int steady_grid(int nb, bool all_halves) { return all_halves ? 2 * ((nb + 7) & ~7) : nb + dev::kMaxSplit; }
 

@@ -687,6 +687,56 @@ def test_batch_run_and_align_many(ctx):
         np.testing.assert_array_equal(c.align(2, cost_drop_thresh=0.0, inner_steps=1)["history"][-1], Tu[3])
 
 
+@pytest.mark.parametrize("m", [10, 5, 8])
+def test_verlet_lists_keep_every_association_exact(m):
+    """Steady state (csrc/ppcr_device.hip.h: VerletLists): once the source barely moves, workgroups answer their rows from
+    per-row lists instead of searching the grid, for as long as each list provably holds every target the exact search
+    could return; a workgroup with a failing row searches and rebuilds.  Every association of a source that drifts by
+    small and not so small rigid moves equals the oracle's — neighbour sets and float d2 bit for bit — and the counters
+    say that both paths ran."""
+    src, tgt, _, _ = synth.make_pair(30000, cfg=2, stride=3)
+    rng = np.random.default_rng(515 + m)
+    with _lib.Context(0) as c, _lib.Context(0) as plain:
+        plain.set_option("verlet", 0)
+        for h in (c, plain):
+            h.set_option("defer_moves", 1)      # the moves ride in the next association's prologue, as in the align loop
+            h.set_params(1.0, m, 5.0, 3)
+            h.set_target(tgt)
+            h.set_source(src)
+        cur = src.copy()
+        seen = []
+        #            (rotation angle, translation / radius) per step: tiny, small, a jolt, tiny again, none at all
+        steps = [(2e-4, 2e-3)] * 3 + [(1e-3, 8e-3)] * 3 + [(2e-2, 0.2)] + [(1e-4, 5e-4)] * 5 + [(0.0, 0.0)] * 2
+        for k, (ang, tr) in enumerate([(0.0, 0.0)] + steps):
+            c.associate()
+            plain.associate()
+            rp, col, d2 = c.get_association()
+            orp, ocol, od2 = po.radius_search(cur, tgt, 1.0, m, method=1)
+            np.testing.assert_array_equal(rp, orp, err_msg=f"step {k}")
+            np.testing.assert_array_equal(col, ocol, err_msg=f"step {k}")
+            np.testing.assert_array_equal(d2, od2, err_msg=f"step {k}")
+            prp, pcol, pd2 = plain.get_association()
+            np.testing.assert_array_equal(rp, prp)
+            np.testing.assert_array_equal(col, pcol)
+            np.testing.assert_array_equal(d2, pd2)
+            seen.append(c.debug_verlet())
+            T = np.eye(4)
+            T[:3, :3] = synth.rodrigues(rng.normal(size=3), ang)
+            T[:3, 3] = rng.normal(0, tr / np.sqrt(3), size=3)
+            for h in (c, plain):
+                h.apply_transform(T)
+            po.transform_cloud(cur, T)
+        assert seen[1]["trusted"] and seen[1]["rows"] == 30000 and seen[1]["mean_list"] >= min(m, 1), seen[:3]
+        rebuilt = np.diff([s["rebuilt"] for s in seen])
+        real = seen[-1]["workgroups"] - 128                     # (the grid carries 128 slots for split blocks)
+        # (rebuilt[j]: workgroups that searched again in association j + 1; association 1 built the lists, 2 - 4 follow the
+        #  tiny moves, 8 the jolt, 14 and 15 a source that did not move)
+        assert rebuilt[1] < real // 2, ("after a tiny move most workgroups must have answered from their lists", rebuilt.tolist())
+        assert rebuilt[7] >= real, ("after the jolt no list can hold: every workgroup searches again", rebuilt.tolist())
+        assert rebuilt[-1] == 0 and rebuilt[-2] == 0, ("a source that did not move at all is answered from the lists alone", rebuilt.tolist())
+        assert plain.debug_verlet()["rows"] == 0                # (the plain context never built a list)
+
+
 def test_device_memory_pool_serves_fresh_handles_without_driver_calls(ctx):
     """The handles' buffers are blocks of a per-device pool (csrc/ppcr_pool.hpp, ppcr_memory_stats / ppcr_memory_trim): a
     second fresh handle registering a pair of the same size makes NO hipMalloc call, recycled memory changes no result,
