@@ -783,6 +783,23 @@ def run_rank(a):
                     worst = max(worst, float(np.abs(one - gathered[p]).max()))
             out["batch_verification"] = {"pairs_checked": n_pairs, "max_abs_diff_vs_single_rank_run": worst}
             assert worst < 1e-9, f"a gathered transform differs from its single-rank run by {worst}"
+            # ... and four sampled pairs against the ORACLE (the comparison above is GPU against GPU): same clouds, same
+            # schedule, transform within the north-star's 1e-5 rad / 1e-5 m
+            if rank == 0 and not a.no_cpu_baseline:
+                from oracle import binding as po  # noqa: F811  (checker side)
+                sample = sorted({0, n_pairs // 3, (2 * n_pairs) // 3, n_pairs - 1})
+                rot_w = tr_w = 0.0
+                for p in sample:
+                    s, t, _, _ = synth.make_config(a.config, pair=p, n=n)
+                    hist = po.align(s, t, cfg["radius"], cfg["max_neighbours"], cfg["dof"], a.warmup + a.steps,
+                                    cost_drop_thresh=timed_thresh, inner_max_steps=a.inner_steps)["history"]
+                    # (the gathered transform is the timed call's own: what came after the warm-up iterations)
+                    to4 = lambda T: np.vstack([T, [0.0, 0.0, 0.0, 1.0]])
+                    ora = (to4(hist[-1]) @ np.linalg.inv(to4(hist[a.warmup - 1]) if a.warmup > 0 else np.eye(4)))[:3]
+                    rot_w = max(rot_w, float(synth.rotation_angle(gathered[p][:, :3], ora[:, :3])))
+                    tr_w = max(tr_w, float(np.linalg.norm(gathered[p][:, 3] - ora[:, 3])))
+                out["batch_verification"]["oracle_sample"] = {"pairs": sample, "rot_err_rad": rot_w, "trans_err_m": tr_w}
+                assert rot_w < 1e-5 and tr_w < 1e-5, f"a gathered transform differs from the oracle's: {rot_w} rad, {tr_w} m"
 
     if world == 1 and not a.no_cpu_baseline:
         from oracle import binding as po  # noqa: F401  (checker side)

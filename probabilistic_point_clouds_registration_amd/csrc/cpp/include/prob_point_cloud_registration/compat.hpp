@@ -1,8 +1,11 @@
 // Minimal stand-ins for the third-party types on the reference's public surface (PCL point clouds,
-// Eigen Affine3d / row-major sparse matrix, ceres::Solver::Options/Summary).  None of PCL, Eigen or
-// Ceres is needed to build or use this library; the names, members and semantics below are the subset
-// the reference's API touches.  When the real libraries are present, define
-// PPCR_NO_COMPAT_TYPES before including any header of this directory and provide equivalent aliases.
+// Eigen Affine3d / row-major sparse matrix, ceres::Solver::Options/Summary, the loss-function wrapper).  None of PCL,
+// Eigen or Ceres is needed to build or use this library; the names, members and semantics below are a SUBSET of the real
+// libraries' — every member a header of this directory touches exists under that name in the real library (what is
+// specific to this implementation lives in adapters.hpp as free functions written against those members only).
+// With the real libraries present, define PPCR_NO_COMPAT_TYPES: this header then includes them instead.
+// tests/test_cpp_headers.py compiles every header and source of this directory against an API-subset mock of the three
+// (tests/cpp/mock_real: real member names only), so a stand-in-only member cannot creep back in.
 #pragma once
 #include <cmath>
 #include <cstddef>
@@ -11,7 +14,17 @@
 #include <string>
 #include <vector>
 
-#ifndef PPCR_NO_COMPAT_TYPES
+#ifdef PPCR_NO_COMPAT_TYPES
+
+#include <Eigen/Geometry>
+#include <Eigen/Sparse>
+#include <ceres/ceres.h>
+#include <pcl/common/angles.h>
+#include <pcl/common/transforms.h>
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+
+#else
 
 namespace pcl {
 
@@ -111,44 +124,33 @@ struct AngleAxisd {
 };
 inline Quaterniond operator*(const Quaterniond &q, const AngleAxisd &a) { return q * Quaterniond(a); }
 
-// rigid transform [R|t]; operator* composes (this applied after rhs), like Eigen::Affine3d
+// rigid transform [R|t]; operator* composes (this applied after rhs), like Eigen::Affine3d.  Members as in Eigen:
+// linear() / translation() (writable), rotation() (by value), Identity(), operator*
 class Affine3d {
 public:
-    Matrix3d R;
-    Vector3d t;
     static Affine3d Identity() { return Affine3d(); }
-    const Matrix3d &rotation() const { return R; }
-    const Vector3d &translation() const { return t; }
+    Matrix3d &linear() { return R_; }
+    const Matrix3d &linear() const { return R_; }
+    Matrix3d rotation() const { return R_; }
+    Vector3d &translation() { return t_; }
+    const Vector3d &translation() const { return t_; }
     Affine3d operator*(const Affine3d &o) const
     {
         Affine3d r;
         for (int a = 0; a < 3; a++) {
             for (int b = 0; b < 3; b++) {
                 double acc = 0;
-                for (int k = 0; k < 3; k++) acc += R.m[a][k] * o.R.m[k][b];
-                r.R.m[a][b] = acc;
+                for (int k = 0; k < 3; k++) acc += R_.m[a][k] * o.R_.m[k][b];
+                r.R_.m[a][b] = acc;
             }
-            r.t.v[a] = R.m[a][0] * o.t.v[0] + R.m[a][1] * o.t.v[1] + R.m[a][2] * o.t.v[2] + t.v[a];
+            r.t_.v[a] = R_.m[a][0] * o.t_.v[0] + R_.m[a][1] * o.t_.v[1] + R_.m[a][2] * o.t_.v[2] + t_.v[a];
         }
         return r;
     }
-    // row-major top three rows of the 4x4 (the C ABI's T[12])
-    void to_rows(double T[12]) const
-    {
-        for (int a = 0; a < 3; a++) {
-            for (int b = 0; b < 3; b++) T[4 * a + b] = R.m[a][b];
-            T[4 * a + 3] = t.v[a];
-        }
-    }
-    static Affine3d from_rows(const double T[12])
-    {
-        Affine3d r;
-        for (int a = 0; a < 3; a++) {
-            for (int b = 0; b < 3; b++) r.R.m[a][b] = T[4 * a + b];
-            r.t.v[a] = T[4 * a + 3];
-        }
-        return r;
-    }
+
+private:
+    Matrix3d R_;
+    Vector3d t_;
 };
 
 template <class T>
@@ -190,11 +192,11 @@ public:
     const int *innerIndexPtr() const { return inner_.data(); }
     const T *valuePtr() const { return values_.data(); }
     T *valuePtr() { return values_.data(); }
-    // adopt raw CSR arrays (used by the device round trips)
-    void assign_csr(long rows, long cols, std::vector<int> outer, std::vector<int> inner, std::vector<T> values)
+    void resize(long rows, long cols)
     {
         rows_ = rows, cols_ = cols;
-        outer_ = std::move(outer), inner_ = std::move(inner), values_ = std::move(values);
+        outer_.assign(static_cast<std::size_t>(rows) + 1, 0);
+        inner_.clear(), values_.clear();
     }
     class InnerIterator {
     public:
@@ -226,6 +228,60 @@ private:
 }  // namespace Eigen
 
 namespace ceres {
+// rho(s) and its derivatives; ScaledLoss(NULL, a): a * s; LossFunctionWrapper: a loss that can be swapped while a
+// problem holds it — the three classes ErrorTerm::weight() / updateWeight() are written against (error_term.hpp:17-19,39-45)
+enum Ownership { DO_NOT_TAKE_OWNERSHIP, TAKE_OWNERSHIP };
+class LossFunction {
+public:
+    virtual ~LossFunction() {}
+    virtual void Evaluate(double sq_norm, double out[3]) const = 0;
+};
+class ScaledLoss : public LossFunction {
+public:
+    ScaledLoss(const LossFunction *rho, double a, Ownership ownership) : rho_(rho), a_(a), ownership_(ownership) {}
+    ~ScaledLoss() override
+    {
+        if (ownership_ == TAKE_OWNERSHIP) delete rho_;
+    }
+    void Evaluate(double s, double out[3]) const override
+    {
+        if (rho_ == nullptr) {
+            out[0] = a_ * s, out[1] = a_, out[2] = 0.0;
+        } else {
+            rho_->Evaluate(s, out);
+            out[0] *= a_, out[1] *= a_, out[2] *= a_;
+        }
+    }
+
+private:
+    const LossFunction *rho_;
+    double a_;
+    Ownership ownership_;
+};
+class LossFunctionWrapper : public LossFunction {
+public:
+    LossFunctionWrapper(LossFunction *rho, Ownership ownership) : rho_(rho), ownership_(ownership) {}
+    ~LossFunctionWrapper() override
+    {
+        if (ownership_ == TAKE_OWNERSHIP) delete rho_;
+    }
+    LossFunctionWrapper(const LossFunctionWrapper &) = delete;
+    LossFunctionWrapper &operator=(const LossFunctionWrapper &) = delete;
+    void Evaluate(double sq_norm, double out[3]) const override
+    {
+        if (rho_ == nullptr) out[0] = sq_norm, out[1] = 1.0, out[2] = 0.0;
+        else rho_->Evaluate(sq_norm, out);
+    }
+    void Reset(LossFunction *rho, Ownership ownership)
+    {
+        if (ownership_ == TAKE_OWNERSHIP) delete rho_;
+        rho_ = rho, ownership_ = ownership;
+    }
+
+private:
+    LossFunction *rho_;
+    Ownership ownership_;
+};
 enum LinearSolverType { DENSE_QR, SPARSE_NORMAL_CHOLESKY };
 // the callback protocol WeightUpdaterCallback is written against (weight_updater_callback.hpp:15,36)
 enum CallbackReturnType { SOLVER_CONTINUE, SOLVER_ABORT, SOLVER_TERMINATE_SUCCESSFULLY };

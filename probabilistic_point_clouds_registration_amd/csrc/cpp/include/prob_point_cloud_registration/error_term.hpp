@@ -5,33 +5,19 @@
 // for every stored pair inside the HIP kernels (sq_residual in ppcr_device.hip.h).
 #pragma once
 #include <cmath>
+#include <memory>
 
 #include "prob_point_cloud_registration/compat.hpp"
 
 namespace prob_point_cloud_registration {
 
-// stand-in for ceres::LossFunctionWrapper(ScaledLoss(NULL, w)): rho(s) = w * s
-class ScaledLossHandle {
-public:
-    explicit ScaledLossHandle(double w = 1.0) : w_(w) {}
-    void Reset(double w) { w_ = w; }
-    double scale() const { return w_; }
-    void Evaluate(double s, double rho[3]) const
-    {
-        rho[0] = w_ * s;
-        rho[1] = w_;
-        rho[2] = 0.0;
-    }
-
-private:
-    double w_;
-};
-
 class ErrorTerm {
 public:
     static const int kResiduals = 3;
     ErrorTerm(const pcl::PointXYZ source_point, const pcl::PointXYZ target_point)
-        : source_{source_point.x, source_point.y, source_point.z}, target_{target_point.x, target_point.y, target_point.z}
+        : source_{source_point.x, source_point.y, source_point.z}, target_{target_point.x, target_point.y, target_point.z},
+          // rho(s) = w s with w = 1 to begin with, swappable while a problem holds the wrapper (error_term.hpp:17-19)
+          weight_(std::make_shared<ceres::LossFunctionWrapper>(new ceres::ScaledLoss(NULL, 1.0, ceres::TAKE_OWNERSHIP), ceres::TAKE_OWNERSHIP))
     {
     }
 
@@ -51,11 +37,12 @@ public:
         return true;
     }
 
-    void updateWeight(double new_weight) { weight_.Reset(new_weight); }
-    // The reference returns the term's ceres::LossFunctionWrapper * here (error_term.hpp:45) for AddResidualBlock; this
-    // library never builds a Ceres problem, so the handle is its own rho(s) = w s object ("Behavioural
-    // differences").
-    ScaledLossHandle *weight() { return &weight_; }
+    // error_term.hpp:39-43: a new ScaledLoss(NULL, w) behind the same wrapper
+    void updateWeight(double new_weight) { weight_->Reset(new ceres::ScaledLoss(NULL, new_weight, ceres::TAKE_OWNERSHIP), ceres::TAKE_OWNERSHIP); }
+    // error_term.hpp:45: the wrapper a caller hands to ceres::Problem::AddResidualBlock (this library never builds a Ceres
+    // problem itself; with the real Ceres — PPCR_NO_COMPAT_TYPES — this IS ceres::LossFunctionWrapper).  The term keeps
+    // the wrapper alive: add it with ceres::DO_NOT_TAKE_OWNERSHIP problem options, as a shared loss must be.
+    ceres::LossFunctionWrapper *weight() { return weight_.get(); }
 
     // additions of this implementation: the two points as the functor holds them (float values widened to double,
     // error_term.hpp:15-16) — what WeightUpdaterCallback uploads for its device route
@@ -65,7 +52,7 @@ public:
 private:
     double source_[3];
     double target_[3];
-    ScaledLossHandle weight_;
+    std::shared_ptr<ceres::LossFunctionWrapper> weight_;
 };
 
 }  // namespace prob_point_cloud_registration

@@ -7,7 +7,7 @@
 #pragma once
 #include <memory>
 
-#include "prob_point_cloud_registration/compat.hpp"
+#include "prob_point_cloud_registration/adapters.hpp"
 #include "prob_point_cloud_registration/device.hpp"
 #include "prob_point_cloud_registration/error_term.hpp"
 #include "prob_point_cloud_registration/prob_point_cloud_registration_params.hpp"
@@ -63,12 +63,12 @@ public:
     // estimated transform; before solve(): the (normalised) initial rotation / translation of the params
     Eigen::Affine3d transformation()
     {
-        if (solved_) return Eigen::Affine3d::from_rows(T_);
+        if (solved_) return affineFromRows(T_);
         Eigen::Quaterniond q(rotation_[0], rotation_[1], rotation_[2], rotation_[3]);
         q.normalize();
-        Eigen::Affine3d a;
-        a.R = q.toRotationMatrix();
-        a.t = Eigen::Vector3d(translation_[0], translation_[1], translation_[2]);
+        Eigen::Affine3d a = Eigen::Affine3d::Identity();
+        a.linear() = q.toRotationMatrix();
+        a.translation() = Eigen::Vector3d(translation_[0], translation_[1], translation_[2]);
         return a;
     }
 

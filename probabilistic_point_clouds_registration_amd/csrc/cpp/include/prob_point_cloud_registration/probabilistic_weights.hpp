@@ -10,7 +10,7 @@
 #include <vector>
 
 #include "ppcr.h"
-#include "prob_point_cloud_registration/compat.hpp"
+#include "prob_point_cloud_registration/adapters.hpp"
 
 namespace prob_point_cloud_registration {
 
@@ -34,11 +34,7 @@ public:
         const int rc = ppcr_update_weights(device_id_, data_association.outerIndexPtr(), rows, squared_errors.data(), v_,
                                            dimension_, w.data());
         if (rc != PPCR_OK) throw std::runtime_error(std::string("ppcr_update_weights: ") + ppcr_last_error(nullptr));
-        Eigen::SparseMatrix<double, Eigen::RowMajor> out;
-        out.assign_csr(rows, data_association.cols(),
-                       std::vector<int>(data_association.outerIndexPtr(), data_association.outerIndexPtr() + rows + 1),
-                       std::vector<int>(data_association.innerIndexPtr(), data_association.innerIndexPtr() + nnz), std::move(w));
-        return out;
+        return sparseFromCsr(rows, data_association.cols(), data_association.outerIndexPtr(), data_association.innerIndexPtr(), w.data());
     }
 
     bool isNormal() const { return !(v_ < std::numeric_limits<double>::infinity()); }

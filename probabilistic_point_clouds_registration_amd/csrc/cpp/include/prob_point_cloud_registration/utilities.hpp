@@ -143,7 +143,9 @@ inline Eigen::Quaterniond euler2Quaternion(const double roll, const double pitch
     return about_z * about_y * about_x;
 }
 
+#ifndef PPCR_NO_COMPAT_TYPES
 // in-place/out-of-place pcl::transformPointCloud(cloud_in, cloud_out, Affine3d): f64 math, f32 store
+// (stand-in builds only: with the real libraries pcl/common/transforms.h provides it)
 inline void transformPointCloud(const pcl::PointCloud<pcl::PointXYZ> &in, pcl::PointCloud<pcl::PointXYZ> &out,
                                 const Eigen::Affine3d &T)
 {
@@ -151,15 +153,20 @@ inline void transformPointCloud(const pcl::PointCloud<pcl::PointXYZ> &in, pcl::P
     for (std::size_t i = 0; i < in.size(); i++) {
         const double x = in[i].x, y = in[i].y, z = in[i].z;
         pcl::PointXYZ p = in[i];
-        p.x = static_cast<float>(((T.R.m[0][0] * x + T.R.m[0][1] * y) + T.R.m[0][2] * z) + T.t.v[0]);
-        p.y = static_cast<float>(((T.R.m[1][0] * x + T.R.m[1][1] * y) + T.R.m[1][2] * z) + T.t.v[1]);
-        p.z = static_cast<float>(((T.R.m[2][0] * x + T.R.m[2][1] * y) + T.R.m[2][2] * z) + T.t.v[2]);
+        const Eigen::Matrix3d &R = T.linear();
+        const Eigen::Vector3d &t = T.translation();
+        p.x = static_cast<float>(((R(0, 0) * x + R(0, 1) * y) + R(0, 2) * z) + t(0));
+        p.y = static_cast<float>(((R(1, 0) * x + R(1, 1) * y) + R(1, 2) * z) + t(1));
+        p.z = static_cast<float>(((R(2, 0) * x + R(2, 1) * y) + R(2, 2) * z) + t(2));
         out[i] = p;
     }
 }
+#endif
 
 }  // namespace prob_point_cloud_registration
 
+#ifndef PPCR_NO_COMPAT_TYPES
 namespace pcl {
 using prob_point_cloud_registration::transformPointCloud;
 }
+#endif

@@ -9,6 +9,7 @@
 #include <iostream>
 #include <sstream>
 
+#include "prob_point_cloud_registration/adapters.hpp"
 #include "prob_point_cloud_registration/utilities.hpp"
 
 namespace prob_point_cloud_registration {
@@ -132,7 +133,7 @@ struct ProbPointCloudRegistration::State {
 
     void absorb(const ppcr_iteration_info &it)
     {
-        const Eigen::Affine3d delta = Eigen::Affine3d::from_rows(it.T_step);
+        const Eigen::Affine3d delta = affineFromRows(it.T_step);
         cumulative.push_back(cumulative.empty() ? delta : delta * cumulative.back());
         log << "iteration " << it.iteration << ": initial_cost " << it.cost[0] << " final_cost " << it.cost[1] << " inner steps "
             << it.inner_steps << "\n";

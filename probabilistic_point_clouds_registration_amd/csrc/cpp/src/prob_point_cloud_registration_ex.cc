@@ -22,6 +22,7 @@
 #include <thread>
 #include <vector>
 
+#include "prob_point_cloud_registration/adapters.hpp"
 #include "prob_point_cloud_registration/pcd_io.hpp"
 #include "prob_point_cloud_registration/prob_point_cloud_registration.h"
 #include "prob_point_cloud_registration/utilities.hpp"
@@ -427,7 +428,7 @@ int runBatch(const Job &job)
         iterations = it_mine;
     }
     for (std::size_t k = 0; k < n_pairs; k++) {
-        const Eigen::Affine3d A = Eigen::Affine3d::from_rows(&T[12 * k]);
+        const Eigen::Affine3d A = reg::affineFromRows(&T[12 * k]);
         const Eigen::Quaterniond q(A.rotation());
         std::cout << "pair " << k << " (" << files[k].first << " -> " << files[k].second << "), " << iterations[k]
                   << " iterations: T: " << A.translation().x() << ", " << A.translation().y() << ", " << A.translation().z()

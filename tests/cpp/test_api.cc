@@ -17,6 +17,14 @@
 
 using namespace prob_point_cloud_registration;
 
+// rho(1) of a term's loss = its weight (ScaledLoss(NULL, w): rho(s) = w s) — through ceres::LossFunction::Evaluate only
+static double lossScale(const ceres::LossFunction *loss)
+{
+    double rho[3];
+    loss->Evaluate(1.0, rho);
+    return rho[0];
+}
+
 static int g_failed = 0, g_checks = 0;
 #define EXPECT_NEAR(a, b, tol)                                                                            \
     do {                                                                                                  \
@@ -84,10 +92,10 @@ static pcl::PointCloud<pcl::PointXYZ> generateCloud()
 static Eigen::Affine3d testTransform()
 {
     // translation (2.5, 0, 0) then prerotate Rz(0.34): y = Rz (p + (2.5,0,0))
-    Eigen::Affine3d T;
+    Eigen::Affine3d T = Eigen::Affine3d::Identity();
     const double a = 0.34;
-    T.R.m[0][0] = std::cos(a), T.R.m[0][1] = -std::sin(a), T.R.m[1][0] = std::sin(a), T.R.m[1][1] = std::cos(a);
-    T.t = Eigen::Vector3d(2.5 * std::cos(a), 2.5 * std::sin(a), 0);
+    T.linear()(0, 0) = std::cos(a), T.linear()(0, 1) = -std::sin(a), T.linear()(1, 0) = std::sin(a), T.linear()(1, 1) = std::cos(a);
+    T.translation() = Eigen::Vector3d(2.5 * std::cos(a), 2.5 * std::sin(a), 0);
     return T;
 }
 
@@ -130,16 +138,16 @@ static void alignTest()
 {
     // a jittered copy of the test surface, moved by a small known motion; full align() with kd-tree-free NN
     auto target = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>(generateCloud());
-    Eigen::Affine3d T;
+    Eigen::Affine3d T = Eigen::Affine3d::Identity();
     const double a = 0.02;
-    T.R.m[0][0] = std::cos(a), T.R.m[0][1] = -std::sin(a), T.R.m[1][0] = std::sin(a), T.R.m[1][1] = std::cos(a);
-    T.t = Eigen::Vector3d(0.05, -0.03, 0.02);
+    T.linear()(0, 0) = std::cos(a), T.linear()(0, 1) = -std::sin(a), T.linear()(1, 0) = std::sin(a), T.linear()(1, 1) = std::cos(a);
+    T.translation() = Eigen::Vector3d(0.05, -0.03, 0.02);
     auto source = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
     // source = T^-1 target
-    Eigen::Affine3d Ti;
+    Eigen::Affine3d Ti = Eigen::Affine3d::Identity();
     for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) Ti.R.m[r][c] = T.R.m[c][r];
-    for (int r = 0; r < 3; r++) Ti.t.v[r] = -(Ti.R.m[r][0] * T.t.v[0] + Ti.R.m[r][1] * T.t.v[1] + Ti.R.m[r][2] * T.t.v[2]);
+        for (int c = 0; c < 3; c++) Ti.linear()(r, c) = T.linear()(c, r);
+    for (int r = 0; r < 3; r++) Ti.translation()(r) = -(Ti.linear()(r, 0) * T.translation()(0) + Ti.linear()(r, 1) * T.translation()(1) + Ti.linear()(r, 2) * T.translation()(2));
     pcl::transformPointCloud(*target, *source, Ti);
     ProbPointCloudRegistrationParams params;
     params.radius = 0.4;
@@ -193,7 +201,7 @@ static void errorTermTest()
     EXPECT_NEAR(r[1], 0, 1e-12);
     EXPECT_NEAR(r[2], 0, 1e-12);
     e.updateWeight(0.25);
-    EXPECT_NEAR(e.weight()->scale(), 0.25, 0);
+    EXPECT_NEAR(lossScale(e.weight()), 0.25, 0);
 }
 
 // weight_updater_callback.hpp:15-64 driven the way ..._iteration.hpp:37-49 drives it: one ErrorTerm per nonzero of the
@@ -237,7 +245,7 @@ static void weightUpdaterCallbackTest(double dof)
         WeightUpdaterCallback callback(&assoc, &params, &terms, &weight_updater, rotation, translation);
         EXPECT_TRUE(callback(ceres::IterationSummary()) == ceres::SOLVER_CONTINUE);
         EXPECT_TRUE(callback.onDevice());  // rows share their source point: K2 on the device
-        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(terms[k]->weight()->scale(), expected.valuePtr()[k], 1e-12);
+        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(lossScale(terms[k]->weight()), expected.valuePtr()[k], 1e-12);
         // the pose is read through the pointers at every call (the reference's callback sees Ceres' live state)
         translation[0] += 0.25;
         callback(ceres::IterationSummary());
@@ -248,7 +256,7 @@ static void weightUpdaterCallbackTest(double dof)
             sq.push_back(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
         }
         const auto moved = weight_updater.updateWeights(assoc, sq);
-        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(terms[k]->weight()->scale(), moved.valuePtr()[k], 1e-12);
+        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(lossScale(terms[k]->weight()), moved.valuePtr()[k], 1e-12);
     }
     {
         // a row whose terms hold different source points cannot be one row of a device association: host residuals
@@ -265,7 +273,7 @@ static void weightUpdaterCallbackTest(double dof)
             sq.push_back(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
         }
         const auto mixed = weight_updater.updateWeights(assoc, sq);
-        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(terms[k]->weight()->scale(), mixed.valuePtr()[k], 1e-15);
+        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(lossScale(terms[k]->weight()), mixed.valuePtr()[k], 1e-15);
         terms[1] = keep;
     }
     {
@@ -299,7 +307,7 @@ static void weightUpdaterCallbackTest(double dof)
             sq.push_back(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
         }
         const auto rebuilt = weight_updater.updateWeights(assoc, sq);
-        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(terms[k]->weight()->scale(), rebuilt.valuePtr()[k], 1e-12);
+        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(lossScale(terms[k]->weight()), rebuilt.valuePtr()[k], 1e-12);
     }
 }
 
@@ -384,10 +392,10 @@ static void alignIsTheDevicePacedLoop()
 {
     auto target = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>(generateCloud());
     auto source = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
-    Eigen::Affine3d Ti;
+    Eigen::Affine3d Ti = Eigen::Affine3d::Identity();
     const double a = -0.015;
-    Ti.R.m[0][0] = std::cos(a), Ti.R.m[0][1] = -std::sin(a), Ti.R.m[1][0] = std::sin(a), Ti.R.m[1][1] = std::cos(a);
-    Ti.t = Eigen::Vector3d(-0.04, 0.02, -0.03);
+    Ti.linear()(0, 0) = std::cos(a), Ti.linear()(0, 1) = -std::sin(a), Ti.linear()(1, 0) = std::sin(a), Ti.linear()(1, 1) = std::cos(a);
+    Ti.translation() = Eigen::Vector3d(-0.04, 0.02, -0.03);
     pcl::transformPointCloud(*target, *source, Ti);
     for (int inner : {1, 100})
         for (int dof : {5, 3, 10})

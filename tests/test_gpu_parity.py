@@ -772,6 +772,68 @@ def test_device_memory_pool_serves_fresh_handles_without_driver_calls(ctx):
         _lib.memory_stats(99)
 
 
+@pytest.mark.timeout(600)
+def test_batch_run_from_two_caller_threads_with_a_failing_pair(ctx):
+    """The host side of ppcr_batch_run — its preparing threads, the hand-over queues, the handle pool, the device memory
+    pool — under two CALLER threads at once (round-4 review, item 9): fifty rounds, lanes 1 / 3 / 6 in turn, every
+    transform bit-identical to the pair's solo registration; in every fifth round one of the two batches carries a pair
+    that cannot be uploaded (null target) in its middle: that call fails naming the pair, the other thread's batch is
+    untouched, and the next round runs as if nothing had happened."""
+    import ctypes as C
+    import threading
+    prm = dict(radius=1.0, max_neighbours=10, dof=5.0)
+    sets = [[synth.make_pair(2200 + 130 * p + 700 * t, cfg=5, pair=p + 20 * t, stride=3)[:2] for p in range(9)] for t in range(2)]
+    solo = []
+    for pairs in sets:
+        ref = []
+        for s, t in pairs:
+            with _lib.Context(0) as c:
+                c.set_params(1.0, 10, 5.0, 3)
+                c.set_target(t)
+                c.set_source(s)
+                ref.append(c.align(4, cost_drop_thresh=0.0, inner_steps=1)["history"][-1])
+        solo.append(np.array(ref))
+
+    def broken_batch(pairs, lanes):
+        """ppcr_batch_run through ctypes with the target pointer of the middle pair nulled"""
+        L = _lib.load()
+        keep = [(np.ascontiguousarray(s, np.float32), np.ascontiguousarray(t, np.float32)) for s, t in pairs]
+        arr = (_lib.Pair * len(keep))()
+        for k, (s, t) in enumerate(keep):
+            arr[k] = _lib.Pair(s.ctypes.data, s.shape[0], 12, t.ctypes.data if k != len(keep) // 2 else None, t.shape[0], 12)
+        opt = _lib.BatchOptions(1.0, 5.0, 0.0, 5.0, 1e-5, (C.c_double * 4)(1, 0, 0, 0), (C.c_double * 3)(0, 0, 0), 10, 3, 4, 1)
+        T = np.zeros((len(keep), 3, 4))
+        err = C.create_string_buffer(512)
+        rc = L.ppcr_batch_run(arr, len(keep), C.byref(opt), (C.c_int * 1)(0), 1, lanes, T.ctypes.data, None, err, 512)
+        return rc, err.value.decode()
+
+    problems = []
+
+    def caller(t, rounds):
+        try:
+            for r in rounds:
+                lanes = (1, 3, 6)[r % 3]
+                if r % 5 == 4 and t == r % 2:
+                    rc, msg = broken_batch(sets[t], lanes)
+                    if rc == 0 or f"pair {len(sets[t]) // 2}" not in msg:
+                        problems.append(f"thread {t} round {r}: the broken batch returned {rc} '{msg}'")
+                    continue
+                T, done = _lib.batch_run(sets[t], n_iter=4, device_ids=(0,), lanes_per_device=lanes, **prm)
+                if list(done) != [4] * len(sets[t]) or not np.array_equal(T, solo[t]):
+                    problems.append(f"thread {t} round {r} lanes {lanes}: result differs from the solo registrations")
+        except Exception as e:   # noqa: BLE001  (reported by the main thread)
+            problems.append(f"thread {t}: {type(e).__name__}: {e}")
+
+    threads = [threading.Thread(target=caller, args=(t, range(50))) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=540)
+    assert not any(th.is_alive() for th in threads), "a caller thread hangs"
+    assert not problems, problems[:5]
+    _lib.batch_release()
+
+
 @pytest.mark.timeout(120)
 def test_batch_run_with_empty_device_shares(ctx):
     """Fewer pairs than devices / a device listed more than once: some shares of ppcr_batch_run are empty.  The two-thread
@@ -1246,8 +1308,9 @@ def test_device_pointer_inputs(ctx):
         hip.hipFree(d_src)
 
 
-@pytest.mark.parametrize("opts", [dict(short_lists=0), dict(mailbox=0), dict(sort_source=0), dict(sort_source=2),
-                                  dict(temporal=0, short_lists=0), dict(run_ahead=0), dict(fuse_k23=0), dict(merge_fold=0)])
+@pytest.mark.parametrize("opts", [dict(short_lists=0), dict(sort_source=0), dict(temporal=0, short_lists=0), dict(run_ahead=0),
+                                  dict(fuse_k23=0), dict(merge_fold=0), dict(verlet=0), dict(verlet=2), dict(verlet_order=0),
+                                  dict(verlet_skin=20), dict(verlet_skin=1500)])
 def test_every_tuning_option_keeps_the_result(ctx, opts):
     """ppcr_set_option knobs never change results: the association of every iteration is identical and the transforms
     agree to rounding with the default configuration."""
