@@ -600,6 +600,7 @@ struct PendingMove {
 struct VerletLists {
     int *vl;              // [kVerletSlots][ns], k-major: base positions (sorted target) of the listed targets
     unsigned char *vn;    // [ns] how many
+    unsigned short *vmask; // [ns] the list slots the row's association was last written from (bit k: slot k; all-ones: unknown)
     float *vg2;           // [ns] the list holds every target whose float d2 at the BUILD position is <= this; 0: no list
     float *vacc;          // [ns] path length the query has travelled since the build (bounds its displacement)
     unsigned *rebuilt;    // diagnostic (nullable): workgroups that failed the test and searched again, cumulative

@@ -223,11 +223,18 @@ struct ppcr_ctx {
     // the radius (default 500: lists reach up to 2 x 0.05 radius beyond the cut-off bound — less where more than sixteen targets lie
     // that close; the grid's cells are that much larger)
     int opt_verlet = 1, opt_verlet_skin = 500;
+    // option "verlet_engage" in 1e-4 of the radius: lists are built once the source moves less than this per iteration;
+    // -1 (default): 500 for grids larger than the chip holds at once (throughput-bound: searching workgroups mix with
+    // answering ones, dispatched first), 40 for smaller ones (latency-bound: ONE searching workgroup is the launch's length,
+    // and the search that builds lists is the longer one)
+    int opt_verlet_engage = -1;
+    double move_estimate = std::numeric_limits<double>::infinity();  // how far the last known rigid move displaced the cloud at most (corners of its box)
     int opt_verlet_order = 1;    // option "verlet_order": workgroups forecast to search again are dispatched first (default 1)
     double grid_skin2 = 0;       // 2 x skin the grid in use was built for (0: its cells do not cover a list's reach)
     bool verlet_ok = false;      // the rows' lists were (re)built or verified by the previous association and nothing moved the source since but K1's own prologue
     DevBuf<int> vl;
     DevBuf<unsigned char> vn;
+    DevBuf<unsigned short> vmask;
     DevBuf<unsigned> vcount;     // [0]: diagnostic rebuild counter; [16 .. 64): three sets of dispatch-order counters
     DevBuf<int> vorder;          // two dispatch orders (this launch's, the next one's), 2 x 8 x ceil(grid / 8) slots each
     unsigned verlet_launches = 0;  // Verlet launches enqueued on this handle (the rotation of the order buffers and counters)

@@ -923,6 +923,9 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
 #ifndef PPCR_VERLET_RETRY
 #define PPCR_VERLET_RETRY 1
 #endif
+#ifndef PPCR_VERLET_MASK
+#define PPCR_VERLET_MASK 1
+#endif
 
 // (the unclamped list stores lean on gfx950 dropping DS stores beyond the workgroup's allocation — probed by
 //  tools/micro/lds_oob.hip and tests/test_gpu_parity.py — so any other device target gets the clamped form; the host
@@ -1013,11 +1016,13 @@ struct UnansweredRows {
 // room and their last move; being wrong costs time, never correctness: what a workgroup does is decided by the test on
 // the spot — and the next launch's g-th workgroup takes the g-th slot of front + back.  Per XCD class (slot % 8 ==
 // workgroup % 8): a slot's block keeps the XCD whose L2 its neighbours' halos are in.
-__device__ __forceinline__ unsigned verlet_slot(const VerletLists &vv)
+__device__ __forceinline__ unsigned verlet_slot(const VerletLists &vv, bool *filed_front)
 {
+    *filed_front = false;
     if (vv.order_now == nullptr) return blockIdx.x;
     const unsigned c = blockIdx.x & 7u, j = blockIdx.x >> 3, per = (gridDim.x + 7u) >> 3;
     const unsigned nf = vv.count_now[2 * c];
+    *filed_front = j < nf;
     return j < nf ? (unsigned)vv.order_now[c * per + j] : (unsigned)vv.order_now[8 * per + c * per + (j - nf)];
 }
 __device__ __forceinline__ void verlet_file_slot(const VerletLists &vv, unsigned wg, bool front)
@@ -1058,15 +1063,20 @@ __device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, c
                                                    const unsigned wg, const float g2, const float acc, const float moved, const float radius)
 {
     constexpr int BLOCK = 256, CV = kVerletSlots;
-    static_assert(M <= CV, "a list holds at least the m winners");
+    static_assert(M <= CV && CV <= 16, "a list holds at least the m winners; the winners' slots fit a 16-bit mask");
     const int nl = valid ? (int)vv.vn[i] : 0;
+    // which list slots the row's association (nbr / cnt) was written from last time (all-ones: somebody else wrote it)
+    const unsigned was = valid ? (unsigned)vv.vmask[i] : 0xFFFFu;
     // ---- re-measure the list: all index loads, then all gathers, in flight together --------------------------------
-    float cx[CV], cy[CV], cz[CV];
-    unsigned d2b[CV];
     // Buffer loads (uniform descriptor + ONE 32-bit offset register per address): the sixteen list slots of a row share
     // the lane's row offset (the slot is the scalar offset), a gather's address is the position * 16 — no 64-bit address
     // pairs, so that all sixteen gathers are in flight together inside the register budget of four workgroups per CU.
     // (host: ns < 2^26 and nt < 2^28 in this mode, so both byte ranges fit 32 bits)
+    // (Issuing these loads earlier — next to the query load, ahead of the completeness test, for the workgroups the
+    //  previous launch did not expect to search — was measured: 1M windows 10.55 k -> 9.71 k it/s, converged 13.35 k ->
+    //  12.74 k: 32 more loads in flight per lane crowd out the ones the test waits for.  Not kept.)
+    float cx[CV], cy[CV], cz[CV];
+    unsigned d2b[CV];
     const unsigned row4 = (unsigned)(valid ? i : 0) * 4u;
     const auto rs_vl = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(vv.vl), 0, (int)((unsigned)ns * (unsigned)(CV * 4)), 0x00020000);
     const auto rs_tgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(tgt), 0, (int)vv.tgt_bytes, 0x00020000);
@@ -1129,14 +1139,19 @@ __device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, c
         for (int k = 0; k < CV; k++) tm = max(tm, ((in >> k) & 1u) ? d2b[k] : 0u);
     }
     if (valid) {
-        int *out = nbr + i;
+        // the association's row only when its members changed: in a registration that has all but converged they do not,
+        // and 44 bytes per row of writes stay away (the m-th distance, which does change, always goes out)
+        if (!PPCR_VERLET_MASK || in != was) {
+            int *out = nbr + i;
 #pragma unroll
-        for (int k = 0; k < CV; k++)
-            if ((in >> k) & 1u) {
-                *out = list_pos(k);
-                out += ns;
-            }
-        cnt[i] = n;
+            for (int k = 0; k < CV; k++)
+                if ((in >> k) & 1u) {
+                    *out = list_pos(k);
+                    out += ns;
+                }
+            cnt[i] = n;
+            vv.vmask[i] = (unsigned short)in;
+        }
         dm2[i] = tm;
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1288,8 +1303,9 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
     // in the dispatch order (verlet_slot).  The slot names the block, the partial sums' column, the hand-over entry.
     unsigned wg = blockIdx.x;
     // (a launch that steps aside does not look at the order: the launch that should have filed it may have stepped aside too)
+    bool filed_front = false;  // (Verlet dispatch order: the previous launch expected this workgroup to search again)
     if constexpr (VERLET)
-        if (!aborted) wg = (unsigned)__builtin_amdgcn_readfirstlane((int)verlet_slot(vv));
+        if (!aborted) wg = (unsigned)__builtin_amdgcn_readfirstlane((int)verlet_slot(vv, &filed_front));
 
     // which block, and which of its waves' queries, this workgroup scans (uniform)
     int bid, half = 0;  // half: 0 whole block, 1 waves 0-1, 2 waves 2-3
@@ -1811,11 +1827,14 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
             if constexpr (VERLET) thr = min(thr, thr_a);  // (the list of such a row ends at its cut-off: no margin, rebuilt next time)
         }
         if constexpr (VERLET) {
-            // The row's Verlet list: the kVerletSlots NEAREST of what the scan accepted (every target whose d2 bits are <= thr;
-            // the scan's lists are half as long again).  A list cut to its nearest sixteen is complete below its farthest
-            // member — for the typical row that is the 16th neighbour's distance against the 10th's: 0.14 radii of room at
-            // the benchmark's density, however little a fixed skin would have allowed.
+            // The row's Verlet list: what the scan accepted (every target whose d2 bits are <= thr; the scan's lists are half
+            // as long again as a Verlet list), cut back to kVerletSlots entries where there are more.
             if (n > kVerletSlots) {
+                // the sixteen NEAREST stay; the list is complete below the farthest of them (for the typical row the 16th
+                // neighbour's distance against the 10th's: 0.14 radii of room at the benchmark's density).  Cutting by reach
+                // instead — the largest of need + skin / 2, / 4, / 8 that holds at most sixteen: a quarter of the selection's
+                // instructions — was measured: the lists' room shrinks, a fifth more workgroups search per iteration and the
+                // timed windows lose 10 % (11.47 k -> 10.32 k it/s at 1M).
                 unsigned t_far = 0;
                 n = select_top_m<kVerletSlots>(L, tgt, q, n, kVerletSlots, t_far);
                 thr = t_far > 0u ? t_far - 1u : 0u;  // (strictly below the farthest kept: equal distances beyond it were dropped)
@@ -1832,6 +1851,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
                 }
                 vv.vn[i] = (unsigned char)n;
                 vv.vacc[i] = 0.f;
+                vv.vmask[i] = (unsigned short)0xFFFFu;  // (the association's row is written from the scan's list below, not from list slots)
             }
             vg_new = n >= 0 ? __uint_as_float(thr) : 0.f;  // (0: no list — also the degenerate row whose sixteen nearest are all at distance 0)
             vv.vg2[i] = vg_new;

@@ -730,9 +730,11 @@ def test_verlet_lists_keep_every_association_exact(m):
         rebuilt = np.diff([s["rebuilt"] for s in seen])
         real = seen[-1]["workgroups"] - 128                     # (the grid carries 128 slots for split blocks)
         # (rebuilt[j]: workgroups that searched again in association j + 1; association 1 built the lists, 2 - 4 follow the
-        #  tiny moves, 8 the jolt, 14 and 15 a source that did not move)
+        #  tiny moves, 8 the jolt — far beyond what a list is worth keeping for: the lists are dropped and built again once
+        #  the source is calm —, 14 and 15 a source that did not move)
         assert rebuilt[1] < real // 2, ("after a tiny move most workgroups must have answered from their lists", rebuilt.tolist())
-        assert rebuilt[7] >= real, ("after the jolt no list can hold: every workgroup searches again", rebuilt.tolist())
+        assert not seen[8]["trusted"], "a move of 0.2 radii: the plain search, no lists"
+        assert seen[10]["trusted"], "calm again: lists again"
         assert rebuilt[-1] == 0 and rebuilt[-2] == 0, ("a source that did not move at all is answered from the lists alone", rebuilt.tolist())
         assert plain.debug_verlet()["rows"] == 0                # (the plain context never built a list)
 
