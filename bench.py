@@ -150,7 +150,7 @@ def k1_instantiation(cfg, inner_steps, two_pass, fused=True, verlet=True):
         # the Verlet variant (csrc/ppcr_device.hip.h: VerletLists): 24-slot scan lists, 1920-candidate halo, four workgroups
         # per CU; rows answered from their lists where the lists still hold
         return f"nn_fast_kernel<{width}, 24, 1920, false, {ftm}, false, true>"
-    return f"nn_fast_kernel<{width}, {c}, {cap}, false, {ftm}, {'true' if multi else 'false'}>"
+    return f"nn_fast_kernel<{width}, {c}, {cap}, false, {ftm}, {'true' if multi else 'false'}, false>"
 
 
 def effective_cores():
