@@ -739,6 +739,80 @@ def test_verlet_lists_keep_every_association_exact(m):
         assert plain.debug_verlet()["rows"] == 0                # (the plain context never built a list)
 
 
+def test_verlet_lists_randomised_soak():
+    """Seeded random sweep aimed at the Verlet lists' completeness test (need + path travelled < the list's reach): lists
+    forced on whatever the moves (verlet_engage = 100000; one-pass, single-level searches throughout), skins from a hundredth
+    to twice the default, both dispatch orders;
+    uniform, clustered and quantised (exact ties) clouds with isolated, far-away and NaN queries; radii 0.5 - 1.5, list widths
+    4 / 5 / 8 / 10; eight associations per trial under rigid moves from nothing to 0.15 radii, rotations about far pivots
+    included (rows of one workgroup travel different distances).  Every association equals the oracle's: neighbour sets and
+    float d2, bit for bit.  PPCR_SOAK_SEED / PPCR_SOAK_TRIALS as in the other soaks."""
+    seed = int(os.environ.get("PPCR_SOAK_SEED", "20251004"))
+    trials = int(os.environ.get("PPCR_SOAK_TRIALS", "10"))
+    rng = np.random.default_rng(seed)
+    trusted_assocs = answered = 0
+    for trial in range(trials):
+        kind = trial % 3
+        nt = int(rng.integers(12000, 30000))
+        side = (nt / 10.0) ** (1 / 3)                          # ~10 points per unit volume, as the benchmark
+        if kind == 0:
+            tgt = rng.uniform(0, side, size=(nt, 3))
+        elif kind == 1:
+            blobs = rng.uniform(0.2 * side, 0.8 * side, size=(6, 3))
+            tgt = np.concatenate([rng.uniform(0, side, size=(nt // 2, 3))] +
+                                 [b + rng.normal(0, 0.6, size=(nt // 12, 3)) for b in blobs])
+        else:
+            tgt = np.round(rng.uniform(0, side, size=(nt, 3)) * 4) / 4      # a quarter-unit lattice: exact ties everywhere
+        tgt = tgt.astype(np.float32)
+        ns = int(rng.integers(8000, 20000))
+        src = (tgt[rng.integers(0, len(tgt), ns)] + rng.normal(0, 0.03 if kind != 2 else 0.0, size=(ns, 3))).astype(np.float32)
+        src[:5] = [[side * 3, 0, 0], [-50, -50, -50], [np.nan, 0, 0], [side / 2, side / 2, side + 0.9], [0, np.inf, 0]]
+        radius = float(rng.choice([0.5, 0.8, 1.0, 1.0, 1.5]))
+        m = int(rng.choice([4, 5, 8, 10]))
+        skin = int(rng.choice([5, 50, 500, 1000]))
+        with _lib.Context(0) as c:
+            c.set_option("defer_moves", 1)
+            c.set_option("two_pass", 0)          # lists belong to the one-pass, single-level search: keep every trial there
+            c.set_option("levels", 0)            # (radius 1.5 then scans ~140 candidates per row: lists with hardly any room)
+            c.set_option("verlet_engage", 100000)
+            c.set_option("verlet_skin", skin)
+            c.set_option("verlet_order", int(rng.integers(0, 2)))
+            c.set_params(radius, m, 5.0, 3)
+            c.set_target(tgt)
+            c.set_source(src)
+            cur = src.copy()
+            prev_rebuilt = 0
+            for k in range(8):
+                c.associate()
+                rp, col, d2 = c.get_association()
+                orp, ocol, od2 = po.radius_search(cur, tgt, radius, m, method=1)
+                tag = f"seed {seed} trial {trial} kind {kind} r {radius} m {m} skin {skin} association {k}"
+                np.testing.assert_array_equal(rp, orp, err_msg=tag)
+                np.testing.assert_array_equal(col, ocol, err_msg=tag)
+                np.testing.assert_array_equal(d2, od2, err_msg=tag)
+                v = c.debug_verlet()
+                if v["trusted"]:
+                    trusted_assocs += 1
+                    if k >= 2 and v["rebuilt"] - prev_rebuilt < v["workgroups"] - 128:
+                        answered += 1                      # at least one workgroup answered from its lists
+                prev_rebuilt = v["rebuilt"]
+                mag = float(rng.choice([0.0, 1e-3, 1e-2, 0.05, 0.15])) * radius
+                T = np.eye(4)
+                if rng.integers(0, 2):
+                    # a rotation about a pivot far outside the cloud: the displacement varies across the cloud, `mag` at its centre
+                    pivot = np.full(3, side / 2) + rng.normal(size=3) * side * 3
+                    arm = np.linalg.norm(np.full(3, side / 2) - pivot)
+                    R = synth.rodrigues(rng.normal(size=3), mag / arm)
+                    T[:3, :3] = R
+                    T[:3, 3] = pivot - R @ pivot
+                else:
+                    d = rng.normal(size=3)
+                    T[:3, 3] = d / np.linalg.norm(d) * mag
+                c.apply_transform(T)
+                po.transform_cloud(cur, T)
+    assert trusted_assocs >= 4 * trials and answered >= trials, (trusted_assocs, answered)
+
+
 def test_device_memory_pool_serves_fresh_handles_without_driver_calls(ctx):
     """The handles' buffers are blocks of a per-device pool (csrc/ppcr_pool.hpp, ppcr_memory_stats / ppcr_memory_trim): a
     second fresh handle registering a pair of the same size makes NO hipMalloc call, recycled memory changes no result,
