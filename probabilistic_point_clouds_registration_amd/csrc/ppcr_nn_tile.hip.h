@@ -1401,7 +1401,10 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
                 acc = vv.vacc[i] + moved;
             }
             const float reach = (need + acc) * 1.0001f;
-            const bool ok = !valid || reach * reach < g2;  // (no list: g2 = 0; a NaN anywhere fails)
+            // (no list: g2 = 0; a NaN anywhere fails — except in the query itself: a row that is not a point has no neighbours
+            //  whatever its list says, and must not send its workgroup through the search in every iteration)
+            const bool is_point = (q.x - q.x) == 0.f && (q.y - q.y) == 0.f && (q.z - q.z) == 0.f;
+            const bool ok = !valid || reach * reach < g2 || !is_point;
             // the workgroup's verdict through four words of s_gbo (idle until the row table is built, two barriers from here)
             const bool wave_ok = __ballot(!ok) == 0ull;  // (every lane votes: NOT inside the one-lane store below)
             if (lane == 0) s_gbo[wave] = wave_ok ? 1 : 0;
