@@ -744,6 +744,48 @@ def run_rank(a):
         if not a.no_cpp_api and not batch_cfg:
             out["cpp_api"] = cpp_api_block(src, tgt, cfg, a)
 
+    if world == 1 and a.config == 3 and not a.no_extras and not a.fake_register and a.n is None:
+        # The reference's OWN defaults (prob_point_cloud_registration_ex.cc:43-56: radius 3, 20 neighbours, inner loop to
+        # function_tolerance) beside the headline, so that every default run times them: bench.py --config 8 / 9 / 10 in
+        # short — a uniform 200k cloud (two-pass search) and the two pinned non-uniform scenes (multi-level search); three
+        # windows of `steps` iterations each after a settle phase, median, same timing rules as `value`.
+        shapes = {}
+        for cid in (8, 9, 10):
+            try:
+                ccfg = synth.CONFIGS[cid]
+                s_c, t_c, _, _ = synth.make_config(cid, pair=0)
+                with _lib.Context(local_rank) as cc:
+                    for kv in a.opt:
+                        k, v = kv.split("=")
+                        cc.set_option(k, int(v))
+                    cc.set_params(ccfg["radius"], ccfg["max_neighbours"], ccfg["dof"], 3)
+                    cc.set_target(t_c)
+                    cc.set_source(s_c)
+                    inner = int(ccfg.get("inner_steps", 1))
+                    ts = time.perf_counter()
+                    while (time.perf_counter() - ts) * 1e3 < 120.0:     # settle
+                        cc.align(50, cost_drop_thresh=-1.0, inner_steps=inner, want_history=False)
+                    rates = []
+                    for _ in range(3):
+                        cc.set_source(s_c)
+                        if a.warmup > 0:
+                            cc.align(a.warmup, cost_drop_thresh=-1.0, inner_steps=inner, want_history=False)
+                        cc.synchronize()
+                        tw = time.perf_counter()
+                        r_c = cc.align(a.steps, cost_drop_thresh=-1.0, inner_steps=inner, want_history=False)
+                        cc.synchronize()
+                        rates.append(a.steps / (time.perf_counter() - tw))
+                        assert int(r_c["n_iter"]) == a.steps, f"early stop: {r_c['n_iter']}"
+                    shapes[f"config_{cid}"] = {"it_per_s": float(np.median(rates)), "min_it_per_s": min(rates), "max_it_per_s": max(rates),
+                                              "points": [int(s_c.shape[0]), int(t_c.shape[0])],
+                                              "cloud": ccfg.get("scene", "uniform"), "radius": ccfg["radius"],
+                                              "max_neighbours": ccfg["max_neighbours"], "inner_steps_max": inner}
+            except Exception as e:   # (a side block must not cost the line)
+                shapes[f"config_{cid}"] = {"error": str(e)}
+        shapes["note"] = ("the command line's default parameters (radius 3, max_neighbours 20, inner IRLS loop to function_tolerance) "
+                          "on 200k-point clouds: uniform / LiDAR-like scene / slab with dense blobs; median of 3 windows; never part of value")
+        out["cli_default_shapes"] = shapes
+
     if batch_cfg or world > 1 or dist_was:
         ok = np.isfinite(gathered).all(axis=(1, 2))
         out["gathered_transforms"] = int(ok.sum())
