@@ -234,7 +234,10 @@ void launch_tile(TileLaunch &t)
         // place of the cleanup launch (nothing is folded in this mode).  A fixed grid of waves strides over the list: its
         // length is only known on the device.
         t.merged = false;
-        constexpr int kWideGrid = 256 * 6;  // six workgroups per CU are resident (74 VGPRs, 22 KB of LDS): 6144 waves, a row each
+#ifndef PPCR_WIDE_PER_CU
+#define PPCR_WIDE_PER_CU 6
+#endif
+        constexpr int kWideGrid = 256 * PPCR_WIDE_PER_CU;  // six workgroups per CU are resident (74 VGPRs, 22 KB of LDS): 6144 waves, a row each
         nn_wide_kernel<M><<<kWideGrid, 256, 0, t.stream>>>(t.src, t.ns, t.tgt, t.cell_start, t.grid, t.reach, t.r2, t.r2_full, t.m, t.nbr,
                                                             t.cnt, t.dm2, t.short_list, t.short_count, t.short_seen, t.loop_st);
         return;

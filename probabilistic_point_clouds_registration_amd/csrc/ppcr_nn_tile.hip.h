@@ -645,6 +645,13 @@ __global__ __launch_bounds__(BLOCK, (C >= 64 ? 2 : 3)) void nn_tile_cleanup_kern
 // The m-th smallest d2 is found bit by bit from the top: "how many entries agree with the prefix so far and have a 0
 // here" is a ballot count per 64 entries, nothing else; ties at the m-th distance that do not all fit are settled by the
 // same descent on their original indices (the oracle's order).
+// (experiment knobs, tools/build_variant.py: loads in flight per lane and list entries per wave of nn_wide_kernel)
+#ifndef PPCR_WIDE_U
+#define PPCR_WIDE_U 4
+#endif
+#ifndef PPCR_WIDE_CAPW
+#define PPCR_WIDE_CAPW 512
+#endif
 template <int PER>
 __device__ __forceinline__ int wave_select_top_m(int *s_pos, unsigned *s_d2, int n, int m, const float4 *__restrict__ tgt, int lane,
                                                  unsigned &thr)
@@ -730,8 +737,8 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
                                                       const int *__restrict__ short_list, const unsigned *__restrict__ short_count,
                                                       unsigned *__restrict__ short_seen, const LoopState *loop_st)
 {
-    constexpr int U = 4;             // chunks of 64 candidates (loads per lane) in flight
-    constexpr int CAPW = 512;        // list entries per wave; compacted to m whenever a round of U * 64 might not fit
+    constexpr int U = PPCR_WIDE_U;        // chunks of 64 candidates (loads per lane) in flight
+    constexpr int CAPW = PPCR_WIDE_CAPW;  // list entries per wave; compacted to m whenever a round of U * 64 might not fit
     constexpr int PER = CAPW / 64;
     constexpr int CAPT = 1024;       // candidates of one batch of 64 runs that are walked as ONE flat sequence
     static_assert(CAPW >= 2 * U * 64 && CAPW - U * 64 >= M, "a compaction leaves room for a round");
