@@ -539,6 +539,38 @@ __device__ __forceinline__ void finish_ell_rows(RowAcc &acc, const EllRowsHead<W
     }
 }
 
+// ONE-PASS rows wider than 10 slots, in two helpings: the first half of the row's neighbours is gathered and added, then
+// the second — pair by pair in slot order, as finish_ell_rows adds them: the same sums.  All 20 slots of the command
+// line's default width at once are 60 coordinate registers on top of the 20 slots: 110 VGPRs for accumulate_ell_kernel
+// (four workgroups per CU), 92 SPILLED registers in inner_steps_kernel's 96-register budget.
+template <int W>
+constexpr bool kEllHelpings = W > 10;
+template <int W, int TM>
+__device__ __forceinline__ void finish_ell_row_helpings(RowAcc &acc, const EllRowsHead<W, 1> &h, const float4 *__restrict__ tgt,
+                                                        const Pose &P, const Model &md)
+{
+    constexpr int CH = (W + 1) / 2;
+    const int n = h.n[0];
+    double xr[3];
+    rotated_point(P, h.xf[0], xr);
+    RowMoments<TM> row;
+    row.begin(md);
+#pragma unroll
+    for (int c0 = 0; c0 < W; c0 += CH) {
+        float yx[CH], yy[CH], yz[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const float4 y = tgt[(c0 + j < W && c0 + j < n) ? h.idx[0][(c0 + j < W) ? c0 + j : 0] : 0];  // slot 0 of the target for unused slots: masked below
+            yx[j] = y.x, yy[j] = y.y, yz[j] = y.z;
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            if (c0 + j < W) row.add(md, xr, yx[j], yy[j], yz[j], c0 + j < n);
+        if (c0 + CH < W) __builtin_amdgcn_sched_barrier(0);  // (the second helping's gathers stay behind the first's arithmetic)
+    }
+    if (n != 0) row.finish(acc, P, h.xf[0], xr);
+}
+
 // the rows [base + r * BLOCK | r < ROWS] of one lane, added to acc
 template <int W, int ROWS, int BLOCK, int TM, bool ONEPASS>
 __device__ __forceinline__ void accumulate_ell_rows(RowAcc &acc, int base, const int *__restrict__ nbr,
@@ -548,9 +580,13 @@ __device__ __forceinline__ void accumulate_ell_rows(RowAcc &acc, int base, const
 {
     EllRowsHead<W, ROWS> h;
     load_ell_rows_head<W, ROWS, BLOCK>(h, base, nbr, cnt, src, ns, width);
-    EllRowsPoints<W, ROWS> pts;
-    gather_ell_rows<W, ROWS>(pts, h, tgt);
-    finish_ell_rows<W, ROWS, BLOCK, TM, ONEPASS>(acc, h, pts, P, md);
+    if constexpr (ONEPASS && ROWS == 1 && kEllHelpings<W>) {
+        finish_ell_row_helpings<W, TM>(acc, h, tgt, P, md);
+    } else {
+        EllRowsPoints<W, ROWS> pts;
+        gather_ell_rows<W, ROWS>(pts, h, tgt);
+        finish_ell_rows<W, ROWS, BLOCK, TM, ONEPASS>(acc, h, pts, P, md);
+    }
 }
 
 template <int W, int ROWS, int BLOCK, int TM = -1, bool ONEPASS = false>
@@ -698,17 +734,26 @@ __global__ __launch_bounds__(kBlock, ONEPASS ? 5 : 3) void inner_steps_kernel(In
     //  form of the solve at that budget: 70 spills.)
     // XCD-aware tile map (xcd_block): workgroup r runs on XCD r % 8 (a step is a multiple of eight workgroups, G is one
     // too whenever a workgroup walks several tiles), and tile g = r + j G goes to the (g % 8)-th eighth of the rows
+    // (wide one-pass rows — the command line's 20 neighbours — go in two helpings and without the next tile's header in
+    //  flight: 92 spilled registers otherwise; a 200k-point cloud is one tile per workgroup anyway)
+    constexpr bool kHelpings = ONEPASS && kEllHelpings<W>;
     EllRowsHead<W, 1> head;
-    load_ell_rows_head<W, 1, kBlock>(head, xcd_block(r, ntiles) * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.ns, a.width);
+    if constexpr (!kHelpings)
+        load_ell_rows_head<W, 1, kBlock>(head, xcd_block(r, ntiles) * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.ns, a.width);
     for (int tile = r; tile < ntiles; tile += G) {
-        const EllRowsHead<W, 1> cur = head;
-        if (tile + G < ntiles) load_ell_rows_head<W, 1, kBlock>(head, xcd_block(tile + G, ntiles) * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.ns, a.width);
-        EllRowsPoints<W, 1> pts;
-        gather_ell_rows<W, 1>(pts, cur, a.tgt);
         RowAcc acc;
 #pragma unroll
         for (int j = 0; j < kNSums; j++) acc.a[j] = 0.0;
-        finish_ell_rows<W, 1, kBlock, TM, ONEPASS>(acc, cur, pts, P, a.md);
+        if constexpr (kHelpings) {
+            load_ell_rows_head<W, 1, kBlock>(head, xcd_block(tile, ntiles) * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.ns, a.width);
+            finish_ell_row_helpings<W, TM>(acc, head, a.tgt, P, a.md);
+        } else {
+            const EllRowsHead<W, 1> cur = head;
+            if (tile + G < ntiles) load_ell_rows_head<W, 1, kBlock>(head, xcd_block(tile + G, ntiles) * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.ns, a.width);
+            EllRowsPoints<W, 1> pts;
+            gather_ell_rows<W, 1>(pts, cur, a.tgt);
+            finish_ell_rows<W, 1, kBlock, TM, ONEPASS>(acc, cur, pts, P, a.md);
+        }
         block_reduce_store<kBlock, true>(acc, nullptr, 0, 0, s_acc);  // (its own thread adds to s_acc[tid]: no barrier needed)
     }
     if (threadIdx.x < kNSums)
