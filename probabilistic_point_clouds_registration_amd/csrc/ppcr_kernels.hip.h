@@ -737,6 +737,9 @@ __global__ __launch_bounds__(kBlock, ONEPASS ? 5 : 3) void inner_steps_kernel(In
     // (wide one-pass rows — the command line's 20 neighbours — go in two helpings and without the next tile's header in
     //  flight: 92 spilled registers otherwise; a 200k-point cloud is one tile per workgroup anyway)
     constexpr bool kHelpings = ONEPASS && kEllHelpings<W>;
+    // (narrow one-pass rows in two helpings as well, the next tile's header still in flight: 8 spilled registers -> 2 at
+    //  this kernel's 96-register budget, the device-paced inner loop at 1M 7.72 k -> 7.89 k it/s)
+    constexpr bool kNarrowHelpings = ONEPASS && !kEllHelpings<W>;
     EllRowsHead<W, 1> head;
     if constexpr (!kHelpings)
         load_ell_rows_head<W, 1, kBlock>(head, xcd_block(r, ntiles) * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.ns, a.width);
@@ -750,9 +753,13 @@ __global__ __launch_bounds__(kBlock, ONEPASS ? 5 : 3) void inner_steps_kernel(In
         } else {
             const EllRowsHead<W, 1> cur = head;
             if (tile + G < ntiles) load_ell_rows_head<W, 1, kBlock>(head, xcd_block(tile + G, ntiles) * kBlock + (int)threadIdx.x, a.nbr, a.cnt, a.src, a.ns, a.width);
-            EllRowsPoints<W, 1> pts;
-            gather_ell_rows<W, 1>(pts, cur, a.tgt);
-            finish_ell_rows<W, 1, kBlock, TM, ONEPASS>(acc, cur, pts, P, a.md);
+            if constexpr (kNarrowHelpings) {
+                finish_ell_row_helpings<W, TM>(acc, cur, a.tgt, P, a.md);
+            } else {
+                EllRowsPoints<W, 1> pts;
+                gather_ell_rows<W, 1>(pts, cur, a.tgt);
+                finish_ell_rows<W, 1, kBlock, TM, ONEPASS>(acc, cur, pts, P, a.md);
+            }
         }
         block_reduce_store<kBlock, true>(acc, nullptr, 0, 0, s_acc);  // (its own thread adds to s_acc[tid]: no barrier needed)
     }
