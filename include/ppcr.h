@@ -313,7 +313,7 @@ int ppcr_profile_enable(ppcr_ctx *ctx, int enable); /* also clears accumulated s
 int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_out);
 
 /* Tuning / debugging knobs (never change results): key is one of
- *   "sort_source"  0 keep caller order, 1 brick order, boustrophedon (default; see "brick_x"), 2 x-fastest cell order;
+ *   "sort_source"  0 keep caller order, 1 brick order, boustrophedon (default; see "brick_x");
  *   "temporal"     1 start each query's cut-off from its previous m-th distance (default), 0 off;
  *   "run_ahead"    1 ppcr_align keeps the device one iteration ahead of the host when the stopping rule allows
  *                  (default), 0 one iteration at a time;
@@ -323,7 +323,6 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *                  to itself (default), 0 always its own launch;
  *   "defer_moves"  1 ppcr_apply_transform leaves the move to the prologue of the next association (what ppcr_iterate
  *                  and ppcr_align always do; the temporal cut-off then survives the move), 0 moves at once (default);
- *   "mailbox"      1 deliver the moments through pinned host memory and spin (default), 0 copy + synchronise;
  *   "inner_dev_steps"  IRLS steps beyond the first that ppcr_align enqueues for the device per outer iteration
  *                  (default 3, 0..8); an inner loop that needs more is finished by the host, one step at a time;
  *   "grid_xf"      x slices per grid cell, 1/2/4/8 (default 4; set before the target): every stencil row is clipped
@@ -335,9 +334,16 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *                  more than max_neighbours points, and every block of queries searches the finest level that covers its
  *                  cut-off radii (default; uniform clouds searched with a radius of a few spacings keep one level),
  *                  0 always one level (set before the first association);
- *   "k1_halves"    the steady-state K1 scans every block of 256 queries as two half-blocks on two workgroups: 0 never
- *                  (default: measured neutral at 100k points and slower from 160k on), 1 always, -1 clouds of up to 640
- *                  blocks;
+ *   "verlet"       1 the steady-state K1 of a one-pass, single-level search with max_neighbours <= 10 keeps per-row Verlet
+ *                  lists and answers a workgroup's rows from them for as long as every list provably holds every target the
+ *                  exact search could return (default), 0 always search, 2 build the lists in every launch and never trust
+ *                  them (testing);
+ *   "verlet_skin"  how far a list reaches beyond what the row needs, in 2e-4 of the radius (default 500: 0.1 radius; 1..2000;
+ *                  set before the first association: the grid's cells grow by twice the skin);
+ *   "verlet_engage"  lists are built once the last known rigid move displaces no corner of the target's box by more than
+ *                  this many 1e-4 radii (and dropped above four times that); -1 (default) 500 for grids larger than the chip
+ *                  holds at once, 40 for smaller ones; 0 never .. 100000 always;
+ *   "verlet_order" 1 workgroups that will probably search are dispatched first (default), 0 launch order;
  *   "two_pass"     1 a bounded search whose radius holds far more than max_neighbours target points runs in two passes
  *                  (default): the grid and the tiled kernel work with radius / k, chosen from the target's density, and
  *                  only the rows that find fewer than max_neighbours there are searched again with the full radius;
@@ -351,7 +357,8 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *   "first_pass_fill"  tenths: the first-pass sphere of a two-pass search should hold this many times max_neighbours points
  *                  where the density allows (default 22: ~2.2 m candidates answer nearly every row in the first pass);
  *   "eager_grid"   1 ppcr_set_target starts the grid build (default, see there), 0 the first association builds it;
- *   "stamps"       1 collect per-phase cycle counts and per-lane run lengths of K1 (diagnostic build of the kernel). */
+ *   "stamps", "fold_stamps", "level_stats", "debug_mbox_seq"  diagnostics (per-phase cycle counts of K1, wall-clock stamps
+ *                  of the fold-and-solve lane, per-level counters of a multi-level search, the sequence counter for tests). */
 int ppcr_set_option(ppcr_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus
