@@ -32,6 +32,24 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.ppcr_abi_version() == 1
 
 
+def test_documented_options_are_the_implemented_ones():
+    """The keys ppcr_set_option accepts (csrc/ppcr_hip_api.inc) and the keys include/ppcr.h documents are the same set: a
+    knob that leaves the implementation leaves the header, a new one is described there."""
+    header = open(os.path.join(ROOT, "include", "ppcr.h")).read()
+    block = header[header.index("Tuning / debugging knobs"):header.index("int ppcr_set_option(")]
+    documented = set()
+    for line in block.splitlines():
+        m = re.match(r'\s*\*\s+((?:"[a-z_0-9]+"(?:,\s*)?)+)\s', line)      # the key(s) a description starts with
+        if m:
+            documented.update(re.findall(r'"([a-z_0-9]+)"', m.group(1)))
+    api = open(os.path.join(ROOT, "probabilistic_point_clouds_registration_amd", "csrc", "ppcr_hip_api.inc")).read()
+    body = api[api.index("int ppcr_set_option("):]
+    body = body[:body.index("\n}\n")]
+    implemented = set(re.findall(r'std::strcmp\(key, "([a-z_0-9]+)"\)', body))
+    assert len(implemented) >= 15
+    assert documented == implemented, (sorted(documented - implemented), sorted(implemented - documented))
+
+
 def test_no_silent_cpu_fallback(lib):
     if _lib.device_count() > 0:
         pytest.skip("a GPU is visible here")
