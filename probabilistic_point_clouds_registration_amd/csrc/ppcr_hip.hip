@@ -185,7 +185,7 @@ struct ppcr_ctx {
     DevBuf<int> level_inv;
     DevBuf<unsigned> level_dbg;        // diagnostic counters of the multi-level search (option "level_stats")
     int opt_level_stats = 0;
-    DevBuf<unsigned short> level_cap;  // per 256-query block of the (sorted) source: cap | floor << 4 | split << 8 (UnansweredRows::level_cap)
+    DevBuf<unsigned short> level_cap;  // two buffers x two words per 256-query block of the (sorted) source: cap | floor << 4 | split << 8 (UnansweredRows::level_in / level_out)
     bool level_cap_clean = false;      // ... all 0xFF for the current source order
     int n_levels = 1, base_level = 0, finest_extra = -1;  // finest_extra: index into extra_levels of the finest level (-1: the base is)
     float level_r2_cap[kMaxLevels] = {};

@@ -1011,7 +1011,13 @@ struct UnansweredRows {
     int n_levels, base_level;
     float r2_full;
     float r2_cap[kMaxLevels];  // the levels' r2_cap, by value (the level choice then needs no memory round trip of its own)
-    unsigned short *level_cap;  // per 256-query block: coarsest level it may pick | finest << 4 | split << 8 (feedback of halos that did not fit)
+    // feedback of halos that did not fit, per 256-query block and HALF of it (two words per block: [2 * block + half]):
+    // coarsest level it may pick | finest << 4 | split << 8.  Read from level_in (what the PREVIOUS launch left), written to
+    // level_out by every workgroup that runs (a block that is scanned whole writes both words) — two buffers that swap per
+    // launch, so that what a workgroup reads never depends on what its sibling or anybody else does in the same launch:
+    // which level a block searches, and with it who answers which row, is the same in every run.
+    const unsigned short *level_in;
+    unsigned short *level_out;
     unsigned *level_dbg;       // diagnostic (nullable): per level {blocks, handed over for the halo's shape, ... for its size,
                                //   short rows listed, staged candidates, rows}, cumulative (ppcr_debug_get_levels)
 };
@@ -1316,7 +1322,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
 
     // which block, and which of its waves' queries, this workgroup scans (uniform)
     int bid, half = 0;  // half: 0 whole block, 1 waves 0-1, 2 waves 2-3
-    unsigned level_fb = 0x0Fu;  // MULTI: the block's feedback byte (UnansweredRows::level_cap)
+    unsigned level_fb = 0x0Fu;  // MULTI: the block's feedback word (UnansweredRows::level_in)
     float4 q_early = make_float4(0.f, 0.f, 0.f, 0.f);
     if (split.all_halves) {
         const int slot = halves_slot((int)wg), nb = (ns + BLOCK - 1) / BLOCK;
@@ -1329,9 +1335,13 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
         half = halves_half((int)wg);
         if constexpr (MULTI) {
             // multi-level searches launch the two-workgroups-per-block grid and use the second workgroup only for the
-            // blocks marked split (bit 8 of level_cap: their halo outgrew the tile at the level their cut-offs ask for;
+            // blocks marked split (bit 8 of the feedback word: their halo outgrew the tile at the level their cut-offs ask for;
             // half a block's halo is ~60 % of the block's): everybody else's second workgroup leaves at once
-            level_fb = un.level_cap != nullptr ? (unsigned)un.level_cap[bid] : 0x0Fu;
+            if (un.level_in != nullptr) {
+                // the two halves' words as one: the finer cap, the coarser floor, split if either asked for it
+                const unsigned fa = un.level_in[2 * bid], fb = un.level_in[2 * bid + 1];
+                level_fb = min(fa & 15u, fb & 15u) | (max((fa >> 4) & 15u, (fb >> 4) & 15u) << 4) | ((fa | fb) & 0x100u);
+            }
             // (the query is asked for in the same breath: which lanes are valid depends on the byte, the load need not wait for it)
             q_early = src[min(bid * BLOCK + tid, ns - 1)];
             if (!(level_fb & 0x100u)) {
@@ -1463,7 +1473,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
             level = un.n_levels - 1;
             for (int l = un.n_levels - 2; l >= 0; l--)
                 if (8 * (s_need[l] + s_need[16 + l] + s_need[32 + l] + s_need[48 + l]) >= 7 * n_rows) level = l;
-            // ... but never a level at which this block's halo has outgrown the tile before (level_cap, see below)
+            // ... but never a level at which this block's halo has outgrown the tile before (the feedback word, see below)
             // cap | floor << 4 | split << 8 (a block that met both keeps the floor)
             level = max(min(level, (int)(level_fb & 15u)), (int)((level_fb >> 4) & 15u));
         }
@@ -1600,6 +1610,22 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
         t_acc[7] = (unsigned long long)((ny_h << 8) | nz_h);
     }
     const bool handed_over = !shape_ok || total > CAP;  // uniform: derived from the shared boxes and cell_start only
+    if constexpr (MULTI) {
+        // the block's feedback for the NEXT launch (UnansweredRows::level_out): what it was, or — after a hand-over —
+        // a halo too LARGE for the tile: a finer level next time (more short rows, but a halo that fits), first the same
+        // level on two workgroups; a halo of too many ROWS (a surface seen at too fine a level): a coarser one
+        if (tid == 0 && un.level_out != nullptr) {
+            unsigned cap = level_fb & 15u, floor_ = (level_fb >> 4) & 15u, split_ = level_fb & 0x100u;
+            if (handed_over) {
+                if (!shape_ok) floor_ = (unsigned)min(level + 1, un.n_levels - 1);
+                else if (!split_ && split.all_halves) split_ = 0x100u;
+                else cap = (unsigned)max(level - 1, 0);
+            }
+            const unsigned short word = (unsigned short)(cap | (floor_ << 4) | split_);
+            if (half == 0) un.level_out[2 * bid] = word, un.level_out[2 * bid + 1] = word;
+            else un.level_out[2 * bid + (half == 2 ? 1 : 0)] = word;
+        }
+    }
     if (tid == 0 && half == 0 && split.flag != nullptr && (handed_over || total > split.presplit) && !split.flag[bid]) {
         // once the fold-and-solve step has rebuilt the list from the flags (the kMaxSplit registered blocks with the
         // smallest ids are split, flag 2: which ones does not depend on the order the registrations arrived in) this
@@ -1625,17 +1651,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
             if (valid) vv.vg2[i] = 0.f;  // (whoever redoes these rows builds no lists: they come back here next time)
             if (tid == 0) verlet_file_slot(vv, wg, true);
         }
-        if constexpr (MULTI) {  // from the next launch on this block searches a finer level (more short rows, but a halo that fits)
-            // (level_cap[bid] = cap | floor << 4.  A halo too LARGE for the tile: a finer level next time, i.e. more short
-            //  rows but a halo that fits; a halo of too many ROWS — a surface seen at too fine a level — a coarser one)
-            if (tid == 0 && un.level_cap != nullptr) {
-                const unsigned cf = level_fb;
-                unsigned cap = cf & 15u, floor_ = (cf >> 4) & 15u, split_ = cf & 0x100u;
-                if (!shape_ok) floor_ = (unsigned)min(level + 1, un.n_levels - 1);
-                else if (!split_ && split.all_halves) split_ = 0x100u;  // first: the same level on two workgroups
-                else cap = (unsigned)max(level - 1, 0);                // a half still does not fit: a finer level
-                un.level_cap[bid] = (unsigned short)(cap | (floor_ << 4) | split_);
-            }
+        if constexpr (MULTI) {
             if (tid == 0 && un.level_dbg != nullptr) {
                 atomicAdd(un.level_dbg + level * kLevelDbgWords + 0, 1u);
                 atomicAdd(un.level_dbg + level * kLevelDbgWords + (shape_ok ? 2 : 1), 1u);

@@ -31,7 +31,8 @@ struct TileLaunch {
     const dev::GridLevel *levels; // multi-level search (n_levels > 1; needs short_count): the level table in device memory,
     int n_levels, base_level;     //      ascending r2_cap; tgt / cell_start / grid above are the base level's
     float r2_cap[dev::kMaxLevels]; //     the levels' r2_cap (host copy of the table's column)
-    unsigned short *level_cap;    //      per block: the feedback word (UnansweredRows::level_cap) [blocks of 256 queries]
+    const unsigned short *level_in;   //  per block and half: the feedback words the previous launch left (UnansweredRows::level_in) ...
+    unsigned short *level_out;        //  ... and where this launch leaves its own [2 x blocks of 256 queries each]
     unsigned *level_dbg;          //      diagnostic counters (nullable)
     int m;                        // max_neighbours (<= the M of the variant that is called)
     int *nbr, *cnt;               // the ELL association [m][ns], [ns]
