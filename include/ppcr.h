@@ -344,6 +344,9 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *                  this many 1e-4 radii (and dropped above four times that); -1 (default) 500 for grids larger than the chip
  *                  holds at once, 40 for smaller ones; 0 never .. 100000 always;
  *   "verlet_order" 1 workgroups that will probably search are dispatched first (default), 0 launch order;
+ *   "verlet_dense" 0 no lists (and radius-sized grid cells) where the halo of a 256-query block would outgrow the list
+ *                  variant's LDS tile — a radius that holds ~35 or more target points, a source much sparser than the target —
+ *                  (default), 1 lists regardless (tests; set before the first association);
  *   "two_pass"     1 a bounded search whose radius holds far more than max_neighbours target points runs in two passes
  *                  (default): the grid and the tiled kernel work with radius / k, chosen from the target's density, and
  *                  only the rows that find fewer than max_neighbours there are searched again with the full radius;

@@ -231,6 +231,8 @@ struct ppcr_ctx {
     double move_estimate = std::numeric_limits<double>::infinity();  // how far the last known rigid move displaced the cloud at most (corners of its box)
     int opt_verlet_order = 1;    // option "verlet_order": workgroups forecast to search again are dispatched first (default 1)
     double grid_skin2 = 0;       // 2 x skin the grid in use was built for (0: its cells do not cover a list's reach)
+    int opt_verlet_dense = 0;      // 1: keep the lists' cells whatever the halo estimate says (tests)
+    bool verlet_grid_off = false;  // this grid: no skin — the halo of a block would outgrow the Verlet variant's tile (grid_finish)
     bool verlet_ok = false;      // the rows' lists were (re)built or verified by the previous association and nothing moved the source since but K1's own prologue
     DevBuf<int> vl;
     DevBuf<unsigned char> vn;
