@@ -232,6 +232,7 @@ struct ppcr_ctx {
     int opt_verlet_order = 1;    // option "verlet_order": workgroups forecast to search again are dispatched first (default 1)
     double grid_skin2 = 0;       // 2 x skin the grid in use was built for (0: its cells do not cover a list's reach)
     int opt_verlet_dense = 0;      // 1: keep the lists' cells whatever the halo estimate says (tests)
+    unsigned assoc_counter = 0;    // associations that found (nearly) every block handed over (associate_impl: list_all)
     bool verlet_grid_off = false;  // this grid: no skin — the halo of a block would outgrow the Verlet variant's tile (grid_finish)
     bool verlet_ok = false;      // the rows' lists were (re)built or verified by the previous association and nothing moved the source since but K1's own prologue
     DevBuf<int> vl;

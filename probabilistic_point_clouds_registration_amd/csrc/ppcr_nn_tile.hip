@@ -115,7 +115,8 @@ void launch_tile(TileLaunch &t)
     const bool multi = t.n_levels > 1 && t.levels != nullptr && t.short_count != nullptr;
     UnansweredRows un{(t.short_count ? t.short_list : nullptr), t.short_count, t.short_next, ((t.reach > 1 || multi) ? t.m : 0),
                       (multi ? t.levels : nullptr), (multi ? t.n_levels : 0), t.base_level, t.r2_full, {},
-                      (multi ? t.level_in : nullptr), (multi ? t.level_out : nullptr), (multi ? t.level_dbg : nullptr)};
+                      (multi ? t.level_in : nullptr), (multi ? t.level_out : nullptr), (multi ? t.level_dbg : nullptr),
+                      ((t.list_all && t.short_count != nullptr) ? 1 : 0)};
     for (int l = 0; l < kMaxLevels; l++) un.r2_cap[l] = (multi && l < t.n_levels) ? t.r2_cap[l] : 0.f;
     // the steady-state (16-slot) variant runs with a halo capacity that gives FIVE workgroups per CU (31.3 KB of LDS)
     // and splits the few blocks that outgrow it; the first association (32 slots, three per CU) keeps the large one

@@ -1020,6 +1020,8 @@ struct UnansweredRows {
     unsigned short *level_out;
     unsigned *level_dbg;       // diagnostic (nullable): per level {blocks, handed over for the halo's shape, ... for its size,
                                //   short rows listed, staged candidates, rows}, cumulative (ppcr_debug_get_levels)
+    int list_all;              // the last association handed (nearly) every block over — a source far sparser than the target:
+                               //   256 of its rows span a halo no tile holds —: move the rows, list them all, try no tile
 };
 
 // Dispatch order of the Verlet variant's workgroups (VerletLists::order_*).  A workgroup that has to search again runs
@@ -1386,6 +1388,20 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
         src[i] = q;
         const float ex = q.x - q0.x, ey = q.y - q0.y, ez = q.z - q0.z;
         moved = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez);  // 1 ulp: far inside the 1e-5 inflation below
+    }
+    if constexpr (FTM == -2 && !VERLET) {
+        if (un.list_all && un.list != nullptr) {
+            // (uniform) every row to nn_wide_kernel, marked unsearched, every block counted as handed over.  The list is the
+            // identity and both counters are known: no atomics (4 000 waves drawing list positions from one counter at the
+            // same moment cost this path 20 us)
+            if (valid) cnt[i] = -1, un.list[i] = i;
+            if (tid == 0 && wg == 0) {
+                *un.count = (unsigned)ns;
+                *ovf_count = (unsigned)((ns + BLOCK - 1) / BLOCK);
+            }
+            flush_stamps();
+            return;
+        }
     }
     // Temporal cut-off.  dm2[i] holds the float d2 of this query's m-th neighbour in the previous association
     // (all-ones when it had fewer than m).  Those m targets are now at most dm + |move| away, so the new m-th distance

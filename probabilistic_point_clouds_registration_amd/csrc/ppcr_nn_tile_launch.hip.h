@@ -39,6 +39,7 @@ struct TileLaunch {
     unsigned *dm2;                // per query: float bits of its m-th neighbour's d2 (the temporal cut-off)
     int dm2_in;                   // dm2 of the previous association is usable
     int short_lists;              // option short_lists
+    int list_all;                 // with short_count: try no tile, list every row (UnansweredRows::list_all)
     int all_halves;               // steady-state variant: scan every block as two half-blocks (small clouds; see SplitTable)
     unsigned long long *stamps;   // diagnostic build only (nullptr otherwise)
     int *ovf_list;                // workgroups handed to the cleanup kernel by this launch ...

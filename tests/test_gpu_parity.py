@@ -1664,3 +1664,38 @@ def test_no_lists_where_a_blocks_halo_would_outgrow_the_tile():
         ora = po.align(src, tgt, 1.0, 10, 5.0, 25, cost_drop_thresh=-1.0, inner_max_steps=1)
         assert synth.rotation_angle(hist[-1][:, :3], ora["history"][-1][:, :3]) < 1e-8
         assert np.linalg.norm(hist[-1][:, 3] - ora["history"][-1][:, 3]) < 1e-7
+
+
+def test_sparse_source_against_a_dense_target():
+    """Scan to map: a source ten times sparser than the target.  256 of its rows span a halo no LDS tile holds, so the tiled
+    kernel hands every block over and the row-per-wave kernel answers every row; from the second such association on the
+    tiles are not even tried (UnansweredRows::list_all; every 32nd association tries again).  Forty iterations follow the
+    oracle, the last association equals its search bit for bit, and the hand-over counter says which path ran."""
+    rng = np.random.default_rng(12)
+    nt, ns = 60000, 6000
+    side = (nt / 10.0) ** (1 / 3)
+    tgt = rng.uniform(0, side, size=(nt, 3)).astype(np.float32)
+    src = (tgt[rng.permutation(nt)[:ns]] + rng.normal(0, 0.02, size=(ns, 3)) + [0.06, -0.04, 0.03]).astype(np.float32)
+    n_it = 40
+    with _lib.Context(0) as c:
+        c.set_params(1.0, 10, 5.0, 3)
+        c.set_target(tgt)
+        c.set_source(src)
+        res = c.align(n_it, cost_drop_thresh=-1.0, inner_steps=1)
+        handed = c.debug_host_figures()[7]
+        rp, col, d2 = c.get_association()
+        moved = c.get_source()
+    n_blocks = (ns + 255) // 256
+    assert handed >= 0.9 * n_blocks * (n_it - 4), (handed, n_blocks)        # (every block, nearly every association)
+    ora = po.align(src, tgt, 1.0, 10, 5.0, n_it, cost_drop_thresh=-1.0, inner_max_steps=1, return_source=True)
+    for k in (0, 1, 2, 5, 20, n_it - 1):
+        assert synth.rotation_angle(res["history"][k][:, :3], ora["history"][k][:, :3]) < 1e-8, k
+        assert np.linalg.norm(res["history"][k][:, 3] - ora["history"][k][:, 3]) < 1e-7, k
+    # the association the loop ended on (before its last move) against the oracle's search at the same positions
+    cur = src.copy()
+    T = np.vstack([res["history"][n_it - 2], [0, 0, 0, 1]])
+    po.transform_cloud(cur, T)
+    orp, ocol, _ = po.radius_search(cur, tgt, 1.0, 10, method=1)
+    np.testing.assert_array_equal(rp, orp)
+    np.testing.assert_array_equal(col, ocol)
+    assert moved.shape == src.shape
