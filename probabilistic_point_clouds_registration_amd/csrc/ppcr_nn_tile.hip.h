@@ -1649,15 +1649,23 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
         split.flag[bid] = 1;
         atomicAdd(split.total, 1u);  // (only says that there is something new)
     }
-    // a wave's unanswered rows go to the list in one piece: one atomic per wave that has any
-    auto list_rows = [&](bool mine) {
+    // the workgroup's unanswered rows go to the list in one piece: ONE atomic per workgroup that has any (every thread
+    // calls; two barriers; the counts travel through six LDS words nobody else touches at that moment — `words`: the box
+    // words at the kernel's end, idle since the halo was staged; the row-offset table for a workgroup that hands its block
+    // over before that table is written, while slower waves may still be reading the boxes).  One atomic per WAVE
+    // was 3 000 of them on one counter within a few microseconds at the end of a one-round launch (a 200k-point cloud: every
+    // workgroup reaches its end at about the same time), and same-address atomics are served one by one.
+    auto list_rows = [&](bool mine, int *words) {
         const unsigned long long b = __ballot(mine);
-        if (b != 0ull) {
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(un.count, (unsigned)__popcll(b));
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            if (mine) un.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))] = i;
-        }
+        if (lane == 0) words[wave] = __popcll(b);
+        lds_barrier();
+        const int c0 = words[0], c1 = words[1], c2 = words[2], c3 = words[3];
+        const int total_listed = c0 + c1 + c2 + c3;
+        if (total_listed == 0) return;  // (uniform)
+        if (tid == 0) words[4] = (int)atomicAdd(un.count, (unsigned)total_listed);
+        lds_barrier();
+        const unsigned base = (unsigned)words[4] + (unsigned)(wave > 0 ? c0 : 0) + (unsigned)(wave > 1 ? c1 : 0) + (unsigned)(wave > 2 ? c2 : 0);
+        if (mine) un.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))] = i;
     };
     if (handed_over) {
         // the cleanup kernel redoes this workgroup's queries (this launch): entry = grid index * 4 + half — or, when the
@@ -1675,7 +1683,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
         }
         if (valid) cnt[i] = -1;
         if constexpr (FTM == -2)  // (a launch that folds K23 in never lists: the cleanup role redoes its hand-overs)
-            if (un.list != nullptr) list_rows(valid);
+            if (un.list != nullptr) list_rows(valid, s_gbo);
         flush_stamps();
         return;
     }
@@ -1990,7 +1998,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
         dm2[i] = tm;
     }
     if constexpr (FTM == -2)
-        if (un.list != nullptr) list_rows(valid && (unanswered || (n < un.m_list && (!MULTI || r2 < un.r2_full))));
+        if (un.list != nullptr) list_rows(valid && (unanswered || (n < un.m_list && (!MULTI || r2 < un.r2_full))), &s_box[0][0]);
     if constexpr (MULTI) {
         if (un.level_dbg != nullptr) {
             const int n_short = __popcll(__ballot(valid && (unanswered || (n < un.m_list && r2 < un.r2_full))));
