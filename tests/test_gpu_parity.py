@@ -1657,7 +1657,7 @@ def test_no_lists_where_a_blocks_halo_would_outgrow_the_tile():
                 assert c.debug_verlet()["trusted"] == (want_lists or bool(dense)), (in_radius, dense, c.debug_verlet())
                 handed = c.debug_host_figures()[7]
                 if not dense:
-                    assert handed <= 25 * 8, (in_radius, handed)      # (a handful of blocks per association at most)
+                    assert handed <= 25 * 16, (in_radius, handed)     # (a handful of blocks per association at most)
                     hist = res["history"]
                 else:
                     np.testing.assert_allclose(res["history"], hist, rtol=0, atol=1e-9)
