@@ -341,7 +341,7 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *   "verlet_skin"  how far a list reaches beyond what the row needs, in 2e-4 of the radius (default 500: 0.1 radius; 1..2000;
  *                  set before the first association: the grid's cells grow by twice the skin);
  *   "verlet_engage"  lists are built once the last known rigid move displaces no corner of the target's box by more than
- *                  this many 1e-4 radii (and dropped above four times that); -1 (default) 500 for grids larger than the chip
+ *                  this many 1e-4 radii (and dropped above four times that); -1 (default) 350 for grids larger than the chip
  *                  holds at once, 40 for smaller ones; 0 never .. 100000 always;
  *   "verlet_order" 1 workgroups that will probably search are dispatched first (default), 0 launch order;
  *   "verlet_dense" 0 no lists (and radius-sized grid cells) where the halo of a 256-query block would outgrow the list

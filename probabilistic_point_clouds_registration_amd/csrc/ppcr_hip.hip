@@ -224,7 +224,7 @@ struct ppcr_ctx {
     // that close; the grid's cells are that much larger)
     int opt_verlet = 1, opt_verlet_skin = 500;
     // option "verlet_engage" in 1e-4 of the radius: lists are built once the source moves less than this per iteration;
-    // -1 (default): 500 for grids larger than the chip holds at once (throughput-bound: searching workgroups mix with
+    // -1 (default): 350 for grids larger than the chip holds at once (throughput-bound: searching workgroups mix with
     // answering ones, dispatched first), 40 for smaller ones (latency-bound: ONE searching workgroup is the launch's length,
     // and the search that builds lists is the longer one)
     int opt_verlet_engage = -1;
