@@ -342,7 +342,7 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *                  set before the first association: the grid's cells grow by twice the skin);
  *   "verlet_engage"  lists are built once the last known rigid move displaces no corner of the target's box by more than
  *                  this many 1e-4 radii (and dropped above four times that); -1 (default) 350 for grids larger than the chip
- *                  holds at once, 40 for smaller ones; 0 never .. 100000 always;
+ *                  holds at once, 60 for smaller ones; 0 never .. 100000 always;
  *   "verlet_order" 1 workgroups that will probably search are dispatched first (default), 0 launch order;
  *   "verlet_dense" 0 no lists (and radius-sized grid cells) where the halo of a 256-query block would outgrow the list
  *                  variant's LDS tile — a radius that holds ~35 or more target points, a source much sparser than the target —

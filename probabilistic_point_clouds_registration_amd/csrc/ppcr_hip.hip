@@ -225,7 +225,7 @@ struct ppcr_ctx {
     int opt_verlet = 1, opt_verlet_skin = 500;
     // option "verlet_engage" in 1e-4 of the radius: lists are built once the source moves less than this per iteration;
     // -1 (default): 350 for grids larger than the chip holds at once (throughput-bound: searching workgroups mix with
-    // answering ones, dispatched first), 40 for smaller ones (latency-bound: ONE searching workgroup is the launch's length,
+    // answering ones, dispatched first), 60 for smaller ones (latency-bound: ONE searching workgroup is the launch's length,
     // and the search that builds lists is the longer one)
     int opt_verlet_engage = -1;
     double move_estimate = std::numeric_limits<double>::infinity();  // how far the last known rigid move displaced the cloud at most (corners of its box)
