@@ -404,13 +404,16 @@ class Context:
 
     def debug_verlet(self):
         """ppcr_debug_get_verlet (diagnostic): the steady-state Verlet lists as the last association left them."""
-        buf = (C.c_longlong * 6)()
+        buf = (C.c_longlong * 20)()
         f = self._L.ppcr_debug_get_verlet
         f.argtypes = [C.c_void_p, C.c_void_p]
         f.restype = C.c_int
         self._ck(f(self._h, buf))
         return dict(workgroups=int(buf[0]), rebuilt=int(buf[1]), rows=int(buf[2]), rows_without_list=int(buf[3]),
-                    mean_list=(buf[4] / max(1, buf[2] - buf[3])), trusted=bool(buf[5]))
+                    mean_list=(buf[4] / max(1, buf[2] - buf[3])), trusted=bool(buf[5]),
+                    ordered=bool(buf[6]), launches=int(buf[7]), rows_rebuilt=int(buf[8]), workgroups_rebuilding_rows=int(buf[9]),
+                    searched_last=[int(buf[10 + j]) for j in range(min(6, int(buf[7])))],
+                    failing_rows_hist=[int(buf[16 + j]) for j in range(4)])
 
     def debug_read(self, name, dtype, count):
         """ppcr_debug_read_buffer (diagnostic): a raw copy of a device buffer of the handle."""

@@ -35,8 +35,9 @@ def hipcc():
 
 
 def flags():
+    # (PPCR_EXTRA_FLAGS: experiment builds only, e.g. tools/build_variant.py --all -DPPCR_VERLET_SLOTS=24)
     return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-            "-Wall", "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+            "-Wall", "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-I", CSRC] + os.environ.get("PPCR_EXTRA_FLAGS", "").split()
 
 
 def needs_build():

@@ -17,7 +17,7 @@ public:
     ErrorTerm(const pcl::PointXYZ source_point, const pcl::PointXYZ target_point)
         : source_{source_point.x, source_point.y, source_point.z}, target_{target_point.x, target_point.y, target_point.z},
           // rho(s) = w s with w = 1 to begin with, swappable while a problem holds the wrapper (error_term.hpp:17-19)
-          weight_(std::make_shared<ceres::LossFunctionWrapper>(new ceres::ScaledLoss(NULL, 1.0, ceres::TAKE_OWNERSHIP), ceres::TAKE_OWNERSHIP))
+          weight_(std::make_shared<Held>(new ceres::LossFunctionWrapper(new ceres::ScaledLoss(NULL, 1.0, ceres::TAKE_OWNERSHIP), ceres::TAKE_OWNERSHIP)))
     {
     }
 
@@ -38,11 +38,21 @@ public:
     }
 
     // error_term.hpp:39-43: a new ScaledLoss(NULL, w) behind the same wrapper
-    void updateWeight(double new_weight) { weight_->Reset(new ceres::ScaledLoss(NULL, new_weight, ceres::TAKE_OWNERSHIP), ceres::TAKE_OWNERSHIP); }
+    void updateWeight(double new_weight) { weight_->wrapper->Reset(new ceres::ScaledLoss(NULL, new_weight, ceres::TAKE_OWNERSHIP), ceres::TAKE_OWNERSHIP); }
     // error_term.hpp:45: the wrapper a caller hands to ceres::Problem::AddResidualBlock (this library never builds a Ceres
-    // problem itself; with the real Ceres — PPCR_NO_COMPAT_TYPES — this IS ceres::LossFunctionWrapper).  The term keeps
-    // the wrapper alive: add it with ceres::DO_NOT_TAKE_OWNERSHIP problem options, as a shared loss must be.
-    ceres::LossFunctionWrapper *weight() { return weight_.get(); }
+    // problem itself; with the real Ceres — PPCR_NO_COMPAT_TYPES — this IS ceres::LossFunctionWrapper).
+    // OWNERSHIP AS IN THE REFERENCE: the reference's term holds a raw pointer and never deletes it — the ceres::Problem the
+    // wrapper is added to does (Problem::Options::loss_function_ownership defaults to TAKE_OWNERSHIP, ..._iteration.hpp:42-44).
+    // So the wrapper is the CALLER'S from the first time this accessor hands it out: the term (and its copies, which
+    // share the one wrapper as the reference's copies do) only deletes a wrapper nobody ever asked for.  A term whose
+    // weight() was taken and then added to no problem leaks it, exactly as in the reference.
+    ceres::LossFunctionWrapper *weight()
+    {
+        weight_->handed_out = true;
+        return weight_->wrapper;
+    }
+    // addition of this implementation: look at the weight without taking the wrapper over
+    const ceres::LossFunctionWrapper *weight() const { return weight_->wrapper; }
 
     // additions of this implementation: the two points as the functor holds them (float values widened to double,
     // error_term.hpp:15-16) — what WeightUpdaterCallback uploads for its device route
@@ -50,9 +60,21 @@ public:
     const double *target() const { return target_; }
 
 private:
+    // the wrapper and whether somebody took it over (shared by the copies of a term)
+    struct Held {
+        explicit Held(ceres::LossFunctionWrapper *w) : wrapper(w) {}
+        ~Held()
+        {
+            if (!handed_out) delete wrapper;
+        }
+        Held(const Held &) = delete;
+        Held &operator=(const Held &) = delete;
+        ceres::LossFunctionWrapper *wrapper;
+        bool handed_out = false;
+    };
     double source_[3];
     double target_[3];
-    std::shared_ptr<ceres::LossFunctionWrapper> weight_;
+    std::shared_ptr<Held> weight_;
 };
 
 }  // namespace prob_point_cloud_registration

@@ -600,10 +600,12 @@ struct PendingMove {
 struct VerletLists {
     int *vl;              // [kVerletSlots][ns], k-major: base positions (sorted target) of the listed targets
     unsigned char *vn;    // [ns] how many
-    unsigned short *vmask; // [ns] the list slots the row's association was last written from (bit k: slot k; all-ones: unknown)
+    unsigned *vmask;      // [ns] the list slots the row's association was last written from (bit k: slot k; all-ones: unknown)
     float *vg2;           // [ns] the list holds every target whose float d2 at the BUILD position is <= this; 0: no list
     float *vacc;          // [ns] path length the query has travelled since the build (bounds its displacement)
-    unsigned *rebuilt;    // diagnostic (nullable): workgroups that failed the test and searched again, cumulative
+    unsigned *rebuilt;    // diagnostic (nullable): [0] workgroups that failed the test and searched again, cumulative
+    unsigned *searched_now;   // diagnostic (nullable): the same count for THIS launch alone (a ring of eight: ppcr_debug_get_verlet) ...
+    unsigned *searched_clear; // ... and the next launch's entry of that ring, zeroed by this one
     // dispatch order (ppcr_nn_tile.hip.h: verlet_slot): per XCD class c the slots filed "front" then those filed "back",
     // [2][8][ceil(grid / 8)] ints, with their counts [8][2]; order_now == nullptr: slot = workgroup index
     const int *order_now;
@@ -615,8 +617,11 @@ struct VerletLists {
     float skin2;          // 2 * skin: how far beyond the cut-off bound a list is built
     int build_all;        // no lists exist yet (or they are not trusted): every workgroup searches and builds
 };
-constexpr int kVerletSlots = 16;
-constexpr int kVerletScanSlots = 24;  // list slots of the search that builds them: the nearest kVerletSlots of up to 24 accepted
+#ifndef PPCR_VERLET_SLOTS
+#define PPCR_VERLET_SLOTS 16
+#endif
+constexpr int kVerletSlots = PPCR_VERLET_SLOTS;
+constexpr int kVerletScanSlots = PPCR_VERLET_SLOTS <= 16 ? 24 : 28;  // list slots of the search that builds them: the nearest kVerletSlots of those accepted
 
 // ---------------------------------------------------------------------------------------------
 // The closed-form weighted rigid solve for ONE lane (it sits on the iteration's critical path right behind the moment

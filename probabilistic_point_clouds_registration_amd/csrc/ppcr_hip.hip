@@ -223,12 +223,17 @@ struct ppcr_ctx {
     // the radius (default 500: lists reach up to 2 x 0.05 radius beyond the cut-off bound — less where more than sixteen targets lie
     // that close; the grid's cells are that much larger)
     int opt_verlet = 1, opt_verlet_skin = 500;
-    // option "verlet_engage" in 1e-4 of the radius: lists are built once the source moves less than this per iteration;
-    // -1 (default): 350 for grids larger than the chip holds at once (throughput-bound: searching workgroups mix with
-    // answering ones, dispatched first), 60 for smaller ones (latency-bound: ONE searching workgroup is the launch's length,
-    // and the search that builds lists is the longer one)
+    // WHEN lists are built: once they are predicted to outlive the registration's remaining moves (associate_impl:
+    // verlet_lists_pay_off).  Known at enqueue time: the largest displacement of the last rigid move this thread has seen
+    // (move_estimate, corners of the target's box), how many iterations old it is (move_lag) and the ratio of the last two
+    // such moves (move_ratio; NaN: unknown).  Option "verlet_engage" >= 0 replaces the rule by a fixed threshold on
+    // move_estimate in 1e-4 of the radius (tests: 100000 = always, 0 = never); -1 (default): the rule.
     int opt_verlet_engage = -1;
-    double move_estimate = std::numeric_limits<double>::infinity();  // how far the last known rigid move displaced the cloud at most (corners of its box)
+    double move_estimate = std::numeric_limits<double>::infinity();
+    double move_ratio = std::numeric_limits<double>::quiet_NaN();
+    int move_lag = 1;
+    bool pending_from_align = false;  // the pending move is an align loop's last transform (its ratio is already known)
+    bool move_forecast_pinned = false;  // an align loop set the three values above for the association being enqueued
     int opt_verlet_order = 1;    // option "verlet_order": workgroups forecast to search again are dispatched first (default 1)
     double grid_skin2 = 0;       // 2 x skin the grid in use was built for (0: its cells do not cover a list's reach)
     int opt_verlet_dense = 0;      // 1: keep the lists' cells whatever the halo estimate says (tests)
@@ -237,11 +242,12 @@ struct ppcr_ctx {
     bool verlet_ok = false;      // the rows' lists were (re)built or verified by the previous association and nothing moved the source since but K1's own prologue
     DevBuf<int> vl;
     DevBuf<unsigned char> vn;
-    DevBuf<unsigned short> vmask;
+    DevBuf<unsigned> vmask;
     DevBuf<unsigned> vcount;     // [0]: diagnostic rebuild counter; [16 .. 64): three sets of dispatch-order counters
     DevBuf<int> vorder;          // two dispatch orders (this launch's, the next one's), 2 x 8 x ceil(grid / 8) slots each
     unsigned verlet_launches = 0;  // Verlet launches enqueued on this handle (the rotation of the order buffers and counters)
     bool verlet_order_ok = false;  // the previous association filed a dispatch order for this one
+    bool verlet_order_used = false;  // (diagnostic) the last Verlet launch took its workgroups in the filed order
     DevBuf<float> vg2, vacc;
     DevBuf<int> gen_counts, gen_row_ptr, gen_pos;
     DevBuf<unsigned long long> gen_keys;

@@ -1067,7 +1067,11 @@ __device__ __forceinline__ void verlet_forecast(const VerletLists &vv, unsigned 
 // VerletLds<M>::kBytes of LDS nobody else is using.
 template <int M>
 struct VerletLds {
-    static constexpr int kWinBytes = 3 * (M + 1) * 256 * 4;  // x[], y[], z[] of up to M winners per lane + one spare slot
+    // per lane: the coordinates of the list entries within the association's threshold, stored as they are measured — up
+    // to M + 2 of them (the m winners and two more that the selection then drops) and one spare slot that everything
+    // beyond lands in (a row with more: its winners are gathered once more, see below)
+    static constexpr int kSlots = M + 3;
+    static constexpr int kWinBytes = 3 * kSlots * 256 * 4;
     static constexpr int kBytes = kWinBytes > kFoldScratchBytes ? kWinBytes : kFoldScratchBytes;
 };
 template <int M, int FTM>
@@ -1077,11 +1081,198 @@ __device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, c
                                                    const FusedMoments &fm, const VerletLists &vv, unsigned char *s_mem,
                                                    const unsigned wg, const float g2, const float acc, const float moved, const float radius)
 {
-    constexpr int BLOCK = 256, CV = kVerletSlots;
-    static_assert(M <= CV && CV <= 16, "a list holds at least the m winners; the winners' slots fit a 16-bit mask");
+    constexpr int BLOCK = 256, CV = kVerletSlots, S = VerletLds<M>::kSlots;
+    static_assert(M <= CV && CV <= 32, "a list holds at least the m winners; the winners' slots fit a 32-bit mask");
     const int nl = valid ? (int)vv.vn[i] : 0;
     // which list slots the row's association (nbr / cnt) was written from last time (all-ones: somebody else wrote it)
-    const unsigned was = valid ? (unsigned)vv.vmask[i] : 0xFFFFu;
+    const unsigned was = valid ? vv.vmask[i] : 0xFFFFFFFFu;
+    // ---- re-measure the list: all index loads, then all gathers, in flight together --------------------------------
+    // Buffer loads (uniform descriptor + ONE 32-bit offset register per address): the list slots of a row share the lane's
+    // row offset (the slot is the scalar offset), a gather's address is the position * 16 — no 64-bit address pairs, so
+    // that all the gathers are in flight together inside the register budget of four workgroups per CU.
+    // (host: ns < 2^26 and nt < 2^28 in this mode, so both byte ranges fit 32 bits)
+    // (Issuing these loads earlier — next to the query load, ahead of the completeness test, for the workgroups the
+    //  previous launch did not expect to search — was measured: 1M windows 10.55 k -> 9.71 k it/s, converged 13.35 k ->
+    //  12.74 k: 32 more loads in flight per lane crowd out the ones the test waits for.  Not kept.)
+    unsigned d2b[CV];
+    const unsigned row4 = (unsigned)(valid ? i : 0) * 4u;
+    const auto rs_vl = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(vv.vl), 0, (int)((unsigned)ns * (unsigned)(CV * 4)), 0x00020000);
+    const auto rs_tgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(tgt), 0, (int)vv.tgt_bytes, 0x00020000);
+    // list entry k of this row (a coalesced, cached load)
+    auto list_pos = [&](int k) { return (int)__builtin_amdgcn_raw_buffer_load_b32(rs_vl, (int)row4, (int)((unsigned)k * (unsigned)ns * 4u), 0); };
+    typedef unsigned v3u __attribute__((ext_vector_type(3)));
+    float *const s_wx = reinterpret_cast<float *>(s_mem), *const s_wy = s_wx + S * BLOCK, *const s_wz = s_wy + S * BLOCK;
+    unsigned in = 0;  // bit k: list entry k is (still) among the answer
+    // the entries' positions stay in registers until the association's row is written (re-loading them there — sixteen
+    // predicated load-then-store pairs, each a round trip of its own — cost every wave with ONE row whose members had changed
+    // 15 us: a third of the launch while the source still moves)
+    int pos[CV];
+    {
+        // every slot of a list is a valid position (the builders pad with 0), so nothing here is predicated
+#pragma unroll
+        for (int k = 0; k < CV; k++) {
+            const int p = list_pos(k);
+            pos[k] = valid ? p : 0;  // (a lane without a query read row 0's slots: whatever they hold is not a position to gather from)
+        }
+        float cx[CV], cy[CV], cz[CV];
+#pragma unroll
+        for (int k = 0; k < CV; k++) {
+            const v3u g = __builtin_amdgcn_raw_buffer_load_b96(rs_tgt, (int)((unsigned)pos[k] << 4), 0, 0);
+            cx[k] = __uint_as_float(g.x), cy[k] = __uint_as_float(g.y), cz[k] = __uint_as_float(g.z);
+        }
+        // Each entry is measured and — K23 folded in — its coordinates go to the lane's LDS cursor at once; only an entry
+        // within the threshold moves the cursor (as in nn_fast_kernel's scan), so the coordinate registers are free again
+        // entry by entry and a list of 24 fits the register budget a list of 16 had.  The cursor stops at the spare slot.
+        int w = tid;
+        const int w_spare = tid + (S - 1) * BLOCK;
+#pragma unroll
+        for (int k = 0; k < CV; k++) {
+            d2b[k] = (k < nl) ? __float_as_uint(dist2_flann(q, make_float4(cx[k], cy[k], cz[k], 0.f))) : 0xFFFFFFFFu;
+            const bool hit = d2b[k] <= thr;
+            in |= hit ? (1u << k) : 0u;
+#ifdef PPCR_DBG_NOSTORE
+            if constexpr (false) {
+#else
+            if constexpr (FTM != -2) {
+#endif
+                s_wx[w] = cx[k];
+                s_wy[w] = cy[k];
+                s_wz[w] = cz[k];
+                w = hit ? min(w + BLOCK, w_spare) : w;
+            }
+        }
+    }
+    const unsigned in_first = in;           // the entries within the threshold, in list order: LDS slot j holds the j-th of them
+    const int n_first = __popc(in_first);
+    unsigned slot_alive = n_first >= 32 ? 0xFFFFFFFFu : ((1u << n_first) - 1u);  // bit j: LDS slot j is (still) among the answer
+    int n = n_first;
+    // ---- more than m within the threshold: the largest by (d2, original index) leave, one per round ------------------
+    int surplus = n - m;
+    while (__ballot(surplus > 0) != 0ull) {
+        if (surplus > 0) {
+            unsigned best = 0;
+#pragma unroll
+            for (int k = 0; k < CV; k++) best = max(best, ((in >> k) & 1u) ? d2b[k] : 0u);
+            int bk = 0, ties = 0;
+#pragma unroll
+            for (int k = 0; k < CV; k++) {
+                const bool hit = ((in >> k) & 1u) && d2b[k] == best;
+                bk = hit ? k : bk;
+                ties += hit ? 1 : 0;
+            }
+            if (ties > 1) {  // equal distances at the boundary: the larger original index leaves (the oracle's order)
+                unsigned worst = 0;
+#pragma unroll
+                for (int k = 0; k < CV; k++)
+                    if (((in >> k) & 1u) && d2b[k] == best) {
+                        const unsigned o = __builtin_amdgcn_raw_buffer_load_b32(rs_tgt, (int)(((unsigned)list_pos(k) << 4) + 12u), 0, 0);
+                        if (o >= worst) worst = o, bk = k;
+                    }
+            }
+            in &= ~(1u << bk);
+            slot_alive &= ~(1u << __popc(in_first & ((1u << bk) - 1u)));  // (its LDS slot: how many accepted entries precede it)
+            surplus--;
+        }
+    }
+    n = min(n, m);
+    unsigned tm = 0xFFFFFFFFu;  // d2 bits of the m-th neighbour (all-ones: fewer than m)
+    if (n == m) {
+        tm = 0;
+#pragma unroll
+        for (int k = 0; k < CV; k++) tm = max(tm, ((in >> k) & 1u) ? d2b[k] : 0u);
+    }
+    if (valid) {
+        // the association's row only when its members changed: in a registration that has all but converged they do not,
+        // and 44 bytes per row of writes stay away (the m-th distance, which does change, always goes out)
+        if (!PPCR_VERLET_MASK || in != was) {
+            int *out = nbr + i;
+#pragma unroll
+            for (int k = 0; k < CV; k++)
+                if ((in >> k) & 1u) {
+                    *out = pos[k];
+                    out += ns;
+                }
+            cnt[i] = n;
+            vv.vmask[i] = in;
+        }
+        dm2[i] = tm;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FTM != -2) {
+        // ---- K23 for this row at fm.P, from the coordinates in LDS ----------------------------------------------------
+        // a row with more entries within the threshold than the lane's slots hold (three or more beyond the m winners: a few
+        // rows in a thousand while the source still moves, none once it has stopped): its winners' coordinates are
+        // gathered once more, into slots 0 .. n - 1
+#ifdef PPCR_DBG_NOLOST
+        const bool lost = false;
+#else
+        const bool lost = n_first > S - 1;
+#endif
+        if (__ballot(lost) != 0ull) {
+            // (in two helpings of CV / 2 entries, each with its loads in flight together: one entry at a time was two dependent
+            //  round trips per winner, 10 us for every wave that holds such a row — four in ten while the source moves 0.005 radii)
+            int w = tid;
+#pragma unroll
+            for (int h0 = 0; h0 < CV; h0 += CV / 2) {
+                int pos[CV / 2];
+#pragma unroll
+                for (int u = 0; u < CV / 2; u++) pos[u] = lost ? list_pos(h0 + u) : 0;
+                v3u g[CV / 2];
+#pragma unroll
+                for (int u = 0; u < CV / 2; u++) g[u] = __builtin_amdgcn_raw_buffer_load_b96(rs_tgt, (int)((unsigned)pos[u] << 4), 0, 0);
+#pragma unroll
+                for (int u = 0; u < CV / 2; u++)
+                    if (lost) {
+                        s_wx[w] = __uint_as_float(g[u].x), s_wy[w] = __uint_as_float(g[u].y), s_wz[w] = __uint_as_float(g[u].z);
+                        w += ((in >> (h0 + u)) & 1u) ? BLOCK : 0;  // (at most m winners: the cursor stays inside the lane's slots)
+                    }
+            }
+            if (lost) slot_alive = (1u << n) - 1u;
+        }
+        RowAcc sums;
+#pragma unroll
+        for (int j = 0; j < kNSums; j++) sums.a[j] = 0.0;
+        if (valid && n > 0) {
+            double xr[3];
+            rotated_point(fm.P, q, xr);
+            RowMoments<FTM> row;
+            row.begin(fm.md);
+            // the j-th winner sits in the slot of the j-th set bit (a per-lane LDS address): m trips, whatever was dropped
+            unsigned rem = slot_alive;
+#pragma unroll
+            for (int j = 0; j < M; j++)
+                if (j < n) {  // nearly every row is full: the branch is uniform for most waves
+                    const int sl = __builtin_ctz(rem) * BLOCK + tid;
+                    rem &= rem - 1u;
+                    row.add_pair(fm.md, xr, s_wx[sl], s_wy[sl], s_wz[sl]);  // (a lane reads what it wrote)
+                }
+            row.finish(sums, fm.P, q, xr);
+        }
+        __syncthreads();  // every lane is through with its winners: the fold borrows the memory
+        double *const scratch = reinterpret_cast<double *>(s_mem);
+        block_reduce_scratch(sums, scratch, scratch + 10 * 257, fm.partials + wg, (size_t)fm.nslots, true);
+        __syncthreads();  // (the forecast below borrows a word of the same memory)
+    }
+    // will this row's list still do after one more move like the last one?  (VerletLists' test with the new m-th distance)
+    const float need_next = (tm != 0xFFFFFFFFu ? __builtin_amdgcn_sqrtf(__uint_as_float(tm)) : radius) + moved;
+    const float reach_next = (need_next + acc + moved) * 1.0001f;
+    verlet_forecast(vv, wg, valid && !(reach_next * reach_next < g2), reinterpret_cast<int *>(s_mem));
+}
+
+#if defined(PPCR_VERLET_ANSWER_V1)
+// (A/B only: the round-5 form of the list path — winners compacted into LDS after the selection)
+template <int M, int FTM>
+__device__ __forceinline__ void verlet_answer_rows_v1(const int tid, const int i, const bool valid, const float4 q, const int ns,
+                                                   const float4 *__restrict__ tgt, const unsigned thr, const int m,
+                                                   int *__restrict__ nbr, int *__restrict__ cnt, unsigned *__restrict__ dm2,
+                                                   const FusedMoments &fm, const VerletLists &vv, unsigned char *s_mem,
+                                                   const unsigned wg, const float g2, const float acc, const float moved, const float radius)
+{
+    constexpr int BLOCK = 256, CV = kVerletSlots;
+    static_assert(M <= CV && CV <= 32, "");
+    const int nl = valid ? (int)vv.vn[i] : 0;
+    // which list slots the row's association (nbr / cnt) was written from last time (all-ones: somebody else wrote it)
+    const unsigned was = valid ? vv.vmask[i] : 0xFFFFFFFFu;
     // ---- re-measure the list: all index loads, then all gathers, in flight together --------------------------------
     // Buffer loads (uniform descriptor + ONE 32-bit offset register per address): the sixteen list slots of a row share
     // the lane's row offset (the slot is the scalar offset), a gather's address is the position * 16 — no 64-bit address
@@ -1165,7 +1356,7 @@ __device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, c
                     out += ns;
                 }
             cnt[i] = n;
-            vv.vmask[i] = (unsigned short)in;
+            vv.vmask[i] = in;
         }
         dm2[i] = tm;
     }
@@ -1174,7 +1365,7 @@ __device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, c
         // ---- K23 for this row at fm.P.  The winners' coordinates are compacted into LDS first — every list entry is
         // stored at the lane's cursor, only a winner moves it, as in nn_fast_kernel's scan — so that the 48 coordinate
         // registers are free while the f64 moments are formed, and the loop below runs over n pairs, not 16 predicated ones
-        float *const s_wx = reinterpret_cast<float *>(s_mem), *const s_wy = s_wx + (M + 1) * BLOCK, *const s_wz = s_wy + (M + 1) * BLOCK;
+        float *const s_wx = reinterpret_cast<float *>(s_mem), *const s_wy = s_wx + VerletLds<M>::kSlots * BLOCK, *const s_wz = s_wy + VerletLds<M>::kSlots * BLOCK;
         {
             int w = tid;
 #pragma unroll
@@ -1208,6 +1399,106 @@ __device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, c
     const float need_next = (tm != 0xFFFFFFFFu ? __builtin_amdgcn_sqrtf(__uint_as_float(tm)) : radius) + moved;
     const float reach_next = (need_next + acc + moved) * 1.0001f;
     verlet_forecast(vv, wg, valid && !(reach_next * reach_next < g2), reinterpret_cast<int *>(s_mem));
+}
+
+#endif
+// PER-ROW REBUILD.  The completeness test is per row; sending a workgroup's 256 rows through the search because ONE of them
+// failed (the ~30 us chain of the tiled search, against ~10 us for answering) was the steady state's largest cost: a row
+// whose list has little room — sixteen targets hardly farther than its tenth — fails every few iterations, and one
+// workgroup in eleven held such a row in the benchmark's timed windows.  A workgroup with at most PPCR_VERLET_ROWS failing
+// rows now rebuilds just THOSE rows' lists, one row per wave (verlet_rebuild_row: the nine clipped stencil runs walked by
+// the 64 lanes as one flat sequence straight from global memory — no halo staging —, accepted candidates appended to a
+// wave-shared LDS list by ballot, the sixteen nearest by (d2, original index) kept by wave_select_top_m), and then answers
+// ALL its rows from their lists as any other workgroup does: the association, the order K23 adds in, the dispatch
+// forecast are the list path's own, whatever the failing rows were.  A fresh list answers its own build position exactly
+// whatever its room (the m <= 16 nearest are among the sixteen nearest).  More failing rows than that: the tiled search,
+// as before (it rebuilds all 256 lists in one go).
+#ifndef PPCR_VERLET_ROWS
+#define PPCR_VERLET_ROWS 0
+#endif
+constexpr int kVerletRowCap = 128;  // entries of a wave's candidate list (compacted to the sixteen nearest when a round might not fit)
+struct VerletRowLds {
+    int pos[4][kVerletRowCap];
+    unsigned d2[4][kVerletRowCap];
+    float4 q[PPCR_VERLET_ROWS > 0 ? PPCR_VERLET_ROWS : 1];     // the failing rows: query (w: the bound `need` on its m-th distance) ...
+    int row[PPCR_VERLET_ROWS > 0 ? PPCR_VERLET_ROWS : 1];      // ... row index ...
+    float g2[PPCR_VERLET_ROWS > 0 ? PPCR_VERLET_ROWS : 1];     // ... and, coming back, the new list's reach
+};
+// one wave, one row: i / q / need are wave-uniform (read from LDS)
+__device__ __forceinline__ float verlet_rebuild_row(const int i, const float4 q, const float need, const int ns, const float4 *__restrict__ tgt,
+                                                    const int *__restrict__ cell_start, const GridDesc &g, const VerletLists &vv,
+                                                    const int lane, int *s_pos, unsigned *s_d2)
+{
+    const float bnd = need + vv.skin2;
+    const unsigned thr_v = __float_as_uint(bnd * bnd);  // the scan's acceptance threshold (nn_fast_kernel: thr_v)
+    unsigned thr = thr_v;
+    const float R2s = bnd * bnd * 1.000004f;
+    const QueryCells c = query_cells(q, g);
+    // lane l < 9: the (dy, dz) row l of the stencil, clipped to the x slices the sphere of radius G can touch there
+    // (the arithmetic of nn_wide_kernel's run_bounds with a reach of one cell)
+    int rb = 0, re = 0;
+    if (lane < 9) {
+        const int dz = lane / 3 - 1, dy = lane % 3 - 1;
+        const int cz = c.cz + dz, cy = c.cy + dy;
+        const float fy = q.y - g.org[1], fz = q.z - g.org[2];
+        if ((unsigned)cz < (unsigned)g.n[2] && (unsigned)cy < (unsigned)g.n[1]) {
+            const float gz = dz < 0 ? fmaxf(fz - (float)(cz + 1) * g.h - g.eps, 0.f) : (dz > 0 ? fmaxf((float)cz * g.h - fz - g.eps, 0.f) : 0.f);
+            const float gy = dy < 0 ? fmaxf(fy - (float)(cy + 1) * g.h - g.eps, 0.f) : (dy > 0 ? fmaxf((float)cy * g.h - fy - g.eps, 0.f) : 0.f);
+            const float w2 = R2s - (gy * gy + gz * gz);
+            if (w2 > 0.f) {
+                const float w = __builtin_amdgcn_sqrtf(w2) * 1.000001f + g.eps;
+                const int fa = max(cell_coord(q.x - w, g.org[0], g.inv_hx, g.n[0]), 0);
+                const int fb = min(cell_coord(q.x + w, g.org[0], g.inv_hx, g.n[0]), g.n[0] - 1);
+                if (fa <= fb) {
+                    const int base = (cz * g.n[1] + cy) * g.n[0];
+                    rb = cell_start[base + fa], re = cell_start[base + fb + 1];
+                }
+            }
+        }
+    }
+    const int len = re - rb;
+    const int incl = wave_scan(len, 0, OpAdd());
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    int sb[9], se[9];  // the nine runs' first positions and their offsets in the flat sequence (scalars)
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        sb[r] = __builtin_amdgcn_readlane(rb, r);
+        se[r] = __builtin_amdgcn_readlane(incl - len, r);
+    }
+    int n = 0;
+    bool cut = false;  // entries were dropped: the list is complete only strictly below the farthest kept
+    for (int j0 = 0; j0 < total; j0 += 64) {
+        if (n > kVerletRowCap - 64) {
+            n = wave_select_top_m<kVerletRowCap / 64>(s_pos, s_d2, n, kVerletSlots, tgt, lane, thr);
+            cut = true;
+        }
+        const int j = j0 + lane;
+        int pos = 0;
+#pragma unroll
+        for (int r = 0; r < 9; r++) pos = (j >= se[r]) ? sb[r] + (j - se[r]) : pos;  // (the last run that starts at or before j: never an empty one while j < total)
+        const bool live = j < total;
+        const float4 t = tgt[live ? pos : 0];
+        const unsigned bits = __float_as_uint(dist2_flann(q, t));
+        const bool acc = live && bits <= thr;
+        const unsigned long long k = __ballot(acc);
+        const int at = n + __builtin_amdgcn_mbcnt_hi((unsigned)(k >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)k, 0u));
+        if (acc) s_pos[at] = pos, s_d2[at] = bits;
+        n += __popcll(k);
+    }
+    if (n > kVerletSlots) {
+        n = wave_select_top_m<kVerletRowCap / 64>(s_pos, s_d2, n, kVerletSlots, tgt, lane, thr);
+        cut = true;
+    }
+    // (strictly below the farthest kept: equal distances beyond it were dropped; 0: no list — sixteen targets at distance 0)
+    const unsigned g2_bits = cut ? (thr > 0u ? thr - 1u : 0u) : thr_v;
+    if (lane < kVerletSlots) vv.vl[(size_t)lane * ns + i] = lane < n ? s_pos[lane] : 0;  // (every slot a valid position)
+    if (lane == 0) {
+        vv.vn[i] = (unsigned char)n;
+        vv.vg2[i] = __uint_as_float(g2_bits);
+        vv.vacc[i] = 0.f;
+        vv.vmask[i] = 0xFFFFFFFFu;  // (the association's row was not written from this list yet)
+    }
+    return __uint_as_float(g2_bits);
 }
 
 // FTM != -2 (0: Gaussian, k > 0: t model with v + dim = k, -3: t model with an integer v + dim read at run time) folds
@@ -1380,6 +1671,8 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
         if constexpr (VERLET)
             if (vv.count_clear != nullptr)
                 for (int k = 0; k < 16; k++) vv.count_clear[k] = 0;  // (the dispatch-order counters of the launch after next)
+        if constexpr (VERLET)
+            if (vv.searched_clear != nullptr) *vv.searched_clear = 0;
     }
     float moved = 0.f;  // how far this query travelled since the association that produced dm2
     if (pm.enabled && valid) {
@@ -1439,18 +1732,61 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
             const bool is_point = (q.x - q.x) == 0.f && (q.y - q.y) == 0.f && (q.z - q.z) == 0.f;
             const bool ok = !valid || reach * reach < g2 || !is_point;
             // the workgroup's verdict through four words of s_gbo (idle until the row table is built, two barriers from here)
-            const bool wave_ok = __ballot(!ok) == 0ull;  // (every lane votes: NOT inside the one-lane store below)
-            if (lane == 0) s_gbo[wave] = wave_ok ? 1 : 0;
+            const unsigned long long failing = __ballot(!ok);  // (every lane votes: NOT inside the one-lane store below)
+            if (lane == 0) s_gbo[wave] = __popcll(failing);
             lds_barrier();
-            const int all_ok = s_gbo[0] & s_gbo[1] & s_gbo[2] & s_gbo[3];
+            const int f0 = s_gbo[0], f1 = s_gbo[1], f2 = s_gbo[2], f3 = s_gbo[3];
+            const int n_fail = f0 + f1 + f2 + f3;
             lds_barrier();  // (everybody has read the verdict: the list path writes its winners over these words)
+            bool all_ok = n_fail == 0;
+            // (diagnostic: how many rows fail where any does — 1, 2-4, 5-16, more)
+            if (tid == 0 && n_fail > 0 && vv.rebuilt != nullptr) atomicAdd(vv.rebuilt + 12 + (n_fail > 16 ? 3 : n_fail > 4 ? 2 : n_fail > 1 ? 1 : 0), 1u);
+            if constexpr (PPCR_VERLET_ROWS > 0) {
+                if (n_fail > 0 && n_fail <= PPCR_VERLET_ROWS) {
+                    // the failing rows, in row order, into LDS; each wave rebuilds every fourth of them (see verlet_rebuild_row)
+                    VerletRowLds &rl = *reinterpret_cast<VerletRowLds *>(s_all);
+                    static_assert(sizeof(VerletRowLds) <= (size_t)Lds::kOffGbo, "the row-rebuild scratch sits below the verdict words");
+                    const int slot = (wave > 0 ? f0 : 0) + (wave > 1 ? f1 : 0) + (wave > 2 ? f2 : 0) +
+                                     __builtin_amdgcn_mbcnt_hi((unsigned)(failing >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)failing, 0u));
+                    if (!ok) {
+                        rl.q[slot] = make_float4(q.x, q.y, q.z, need);
+                        rl.row[slot] = i;
+                    }
+                    lds_barrier();
+                    for (int f = wave; f < n_fail; f += kWaves) {
+                        const float4 fq = rl.q[f];
+                        const int fi = __builtin_amdgcn_readfirstlane(rl.row[f]);
+                        const float fg = verlet_rebuild_row(fi, make_float4(fq.x, fq.y, fq.z, 0.f), fq.w, ns, tgt0, cell_start0, g0, vv, lane, rl.pos[wave], rl.d2[wave]);
+                        if (lane == 0) rl.g2[f] = fg;
+                    }
+                    __syncthreads();  // (the lists the other waves wrote: global memory, read back by the list path below)
+                    if (!ok) {
+                        g2 = rl.g2[slot];
+                        acc = 0.f;
+                    }
+                    if (tid == 0 && vv.rebuilt != nullptr) {
+                        atomicAdd(vv.rebuilt + 1, (unsigned)n_fail);
+                        atomicAdd(vv.rebuilt + 2, 1u);
+                    }
+                    __syncthreads();  // (everybody has its g2: the list path writes its winners over this memory)
+                    all_ok = true;
+                }
+            }
             if (all_ok) {
                 if (valid) vv.vacc[i] = acc;
-                verlet_answer_rows<M, FTM>(tid, i, valid, q, ns, tgt0, min(thr0, __float_as_uint(r2_0) - 1u), m, nbr, cnt, dm2, fm, vv, s_all,
+#if defined(PPCR_VERLET_ANSWER_V1)
+                verlet_answer_rows_v1<M, FTM>(
+#else
+                verlet_answer_rows<M, FTM>(
+#endif
+                    tid, i, valid, q, ns, tgt0, min(thr0, __float_as_uint(r2_0) - 1u), m, nbr, cnt, dm2, fm, vv, s_all,
                                            wg, g2, acc, moved, __builtin_amdgcn_sqrtf(r2_0));
                 return;
             }
-            if (tid == 0 && vv.rebuilt != nullptr) atomicAdd(vv.rebuilt, 1u);  // (diagnostic: workgroups that searched again)
+            if (tid == 0 && vv.rebuilt != nullptr) {  // (diagnostic: workgroups that searched again)
+                atomicAdd(vv.rebuilt, 1u);
+                atomicAdd(vv.searched_now, 1u);
+            }
         }
     }
     // ---- MULTI: which level of the grid this block searches ------------------------------------------------------
@@ -1901,7 +2237,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
                 }
                 vv.vn[i] = (unsigned char)n;
                 vv.vacc[i] = 0.f;
-                vv.vmask[i] = (unsigned short)0xFFFFu;  // (the association's row is written from the scan's list below, not from list slots)
+                vv.vmask[i] = 0xFFFFFFFFu;  // (the association's row is written from the scan's list below, not from list slots)
             }
             vg_new = n >= 0 ? __uint_as_float(thr) : 0.f;  // (0: no list — also the degenerate row whose sixteen nearest are all at distance 0)
             vv.vg2[i] = vg_new;

@@ -201,7 +201,46 @@ static void errorTermTest()
     EXPECT_NEAR(r[1], 0, 1e-12);
     EXPECT_NEAR(r[2], 0, 1e-12);
     e.updateWeight(0.25);
-    EXPECT_NEAR(lossScale(e.weight()), 0.25, 0);
+    EXPECT_NEAR(lossScale(static_cast<const ErrorTerm &>(e).weight()), 0.25, 0);
+}
+
+// Ownership of the loss wrapper as in the reference (error_term.hpp:17-19,45; ..._iteration.hpp:42-44): the reference's term
+// never deletes the wrapper — the ceres::Problem it is added to does (TAKE_OWNERSHIP by default).  Here: a wrapper nobody
+// took is freed with the last copy of the term; one that weight() handed out belongs to whoever took it (the stand-in
+// "problem" below deletes it, as a real ceres::Problem would) and is not freed a second time.  A loss that counts its
+// own destruction is put behind the wrapper to see who deleted what.
+namespace {
+int g_counting_loss_deleted = 0;
+class CountingLoss : public ceres::LossFunction {
+public:
+    ~CountingLoss() override { ++g_counting_loss_deleted; }
+    void Evaluate(double s, double out[3]) const override { out[0] = s, out[1] = 1.0, out[2] = 0.0; }
+};
+}  // namespace
+static void errorTermOwnershipTest()
+{
+    g_counting_loss_deleted = 0;
+    {   // never handed out: the term cleans up after itself
+        ErrorTerm e(pcl::PointXYZ(1, 0, 0), pcl::PointXYZ(0, 1, 0));
+        const_cast<ceres::LossFunctionWrapper *>(static_cast<const ErrorTerm &>(e).weight())->Reset(new CountingLoss, ceres::TAKE_OWNERSHIP);
+        ErrorTerm copy(e);  // copies share the one wrapper (the reference's copies share its raw pointer)
+        EXPECT_TRUE(static_cast<const ErrorTerm &>(copy).weight() == static_cast<const ErrorTerm &>(e).weight());
+    }
+    EXPECT_TRUE(g_counting_loss_deleted == 1);
+    g_counting_loss_deleted = 0;
+    ceres::LossFunctionWrapper *taken = nullptr;
+    {   // handed out (through a copy): the taker owns it, neither the term nor its copy deletes it
+        ErrorTerm e(pcl::PointXYZ(1, 0, 0), pcl::PointXYZ(0, 1, 0));
+        ErrorTerm copy(e);
+        taken = copy.weight();  // what problem.AddResidualBlock(cost, term.weight(), ...) receives
+        taken->Reset(new CountingLoss, ceres::TAKE_OWNERSHIP);
+        e.updateWeight(0.5);    // (replaces the counting loss: one deletion, by Reset)
+        EXPECT_TRUE(g_counting_loss_deleted == 1);
+        taken->Reset(new CountingLoss, ceres::TAKE_OWNERSHIP);
+    }
+    EXPECT_TRUE(g_counting_loss_deleted == 1);  // both terms are gone, the wrapper is not
+    delete taken;                               // the "problem" goes away
+    EXPECT_TRUE(g_counting_loss_deleted == 2);
 }
 
 // weight_updater_callback.hpp:15-64 driven the way ..._iteration.hpp:37-49 drives it: one ErrorTerm per nonzero of the
@@ -245,7 +284,7 @@ static void weightUpdaterCallbackTest(double dof)
         WeightUpdaterCallback callback(&assoc, &params, &terms, &weight_updater, rotation, translation);
         EXPECT_TRUE(callback(ceres::IterationSummary()) == ceres::SOLVER_CONTINUE);
         EXPECT_TRUE(callback.onDevice());  // rows share their source point: K2 on the device
-        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(lossScale(terms[k]->weight()), expected.valuePtr()[k], 1e-12);
+        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(lossScale(static_cast<const ErrorTerm *>(terms[k])->weight()), expected.valuePtr()[k], 1e-12);
         // the pose is read through the pointers at every call (the reference's callback sees Ceres' live state)
         translation[0] += 0.25;
         callback(ceres::IterationSummary());
@@ -256,7 +295,7 @@ static void weightUpdaterCallbackTest(double dof)
             sq.push_back(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
         }
         const auto moved = weight_updater.updateWeights(assoc, sq);
-        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(lossScale(terms[k]->weight()), moved.valuePtr()[k], 1e-12);
+        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(lossScale(static_cast<const ErrorTerm *>(terms[k])->weight()), moved.valuePtr()[k], 1e-12);
     }
     {
         // a row whose terms hold different source points cannot be one row of a device association: host residuals
@@ -273,7 +312,7 @@ static void weightUpdaterCallbackTest(double dof)
             sq.push_back(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
         }
         const auto mixed = weight_updater.updateWeights(assoc, sq);
-        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(lossScale(terms[k]->weight()), mixed.valuePtr()[k], 1e-15);
+        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(lossScale(static_cast<const ErrorTerm *>(terms[k])->weight()), mixed.valuePtr()[k], 1e-15);
         terms[1] = keep;
     }
     {
@@ -307,7 +346,7 @@ static void weightUpdaterCallbackTest(double dof)
             sq.push_back(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
         }
         const auto rebuilt = weight_updater.updateWeights(assoc, sq);
-        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(lossScale(terms[k]->weight()), rebuilt.valuePtr()[k], 1e-12);
+        for (std::size_t k = 0; k < terms.size(); ++k) EXPECT_NEAR(lossScale(static_cast<const ErrorTerm *>(terms[k])->weight()), rebuilt.valuePtr()[k], 1e-12);
     }
 }
 
@@ -549,6 +588,7 @@ int main(int argc, char **argv)
     exactAssociationTest(std::numeric_limits<double>::infinity());
     exactAssociationTest(5);
     errorTermTest();
+    errorTermOwnershipTest();
     weightUpdaterCallbackTest(5);
     weightUpdaterCallbackTest(std::numeric_limits<double>::infinity());
     alignTest();

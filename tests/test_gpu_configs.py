@@ -187,6 +187,138 @@ def test_timed_instantiation_association_vs_oracle(cfg_id, pair):
     np.testing.assert_array_equal(col, ocol)
 
 
+def _raw_association(c, n, nt, m):
+    """The association as it stands in the handle's device buffers (ppcr_debug_read_buffer: no pending move applied, nothing
+    flushed — the registration can go on afterwards), turned into the CSR the reference keeps (cc:77-83: original row order,
+    ascending original columns) with the float d2 of every pair recomputed from the buffers' own coordinates in numpy
+    float32 — (dx dx + dy dy) + dz dz, IEEE, no FMA: FLANN's L2_Simple<float> sum."""
+    src4 = c.debug_read("src", np.float32, 4 * n).reshape(n, 4)
+    tgt4 = c.debug_read("tgt", np.float32, 4 * nt).reshape(nt, 4)
+    nbr = c.debug_read("nbr", np.int32, m * n).reshape(m, n)
+    cnt = c.debug_read("cnt", np.int32, n)
+    assert cnt.min() >= 0 and cnt.max() <= m
+    row_of = src4[:, 3].copy().view(np.int32)               # sorted row -> the caller's row
+    col_of = tgt4[:, 3].copy().view(np.int32)               # cell-sorted target position -> the caller's column
+    assert np.array_equal(np.sort(row_of), np.arange(n)) and np.array_equal(np.sort(col_of), np.arange(nt))
+    live = np.arange(m)[:, None] < cnt[None, :]
+    k_idx, r_idx = np.nonzero(live)
+    pos = nbr[k_idx, r_idx]
+    assert pos.min() >= 0 and pos.max() < nt
+    rows, cols = row_of[r_idx], col_of[pos]
+    d = src4[r_idx, :3] - tgt4[pos, :3]                     # float32 throughout
+    d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    order = np.lexsort((cols, rows))
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))])
+    return rp.astype(np.int32), cols[order].astype(np.int32), d2[order].astype(np.float32)
+
+
+@pytest.mark.parametrize("cfg_id,pair", [(3, 0), (5, 11)])
+def test_verlet_lists_at_the_timed_size_whole_association_vs_oracle(cfg_id, pair):
+    """What bench.py times, at the size it times it (round-5 review, task 1): BASELINE configs[2] (1M <-> 1M) and one pair
+    of configs[4] (250k <-> 250k) through a pipelined ppcr_align with the Verlet lists and the forecast-ordered dispatch
+    on (both grids are larger than one residency round: k1_steady_slots > 1024).  At two points of ONE registration — the
+    association of iteration 12 (lists in use, rows still outliving their lists: rebuilds in flight) and of iteration 40
+    (all but converged) — the test ASSERTS that the lists answered (trusted, every row has a list entry, the last launch
+    took its workgroups in the filed order, under half of them searched) and then compares the WHOLE association — row_ptr,
+    columns and float d2 bits of every row — with the oracle's search on the oracle-moved cloud
+    (src/prob_point_cloud_registration.cc:72-83 on the cloud of :110-112)."""
+    cfg = synth.CONFIGS[cfg_id]
+    m = cfg["max_neighbours"]
+    src, tgt, _, _ = synth.make_pair(cfg["n"], cfg=cfg_id, pair=pair)
+    n, nt = src.shape[0], tgt.shape[0]
+    cur = np.ascontiguousarray(src[:, :3]).copy()
+    activity = []
+    with _lib.Context(0) as c:
+        c.set_params(cfg["radius"], m, cfg["dof"], 3)
+        c.set_target(tgt)
+        c.set_source(src)
+        done = 0
+        for upto, regime in ((13, "rebuilds in flight"), (41, "converged")):
+            v_before = c.debug_verlet()
+            rep = c.align_report(upto - done, cost_drop_thresh=-1.0, inner_steps=1)
+            assert rep["n_iter"] == upto - done
+            steps = [r["T_step"] for r in rep["iterations"]]
+            # the association the handle holds was made by the call's LAST iteration, on the source as moved by every
+            # earlier increment (the last increment is still pending)
+            for T in steps[:-1]:
+                po.transform_cloud(cur, np.vstack([T, [0, 0, 0, 1]]))
+            v = c.debug_verlet()
+            real = v["workgroups"] - 128                            # (the grid carries 128 slots for split blocks)
+            assert real > 1024 - 128, v
+            assert v["trusted"] and v["rows"] == n, (regime, v)
+            assert v["rows_without_list"] < n // 50, (regime, v)     # (rows of handed-over blocks keep none)
+            assert v["ordered"], (regime, "the last launch must have taken the filed dispatch order", v)
+            assert len(v["searched_last"]) >= 4 and max(v["searched_last"][:4]) < real // 2, (regime, v)
+            activity.append((v["rebuilt"] - v_before["rebuilt"]) + (v["rows_rebuilt"] - v_before["rows_rebuilt"]))
+            rp, col, d2 = _raw_association(c, n, nt, m)
+            orp, ocol, od2 = po.radius_search(cur, tgt[:, :3], cfg["radius"], m, method=1)
+            np.testing.assert_array_equal(rp, orp, err_msg=regime)
+            np.testing.assert_array_equal(col, ocol, err_msg=regime)
+            np.testing.assert_array_equal(d2.view(np.uint32), od2.view(np.uint32), err_msg=regime)
+            po.transform_cloud(cur, np.vstack([steps[-1], [0, 0, 0, 1]]))
+            done = upto
+    # lists were rebuilt while the source still moved (workgroups searching again, or rows rebuilt one by one) ...
+    assert activity[0] > 0, activity
+    # ... and next to none once it has all but stopped (the last launch: under a twentieth of the workgroups searched)
+    assert v["searched_last"][0] <= real // 20, v
+
+
+@pytest.mark.parametrize("order", [1, 0])
+def test_verlet_lists_soak_on_a_grid_larger_than_one_residency_round(order):
+    """The randomised Verlet soak of tests/test_gpu_parity.py runs 12-30k points: one residency round, where the
+    forecast-ordered dispatch (verlet_slot / verlet_file_slot) is never taken.  Here the same sweep on 320k rows (1250
+    blocks + 128 > 1024 slots), the dispatch order on and off: lists forced on whatever the moves, eight associations under
+    rigid moves from nothing to 0.15 radii (rotations about far pivots: rows of one workgroup travel different distances),
+    a clustered part, NaN / far-away rows; every association against the oracle, neighbour sets and float d2 bit for bit."""
+    rng = np.random.default_rng(6100 + order)
+    nt = 330_000
+    side = (nt / 3.8) ** (1 / 3)
+    blobs = rng.uniform(0.2 * side, 0.8 * side, size=(5, 3))
+    tgt = np.concatenate([rng.uniform(0, side, size=(nt - 5 * 4000, 3))] + [b + rng.normal(0, 2.0, size=(4000, 3)) for b in blobs]).astype(np.float32)
+    ns = 320_000
+    src = (tgt[rng.permutation(nt)[:ns]] + rng.normal(0, 0.02, size=(ns, 3))).astype(np.float32)
+    src[:4] = [[side * 3, 0, 0], [np.nan, 0, 0], [0, np.inf, 0], [-50, -50, -50]]
+    with _lib.Context(0) as c:
+        c.set_option("defer_moves", 1)
+        c.set_option("two_pass", 0)
+        c.set_option("levels", 0)
+        c.set_option("verlet_engage", 100000)
+        c.set_option("verlet_dense", 1)
+        c.set_option("verlet_order", order)
+        c.set_params(1.0, 10, 5.0, 3)
+        c.set_target(tgt)
+        c.set_source(src)
+        cur = src.copy()
+        ordered_launches = answered = 0
+        for k, mag in enumerate([0.0, 2e-3, 1e-2, 1e-3, 0.05, 1e-3, 0.15, 5e-4]):
+            c.associate()
+            rp, col, d2 = c.get_association()
+            orp, ocol, od2 = po.radius_search(cur, tgt, 1.0, 10, method=1)
+            np.testing.assert_array_equal(rp, orp, err_msg=f"association {k}")
+            np.testing.assert_array_equal(col, ocol, err_msg=f"association {k}")
+            np.testing.assert_array_equal(d2, od2, err_msg=f"association {k}")
+            v = c.debug_verlet()
+            if k >= 1:                     # (the first association has no cut-offs yet: the plain search, no lists)
+                assert v["workgroups"] > 1024 and v["trusted"] and v["rows"] == ns, v
+            ordered_launches += int(v["ordered"])
+            if k >= 2 and v["searched_last"][0] < v["workgroups"] - 128:
+                answered += 1
+            T = np.eye(4)
+            if k % 2:
+                pivot = np.full(3, side / 2) + rng.normal(size=3) * side * 3
+                arm = np.linalg.norm(np.full(3, side / 2) - pivot)
+                R = synth.rodrigues(rng.normal(size=3), mag / arm)
+                T[:3, :3] = R
+                T[:3, 3] = pivot - R @ pivot
+            else:
+                dvec = rng.normal(size=3)
+                T[:3, 3] = dvec / np.linalg.norm(dvec) * mag
+            c.apply_transform(T)
+            po.transform_cloud(cur, T)
+        assert answered >= 3, answered
+        assert (ordered_launches >= 5) if order else (ordered_launches == 0), ordered_launches
+
+
 @pytest.mark.parametrize("fuse_max_handed_over", [1 << 20, 4])
 def test_fused_association_with_handovers_on_a_clustered_cloud(fuse_max_handed_over):
     """(fuse_max_handed_over = 2^20: K23 stays folded in however many workgroups are handed over, the cleanup role redoes
