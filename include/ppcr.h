@@ -334,15 +334,20 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *                  more than max_neighbours points, and every block of queries searches the finest level that covers its
  *                  cut-off radii (default; uniform clouds searched with a radius of a few spacings keep one level),
  *                  0 always one level (set before the first association);
- *   "verlet"       1 the steady-state K1 of a one-pass, single-level search with max_neighbours <= 10 keeps per-row Verlet
- *                  lists and answers a workgroup's rows from them for as long as every list provably holds every target the
- *                  exact search could return (default), 0 always search, 2 build the lists in every launch and never trust
- *                  them (testing);
- *   "verlet_skin"  how far a list reaches beyond what the row needs, in 2e-4 of the radius (default 500: 0.1 radius; 1..2000;
- *                  set before the first association: the grid's cells grow by twice the skin);
- *   "verlet_engage"  lists are built once the last known rigid move displaces no corner of the target's box by more than
- *                  this many 1e-4 radii (and dropped above four times that); -1 (default) 350 for grids larger than the chip
- *                  holds at once, 60 for smaller ones; 0 never .. 100000 always;
+ *   "verlet"       1 the steady-state K1 keeps per-row Verlet lists and answers a workgroup's rows from them for as long as
+ *                  every list provably holds every target the exact search could return (default) — one-pass searches of up
+ *                  to 20 neighbours (16 slots per row up to 10 neighbours, 32 beyond), two-pass searches of 11 .. 20: the
+ *                  command line's own defaults —, 0 always search, 2 build the lists in every launch and never trust them
+ *                  (testing);
+ *   "verlet_levels"  1 lists in multi-level searches too, 0 not (default: measured on the two pinned non-uniform scenes, a
+ *                  gain on one and a loss on the other: csrc/ppcr_hip.hip);
+ *   "verlet_skin"  how far a list reaches beyond what the row needs, in 2e-4 of the (first-pass) search radius (1..2000;
+ *                  default by width: 500 — 0.1 radius — up to 10 neighbours, 350 beyond; set before the first association:
+ *                  the grid's cells grow by twice the skin);
+ *   "verlet_engage"  -1 (default) lists are built once the moves the registration still has to make — forecast from the last
+ *                  known rigid move and the ratio of the last two — fit the lists' skin, and dropped when the forecast exceeds
+ *                  four times that; >= 0: a fixed threshold instead, lists are built once the last known rigid move displaces
+ *                  no corner of the target's box by more than this many 1e-4 radii (0 never .. 100000 always: tests);
  *   "verlet_order" 1 workgroups that will probably search are dispatched first (default), 0 launch order;
  *   "verlet_dense" 0 no lists (and radius-sized grid cells) where the halo of a 256-query block would outgrow the list
  *                  variant's LDS tile — a radius that holds ~35 or more target points, a source much sparser than the target —

@@ -598,11 +598,18 @@ struct PendingMove {
 // the rest of it; the first iterations of a registration rebuild every time and cost what they cost before plus the
 // list's 64 bytes per query.
 struct VerletLists {
-    int *vl;              // [kVerletSlots][ns], k-major: base positions (sorted target) of the listed targets
+    int *vl;              // [verlet_slots(M)][ns], k-major: base positions (sorted target) of the listed targets
     unsigned char *vn;    // [ns] how many
     unsigned *vmask;      // [ns] the list slots the row's association was last written from (bit k: slot k; all-ones: unknown)
     float *vg2;           // [ns] the list holds every target whose float d2 at the BUILD position is <= this; 0: no list
     float *vacc;          // [ns] path length the query has travelled since the build (bounds its displacement)
+    unsigned char *streak; // [workgroup slots] (nullable) how HOT the slot's block is: + 4 (up to 16) whenever it searches, - 2 whenever it
+                          //     answers.  A block that keeps searching — rows that can keep no list (a dense blob's, a handed-over
+                          //     block's), lists that last one launch — stops paying for lists it does not get to use (the
+                          //     list-building scan costs twice the plain one, and in a one-round launch the slowest workgroup IS the
+                          //     launch): at 8 and above it searches as the plain kernel does; one launch in sixteen (by slot:
+                          //     launch_tag) it builds again, in case things have calmed down
+    unsigned launch_tag;  // (the launch's index mod 16)
     unsigned *rebuilt;    // diagnostic (nullable): [0] workgroups that failed the test and searched again, cumulative
     unsigned *searched_now;   // diagnostic (nullable): the same count for THIS launch alone (a ring of eight: ppcr_debug_get_verlet) ...
     unsigned *searched_clear; // ... and the next launch's entry of that ring, zeroed by this one
@@ -614,14 +621,20 @@ struct VerletLists {
     unsigned *count_next;
     unsigned *count_clear; // the counters of the launch after next: zeroed by this launch (nullable)
     unsigned tgt_bytes;   // size of the sorted target in bytes (the gathers go through a buffer descriptor)
-    float skin2;          // 2 * skin: how far beyond the cut-off bound a list is built
+    float skin2;          // 2 * skin: how far beyond the cut-off bound a list is built ...
+    float skin_rel;       // ... or this fraction of the bound, whichever is more (multi-level searches: the rows of a cloud whose
+                          //     density varies a hundredfold have bounds from a twentieth of the radius to all of it, and a skin
+                          //     sized for the finest level's rows is nothing to the coarsest's; 0 elsewhere)
     int build_all;        // no lists exist yet (or they are not trusted): every workgroup searches and builds
 };
 #ifndef PPCR_VERLET_SLOTS
 #define PPCR_VERLET_SLOTS 16
 #endif
-constexpr int kVerletSlots = PPCR_VERLET_SLOTS;
-constexpr int kVerletScanSlots = PPCR_VERLET_SLOTS <= 16 ? 24 : 28;  // list slots of the search that builds them: the nearest kVerletSlots of those accepted
+// list slots per row by the association's compiled-in width M (10 neighbours: 16 slots hold the ~13.5 targets a list's reach
+// holds at the benchmark's density; the command line's 20: 32), and the LDS list slots of the search that builds the lists
+constexpr int verlet_slots(int M) { return M <= 12 ? PPCR_VERLET_SLOTS : 32; }
+constexpr int verlet_scan_slots(int M) { return M <= 12 ? (PPCR_VERLET_SLOTS <= 16 ? 24 : 28) : 36; }
+constexpr int kVerletSlotsMax = 32;
 
 // ---------------------------------------------------------------------------------------------
 // The closed-form weighted rigid solve for ONE lane (it sits on the iteration's critical path right behind the moment

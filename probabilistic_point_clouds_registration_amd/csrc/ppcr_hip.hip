@@ -222,7 +222,14 @@ struct ppcr_ctx {
     // Verlet lists (steady state, ppcr_device.hip.h: VerletLists): option "verlet" 1 (default) / 0, "verlet_skin" in 1e-4 of
     // the radius (default 500: lists reach up to 2 x 0.05 radius beyond the cut-off bound — less where more than sixteen targets lie
     // that close; the grid's cells are that much larger)
-    int opt_verlet = 1, opt_verlet_skin = 500;
+    int opt_verlet = 1, opt_verlet_skin = -1;  // (-1: by width — verlet_skin_units)
+    // option "verlet_levels": lists in MULTI-LEVEL searches too (default 0).  Built, exact (tests/test_gpu_configs.py runs the
+    // command line's defaults on both pinned scenes with it on) and measured on them: the rows nn_wide_kernel searches come
+    // there once per list lifetime instead of every iteration (slab with blobs: 83 -> 55 us of that kernel, 4.3 k -> 4.7-4.8 k
+    // it/s), but a one-round launch lasts as long as its slowest workgroup, and the dense blocks that never keep lists — or
+    // build them, twice the plain scan, every few launches — are exactly those (LiDAR-like scene: K1 119 -> 136 us, 4.5 k ->
+    // 4.3 k it/s).  Off until the dense blocks' search itself is cheaper.
+    int opt_verlet_levels = 0;
     // WHEN lists are built: once they are predicted to outlive the registration's remaining moves (associate_impl:
     // verlet_lists_pay_off).  Known at enqueue time: the largest displacement of the last rigid move this thread has seen
     // (move_estimate, corners of the target's box), how many iterations old it is (move_lag) and the ratio of the last two
@@ -249,6 +256,7 @@ struct ppcr_ctx {
     bool verlet_order_ok = false;  // the previous association filed a dispatch order for this one
     bool verlet_order_used = false;  // (diagnostic) the last Verlet launch took its workgroups in the filed order
     DevBuf<float> vg2, vacc;
+    DevBuf<unsigned char> vstreak;  // VerletLists::streak, one byte per workgroup slot of the largest K1 grid
     DevBuf<int> gen_counts, gen_row_ptr, gen_pos;
     DevBuf<unsigned long long> gen_keys;
     DevBuf<unsigned long long> d_total;

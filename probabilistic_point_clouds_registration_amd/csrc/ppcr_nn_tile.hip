@@ -41,7 +41,7 @@ bool fast_kernel_lds_ok()
 #if PPCR_LIST_NOCLAMP
     hipFuncAttributes attr;
     if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&nn_fast_kernel<M, C, CAP, STAMPS, FTM, MULTI, VERLET>)) != hipSuccess) return false;
-    return (int)attr.sharedSizeBytes == FastLds<C, CAP, MULTI, (VERLET ? M : 0)>::kAllocBytes;
+    return (int)attr.sharedSizeBytes == FastLds<C, CAP, MULTI, ((VERLET && FTM != -2) ? M : 0)>::kAllocBytes;
 #else
     return true;
 #endif
@@ -53,17 +53,19 @@ void check_fast_kernel_lds()
         constexpr int C = (M <= 24) ? 32 : 48;
         constexpr int CAP = (M <= 24) ? 2240 : 2048;
         bool good = fast_kernel_lds_ok<M, C, CAP, false, -2, false>() && fast_kernel_lds_ok<M, C, CAP, false, -2, true>();
+        if constexpr (M <= 24) good = good && fast_kernel_lds_ok<M, verlet_scan_slots(M), (M <= 12 ? kCapVerlet : CAP), false, -2, true, true>();
         if constexpr (M > 12 && M <= 24)
-            good = good && fast_kernel_lds_ok<M, (M <= 16 ? 24 : 28), (M <= 16 ? 2048 : 1920), false, -2, false>();
+            good = good && fast_kernel_lds_ok<M, (M <= 16 ? 24 : 28), (M <= 16 ? 2048 : 1920), false, -2, false>() &&
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerletMid, false, -2, false, true>();
         if constexpr (M <= 12)
             good = good && fast_kernel_lds_ok<M, 16, kCapSteady, false, -2, false>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, 8, false>() &&
                    fast_kernel_lds_ok<M, 16, kCapSteady, false, 0, false>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, -3, false>() &&
                    fast_kernel_lds_ok<M, 16, kCapSteady, false, -2, true>() &&
                    // (the Verlet variants: their allocation is the larger of the search's and the list path's)
-                   fast_kernel_lds_ok<M, kVerletScanSlots, kCapVerlet, false, -2, false, true>() &&
-                   fast_kernel_lds_ok<M, kVerletScanSlots, kCapVerlet, false, 8, false, true>() &&
-                   fast_kernel_lds_ok<M, kVerletScanSlots, kCapVerlet, false, 0, false, true>() &&
-                   fast_kernel_lds_ok<M, kVerletScanSlots, kCapVerlet, false, -3, false, true>();
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, -2, false, true>() &&
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, 8, false, true>() &&
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, 0, false, true>() &&
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, -3, false, true>();
         // the diagnostic (option "stamps") instantiations launch_tile can reach
         if constexpr (M == 10)
             good = good && fast_kernel_lds_ok<M, 16, kCapSteady, true, -2, true>() && fast_kernel_lds_ok<M, 16, kCapSteady, true, -2, false>() &&
@@ -126,7 +128,7 @@ void launch_tile(TileLaunch &t)
         t.ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc, lr, un, vv_none)
     // steady state with Verlet lists: nn_fast_kernel<..., VERLET> answers from the lists where they still hold
 #define PPCR_FAST_V(FTMc, FMc)                                                                                          \
-    nn_fast_kernel<M, kVerletScanSlots, kCapVerlet, false, FTMc, false, true><<<grid_steady, 256, 0, t.stream>>>(                      \
+    nn_fast_kernel<M, verlet_scan_slots(M), kCapVerlet, false, FTMc, false, true><<<grid_steady, 256, 0, t.stream>>>(                      \
         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,    \
         t.ovf_next, split_on_v, nullptr, FMc, lr, un, vv)
     t.fused = false;
@@ -158,6 +160,23 @@ void launch_tile(TileLaunch &t)
         // (the mid-width steady-state variant — 28 slots, four workgroups per CU — was measured here as well: rows that search
         //  a level's whole radius accept more than 28 candidates more often, overflow twice and go to nn_wide_kernel: 3.92 k
         //  against 4.07 k it/s on the LiDAR-like scene, 4.13 k against 4.44 k on the slab.  Multi-level searches keep 32 slots.)
+        // Verlet lists in a multi-level search: every level's scan builds the lists of the rows whose reach its stencil covers
+        // (in base positions: to_base), nn_wide_kernel those of the rows it searches; a block whose rows' lists all hold —
+        // or all but a few: see the kernel — picks no level at all.  (No dispatch order: the two-workgroups-per-block grid
+        // is not the one the order's buffers were sized for.)
+        if constexpr (M <= 24) {
+            if (!done && !st && t.verlet_mode != 0 && t.dm2_in && t.short_lists) {
+                VerletLists vv = t.verlet;
+                vv.build_all = t.verlet_mode == 2 ? 0 : 1;
+                vv.order_now = nullptr, vv.order_next = nullptr, vv.count_now = nullptr, vv.count_next = nullptr, vv.count_clear = nullptr;
+                constexpr int CAPV = M <= 12 ? kCapVerlet : CAP;
+                nn_fast_kernel<M, verlet_scan_slots(M), CAPV, false, -2, true, true><<<grid_multi, 256, 0, t.stream>>>(
+                    t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
+                    two_per_block, nullptr, fm_none, lr, un, vv);
+                t.verlet_built = true;
+                done = true;
+            }
+        }
         if constexpr (M <= 12) {
             if (!done && t.dm2_in && t.short_lists) {
                 nn_fast_kernel<M, 16, kCapSteady, false, -2, true><<<grid_multi, 256, 0, t.stream>>>(
@@ -211,10 +230,23 @@ void launch_tile(TileLaunch &t)
     } else if constexpr (kMid) {
         if (t.dm2_in && t.short_lists && !halves && t.short_count != nullptr) {
             steady = true;
-            const SplitTable split_mid{t.split_flag, t.split_list, t.split_state, t.split_state + 1, kMaxSplit, CAP2 * 15 / 16, 0};
-            nn_fast_kernel<M, C2, CAP2, false, -2, false><<<nb + kMaxSplit, 256, 0, t.stream>>>(
-                t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
-                split_mid, nullptr, fm_none, lr, un, vv_none);
+            if (t.verlet_mode != 0 && !st) {
+                // Verlet lists (32 slots): rows are answered from their lists where those still hold; the rows this launch
+                // leaves unanswered — short rows of a two-pass search, a few failing rows of an answering workgroup — are
+                // searched AND given fresh lists by nn_wide_kernel below
+                VerletLists vv = t.verlet;
+                vv.build_all = t.verlet_mode == 2 ? 0 : 1;
+                const SplitTable split_mid_v{t.split_flag, t.split_list, t.split_state, t.split_state + 1, kMaxSplit, kCapVerletMid * 15 / 16, 0};
+                nn_fast_kernel<M, verlet_scan_slots(M), kCapVerletMid, false, -2, false, true><<<nb + kMaxSplit, 256, 0, t.stream>>>(
+                    t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
+                    split_mid_v, nullptr, fm_none, lr, un, vv);
+                t.verlet_built = true;
+            } else {
+                const SplitTable split_mid{t.split_flag, t.split_list, t.split_state, t.split_state + 1, kMaxSplit, CAP2 * 15 / 16, 0};
+                nn_fast_kernel<M, C2, CAP2, false, -2, false><<<nb + kMaxSplit, 256, 0, t.stream>>>(
+                    t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
+                    split_mid, nullptr, fm_none, lr, un, vv_none);
+            }
         }
     }
     if (!steady && !multi) {
@@ -239,8 +271,10 @@ void launch_tile(TileLaunch &t)
 #define PPCR_WIDE_PER_CU 6
 #endif
         constexpr int kWideGrid = 256 * PPCR_WIDE_PER_CU;  // six workgroups per CU are resident (74 VGPRs, 22 KB of LDS): 6144 waves, a row each
+        // (with Verlet lists in use the rows searched here get theirs; otherwise vl is null and the kernel is the plain search)
+        VerletLists vv_wide = t.verlet_built ? t.verlet : vv_none;
         nn_wide_kernel<M><<<kWideGrid, 256, 0, t.stream>>>(t.src, t.ns, t.tgt, t.cell_start, t.grid, t.reach, t.r2, t.r2_full, t.m, t.nbr,
-                                                            t.cnt, t.dm2, t.short_list, t.short_count, t.short_seen, t.loop_st);
+                                                            t.cnt, t.dm2, t.short_list, t.short_count, t.short_seen, t.loop_st, vv_wide);
         return;
     }
     // persistent workgroups over the list: few when the last association this handle heard from handed nothing over

@@ -730,18 +730,25 @@ __device__ __forceinline__ int wave_select_top_m(int *s_pos, unsigned *s_d2, int
     return base;
 }
 
+// vv.vl != nullptr: the rows searched here also get their Verlet lists (VerletLists) — one more sweep over the sphere of
+// radius G = the row's m-th distance (or the full radius where it has fewer than m neighbours) + 2 x skin, the nearest
+// verlet_slots(M) of what lies inside kept by the wave's selection — so that from the next association on nn_fast_kernel
+// answers them from their lists like any other row, for as long as the lists hold: the rows a two-pass search finds short
+// every time (a cloud's fringe, its sparse parts: thousands of rows, 13-55 us of this kernel per iteration at the command
+// line's defaults) come here once per list lifetime instead of once per iteration.
 template <int M>
 __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt,
                                                       const int *__restrict__ cell_start, GridDesc g, int reach, float r1_sq, float r2, int m,
                                                       int *__restrict__ nbr, int *__restrict__ cnt, unsigned *__restrict__ dm2,
                                                       const int *__restrict__ short_list, const unsigned *__restrict__ short_count,
-                                                      unsigned *__restrict__ short_seen, const LoopState *loop_st)
+                                                      unsigned *__restrict__ short_seen, const LoopState *loop_st, VerletLists vv)
 {
     constexpr int U = PPCR_WIDE_U;        // chunks of 64 candidates (loads per lane) in flight
-    constexpr int CAPW = PPCR_WIDE_CAPW;  // list entries per wave; compacted to m whenever a round of U * 64 might not fit
+    constexpr int CAPW = PPCR_WIDE_CAPW;  // list entries per wave; compacted whenever a round of U * 64 might not fit
     constexpr int PER = CAPW / 64;
     constexpr int CAPT = 1024;       // candidates of one batch of 64 runs that are walked as ONE flat sequence
-    static_assert(CAPW >= 2 * U * 64 && CAPW - U * 64 >= M, "a compaction leaves room for a round");
+    constexpr int CVs = verlet_slots(M);
+    static_assert(CAPW >= 2 * U * 64 && CAPW - U * 64 >= M && CAPW - U * 64 >= CVs, "a compaction leaves room for a round");
     if (loop_aborted(loop_st)) return;
     __shared__ int s_pos_all[4][CAPW];
     __shared__ unsigned s_d2_all[4][CAPW];
@@ -760,6 +767,7 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
         const int i = __builtin_amdgcn_readfirstlane(i_next);
         i_next = entry + gridDim.x * 4 < n_short ? short_list[entry + gridDim.x * 4] : 0;  // (travels under this row's search)
         const int found = __builtin_amdgcn_readfirstlane(cnt[i]);  // < 0: its workgroup left the first pass to this one
+        const unsigned prev_bits = (unsigned)__builtin_amdgcn_readfirstlane((int)dm2[i]);
         const float4 q = src[i];
         const QueryCells c = query_cells(q, g);
         const float fy = q.y - g.org[1], fz = q.z - g.org[2];
@@ -768,11 +776,15 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
         // the first attempt that holds m candidates ends the search (the m nearest overall are among the candidates within
         // ITS radius: everything beyond is farther than all of them).  The estimate: a row that found `found` < m points
         // within the first pass's radius r1 has m of them within ~r1 cbrt(m / found) if the density holds; an unsearched
-        // row (a workgroup whose halo outgrew the LDS tile: a dense neighbourhood) takes the density of its own cell.
+        // row (a workgroup whose halo outgrew the LDS tile, a row whose Verlet list ran out) takes its m-th distance of the
+        // previous association where it has one — the source has hardly moved since — and the density of its own cell
+        // where it has not.
         float R2;
         if (found >= 0) {
             const float k = cbrtf((float)m / fmaxf((float)found, 0.5f)) * 1.15f;
             R2 = r1_sq * k * k;
+        } else if (prev_bits != 0xFFFFFFFFu && vv.vl != nullptr) {
+            R2 = fminf(__uint_as_float(prev_bits) * 1.05f + 1e-30f, r2);
         } else {
             const bool inside = (unsigned)c.cx < (unsigned)g.n[0] && (unsigned)c.cy < (unsigned)g.n[1] && (unsigned)c.cz < (unsigned)g.n[2];
             const int cell = inside ? (c.cz * g.n[1] + c.cy) * g.n[0] + c.cx : 0;
@@ -784,12 +796,11 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
         R2 *= (1.0f / 2.25f);  // (the loop below grows before it scans)
         unsigned thr = 0;
         int n = 0;
-        for (;;) {
-            R2 = fminf(R2 * 2.25f, r2);
-            // d2 >= +0 and r2 > 0: "d2 < r2" is "bits(d2) <= bits(r2) - 1"; an intermediate radius may include its sphere's surface
-            thr = R2 < r2 ? __float_as_uint(R2) : __float_as_uint(r2) - 1u;
+        bool cut = false;  // a compaction dropped entries: what is left is complete only below thr
+        // one sweep over the sphere of radius^2 R2s around the query: every target whose d2 bits are <= thr is appended to the
+        // wave's list, which is compacted to its `keep` smallest (tightening thr) whenever a round might not fit
+        auto sweep = [&](const float R2s, const int keep) {
             n = 0;
-            const float R2s = R2 * 1.000004f;
             const int rows = min(reach, (int)(__builtin_amdgcn_sqrtf(R2s) * g.inv_h) + 1);  // cells the sphere can reach in y / z
             const int side = 2 * rows + 1, nrun = side * side;
             // lane l of batch k0: the (dy, dz) row k0 + l of the stencil, clipped to the x slices the sphere can touch there
@@ -822,6 +833,12 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
                 if (acc) s_pos[at] = pos, s_d2[at] = bits;
                 n += __popcll(k);
             };
+            auto make_room = [&]() {
+                if (n > CAPW - U * 64) {
+                    cut = cut || n > keep;
+                    n = wave_select_top_m<PER>(s_pos, s_d2, n, keep, tgt, lane, thr);
+                }
+            };
             int nb_, ne_;
             run_bounds(0, nb_, ne_);
             for (int k0 = 0; k0 < nrun; k0 += 64) {
@@ -839,7 +856,7 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
                     if (len > 0) s_mark[incl - len] = (unsigned char)(lane + 1);
                     int carry = 0;
                     for (int j0 = 0; j0 < total; j0 += U * 64) {
-                        if (n > CAPW - U * 64) n = wave_select_top_m<PER>(s_pos, s_d2, n, m, tgt, lane, thr);
+                        make_room();
                         int pos[U];
                         float4 t[U];
 #pragma unroll
@@ -873,7 +890,7 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
                             }
                         }
                         for (int off = 0; off < longest; off += 64) {
-                            if (n > CAPW - U * 64) n = wave_select_top_m<PER>(s_pos, s_d2, n, m, tgt, lane, thr);
+                            make_room();
                             float4 t[U];
 #pragma unroll
                             for (int u = 0; u < U; u++) t[u] = tgt[b[u] + min(off + lane, max(ln[u] - 1, 0))];
@@ -884,6 +901,12 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
                     }
                 }
             }
+        };
+        for (;;) {
+            R2 = fminf(R2 * 2.25f, r2);
+            // d2 >= +0 and r2 > 0: "d2 < r2" is "bits(d2) <= bits(r2) - 1"; an intermediate radius may include its sphere's surface
+            thr = R2 < r2 ? __float_as_uint(R2) : __float_as_uint(r2) - 1u;
+            sweep(R2 * 1.000004f, m);
             if (n >= m || !(R2 < r2)) break;
         }
         unsigned tm = 0xFFFFFFFFu;
@@ -893,6 +916,29 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
         }
         if (lane < n) nbr[(size_t)lane * ns + i] = s_pos[lane];
         if (lane == 0) cnt[i] = n, dm2[i] = tm;
+        if (vv.vl != nullptr) {
+            // ---- the row's Verlet list: everything within G of where the row is now -----------------------------------------
+            const float need = tm != 0xFFFFFFFFu ? __builtin_amdgcn_sqrtf(__uint_as_float(tm)) : __builtin_amdgcn_sqrtf(r2);
+            // (... as far as this grid's stencil reaches: `reach` cells of edge h around the query's own)
+            const float G = fminf(need + fmaxf(vv.skin2, vv.skin_rel * need), (float)reach * g.h * 0.999f);
+            const unsigned thr_g = __float_as_uint(G * G);
+            thr = thr_g;
+            cut = false;
+            sweep(G * G * 1.000004f, CVs);
+            if (n > CVs) {
+                n = wave_select_top_m<PER>(s_pos, s_d2, n, CVs, tgt, lane, thr);
+                cut = true;
+            }
+            // (cut: strictly below the farthest kept — equal distances beyond it were dropped; 0: no list)
+            const unsigned g2_bits = cut ? (thr > 0u ? thr - 1u : 0u) : thr_g;
+            if (lane < CVs) vv.vl[(size_t)lane * ns + i] = lane < n ? s_pos[lane] : 0;  // (every slot a valid position)
+            if (lane == 0) {
+                vv.vn[i] = (unsigned char)n;
+                vv.vg2[i] = __uint_as_float(g2_bits);
+                vv.vacc[i] = 0.f;
+                vv.vmask[i] = 0xFFFFFFFFu;  // (the association's row was not written from this list)
+            }
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) *short_seen = n_short;  // (diagnostic: ppcr_debug_get_short_rows)
 }
@@ -1024,6 +1070,23 @@ struct UnansweredRows {
                                //   256 of its rows span a halo no tile holds —: move the rows, list them all, try no tile
 };
 
+// A workgroup's unanswered rows go to the list in one piece (every thread calls; two barriers; `words`: six LDS words nobody
+// else touches at that moment).
+__device__ __forceinline__ void list_rows_of(const UnansweredRows &un, const bool mine, const int i, int *words)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long b = __ballot(mine);
+    if (lane == 0) words[wave] = __popcll(b);
+    lds_barrier();
+    const int c0 = words[0], c1 = words[1], c2 = words[2], c3 = words[3];
+    const int total_listed = c0 + c1 + c2 + c3;
+    if (total_listed == 0) return;  // (uniform)
+    if (threadIdx.x == 0) words[4] = (int)atomicAdd(un.count, (unsigned)total_listed);
+    lds_barrier();
+    const unsigned base = (unsigned)words[4] + (unsigned)(wave > 0 ? c0 : 0) + (unsigned)(wave > 1 ? c1 : 0) + (unsigned)(wave > 2 ? c2 : 0);
+    if (mine) un.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))] = i;
+}
+
 // Dispatch order of the Verlet variant's workgroups (VerletLists::order_*).  A workgroup that has to search again runs
 // ~3 times as long as one that answers from its lists; dispatched late, it IS the launch's tail (493 of 4035 workgroups
 // searching: 100 us where their share of the work is 69).  So every workgroup, when it is done, files its slot for the
@@ -1060,7 +1123,7 @@ __device__ __forceinline__ void verlet_forecast(const VerletLists &vv, unsigned 
 }
 
 // Answer a workgroup's rows from their Verlet lists (see VerletLists; called by nn_fast_kernel<..., VERLET> once every row
-// of the workgroup has passed the completeness test): kVerletSlots gathers of 16 bytes per row, the same float d2 as
+// of the workgroup has passed the completeness test): verlet_slots(M) gathers of 16 bytes per row, the same float d2 as
 // everywhere, the m smallest by (d2, original index), the association's row written in list order, K23 folded in from the
 // winners (compacted through LDS so that the f64 phase runs without the 48 coordinate registers).
 // thr: the association's threshold (radius and temporal cut-off in one, as the scan uses it); s_mem: at least
@@ -1081,7 +1144,7 @@ __device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, c
                                                    const FusedMoments &fm, const VerletLists &vv, unsigned char *s_mem,
                                                    const unsigned wg, const float g2, const float acc, const float moved, const float radius)
 {
-    constexpr int BLOCK = 256, CV = kVerletSlots, S = VerletLds<M>::kSlots;
+    constexpr int BLOCK = 256, CV = verlet_slots(M), S = VerletLds<M>::kSlots;
     static_assert(M <= CV && CV <= 32, "a list holds at least the m winners; the winners' slots fit a 32-bit mask");
     const int nl = valid ? (int)vv.vn[i] : 0;
     // which list slots the row's association (nbr / cnt) was written from last time (all-ones: somebody else wrote it)
@@ -1103,42 +1166,48 @@ __device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, c
     typedef unsigned v3u __attribute__((ext_vector_type(3)));
     float *const s_wx = reinterpret_cast<float *>(s_mem), *const s_wy = s_wx + S * BLOCK, *const s_wz = s_wy + S * BLOCK;
     unsigned in = 0;  // bit k: list entry k is (still) among the answer
-    // the entries' positions stay in registers until the association's row is written (re-loading them there — sixteen
-    // predicated load-then-store pairs, each a round trip of its own — cost every wave with ONE row whose members had changed
-    // 15 us: a third of the launch while the source still moves)
-    int pos[CV];
+    // Lists of up to 16 slots keep their entries' positions in registers until the association's row is written (re-loading
+    // them there one by one — predicated load-then-store pairs, each a round trip of its own — cost every wave with ONE row
+    // whose members had changed 15 us: a third of the launch while the source still moves); wider lists are measured in
+    // helpings of 16 entries and load the positions once more, all in flight together, where a row is written.
+    constexpr int H = CV <= 16 ? CV : 16;
+    constexpr bool kKeepPos = CV <= 16;
+    static_assert(CV % H == 0, "helpings of equal size");
+    int pos_kept[kKeepPos ? CV : 1];
     {
-        // every slot of a list is a valid position (the builders pad with 0), so nothing here is predicated
-#pragma unroll
-        for (int k = 0; k < CV; k++) {
-            const int p = list_pos(k);
-            pos[k] = valid ? p : 0;  // (a lane without a query read row 0's slots: whatever they hold is not a position to gather from)
-        }
-        float cx[CV], cy[CV], cz[CV];
-#pragma unroll
-        for (int k = 0; k < CV; k++) {
-            const v3u g = __builtin_amdgcn_raw_buffer_load_b96(rs_tgt, (int)((unsigned)pos[k] << 4), 0, 0);
-            cx[k] = __uint_as_float(g.x), cy[k] = __uint_as_float(g.y), cz[k] = __uint_as_float(g.z);
-        }
-        // Each entry is measured and — K23 folded in — its coordinates go to the lane's LDS cursor at once; only an entry
-        // within the threshold moves the cursor (as in nn_fast_kernel's scan), so the coordinate registers are free again
-        // entry by entry and a list of 24 fits the register budget a list of 16 had.  The cursor stops at the spare slot.
         int w = tid;
         const int w_spare = tid + (S - 1) * BLOCK;
 #pragma unroll
-        for (int k = 0; k < CV; k++) {
-            d2b[k] = (k < nl) ? __float_as_uint(dist2_flann(q, make_float4(cx[k], cy[k], cz[k], 0.f))) : 0xFFFFFFFFu;
-            const bool hit = d2b[k] <= thr;
-            in |= hit ? (1u << k) : 0u;
-#ifdef PPCR_DBG_NOSTORE
-            if constexpr (false) {
-#else
-            if constexpr (FTM != -2) {
-#endif
-                s_wx[w] = cx[k];
-                s_wy[w] = cy[k];
-                s_wz[w] = cz[k];
-                w = hit ? min(w + BLOCK, w_spare) : w;
+        for (int h0 = 0; h0 < CV; h0 += H) {
+            // every slot of a list is a valid position (the builders pad with 0), so nothing here is predicated
+            int pos[H];
+#pragma unroll
+            for (int u = 0; u < H; u++) {
+                const int p = list_pos(h0 + u);
+                pos[u] = valid ? p : 0;  // (a lane without a query read row 0's slots: whatever they hold is not a position to gather from)
+                if constexpr (kKeepPos) pos_kept[h0 + u] = pos[u];
+            }
+            float cx[H], cy[H], cz[H];
+#pragma unroll
+            for (int u = 0; u < H; u++) {
+                const v3u g = __builtin_amdgcn_raw_buffer_load_b96(rs_tgt, (int)((unsigned)pos[u] << 4), 0, 0);
+                cx[u] = __uint_as_float(g.x), cy[u] = __uint_as_float(g.y), cz[u] = __uint_as_float(g.z);
+            }
+            // Each entry is measured and — K23 folded in — its coordinates go to the lane's LDS cursor at once; only an entry
+            // within the threshold moves the cursor (as in nn_fast_kernel's scan), so the coordinate registers are free again
+            // entry by entry.  The cursor stops at the spare slot.
+#pragma unroll
+            for (int u = 0; u < H; u++) {
+                const int k = h0 + u;
+                d2b[k] = (k < nl) ? __float_as_uint(dist2_flann(q, make_float4(cx[u], cy[u], cz[u], 0.f))) : 0xFFFFFFFFu;
+                const bool hit = d2b[k] <= thr;
+                in |= hit ? (1u << k) : 0u;
+                if constexpr (FTM != -2) {
+                    s_wx[w] = cx[u];
+                    s_wy[w] = cy[u];
+                    s_wz[w] = cz[u];
+                    w = hit ? min(w + BLOCK, w_spare) : w;
+                }
             }
         }
     }
@@ -1186,12 +1255,27 @@ __device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, c
         // and 44 bytes per row of writes stay away (the m-th distance, which does change, always goes out)
         if (!PPCR_VERLET_MASK || in != was) {
             int *out = nbr + i;
+            if constexpr (kKeepPos) {
 #pragma unroll
-            for (int k = 0; k < CV; k++)
-                if ((in >> k) & 1u) {
-                    *out = pos[k];
-                    out += ns;
+                for (int k = 0; k < CV; k++)
+                    if ((in >> k) & 1u) {
+                        *out = pos_kept[k];
+                        out += ns;
+                    }
+            } else {
+#pragma unroll
+                for (int h0 = 0; h0 < CV; h0 += H) {
+                    int pos[H];
+#pragma unroll
+                    for (int u = 0; u < H; u++) pos[u] = list_pos(h0 + u);  // (all in flight, then the stores)
+#pragma unroll
+                    for (int u = 0; u < H; u++)
+                        if ((in >> (h0 + u)) & 1u) {
+                            *out = pos[u];
+                            out += ns;
+                        }
                 }
+            }
             cnt[i] = n;
             vv.vmask[i] = in;
         }
@@ -1203,11 +1287,7 @@ __device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, c
         // a row with more entries within the threshold than the lane's slots hold (three or more beyond the m winners: a few
         // rows in a thousand while the source still moves, none once it has stopped): its winners' coordinates are
         // gathered once more, into slots 0 .. n - 1
-#ifdef PPCR_DBG_NOLOST
-        const bool lost = false;
-#else
         const bool lost = n_first > S - 1;
-#endif
         if (__ballot(lost) != 0ull) {
             // (in two helpings of CV / 2 entries, each with its loads in flight together: one entry at a time was two dependent
             //  round trips per winner, 10 us for every wave that holds such a row — four in ten while the source moves 0.005 radii)
@@ -1259,149 +1339,6 @@ __device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, c
     verlet_forecast(vv, wg, valid && !(reach_next * reach_next < g2), reinterpret_cast<int *>(s_mem));
 }
 
-#if defined(PPCR_VERLET_ANSWER_V1)
-// (A/B only: the round-5 form of the list path — winners compacted into LDS after the selection)
-template <int M, int FTM>
-__device__ __forceinline__ void verlet_answer_rows_v1(const int tid, const int i, const bool valid, const float4 q, const int ns,
-                                                   const float4 *__restrict__ tgt, const unsigned thr, const int m,
-                                                   int *__restrict__ nbr, int *__restrict__ cnt, unsigned *__restrict__ dm2,
-                                                   const FusedMoments &fm, const VerletLists &vv, unsigned char *s_mem,
-                                                   const unsigned wg, const float g2, const float acc, const float moved, const float radius)
-{
-    constexpr int BLOCK = 256, CV = kVerletSlots;
-    static_assert(M <= CV && CV <= 32, "");
-    const int nl = valid ? (int)vv.vn[i] : 0;
-    // which list slots the row's association (nbr / cnt) was written from last time (all-ones: somebody else wrote it)
-    const unsigned was = valid ? vv.vmask[i] : 0xFFFFFFFFu;
-    // ---- re-measure the list: all index loads, then all gathers, in flight together --------------------------------
-    // Buffer loads (uniform descriptor + ONE 32-bit offset register per address): the sixteen list slots of a row share
-    // the lane's row offset (the slot is the scalar offset), a gather's address is the position * 16 — no 64-bit address
-    // pairs, so that all sixteen gathers are in flight together inside the register budget of four workgroups per CU.
-    // (host: ns < 2^26 and nt < 2^28 in this mode, so both byte ranges fit 32 bits)
-    // (Issuing these loads earlier — next to the query load, ahead of the completeness test, for the workgroups the
-    //  previous launch did not expect to search — was measured: 1M windows 10.55 k -> 9.71 k it/s, converged 13.35 k ->
-    //  12.74 k: 32 more loads in flight per lane crowd out the ones the test waits for.  Not kept.)
-    float cx[CV], cy[CV], cz[CV];
-    unsigned d2b[CV];
-    const unsigned row4 = (unsigned)(valid ? i : 0) * 4u;
-    const auto rs_vl = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(vv.vl), 0, (int)((unsigned)ns * (unsigned)(CV * 4)), 0x00020000);
-    const auto rs_tgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(tgt), 0, (int)vv.tgt_bytes, 0x00020000);
-    // list entry k of this row (a coalesced, cached load: the positions are not kept in registers between the gathers and the output)
-    auto list_pos = [&](int k) { return (int)__builtin_amdgcn_raw_buffer_load_b32(rs_vl, (int)row4, (int)((unsigned)k * (unsigned)ns * 4u), 0); };
-    {
-        // every slot of a list is a valid position (nn_fast_kernel pads with 0), so nothing here is predicated
-        int pos[CV];
-#pragma unroll
-        for (int k = 0; k < CV; k++) {
-            const int p = list_pos(k);
-            pos[k] = valid ? p : 0;  // (a lane without a query read row 0's slots: whatever they hold is not a position to gather from)
-        }
-#pragma unroll
-        for (int k = 0; k < CV; k++) {
-            typedef unsigned v3u __attribute__((ext_vector_type(3)));
-            const v3u g = __builtin_amdgcn_raw_buffer_load_b96(rs_tgt, (int)((unsigned)pos[k] << 4), 0, 0);
-            cx[k] = __uint_as_float(g.x), cy[k] = __uint_as_float(g.y), cz[k] = __uint_as_float(g.z);
-        }
-    }
-    unsigned in = 0;  // bit k: list entry k is (still) among the answer
-#pragma unroll
-    for (int k = 0; k < CV; k++) {
-        d2b[k] = (k < nl) ? __float_as_uint(dist2_flann(q, make_float4(cx[k], cy[k], cz[k], 0.f))) : 0xFFFFFFFFu;
-        in |= (d2b[k] <= thr) ? (1u << k) : 0u;
-    }
-    int n = __popc(in);
-    // ---- more than m within the threshold: the largest by (d2, original index) leave, one per round ------------------
-    int surplus = n - m;
-    while (__ballot(surplus > 0) != 0ull) {
-        if (surplus > 0) {
-            unsigned best = 0;
-#pragma unroll
-            for (int k = 0; k < CV; k++) best = max(best, ((in >> k) & 1u) ? d2b[k] : 0u);
-            int bk = 0, ties = 0;
-#pragma unroll
-            for (int k = 0; k < CV; k++) {
-                const bool hit = ((in >> k) & 1u) && d2b[k] == best;
-                bk = hit ? k : bk;
-                ties += hit ? 1 : 0;
-            }
-            if (ties > 1) {  // equal distances at the boundary: the larger original index leaves (the oracle's order)
-                unsigned worst = 0;
-#pragma unroll
-                for (int k = 0; k < CV; k++)
-                    if (((in >> k) & 1u) && d2b[k] == best) {
-                        const unsigned o = __builtin_amdgcn_raw_buffer_load_b32(rs_tgt, (int)(((unsigned)list_pos(k) << 4) + 12u), 0, 0);
-                        if (o >= worst) worst = o, bk = k;
-                    }
-            }
-            in &= ~(1u << bk);
-            surplus--;
-        }
-    }
-    n = min(n, m);
-    unsigned tm = 0xFFFFFFFFu;  // d2 bits of the m-th neighbour (all-ones: fewer than m)
-    if (n == m) {
-        tm = 0;
-#pragma unroll
-        for (int k = 0; k < CV; k++) tm = max(tm, ((in >> k) & 1u) ? d2b[k] : 0u);
-    }
-    if (valid) {
-        // the association's row only when its members changed: in a registration that has all but converged they do not,
-        // and 44 bytes per row of writes stay away (the m-th distance, which does change, always goes out)
-        if (!PPCR_VERLET_MASK || in != was) {
-            int *out = nbr + i;
-#pragma unroll
-            for (int k = 0; k < CV; k++)
-                if ((in >> k) & 1u) {
-                    *out = list_pos(k);
-                    out += ns;
-                }
-            cnt[i] = n;
-            vv.vmask[i] = in;
-        }
-        dm2[i] = tm;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (FTM != -2) {
-        // ---- K23 for this row at fm.P.  The winners' coordinates are compacted into LDS first — every list entry is
-        // stored at the lane's cursor, only a winner moves it, as in nn_fast_kernel's scan — so that the 48 coordinate
-        // registers are free while the f64 moments are formed, and the loop below runs over n pairs, not 16 predicated ones
-        float *const s_wx = reinterpret_cast<float *>(s_mem), *const s_wy = s_wx + VerletLds<M>::kSlots * BLOCK, *const s_wz = s_wy + VerletLds<M>::kSlots * BLOCK;
-        {
-            int w = tid;
-#pragma unroll
-            for (int k = 0; k < CV; k++) {
-                s_wx[w] = cx[k];
-                s_wy[w] = cy[k];
-                s_wz[w] = cz[k];
-                w += ((in >> k) & 1u) ? BLOCK : 0;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);  // (nothing of the f64 phase is to be hoisted above the stores that free the registers)
-        RowAcc sums;
-#pragma unroll
-        for (int j = 0; j < kNSums; j++) sums.a[j] = 0.0;
-        if (valid && n > 0) {
-            double xr[3];
-            rotated_point(fm.P, q, xr);
-            RowMoments<FTM> row;
-            row.begin(fm.md);
-#pragma unroll
-            for (int j = 0; j < M; j++)
-                if (j < n) row.add_pair(fm.md, xr, s_wx[j * BLOCK + tid], s_wy[j * BLOCK + tid], s_wz[j * BLOCK + tid]);  // (a lane reads what it wrote)
-            row.finish(sums, fm.P, q, xr);
-        }
-        __syncthreads();  // every lane is through with its winners: the fold borrows the memory
-        double *const scratch = reinterpret_cast<double *>(s_mem);
-        block_reduce_scratch(sums, scratch, scratch + 10 * 257, fm.partials + wg, (size_t)fm.nslots, true);
-        __syncthreads();  // (the forecast below borrows a word of the same memory)
-    }
-    // will this row's list still do after one more move like the last one?  (VerletLists' test with the new m-th distance)
-    const float need_next = (tm != 0xFFFFFFFFu ? __builtin_amdgcn_sqrtf(__uint_as_float(tm)) : radius) + moved;
-    const float reach_next = (need_next + acc + moved) * 1.0001f;
-    verlet_forecast(vv, wg, valid && !(reach_next * reach_next < g2), reinterpret_cast<int *>(s_mem));
-}
-
-#endif
 // PER-ROW REBUILD.  The completeness test is per row; sending a workgroup's 256 rows through the search because ONE of them
 // failed (the ~30 us chain of the tiled search, against ~10 us for answering) was the steady state's largest cost: a row
 // whose list has little room — sixteen targets hardly farther than its tenth — fails every few iterations, and one
@@ -1416,20 +1353,32 @@ __device__ __forceinline__ void verlet_answer_rows_v1(const int tid, const int i
 #ifndef PPCR_VERLET_ROWS
 #define PPCR_VERLET_ROWS 0
 #endif
-constexpr int kVerletRowCap = 128;  // entries of a wave's candidate list (compacted to the sixteen nearest when a round might not fit)
+// ... where the kernel's unanswered rows are searched one row per wave anyway (nn_wide_kernel: two-pass and multi-level
+// searches), a workgroup with at most this many failing rows lists them there and answers the others
+#ifndef PPCR_VERLET_LIST_ROWS
+#define PPCR_VERLET_LIST_ROWS 4
+#endif
+constexpr int kVerletRowCap = 128;  // entries of a wave's candidate list (compacted to the list's slots when a round might not fit)
+template <int ROWS>
 struct VerletRowLds {
     int pos[4][kVerletRowCap];
     unsigned d2[4][kVerletRowCap];
-    float4 q[PPCR_VERLET_ROWS > 0 ? PPCR_VERLET_ROWS : 1];     // the failing rows: query (w: the bound `need` on its m-th distance) ...
-    int row[PPCR_VERLET_ROWS > 0 ? PPCR_VERLET_ROWS : 1];      // ... row index ...
-    float g2[PPCR_VERLET_ROWS > 0 ? PPCR_VERLET_ROWS : 1];     // ... and, coming back, the new list's reach
+    float4 q[ROWS > 0 ? ROWS : 1];     // the failing rows: query (w: the bound `need` on its m-th distance) ...
+    int row[ROWS > 0 ? ROWS : 1];      // ... row index ...
+    float g2[ROWS > 0 ? ROWS : 1];     // ... and, coming back, the new list's reach
 };
+// rows a workgroup rebuilds one by one before it gives in and searches: the widths with K23 folded in — none (measured:
+// PPCR_VERLET_ROWS above); the mid widths (the command line's 20 neighbours: clouds of a few hundred blocks, ONE residency
+// round, where a searching workgroup is the launch's length, and a launch of nn_wide_kernel for a handful of rows costs
+// 20 us of latency) — eight
+constexpr int verlet_rows_in_kernel(int M) { return M > 12 ? 8 : PPCR_VERLET_ROWS; }
 // one wave, one row: i / q / need are wave-uniform (read from LDS)
+template <int CVS>
 __device__ __forceinline__ float verlet_rebuild_row(const int i, const float4 q, const float need, const int ns, const float4 *__restrict__ tgt,
                                                     const int *__restrict__ cell_start, const GridDesc &g, const VerletLists &vv,
                                                     const int lane, int *s_pos, unsigned *s_d2)
 {
-    const float bnd = need + vv.skin2;
+    const float bnd = need + fmaxf(vv.skin2, vv.skin_rel * need);
     const unsigned thr_v = __float_as_uint(bnd * bnd);  // the scan's acceptance threshold (nn_fast_kernel: thr_v)
     unsigned thr = thr_v;
     const float R2s = bnd * bnd * 1.000004f;
@@ -1469,7 +1418,7 @@ __device__ __forceinline__ float verlet_rebuild_row(const int i, const float4 q,
     bool cut = false;  // entries were dropped: the list is complete only strictly below the farthest kept
     for (int j0 = 0; j0 < total; j0 += 64) {
         if (n > kVerletRowCap - 64) {
-            n = wave_select_top_m<kVerletRowCap / 64>(s_pos, s_d2, n, kVerletSlots, tgt, lane, thr);
+            n = wave_select_top_m<kVerletRowCap / 64>(s_pos, s_d2, n, CVS, tgt, lane, thr);
             cut = true;
         }
         const int j = j0 + lane;
@@ -1485,13 +1434,13 @@ __device__ __forceinline__ float verlet_rebuild_row(const int i, const float4 q,
         if (acc) s_pos[at] = pos, s_d2[at] = bits;
         n += __popcll(k);
     }
-    if (n > kVerletSlots) {
-        n = wave_select_top_m<kVerletRowCap / 64>(s_pos, s_d2, n, kVerletSlots, tgt, lane, thr);
+    if (n > CVS) {
+        n = wave_select_top_m<kVerletRowCap / 64>(s_pos, s_d2, n, CVS, tgt, lane, thr);
         cut = true;
     }
     // (strictly below the farthest kept: equal distances beyond it were dropped; 0: no list — sixteen targets at distance 0)
     const unsigned g2_bits = cut ? (thr > 0u ? thr - 1u : 0u) : thr_v;
-    if (lane < kVerletSlots) vv.vl[(size_t)lane * ns + i] = lane < n ? s_pos[lane] : 0;  // (every slot a valid position)
+    if (lane < CVS) vv.vl[(size_t)lane * ns + i] = lane < n ? s_pos[lane] : 0;  // (every slot a valid position)
     if (lane == 0) {
         vv.vn[i] = (unsigned char)n;
         vv.vg2[i] = __uint_as_float(g2_bits);
@@ -1545,7 +1494,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
     // then this one must touch nothing.  A uniform scalar load, tested below once the query load is in flight.
     const unsigned aborted = lr.st ? lr.st->abort : 0u;
     static_assert(C > M, "a re-scan must leave room in the list");
-    static_assert(!VERLET || (C >= kVerletSlots && !MULTI && !STAMPS), "Verlet lists are built by the steady-state variant: a list is the nearest part of the scan's LDS list");
+    static_assert(!VERLET || (C >= verlet_slots(M) && !STAMPS), "Verlet lists are built by the steady-state variant: a list is the nearest part of the scan's LDS list");
     static_assert(!MULTI || FTM == -2, "a multi-level search leaves rows to nn_wide_kernel: K23 is its own kernel");
     static_assert(FTM == -2 || (3 * CAP + CAP / 4) * 4 >= kFoldScratchBytes, "the final fold borrows the halo buffer");
     static_assert(CAP % 4 == 0 && CAP * 4 < 65536, "list entries are 16-bit byte offsets into the halo arrays");
@@ -1558,7 +1507,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
     // tests/test_gpu_parity.py builds and runs) — the scan stores at its cursor without clamping it to the list's end:
     // two v_min_u32 less on a 22-VALU trip (2508 -> 2427 VALU per wave, +1.6 % iterations/s; -DPPCR_LIST_NOCLAMP=0 is
     // the clamped form with separate arrays).
-    using Lds = FastLds<C, CAP, MULTI, (VERLET ? M : 0)>;
+    using Lds = FastLds<C, CAP, MULTI, ((VERLET && FTM != -2) ? M : 0)>;  // (the list path keeps coordinates in LDS only where K23 is folded in)
     constexpr int kListBytes = Lds::kListBytes, kOffGbo = Lds::kOffGbo, kOffBox = Lds::kOffBox, kOffBail = Lds::kOffBail,
                   kOffNeed = Lds::kOffNeed, kOffList = Lds::kOffList;
     static_assert(BLOCK == 256 && kWaves == 4 && kRows == 128, "FastLds mirrors these");
@@ -1702,23 +1651,39 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
     // bound is inflated by 1e-5 (float rounding of d2 and of the two roots is ~1e-6 relative); the final selection is
     // exact — only the amount of list traffic changes.
     unsigned thr0 = 0xFFFFFFFFu;
+    // VERLET: the same bound against the FULL radius (a two-pass search's first-pass radius r2_0 is smaller: a row whose m-th
+    // neighbour lies beyond it has no cut-off for the tiled scan, but nn_wide_kernel gave it one — and a list — all the same)
+    // (K23 folded in: a one-pass search — its radius IS the full radius, and the argument is at hand in a register)
+    const float r2_far = (FTM != -2) ? r2_0 : un.r2_full;
+    float need2_full = r2_far;
     if (dm2_valid && valid) {
         const unsigned prev = dm2[i];
         if (prev != 0xFFFFFFFFu) {
             const float bound = __builtin_amdgcn_sqrtf(__uint_as_float(prev)) + moved;
             const float t2 = bound * bound * 1.00001f + 1e-30f;
             thr0 = (t2 < (MULTI ? un.r2_full : r2_0)) ? __float_as_uint(t2) : 0xFFFFFFFFu;
+            need2_full = fminf(t2, r2_far);
         }
     }
     // VERLET: the scan collects every target within G = bound + 2 skin (the bound on the m-th distance, or the radius for a
-    // row that has none); the grid was built with cells of at least radius + 2 skin, so the stencil covers G
+    // row that has none) — where its stencil covers G: the grid's cells are at least (first-pass) radius + 2 skin wide, so
+    // in a one-pass search always, in a two-pass search for the rows whose bound lies inside the first-pass radius (the
+    // others' lists are built by nn_wide_kernel, which searches them anyway)
     unsigned thr_v = 0;
-    float need = 0.f;
+    float need = 0.f, bnd_v = 0.f;
+    bool scan_lists = false;  // this launch's scan (if it comes to that) builds this row's list (decided once the grid is known)
+    bool plain_search = false;  // (VerletLists::streak: this block keeps searching — no lists from its scan)
     if constexpr (VERLET) {
-        // how far the m-th neighbour (or, without a cut-off, the radius) can be from the query where it is now
-        need = __builtin_amdgcn_sqrtf(thr0 != 0xFFFFFFFFu ? __uint_as_float(thr0) : r2_0);
-        const float bnd = need + vv.skin2;
-        thr_v = __float_as_uint(bnd * bnd);
+        // how far the m-th neighbour (or, without a bound, the radius) can be from the query where it is now
+        need = __builtin_amdgcn_sqrtf(need2_full);
+        bnd_v = need + (MULTI ? fmaxf(vv.skin2, vv.skin_rel * need) : vv.skin2);
+        // `near`: the 27-cell stencil of the BASE grid covers the list's reach — the row's list can be rebuilt in this
+        // kernel, one row per wave; the others' bounds lie beyond (a two-pass search's short rows, a multi-level search's
+        // rows of coarser levels): nn_wide_kernel's
+        // (K23 folded in: a one-pass, single-level search — every row is near, and nothing below is compiled for the others)
+        const bool near = (FTM != -2) ? true : (bnd_v <= g0.h);
+        if constexpr (FTM == -2)
+            if (vv.build_all && tid == 0 && vv.streak != nullptr) vv.streak[wg] = 0;  // (a launch that builds every list starts the count over)
         if (!vv.build_all) {
             // ---- are the lists still complete?  (VerletLists: need + path travelled < the list's reach, with float slack) ----
             float g2 = 0.f, acc = 0.f;
@@ -1732,60 +1697,101 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
             const bool is_point = (q.x - q.x) == 0.f && (q.y - q.y) == 0.f && (q.z - q.z) == 0.f;
             const bool ok = !valid || reach * reach < g2 || !is_point;
             // the workgroup's verdict through four words of s_gbo (idle until the row table is built, two barriers from here)
-            const unsigned long long failing = __ballot(!ok);  // (every lane votes: NOT inside the one-lane store below)
-            if (lane == 0) s_gbo[wave] = __popcll(failing);
+            // failing rows: `near` — the list can be rebuilt from the 27-cell stencil, here or by the tiled scan — and `far` —
+            // the row's bound lies beyond the first pass's radius: nn_wide_kernel's
+            const unsigned long long failing = __ballot(!ok && near), failing_far = __ballot(!ok && !near);  // (every lane votes)
+            if (lane == 0) s_gbo[wave] = __popcll(failing) | (__popcll(failing_far) << 16);
             lds_barrier();
-            const int f0 = s_gbo[0], f1 = s_gbo[1], f2 = s_gbo[2], f3 = s_gbo[3];
-            const int n_fail = f0 + f1 + f2 + f3;
+            const int w0 = s_gbo[0], w1 = s_gbo[1], w2 = s_gbo[2], w3 = s_gbo[3];
+            const int f0 = w0 & 0xFFFF, f1 = w1 & 0xFFFF, f2 = w2 & 0xFFFF, f3 = w3 & 0xFFFF;
+            const int n_near = f0 + f1 + f2 + f3, n_far = (w0 >> 16) + (w1 >> 16) + (w2 >> 16) + (w3 >> 16);
+            const int n_fail = n_near + n_far;
             lds_barrier();  // (everybody has read the verdict: the list path writes its winners over these words)
             bool all_ok = n_fail == 0;
             // (diagnostic: how many rows fail where any does — 1, 2-4, 5-16, more)
             if (tid == 0 && n_fail > 0 && vv.rebuilt != nullptr) atomicAdd(vv.rebuilt + 12 + (n_fail > 16 ? 3 : n_fail > 4 ? 2 : n_fail > 1 ? 1 : 0), 1u);
-            if constexpr (PPCR_VERLET_ROWS > 0) {
-                if (n_fail > 0 && n_fail <= PPCR_VERLET_ROWS) {
-                    // the failing rows, in row order, into LDS; each wave rebuilds every fourth of them (see verlet_rebuild_row)
-                    VerletRowLds &rl = *reinterpret_cast<VerletRowLds *>(s_all);
-                    static_assert(sizeof(VerletRowLds) <= (size_t)Lds::kOffGbo, "the row-rebuild scratch sits below the verdict words");
-                    const int slot = (wave > 0 ? f0 : 0) + (wave > 1 ? f1 : 0) + (wave > 2 ? f2 : 0) +
-                                     __builtin_amdgcn_mbcnt_hi((unsigned)(failing >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)failing, 0u));
-                    if (!ok) {
-                        rl.q[slot] = make_float4(q.x, q.y, q.z, need);
-                        rl.row[slot] = i;
+            bool answers = true;  // this lane's row is answered from its list
+            constexpr int kRows = verlet_rows_in_kernel(M);
+            // A FEW failing rows: the near ones are rebuilt here, one row per wave (verlet_rebuild_row), and answered with
+            // the others; the far ones go to nn_wide_kernel's list (where there is one: two-pass and multi-level searches,
+            // every launch that folds nothing in), which answers them and leaves them fresh lists.  More than a few: the
+            // tiled search, which renews all 256 lists at once (a workgroup's rows age together; tools/exp_verlet_rows.py).
+            // (K23 folded in and no rows rebuilt in the kernel: none of this is compiled — the verdict is all or nothing)
+            bool few = false;
+            if constexpr (FTM == -2 || kRows > 0) {
+                const bool far_ok = n_far == 0 || (FTM == -2 && un.list != nullptr && n_far <= PPCR_VERLET_LIST_ROWS);
+                const bool near_ok = n_near == 0 || n_near <= kRows || (FTM == -2 && un.list != nullptr && n_fail <= PPCR_VERLET_LIST_ROWS);
+                few = !all_ok && far_ok && near_ok;
+            }
+            if (few) {
+                bool to_wide = !ok && !near;  // this lane's row goes to nn_wide_kernel
+                if constexpr (kRows > 0) {
+                    if (n_near > 0 && n_near <= kRows) {
+                        // the failing rows, in row order, into LDS; each wave rebuilds every fourth of them
+                        VerletRowLds<kRows> &rl = *reinterpret_cast<VerletRowLds<kRows> *>(s_all);
+                        static_assert(sizeof(VerletRowLds<kRows>) <= (size_t)Lds::kOffGbo, "the row-rebuild scratch sits below the verdict words");
+                        const int slot = (wave > 0 ? f0 : 0) + (wave > 1 ? f1 : 0) + (wave > 2 ? f2 : 0) +
+                                         __builtin_amdgcn_mbcnt_hi((unsigned)(failing >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)failing, 0u));
+                        const bool mine = !ok && near;
+                        if (mine) {
+                            rl.q[slot] = make_float4(q.x, q.y, q.z, need);
+                            rl.row[slot] = i;
+                        }
+                        lds_barrier();
+                        for (int f = wave; f < n_near; f += kWaves) {
+                            const float4 fq = rl.q[f];
+                            const int fi = __builtin_amdgcn_readfirstlane(rl.row[f]);
+                            const float fg = verlet_rebuild_row<verlet_slots(M)>(fi, make_float4(fq.x, fq.y, fq.z, 0.f), fq.w, ns, tgt0, cell_start0, g0, vv, lane,
+                                                                                 rl.pos[wave], rl.d2[wave]);
+                            if (lane == 0) rl.g2[f] = fg;
+                        }
+                        __syncthreads();  // (the lists the other waves wrote: global memory, read back by the list path below)
+                        if (mine) {
+                            g2 = rl.g2[slot];
+                            acc = 0.f;
+                        }
+                        __syncthreads();  // (everybody has its g2: the list path may write over this memory)
+                    } else {
+                        to_wide = !ok;  // (more near rows than are rebuilt here, few enough for nn_wide_kernel)
                     }
-                    lds_barrier();
-                    for (int f = wave; f < n_fail; f += kWaves) {
-                        const float4 fq = rl.q[f];
-                        const int fi = __builtin_amdgcn_readfirstlane(rl.row[f]);
-                        const float fg = verlet_rebuild_row(fi, make_float4(fq.x, fq.y, fq.z, 0.f), fq.w, ns, tgt0, cell_start0, g0, vv, lane, rl.pos[wave], rl.d2[wave]);
-                        if (lane == 0) rl.g2[f] = fg;
-                    }
-                    __syncthreads();  // (the lists the other waves wrote: global memory, read back by the list path below)
-                    if (!ok) {
-                        g2 = rl.g2[slot];
-                        acc = 0.f;
-                    }
-                    if (tid == 0 && vv.rebuilt != nullptr) {
-                        atomicAdd(vv.rebuilt + 1, (unsigned)n_fail);
-                        atomicAdd(vv.rebuilt + 2, 1u);
-                    }
-                    __syncthreads();  // (everybody has its g2: the list path writes its winners over this memory)
-                    all_ok = true;
+                } else {
+                    to_wide = !ok;
                 }
+                if constexpr (FTM == -2) {
+                    if (un.list != nullptr && (n_far > 0 || (n_near > 0 && !(kRows > 0 && n_near <= kRows)))) {
+                        answers = !to_wide;
+                        if (valid && to_wide) cnt[i] = -1;
+                        list_rows_of(un, valid && to_wide, i, s_gbo);
+                    }
+                }
+                if (tid == 0 && vv.rebuilt != nullptr) {
+                    atomicAdd(vv.rebuilt + 1, (unsigned)n_fail);
+                    atomicAdd(vv.rebuilt + 2, 1u);
+                }
+                all_ok = true;
             }
             if (all_ok) {
                 if (valid) vv.vacc[i] = acc;
-#if defined(PPCR_VERLET_ANSWER_V1)
-                verlet_answer_rows_v1<M, FTM>(
-#else
-                verlet_answer_rows<M, FTM>(
-#endif
-                    tid, i, valid, q, ns, tgt0, min(thr0, __float_as_uint(r2_0) - 1u), m, nbr, cnt, dm2, fm, vv, s_all,
-                                           wg, g2, acc, moved, __builtin_amdgcn_sqrtf(r2_0));
+                if constexpr (FTM == -2)
+                    if (tid == 0 && vv.streak != nullptr) {
+                        const unsigned st = vv.streak[wg];
+                        if (st != 0) vv.streak[wg] = (unsigned char)(st > 2u ? st - 2u : 0u);
+                    }
+                // (the association's own threshold: the bound where there is one, strictly inside the full radius)
+                const unsigned thr_row = need2_full < r2_far ? __float_as_uint(need2_full) : __float_as_uint(r2_far) - 1u;
+                verlet_answer_rows<M, FTM>(tid, i, valid && answers, q, ns, tgt0, thr_row, m, nbr, cnt, dm2, fm, vv, s_all, wg, g2, acc, moved,
+                                           __builtin_amdgcn_sqrtf(r2_far));
                 return;
             }
             if (tid == 0 && vv.rebuilt != nullptr) {  // (diagnostic: workgroups that searched again)
                 atomicAdd(vv.rebuilt, 1u);
                 atomicAdd(vv.searched_now, 1u);
+            }
+            if (FTM == -2 && vv.streak != nullptr) {  // (uniform: one byte per workgroup, read by everybody, written by one)
+                const unsigned st = vv.streak[wg];
+                plain_search = st >= 8u && (wg & 15u) != vv.launch_tag;
+                __builtin_amdgcn_s_barrier();  // (everybody has read it)
+                if (tid == 0) vv.streak[wg] = (unsigned char)min(st + 4u, 16u);
             }
         }
     }
@@ -1808,7 +1814,8 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
             // cloud's edge then drags its whole block to a level whose halo no tile holds (uniform 200k cloud at radius 3:
             // 22 % of the rows sit in such blocks).  Each lane finds the finest level that covers its own cut-off, the
             // waves count their lanes per level, the block adds the counts up.
-            const float need_f = __uint_as_float(min(thr0, __float_as_uint(un.r2_full)));  // no cut-off: the full radius
+            // (VERLET: by the reach of the row's list — the level that covers it builds it)
+            const float need_f = (VERLET && !plain_search) ? bnd_v * bnd_v : __uint_as_float(min(thr0, __float_as_uint(un.r2_full)));  // no cut-off: the full radius
             int mine = un.n_levels - 1;
 #pragma unroll
             for (int l = kMaxLevels - 2; l >= 0; l--)
@@ -1840,6 +1847,13 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
     const float4 *__restrict__ const tgt = MULTI ? tgt_l : tgt0;
     const int *__restrict__ const cell_start = MULTI ? cell_start_l : cell_start0;
     const float r2 = MULTI ? r2_l : r2_0;
+    if constexpr (VERLET) {
+        // the scan builds the lists of the rows whose reach its stencil covers (cells of at least the (first-pass / level's)
+        // radius + 2 skin: in a one-pass search every row); the others are scanned as the plain search would — their own
+        // cut-off, no margin — and get their lists from nn_wide_kernel when it searches them
+        scan_lists = (FTM != -2) ? true : (bnd_v <= g.h && !plain_search);
+        thr_v = scan_lists ? __float_as_uint(bnd_v * bnd_v) : min(thr0, __float_as_uint(r2));
+    }
     const QueryCells qc = query_cells(q, g);
 
     // ---- the nine stencil runs [rb, re) in sorted-target positions, clipped in x --------------------------------
@@ -1991,18 +2005,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
     // over before that table is written, while slower waves may still be reading the boxes).  One atomic per WAVE
     // was 3 000 of them on one counter within a few microseconds at the end of a one-round launch (a 200k-point cloud: every
     // workgroup reaches its end at about the same time), and same-address atomics are served one by one.
-    auto list_rows = [&](bool mine, int *words) {
-        const unsigned long long b = __ballot(mine);
-        if (lane == 0) words[wave] = __popcll(b);
-        lds_barrier();
-        const int c0 = words[0], c1 = words[1], c2 = words[2], c3 = words[3];
-        const int total_listed = c0 + c1 + c2 + c3;
-        if (total_listed == 0) return;  // (uniform)
-        if (tid == 0) words[4] = (int)atomicAdd(un.count, (unsigned)total_listed);
-        lds_barrier();
-        const unsigned base = (unsigned)words[4] + (unsigned)(wave > 0 ? c0 : 0) + (unsigned)(wave > 1 ? c1 : 0) + (unsigned)(wave > 2 ? c2 : 0);
-        if (mine) un.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))] = i;
-    };
+    auto list_rows = [&](bool mine, int *words) { list_rows_of(un, mine, i, words); };
     if (handed_over) {
         // the cleanup kernel redoes this workgroup's queries (this launch): entry = grid index * 4 + half — or, when the
         // unanswered rows are listed, nn_wide_kernel searches them (marked unsearched)
@@ -2143,7 +2146,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
         // d2 >= +0 and r2 > 0, so "d2 < r2" is "bits(d2) <= bits(r2) - 1" (a NaN d2 has larger bits and fails): the
         // radius test and the running cut-off are ONE unsigned compare per candidate
         const unsigned thr_a = min(thr0, __float_as_uint(r2) - 1u);  // the association's own threshold
-        unsigned thr = VERLET ? thr_v : thr_a;                       // what the scan accepts
+        unsigned thr = (VERLET && scan_lists) ? thr_v : thr_a;       // what the scan accepts
         typedef float v2f __attribute__((ext_vector_type(2)));
         const v2f qx2 = {q.x, q.x}, qy2 = {q.y, q.y}, qz2 = {q.z, q.z};
         // LDS addresses as plain 32-bit integers (address space 3): the write cursor and the candidate cursor are
@@ -2197,8 +2200,8 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
                 // more than C targets within the list's reach (one row in 10^5 at the benchmark's density): a quarter of the
                 // skin first — a list with less room, rebuilt sooner, but not one without any room, which would send its
                 // workgroup through the search in every iteration
-                if (PPCR_VERLET_RETRY && attempt == 0) {
-                    const float b = need + 0.25f * vv.skin2;
+                if (PPCR_VERLET_RETRY && attempt == 0 && scan_lists) {
+                    const float b = need + 0.25f * (bnd_v - need);
                     thr = __float_as_uint(b * b);
                     continue;
                 }
@@ -2214,24 +2217,52 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
         }
         if constexpr (VERLET) {
             // The row's Verlet list: what the scan accepted (every target whose d2 bits are <= thr; the scan's lists are half
-            // as long again as a Verlet list), cut back to kVerletSlots entries where there are more.
-            if (n > kVerletSlots) {
-                // the sixteen NEAREST stay; the list is complete below the farthest of them (for the typical row the 16th
-                // neighbour's distance against the 10th's: 0.14 radii of room at the benchmark's density).  Cutting by reach
-                // instead — the largest of need + skin / 2, / 4, / 8 that holds at most sixteen: a quarter of the selection's
-                // instructions — was measured: the lists' room shrinks, a fifth more workgroups search per iteration and the
-                // timed windows lose 10 % (11.47 k -> 10.32 k it/s at 1M).
-                unsigned t_far = 0;
-                n = select_top_m<kVerletSlots>(L, tgt, q, n, kVerletSlots, t_far);
-                thr = t_far > 0u ? t_far - 1u : 0u;  // (strictly below the farthest kept: equal distances beyond it were dropped)
+            // as long again as a Verlet list), cut back to the list's slots where there are more.
+            constexpr int CVs = verlet_slots(M);
+            bool listed = scan_lists && n >= 0;
+            if (listed && n > CVs) {
+                if constexpr (M <= 12) {
+                    // the sixteen NEAREST stay; the list is complete below the farthest of them (for the typical row the 16th
+                    // neighbour's distance against the 10th's: 0.14 radii of room at the benchmark's density).  Cutting by reach
+                    // instead — the largest of need + skin / 2, / 4, / 8 that holds at most sixteen: a quarter of the selection's
+                    // instructions — was measured: the lists' room shrinks, a fifth more workgroups search per iteration and the
+                    // timed windows lose 10 % (11.47 k -> 10.32 k it/s at 1M).
+                    unsigned t_far = 0;
+                    n = select_top_m<CVs>(L, tgt, q, n, CVs, t_far);
+                    thr = t_far > 0u ? t_far - 1u : 0u;  // (strictly below the farthest kept: equal distances beyond it were dropped)
+                }
             }
-            if (n >= 0) {
+            if constexpr (M > 12) {
+                // wide lists (32 slots of a 36-slot scan list): the few FARTHEST entries leave, one per pass — no 32-register
+                // selection network in this kernel — and the list is complete strictly below the nearest of those that left
+                int drop = (listed && n > CVs) ? n - CVs : 0;
+                unsigned gone = 0xFFFFFFFFu;  // smallest d2 among the entries dropped
+                while (__ballot(drop > 0) != 0ull) {
+                    if (drop > 0) {
+                        unsigned far = 0;
+                        int at = 0;
+                        for_each_entry(L, q, n, [&](int t, int, unsigned b) {
+                            at = b >= far ? t : at;
+                            far = max(far, b);
+                        });
+                        L.store(at, L.load(n - 1));
+                        n -= 1;
+                        gone = min(gone, far);
+                        drop -= 1;
+                    }
+                }
+                if (gone != 0xFFFFFFFFu) thr = gone > 0u ? gone - 1u : 0u;
+            }
+            if (listed) {
                 int *out = vv.vl + i;
                 for (int j = 0; j < n; j++) {
-                    *out = L.pos_of(L.load(j));
+                    int pos = L.pos_of(L.load(j));
+                    if constexpr (MULTI)
+                        if (to_base != nullptr) pos = to_base[pos];  // (lists hold base positions whatever level built them)
+                    *out = pos;
                     out += ns;
                 }
-                for (int j = n; j < kVerletSlots; j++) {  // (every slot a valid position: the verification loads all of them)
+                for (int j = n; j < CVs; j++) {  // (every slot a valid position: the verification loads all of them)
                     *out = 0;
                     out += ns;
                 }
@@ -2239,7 +2270,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
                 vv.vacc[i] = 0.f;
                 vv.vmask[i] = 0xFFFFFFFFu;  // (the association's row is written from the scan's list below, not from list slots)
             }
-            vg_new = n >= 0 ? __uint_as_float(thr) : 0.f;  // (0: no list — also the degenerate row whose sixteen nearest are all at distance 0)
+            vg_new = listed ? __uint_as_float(thr) : 0.f;  // (0: no list — also the degenerate row whose nearest are all at distance 0)
             vv.vg2[i] = vg_new;
             // ... and what lies beyond the association's own threshold (radius, temporal cut-off) leaves the list now
             if (n > 0 && thr > thr_a) {
@@ -2378,7 +2409,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
     if constexpr (VERLET) {
         // the forecast for the next launch's dispatch order (verlet_forecast): will the fresh list still do after one more
         // move like this one?  (a row without a list, or a block the cleanup kernel redoes: no)
-        const float need_next = (tm != 0xFFFFFFFFu ? __builtin_amdgcn_sqrtf(__uint_as_float(tm)) : __builtin_amdgcn_sqrtf(r2_0)) + moved;
+        const float need_next = (tm != 0xFFFFFFFFu ? __builtin_amdgcn_sqrtf(__uint_as_float(tm)) : __builtin_amdgcn_sqrtf(r2_far)) + moved;
         const float reach_next = (need_next + moved) * 1.0001f;
         verlet_forecast(vv, wg, valid && !(reach_next * reach_next < vg_new), s_need);
     }

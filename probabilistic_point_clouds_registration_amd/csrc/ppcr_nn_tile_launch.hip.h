@@ -10,6 +10,9 @@ constexpr int kCapSteady = 1728;
 // ... of the Verlet variant (four workgroups per CU either way: its list path holds 48 coordinates in registers), whose
 // lists reach further than the plain search's cut-off: larger cells, larger halos
 constexpr int kCapVerlet = 1920;
+// ... and of the Verlet variant of the mid-width lists (the command line's 20 neighbours: 32-slot Verlet lists, 36-slot scan
+// lists — 18.9 KB — beside the halo: 1600 candidates keep the kernel at four workgroups per CU)
+constexpr int kCapVerletMid = 1600;
 // workgroups (= partial-sum slots when K23 is folded in) of a steady-state K1 launch over nb blocks of 256 queries
 inline int steady_grid(int nb, bool all_halves) { return all_halves ? 2 * ((nb + 7) & ~7) : nb + dev::kMaxSplit; }
 

@@ -435,6 +435,47 @@ def test_cli_default_shape_through_align(scene):
     np.testing.assert_allclose(res["costs"], ora["costs"], rtol=1e-8)
 
 
+@pytest.mark.parametrize("scene", ["slab", "lidar"])
+def test_multi_level_verlet_lists_keep_every_association_exact(scene):
+    """Verlet lists in a MULTI-LEVEL search (option verlet_levels; off by default — see csrc/ppcr_hip.hip): every level's scan
+    builds the lists of the rows whose reach its stencil covers (kept in base positions), nn_wide_kernel those of the rows it
+    searches; blocks that keep searching stop building lists (VerletLists::streak).  The command line's defaults on the two
+    pinned non-uniform 200k scenes, lists forced on, a source that drifts by small rigid moves and one jolt: every association
+    equals the oracle's — row_ptr, columns, float d2 bits — and the counters say that levels were in use and lists answered."""
+    src, tgt, _, _ = synth.make_scene(scene, 200_000, stride=3)
+    rng = np.random.default_rng(77)
+    with _lib.Context(0) as c:
+        c.set_option("defer_moves", 1)
+        c.set_option("verlet_levels", 1)
+        c.set_option("verlet_engage", 100000)
+        c.set_params(3.0, 20, 5.0, 3)
+        c.set_target(tgt)
+        c.set_source(src)
+        cur = src.copy()
+        seen = []
+        for k, (ang, tr) in enumerate([(0.0, 0.0), (1e-4, 2e-3), (1e-4, 1e-3), (2e-3, 0.05), (5e-5, 5e-4), (0.0, 0.0)]):
+            T = np.eye(4)
+            T[:3, :3] = synth.rodrigues(rng.normal(size=3), ang)
+            T[:3, 3] = rng.normal(0, tr / np.sqrt(3), size=3)
+            if k > 0:
+                c.apply_transform(T)
+                po.transform_cloud(cur, T)
+            c.associate()
+            rp, col, d2 = c.get_association()
+            orp, ocol, od2 = po.radius_search(cur, tgt, 3.0, 20, method=1)
+            np.testing.assert_array_equal(rp, orp, err_msg=f"association {k}")
+            np.testing.assert_array_equal(col, ocol, err_msg=f"association {k}")
+            np.testing.assert_array_equal(d2, od2, err_msg=f"association {k}")
+            seen.append(c.debug_verlet())
+        lv = c.debug_levels()
+        assert lv["levels"] >= 3, lv
+        assert seen[1]["trusted"] and seen[1]["rows"] == src.shape[0], seen[1]
+        real = seen[-1]["workgroups"] - 128
+        searched = np.diff([s_["rebuilt"] for s_ in seen])
+        assert searched[1] < real, ("after a tiny move some blocks must have answered from their lists", searched.tolist())
+        assert seen[-1]["rows_rebuilt"] > 0
+
+
 def test_native_rccl_gather_of_transforms():
     """ppcr_comm_* / ppcr_gather_transforms: the job's one collective below Python (RCCL bound at run time).  One rank is
     all a one-GPU box can run — communicator creation, the all-gather and the pair -> rank deal are still the real code

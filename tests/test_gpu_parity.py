@@ -739,6 +739,60 @@ def test_verlet_lists_keep_every_association_exact(m):
         assert plain.debug_verlet()["rows"] == 0                # (the plain context never built a list)
 
 
+@pytest.mark.parametrize("m,radius", [(20, 3.0), (16, 3.0), (20, 1.4), (12, 2.0)])
+def test_wide_verlet_lists_keep_every_association_exact(m, radius):
+    """The command line's own width (20 neighbours, radius 3: ..._ex.cc:43-50) keeps Verlet lists too: 32 slots per row, in a
+    TWO-PASS search — the tiled first pass builds the lists of the rows whose bound lies inside its radius, nn_wide_kernel
+    those of the rows it searches (short rows, rows whose list ran out: a few failing rows of a workgroup go there while the
+    workgroup answers the others) — and in a one-pass search of the same width.  Every association of a source that drifts
+    by small and not so small rigid moves equals the oracle's, neighbour sets and float d2 bit for bit; the counters say that
+    lists answered, that rows were rebuilt one by one, and that a jolt drops the lists."""
+    src, tgt, _, _ = synth.make_pair(40000, cfg=2, stride=3)
+    rng = np.random.default_rng(1515 + m)
+    with _lib.Context(0) as c, _lib.Context(0) as plain:
+        plain.set_option("verlet", 0)
+        for h in (c, plain):
+            h.set_option("defer_moves", 1)
+            h.set_option("verlet_dense", 1)       # (lists whatever the halo estimate says: the test is about exactness)
+            h.set_params(radius, m, 5.0, 3)
+            h.set_target(tgt)
+            h.set_source(src)
+        cur = src.copy()
+        seen = []
+        steps = [(2e-4, 2e-3)] * 3 + [(1e-3, 8e-3)] * 3 + [(2e-2, 0.3)] + [(1e-4, 5e-4)] * 5 + [(0.0, 0.0)] * 2
+        for k, (ang, tr) in enumerate([(0.0, 0.0)] + steps):
+            c.associate()
+            plain.associate()
+            rp, col, d2 = c.get_association()
+            orp, ocol, od2 = po.radius_search(cur, tgt, radius, m, method=1)
+            np.testing.assert_array_equal(rp, orp, err_msg=f"step {k}")
+            np.testing.assert_array_equal(col, ocol, err_msg=f"step {k}")
+            np.testing.assert_array_equal(d2, od2, err_msg=f"step {k}")
+            prp, pcol, pd2 = plain.get_association()
+            np.testing.assert_array_equal(rp, prp)
+            np.testing.assert_array_equal(col, pcol)
+            np.testing.assert_array_equal(d2, pd2)
+            seen.append(c.debug_verlet())
+            T = np.eye(4)
+            T[:3, :3] = synth.rodrigues(rng.normal(size=3), ang)
+            T[:3, 3] = rng.normal(0, tr * radius / np.sqrt(3), size=3)
+            for h in (c, plain):
+                h.apply_transform(T)
+            po.transform_cloud(cur, T)
+        if radius >= 2.0:
+            assert c.search_reach() > 1, "the case is meant to be a two-pass search"
+        assert seen[2]["trusted"] and seen[2]["rows"] == 40000, seen[:3]
+        real = seen[-1]["workgroups"] - 128
+        searched = np.diff([s_["rebuilt"] for s_ in seen])
+        assert searched[2] < real // 2, ("after a tiny move most workgroups must have answered from their lists", searched.tolist())
+        if radius >= 2.0:
+            assert seen[-1]["rows_rebuilt"] > 0, "rows whose lists ran out must have been rebuilt one by one while their workgroups answered"
+        assert not seen[8]["trusted"], "a move of 0.3 radii: the plain search, no lists"
+        assert seen[11]["trusted"], "calm again: lists again"
+        assert searched[-1] == 0 and searched[-2] == 0, ("a source that did not move at all is answered from the lists alone", searched.tolist())
+        assert seen[-1]["rows_without_list"] < 400, seen[-1]     # (the rows nn_wide_kernel searches get their lists there)
+
+
 def test_verlet_lists_randomised_soak():
     """Seeded random sweep aimed at the Verlet lists' completeness test (need + path travelled < the list's reach): lists
     forced on whatever the moves (verlet_engage = 100000; one-pass, single-level searches throughout), skins from a hundredth
@@ -826,6 +880,82 @@ def test_verlet_lists_randomised_soak():
                 assert c.debug_verlet()["rebuilt"] == v0["rebuilt"], (seed, trial, v0, c.debug_verlet())
                 stood_still += 1
     assert trusted_assocs >= 4 * trials and answered >= trials and stood_still >= 1, (trusted_assocs, answered, stood_still)
+
+
+def test_wide_verlet_lists_randomised_soak():
+    """The same sweep aimed at the WIDE lists (11 .. 20 neighbours: 32 slots) and at what they add: two-pass searches (automatic
+    and forced reaches) whose short rows get their lists from nn_wide_kernel, rows rebuilt one by one inside an answering
+    workgroup, a few failing rows listed for nn_wide_kernel while the others are answered, lists cut to their 32 nearest,
+    multi-level grids (option verlet_levels), blocks that stop building lists.  Lists forced on whatever the moves; uniform,
+    clustered and quantised clouds with far-away and NaN queries; eight associations per trial under rigid moves from nothing
+    to 0.15 radii.  Every association equals the oracle's, neighbour sets and float d2 bit for bit."""
+    seed = int(os.environ.get("PPCR_SOAK_SEED", "20251004")) + 7
+    trials = int(os.environ.get("PPCR_SOAK_TRIALS", "8"))
+    rng = np.random.default_rng(seed)
+    trusted_assocs = answered = rebuilt_rows = 0
+    for trial in range(trials):
+        kind = trial % 3
+        nt = int(rng.integers(12000, 26000))
+        side = (nt / 3.8) ** (1 / 3)
+        if kind == 0:
+            tgt = rng.uniform(0, side, size=(nt, 3))
+        elif kind == 1:
+            blobs = rng.uniform(0.2 * side, 0.8 * side, size=(5, 3))
+            tgt = np.concatenate([rng.uniform(0, side, size=(nt // 2, 3))] +
+                                 [b + rng.normal(0, 1.0, size=(nt // 10, 3)) for b in blobs])
+        else:
+            tgt = np.round(rng.uniform(0, side, size=(nt, 3)) * 2) / 2      # a half-unit lattice: exact ties everywhere
+        tgt = tgt.astype(np.float32)
+        ns = int(len(tgt) * rng.uniform(0.8, 1.0))
+        src = (tgt[rng.permutation(len(tgt))[:ns]] + rng.normal(0, 0.03 if kind != 2 else 0.0, size=(ns, 3))).astype(np.float32)
+        src[:4] = [[side * 3, 0, 0], [-50, -50, -50], [np.nan, 0, 0], [0, np.inf, 0]]
+        radius = float(rng.choice([1.4, 2.0, 3.0]))
+        m = int(rng.choice([12, 16, 20]))
+        skin = int(rng.choice([50, 350, 700]))
+        two_pass = int(rng.choice([1, 1, 2, 3]))          # 1: automatic
+        levels = int(rng.integers(0, 2))
+        with _lib.Context(0) as c:
+            c.set_option("defer_moves", 1)
+            c.set_option("two_pass", two_pass)
+            c.set_option("levels", levels)
+            c.set_option("verlet_levels", 1)
+            c.set_option("verlet_engage", 100000)
+            c.set_option("verlet_dense", 1)
+            c.set_option("verlet_skin", skin)
+            c.set_params(radius, m, 5.0, 3)
+            c.set_target(tgt)
+            c.set_source(src)
+            cur = src.copy()
+            prev = c.debug_verlet()
+            for k in range(8):
+                c.associate()
+                rp, col, d2 = c.get_association()
+                orp, ocol, od2 = po.radius_search(cur, tgt, radius, m, method=1)
+                tag = f"seed {seed} trial {trial} kind {kind} r {radius} m {m} skin {skin} two_pass {two_pass} levels {levels} association {k}"
+                np.testing.assert_array_equal(rp, orp, err_msg=tag)
+                np.testing.assert_array_equal(col, ocol, err_msg=tag)
+                np.testing.assert_array_equal(d2, od2, err_msg=tag)
+                v = c.debug_verlet()
+                if v["trusted"]:
+                    trusted_assocs += 1
+                    if k >= 2 and v["rebuilt"] - prev["rebuilt"] < v["workgroups"] - 128:
+                        answered += 1
+                rebuilt_rows += v["rows_rebuilt"] - prev["rows_rebuilt"]
+                prev = v
+                mag = float(rng.choice([0.0, 1e-3, 1e-2, 0.05, 0.15])) * radius
+                T = np.eye(4)
+                if rng.integers(0, 2):
+                    pivot = np.full(3, side / 2) + rng.normal(size=3) * side * 3
+                    arm = np.linalg.norm(np.full(3, side / 2) - pivot)
+                    R = synth.rodrigues(rng.normal(size=3), mag / arm)
+                    T[:3, :3] = R
+                    T[:3, 3] = pivot - R @ pivot
+                else:
+                    dvec = rng.normal(size=3)
+                    T[:3, 3] = dvec / np.linalg.norm(dvec) * mag
+                c.apply_transform(T)
+                po.transform_cloud(cur, T)
+    assert trusted_assocs >= 4 * trials and answered >= trials // 2 and rebuilt_rows > 0, (trusted_assocs, answered, rebuilt_rows)
 
 
 def test_rows_that_are_not_points_do_not_keep_their_workgroups_searching():

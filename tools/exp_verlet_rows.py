@@ -13,27 +13,35 @@ from probabilistic_point_clouds_registration_amd import _lib, synth  # noqa: E40
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 opts = [kv.split("=") for kv in sys.argv[3:]]
-src, tgt, _, _ = synth.make_pair(n, cfg=3 if n >= 1_000_000 else 2)
+inner = 1
+if n in (8, 9, 10):      # (a config of synth.CONFIGS instead of a size: the command line's default shapes)
+    cfg = synth.CONFIGS[n]
+    src, tgt, _, _ = synth.make_config(n, pair=0)
+    prm = (cfg["radius"], cfg["max_neighbours"], cfg["dof"], 3)
+    inner = int(cfg.get("inner_steps", 1))
+else:
+    src, tgt, _, _ = synth.make_pair(n, cfg=3 if n >= 1_000_000 else 2)
+    prm = (1.0, 10, 5.0, 3)
 c = _lib.Context(0)
 for k, v in opts:
     c.set_option(k, int(v))
-c.set_params(1.0, 10, 5.0, 3)
+c.set_params(*prm)
 c.set_target(tgt)
 c.set_source(src)
 c.profile_enable(True)
 prev = c.debug_verlet()
 prev_t = {}
 for it in range(iters):
-    rep = c.align_report(1, cost_drop_thresh=-1.0, inner_steps=1)
+    rep = c.align_report(1, cost_drop_thresh=-1.0, inner_steps=inner, f_tol=10e-6)
     T = rep["iterations"][0]["T_step"]
     v = c.debug_verlet()
     st = c.profile_get()
-    k1 = {k: (x["total_ms"], x["launches"]) for k, x in st.items() if k.startswith("nn_")}
+    k1 = {k: (x["total_ms"], x["launches"]) for k, x in st.items() if k.startswith("nn_") or n in (8, 9, 10)}
     dt = {k: 1e3 * (k1[k][0] - prev_t.get(k, (0, 0))[0]) for k in k1 if k1[k][1] > prev_t.get(k, (0, 0))[1]}
     prev_t = k1
     hist = [a - b for a, b in zip(v["failing_rows_hist"], prev["failing_rows_hist"])]
     print(f"it {it:2d} |t| {np.linalg.norm(T[:, 3]):.5f} trusted {int(v['trusted'])} searched {v['rebuilt'] - prev['rebuilt']:5d} "
           f"rows {v['rows_rebuilt'] - prev['rows_rebuilt']:6d} in {v['workgroups_rebuilding_rows'] - prev['workgroups_rebuilding_rows']:5d} wgs  "
-          f"failing-rows hist {hist}  no-list {v['rows_without_list']}  " + "  ".join(f"{k} {x:.1f}us" for k, x in dt.items()), flush=True)
+          f"failing-rows hist {hist}  no-list {v['rows_without_list']} short {c.debug_short_rows()}  " + "  ".join(f"{k.replace('_kernel', '')} {x:.1f}us" for k, x in dt.items()), flush=True)
     prev = v
 c.close()
