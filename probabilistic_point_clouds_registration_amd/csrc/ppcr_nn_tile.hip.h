@@ -1603,14 +1603,56 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
         half = 2;
     } else {
         bid = xcd_block((int)wg - split.n_extra, (ns + BLOCK - 1) / BLOCK);
-        if (split.n_extra > 0 && split.flag[bid] == 2) half = 1;
+        if (split.n_extra > 0) {
+            // (the block's flag byte through a SCALAR load of the word that holds it — a uniform address; pool blocks are
+            //  multiples of 512 bytes, so the word exists —: as a vector load it was a round trip of its own ahead of the query's)
+            typedef const __attribute__((address_space(4))) unsigned *const_u32p;
+            const unsigned word = ((const_u32p)(__UINTPTR_TYPE__)split.flag)[bid >> 2];
+            if (((word >> (8 * (bid & 3))) & 0xFFu) == 2u) half = 1;
+        }
     }
     const int i = bid * BLOCK + tid;
     const bool valid = i < ns && (half == 0 || (wave >> 1) == half - 1);  // lanes whose query this workgroup owns
     if (tid == 0) s_bail = 0;
 
     // ---- prologue: query, pending move, temporal cut-off ---------------------------------------------------------
-    float4 q = valid ? ((MULTI && split.all_halves) ? q_early : src[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // The row's state — cut-off of the previous association, the list's reach and path — and the pending move are asked for
+    // in the same breath as the query: none of them depends on it, and taken where they are used each was a memory round
+    // trip of its own on every workgroup's critical path (query -> move -> cut-off -> list state: four in a row).
+    // Unconditional loads (row 0 for a lane without a query: every buffer has it), so that they are ONE block of loads.
+    float4 q;
+    unsigned prev_dm2 = 0xFFFFFFFFu;
+    float g2_row = 0.f, acc_row = 0.f;
+    if constexpr (VERLET) {
+        const int ic = valid ? i : 0;
+        const float4 q_ld = src[ic];
+        const unsigned prev_ld = dm2[ic];
+        const float g2_ld = vv.vg2[ic], acc_ld = vv.vacc[ic];
+        q = valid ? q_ld : make_float4(0.f, 0.f, 0.f, 0.f);
+        prev_dm2 = (valid && dm2_valid) ? prev_ld : 0xFFFFFFFFu;
+        g2_row = (valid && !vv.build_all) ? g2_ld : 0.f;
+        acc_row = (valid && !vv.build_all) ? acc_ld : 0.f;
+    } else if constexpr (!MULTI) {
+        const int ic = valid ? i : 0;
+        const float4 q_ld = src[ic];
+        const unsigned prev_ld = dm2[ic];
+        q = valid ? q_ld : make_float4(0.f, 0.f, 0.f, 0.f);
+        prev_dm2 = (valid && dm2_valid) ? prev_ld : 0xFFFFFFFFu;
+    } else {
+        q = valid ? (split.all_halves ? q_early : src[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid && dm2_valid) prev_dm2 = dm2[i];
+    }
+    Pose P_move = pm.P;
+    if (pm.enabled == 2) {
+        // (the previous iteration's transform, left in device memory by the lane that solved it: a uniform address, read with
+        //  SCALAR loads through the constant address space — the launch boundary orders the write before them)
+        typedef const __attribute__((address_space(4))) double *const_f64p;
+        const const_f64p pd = (const_f64p)(__UINTPTR_TYPE__)pm.dev;
+#pragma unroll
+        for (int k = 0; k < 9; k++) P_move.R[k] = pd[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) P_move.t[k] = pd[9 + k];
+    }
     if (aborted) return;
     // the other counter of the ping-pong pair: idle during this launch  (the last workgroup is never an idle split slot;
     // with all_halves the first one never idles)
@@ -1626,7 +1668,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
     float moved = 0.f;  // how far this query travelled since the association that produced dm2
     if (pm.enabled && valid) {
         const float4 q0 = q;
-        q = move_point(q, pm.enabled == 2 ? *pm.dev : pm.P);  // uniform choice, scalar loads
+        q = move_point(q, P_move);
         src[i] = q;
         const float ex = q.x - q0.x, ey = q.y - q0.y, ez = q.z - q0.z;
         moved = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez);  // 1 ulp: far inside the 1e-5 inflation below
@@ -1657,7 +1699,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
     const float r2_far = (FTM != -2) ? r2_0 : un.r2_full;
     float need2_full = r2_far;
     if (dm2_valid && valid) {
-        const unsigned prev = dm2[i];
+        const unsigned prev = prev_dm2;
         if (prev != 0xFFFFFFFFu) {
             const float bound = __builtin_amdgcn_sqrtf(__uint_as_float(prev)) + moved;
             const float t2 = bound * bound * 1.00001f + 1e-30f;
@@ -1686,11 +1728,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
             if (vv.build_all && tid == 0 && vv.streak != nullptr) vv.streak[wg] = 0;  // (a launch that builds every list starts the count over)
         if (!vv.build_all) {
             // ---- are the lists still complete?  (VerletLists: need + path travelled < the list's reach, with float slack) ----
-            float g2 = 0.f, acc = 0.f;
-            if (valid) {
-                g2 = vv.vg2[i];
-                acc = vv.vacc[i] + moved;
-            }
+            float g2 = g2_row, acc = valid ? acc_row + moved : 0.f;
             const float reach = (need + acc) * 1.0001f;
             // (no list: g2 = 0; a NaN anywhere fails — except in the query itself: a row that is not a point has no neighbours
             //  whatever its list says, and must not send its workgroup through the search in every iteration)
