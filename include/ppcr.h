@@ -348,6 +348,8 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *                  known rigid move and the ratio of the last two — fit the lists' skin, and dropped when the forecast exceeds
  *                  four times that; >= 0: a fixed threshold instead, lists are built once the last known rigid move displaces
  *                  no corner of the target's box by more than this many 1e-4 radii (0 never .. 100000 always: tests);
+ *   "verlet_room"  -1 (default) the forecast must fit the whole skin (half of it on grids that are resident all at once, widths
+ *                  up to 10), >= 0: this many per cent of it (experiments: tools/exp_verlet_sweep.py);
  *   "verlet_order" 1 workgroups that will probably search are dispatched first (default), 0 launch order;
  *   "verlet_dense" 0 no lists (and radius-sized grid cells) where the halo of a 256-query block would outgrow the list
  *                  variant's LDS tile — a radius that holds ~35 or more target points, a source much sparser than the target —

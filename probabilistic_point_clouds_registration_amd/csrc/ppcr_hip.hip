@@ -236,11 +236,17 @@ struct ppcr_ctx {
     // such moves (move_ratio; NaN: unknown).  Option "verlet_engage" >= 0 replaces the rule by a fixed threshold on
     // move_estimate in 1e-4 of the radius (tests: 100000 = always, 0 = never); -1 (default): the rule.
     int opt_verlet_engage = -1;
+    int opt_verlet_room = -1;  // (experiments: the forecast must fit this many per cent of the skin; -1: the rule's own)
     double move_estimate = std::numeric_limits<double>::infinity();
     double move_ratio = std::numeric_limits<double>::quiet_NaN();
     int move_lag = 1;
     bool pending_from_align = false;  // the pending move is an align loop's last transform (its ratio is already known)
     bool move_forecast_pinned = false;  // an align loop set the three values above for the association being enqueued
+    // what the last align loop knew about the registration's moves when it ended (AlignJob: estimate_of / ratio_of, the
+    // entry's values, iterations so far): a following align call on the untouched handle continues the SAME sequence of
+    // forecasts — align(a) + align(b) launches the kernels of align(a + b)
+    double al_estimate[4] = {0, 0, 0, 0}, al_ratio[4] = {0, 0, 0, 0}, al_entry_estimate = 0, al_entry_ratio = 0, al_last = 0;
+    int al_iterations = 0;
     int opt_verlet_order = 1;    // option "verlet_order": workgroups forecast to search again are dispatched first (default 1)
     double grid_skin2 = 0;       // 2 x skin the grid in use was built for (0: its cells do not cover a list's reach)
     int opt_verlet_dense = 0;      // 1: keep the lists' cells whatever the halo estimate says (tests)

@@ -35,13 +35,13 @@ using namespace ppcr::dev;
 // t.merged tells whether it did.
 // PPCR_LIST_NOCLAMP: every instantiation of nn_fast_kernel this unit can launch must own exactly FastLds::kBytes of LDS
 // (see FastLds).  Checked once per process and list width; a mismatch is a build defect, not a run-time condition: abort.
-template <int M, int C, int CAP, bool STAMPS, int FTM, bool MULTI, bool VERLET = false>
+template <int M, int C, int CAP, bool STAMPS, int FTM, bool MULTI, int VERLET = 0>
 bool fast_kernel_lds_ok()
 {
 #if PPCR_LIST_NOCLAMP
     hipFuncAttributes attr;
     if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&nn_fast_kernel<M, C, CAP, STAMPS, FTM, MULTI, VERLET>)) != hipSuccess) return false;
-    return (int)attr.sharedSizeBytes == FastLds<C, CAP, MULTI, ((VERLET && FTM != -2) ? M : 0)>::kAllocBytes;
+    return (int)attr.sharedSizeBytes == FastLds<C, CAP, MULTI, ((VERLET != 0 && FTM != -2) ? M : 0)>::kAllocBytes;
 #else
     return true;
 #endif
@@ -53,19 +53,23 @@ void check_fast_kernel_lds()
         constexpr int C = (M <= 24) ? 32 : 48;
         constexpr int CAP = (M <= 24) ? 2240 : 2048;
         bool good = fast_kernel_lds_ok<M, C, CAP, false, -2, false>() && fast_kernel_lds_ok<M, C, CAP, false, -2, true>();
-        if constexpr (M <= 24) good = good && fast_kernel_lds_ok<M, verlet_scan_slots(M), (M <= 12 ? kCapVerlet : CAP), false, -2, true, true>();
+        if constexpr (M <= 24) good = good && fast_kernel_lds_ok<M, verlet_scan_slots(M), (M <= 12 ? kCapVerlet : CAP), false, -2, true, 1>();
         if constexpr (M > 12 && M <= 24)
             good = good && fast_kernel_lds_ok<M, (M <= 16 ? 24 : 28), (M <= 16 ? 2048 : 1920), false, -2, false>() &&
-                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerletMid, false, -2, false, true>();
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerletMid, false, -2, false, 1>();
         if constexpr (M <= 12)
             good = good && fast_kernel_lds_ok<M, 16, kCapSteady, false, -2, false>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, 8, false>() &&
                    fast_kernel_lds_ok<M, 16, kCapSteady, false, 0, false>() && fast_kernel_lds_ok<M, 16, kCapSteady, false, -3, false>() &&
                    fast_kernel_lds_ok<M, 16, kCapSteady, false, -2, true>() &&
                    // (the Verlet variants: their allocation is the larger of the search's and the list path's)
-                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, -2, false, true>() &&
-                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, 8, false, true>() &&
-                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, 0, false, true>() &&
-                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, -3, false, true>();
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, -2, false, 1>() &&
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, 8, false, 1>() &&
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, 0, false, 1>() &&
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, -3, false, 1>() &&
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, -2, false, 2>() &&
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, 8, false, 2>() &&
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, 0, false, 2>() &&
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, -3, false, 2>();
         // the diagnostic (option "stamps") instantiations launch_tile can reach
         if constexpr (M == 10)
             good = good && fast_kernel_lds_ok<M, 16, kCapSteady, true, -2, true>() && fast_kernel_lds_ok<M, 16, kCapSteady, true, -2, false>() &&
@@ -127,10 +131,16 @@ void launch_tile(TileLaunch &t)
         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,  \
         t.ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc, lr, un, vv_none)
     // steady state with Verlet lists: nn_fast_kernel<..., VERLET> answers from the lists where they still hold
-#define PPCR_FAST_V(FTMc, FMc)                                                                                          \
-    nn_fast_kernel<M, verlet_scan_slots(M), kCapVerlet, false, FTMc, false, true><<<grid_steady, 256, 0, t.stream>>>(                      \
+#define PPCR_FAST_V1(FTMc, FMc, Kc)                                                                                     \
+    nn_fast_kernel<M, verlet_scan_slots(M), kCapVerlet, false, FTMc, false, Kc><<<grid_steady, 256, 0, t.stream>>>(         \
         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,    \
         t.ovf_next, split_on_v, nullptr, FMc, lr, un, vv)
+    // (t.verlet_rows: the variant that rebuilds a few failing rows inside the workgroup — grids resident all at once)
+#define PPCR_FAST_V(FTMc, FMc)                                                                                          \
+    do {                                                                                                                \
+        if (t.verlet_rows) PPCR_FAST_V1(FTMc, FMc, 2);                                                                  \
+        else PPCR_FAST_V1(FTMc, FMc, 1);                                                                                \
+    } while (0)
     t.fused = false;
     int ftm = -2;  // model folded into this launch (-2: none)
     bool steady = false;
@@ -170,7 +180,7 @@ void launch_tile(TileLaunch &t)
                 vv.build_all = t.verlet_mode == 2 ? 0 : 1;
                 vv.order_now = nullptr, vv.order_next = nullptr, vv.count_now = nullptr, vv.count_next = nullptr, vv.count_clear = nullptr;
                 constexpr int CAPV = M <= 12 ? kCapVerlet : CAP;
-                nn_fast_kernel<M, verlet_scan_slots(M), CAPV, false, -2, true, true><<<grid_multi, 256, 0, t.stream>>>(
+                nn_fast_kernel<M, verlet_scan_slots(M), CAPV, false, -2, true, 1><<<grid_multi, 256, 0, t.stream>>>(
                     t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
                     two_per_block, nullptr, fm_none, lr, un, vv);
                 t.verlet_built = true;
@@ -237,7 +247,7 @@ void launch_tile(TileLaunch &t)
                 VerletLists vv = t.verlet;
                 vv.build_all = t.verlet_mode == 2 ? 0 : 1;
                 const SplitTable split_mid_v{t.split_flag, t.split_list, t.split_state, t.split_state + 1, kMaxSplit, kCapVerletMid * 15 / 16, 0};
-                nn_fast_kernel<M, verlet_scan_slots(M), kCapVerletMid, false, -2, false, true><<<nb + kMaxSplit, 256, 0, t.stream>>>(
+                nn_fast_kernel<M, verlet_scan_slots(M), kCapVerletMid, false, -2, false, 1><<<nb + kMaxSplit, 256, 0, t.stream>>>(
                     t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
                     split_mid_v, nullptr, fm_none, lr, un, vv);
                 t.verlet_built = true;
@@ -259,6 +269,7 @@ void launch_tile(TileLaunch &t)
     }
 #undef PPCR_FAST
 #undef PPCR_FAST_V
+#undef PPCR_FAST_V1
     if (t.short_count == nullptr && t.between) t.between(t.between_arg);
     if (t.short_count != nullptr) {
         if (t.between2) t.between2(t.between_arg);

@@ -1367,11 +1367,12 @@ struct VerletRowLds {
     int row[ROWS > 0 ? ROWS : 1];      // ... row index ...
     float g2[ROWS > 0 ? ROWS : 1];     // ... and, coming back, the new list's reach
 };
-// rows a workgroup rebuilds one by one before it gives in and searches: the widths with K23 folded in — none (measured:
-// PPCR_VERLET_ROWS above); the mid widths (the command line's 20 neighbours: clouds of a few hundred blocks, ONE residency
-// round, where a searching workgroup is the launch's length, and a launch of nn_wide_kernel for a handful of rows costs
-// 20 us of latency) — eight
-constexpr int verlet_rows_in_kernel(int M) { return M > 12 ? 8 : PPCR_VERLET_ROWS; }
+// rows a workgroup rebuilds one by one before it gives in and searches.  Where launches last many residency rounds (1M rows,
+// K23 folded in) none: the search renews all 256 lists of a workgroup whose rows age together, and hides behind the other
+// workgroups' work (measured: PPCR_VERLET_ROWS above).  Where the whole grid is resident at once — the mid widths' clouds of a
+// few hundred blocks, any cloud of up to ~230k rows — a searching workgroup IS the launch's length (and a launch of
+// nn_wide_kernel for a handful of rows costs 20 us of latency): eight (kernel variant 2).
+constexpr int verlet_rows_in_kernel(int M, int variant) { return (M > 12 || variant == 2) ? 8 : PPCR_VERLET_ROWS; }
 // one wave, one row: i / q / need are wave-uniform (read from LDS)
 template <int CVS>
 __device__ __forceinline__ float verlet_rebuild_row(const int i, const float4 q, const float need, const int ns, const float4 *__restrict__ tgt,
@@ -1478,8 +1479,8 @@ struct FastLds {
 // for both: a rebuild is one workgroup's chain of dependent round trips (~25 us), which a launch of its own would add to
 // every iteration in which a single row of the cloud fails — inside the launch it hides behind the other workgroups' work.
 // Four workgroups per CU (the list path holds 48 coordinates in registers).
-template <int M, int C, int CAP, bool STAMPS, int FTM = -2, bool MULTI = false, bool VERLET = false>
-__global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 4) : (CAP * 13 + C * 512 <= 39400 ? 4 : 3))) void nn_fast_kernel(float4 *__restrict__ src, int ns,
+template <int M, int C, int CAP, bool STAMPS, int FTM = -2, bool MULTI = false, int VERLET_K = 0>
+__global__ __launch_bounds__(256, (VERLET_K != 0 ? 4 : C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 4) : (CAP * 13 + C * 512 <= 39400 ? 4 : 3))) void nn_fast_kernel(float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt0,
                                                          const int *__restrict__ cell_start0, GridDesc g0,
                                                          float r2_0, int m, int *__restrict__ nbr,
@@ -1490,6 +1491,9 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
                                                          unsigned long long *__restrict__ stamps, FusedMoments fm,
                                                          LoopReset lr, UnansweredRows un, VerletLists vv)
 {
+    // VERLET_K: 0 no lists, 1 Verlet lists, 2 Verlet lists and a few failing rows rebuilt inside the workgroup (grids that are
+    // resident all at once: see verlet_rows_in_kernel)
+    constexpr bool VERLET = VERLET_K != 0;
     // an earlier launch may have handed the iteration to the host (LoopState::abort, set before this kernel started):
     // then this one must touch nothing.  A uniform scalar load, tested below once the query load is in flight.
     const unsigned aborted = lr.st ? lr.st->abort : 0u;
@@ -1749,7 +1753,7 @@ __global__ __launch_bounds__(256, (VERLET ? 4 : C <= 16 ? (CAP * 13 + C * 512 <=
             // (diagnostic: how many rows fail where any does — 1, 2-4, 5-16, more)
             if (tid == 0 && n_fail > 0 && vv.rebuilt != nullptr) atomicAdd(vv.rebuilt + 12 + (n_fail > 16 ? 3 : n_fail > 4 ? 2 : n_fail > 1 ? 1 : 0), 1u);
             bool answers = true;  // this lane's row is answered from its list
-            constexpr int kRows = verlet_rows_in_kernel(M);
+            constexpr int kRows = verlet_rows_in_kernel(M, VERLET_K);
             // A FEW failing rows: the near ones are rebuilt here, one row per wave (verlet_rebuild_row), and answered with
             // the others; the far ones go to nn_wide_kernel's list (where there is one: two-pass and multi-level searches,
             // every launch that folds nothing in), which answers them and leaves them fresh lists.  More than a few: the

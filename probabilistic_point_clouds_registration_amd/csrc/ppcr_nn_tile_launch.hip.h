@@ -55,6 +55,7 @@ struct TileLaunch {
     dev::VerletLists verlet;        // steady-state Verlet lists (buffers of [16][ns] + per-row state), used when verlet_mode != 0:
     int verlet_mode;                //   0 off; 1 this association builds every row's list; 2 workgroups whose rows' lists still
                                     //   hold answer from them, the others search and rebuild
+    int verlet_rows;                //   widths up to 10: the kernel variant that rebuilds a few failing rows inside the workgroup
     const dev::FusedMoments *fuse;  // fold K23 into K1 at this pose / model when the steady-state variant runs
     int fuse_tm;                    // ... in this compiled form: 0 Gaussian, 8 t with v + dim = 8, -3 t with another integer v + dim
     const dev::FoldSolve *fold;     // ... and the fold-and-solve step into the cleanup launch

@@ -16,7 +16,7 @@ python3 $R/tools/summarize_rocprof.py $(find $OUT/stats_align -name "*kernel_sta
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --kernel-trace --output-format csv --pmc $set -d $OUT/pmc_$set -o pmc -- python3 $R/tools/exp_align.py 1000000 dof=${3:-5} > $OUT/log_$set.txt 2>&1
 done
-python3 $R/tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/pmc_hbm_traffic.txt 2>&1
+python3 $R/tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE --split "nn_fast_kernel<10, 24, 1920" 90000 > $OUT/pmc_hbm_traffic.txt 2>&1
 if [ "${2:-}" != "nopmcmix" ]; then
   i=0
   for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
