@@ -720,6 +720,34 @@ def run_rank(a):
                         "kernels and schedule, once the source has stopped moving — never part of value"}
         except Exception as e:   # (a diagnostic block must not cost the line)
             out["steady_state"] = {"error": str(e)}
+        # A SECOND trajectory through the same windows (round-5 review, task 6): the same target, permutation and noise draws
+        # with three times the ground-truth motion and three times the noise — when the lists engage is a forecast from the
+        # moves the registration makes (verlet_lists_pay_off), not a constant fitted to the headline pair's convergence ratio.
+        try:
+            src2 = synth.make_pair(n, cfg=synth.CONFIGS[a.config].get("clouds", a.config), stride=src.shape[1], motion_scale=3.0, noise_scale=3.0)[0]
+            rates2, shares2 = [], []
+            for _ in range(3):
+                ctx.set_source(src2)
+                if a.warmup > 0:
+                    ctx.align(a.warmup, cost_drop_thresh=-1.0, inner_steps=a.inner_steps, want_history=False)
+                ctx.synchronize()
+                w0 = ctx.debug_verlet()
+                t2 = time.perf_counter()
+                r2 = ctx.align(a.steps, cost_drop_thresh=-1.0, inner_steps=a.inner_steps, want_history=False)
+                ctx.synchronize()
+                rates2.append(a.steps / (time.perf_counter() - t2))
+                assert int(r2["n_iter"]) == a.steps
+                w1 = ctx.debug_verlet()
+                shares2.append((w1["rebuilt"] - w0["rebuilt"]) / (a.steps * max(1, w1["workgroups"] - 128)) if w1["rows"] else None)
+            if isinstance(out.get("steady_state"), dict) and "error" not in out["steady_state"]:
+                out["steady_state"]["second_trajectory"] = {
+                    "it_per_s": float(np.median(rates2)), "min_it_per_s": min(rates2), "max_it_per_s": max(rates2),
+                    "searched_share": shares2[-1],
+                    "ratio_to_value": (float(np.median(rates2)) / out["value"]) if out.get("value") else None,
+                    "what": "the same windows on the same pair with 3 x the ground-truth motion and 3 x the noise"}
+        except Exception as e:
+            if isinstance(out.get("steady_state"), dict):
+                out["steady_state"]["second_trajectory"] = {"error": str(e)}
         # one whole registration the way the command line runs it by default, HOST BUFFERS IN: uploads, grid build,
         # source sort, first association and the loop until hasConverged() stops it (-c 0.01 -n 5, inner loop to
         # function_tolerance) — what a caller of align() waits for; the handle is warm (its buffers exist)

@@ -48,8 +48,10 @@ def ground_truth(pair=0):
     return rodrigues(GT_AXIS, GT_ANGLE * s), GT_T * s
 
 
-def make_pair(n, cfg=3, pair=0, stride=4):
-    """-> (source[n,stride] f32, target[n,stride] f32, R_gt, t_gt); T_gt maps source onto target."""
+def make_pair(n, cfg=3, pair=0, stride=4, motion_scale=1.0, noise_scale=1.0):
+    """-> (source[n,stride] f32, target[n,stride] f32, R_gt, t_gt); T_gt maps source onto target.
+    motion_scale / noise_scale (bench.py's second trajectory): the same target, permutation and noise draws, the ground-truth
+    motion (angle and translation) and the noise multiplied."""
     off = 10 * pair
     L = 0.64 * float(n) ** (1.0 / 3.0)
     rng_t = np.random.Generator(np.random.PCG64(1000 + cfg + off))
@@ -57,8 +59,11 @@ def make_pair(n, cfg=3, pair=0, stride=4):
     rng_p = np.random.Generator(np.random.PCG64(2000 + cfg + off))
     perm = rng_p.permutation(n)
     rng_n = np.random.Generator(np.random.PCG64(3000 + cfg + off))
-    noise = rng_n.normal(0.0, 0.01, size=(n, 3))
+    noise = rng_n.normal(0.0, 0.01, size=(n, 3)) * noise_scale
     R, t = ground_truth(pair)
+    if motion_scale != 1.0:
+        s_ = (1.0 + pair / 64.0) * motion_scale
+        R, t = rodrigues(GT_AXIS, GT_ANGLE * s_), GT_T * s_
     p = tgt[perm].astype(np.float64)
     src = ((p - t) @ R + noise).astype(np.float32)  # R^T (p - t), row-vector form
     if stride == 4:
