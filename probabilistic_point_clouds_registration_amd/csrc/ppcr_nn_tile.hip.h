@@ -902,6 +902,57 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
                 }
             }
         };
+        // A row that comes here because its Verlet list ran out knows where its m-th neighbour was an association ago, and the
+        // source has hardly moved since: ONE sweep of the sphere that m-th distance (+ 2 %) + the list's skin reaches gives
+        // the new list, and the m nearest of the list inside the radius are the answer — where the sweep holds m of them (it
+        // then holds the m nearest of the cloud: everything outside it is farther) or reaches the whole radius.  Half the
+        // latency of search-then-list for the handful of rows a launch is left with once the lists answer.
+        bool done = false;
+        if (vv.vl != nullptr && found < 0 && prev_bits != 0xFFFFFFFFu) {
+            const float need0 = __builtin_amdgcn_sqrtf(__uint_as_float(prev_bits)) * 1.02f + 1e-30f;
+            const float G1 = fminf(need0 + fmaxf(vv.skin2, vv.skin_rel * need0), (float)reach * g.h * 0.999f);
+            const unsigned thr_g = __float_as_uint(G1 * G1);
+            thr = thr_g;
+            cut = false;
+            sweep(G1 * G1 * 1.000004f, CVs);
+            if (n > CVs) {
+                n = wave_select_top_m<PER>(s_pos, s_d2, n, CVs, tgt, lane, thr);
+                cut = true;
+            }
+            const unsigned in_radius = __float_as_uint(r2) - 1u;
+            const unsigned mine = lane < n ? s_d2[lane] : 0xFFFFFFFFu;  // (n <= CVs <= 64: an entry per lane)
+            const int n_in = __popcll(__ballot(mine <= in_radius));
+            if (n_in >= m || G1 * G1 >= r2) {
+                // the list first (every entry the sweep kept), then its m nearest inside the radius
+                const unsigned g2_bits = cut ? (thr > 0u ? thr - 1u : 0u) : thr_g;
+                if (lane < CVs) vv.vl[(size_t)lane * ns + i] = lane < n ? s_pos[lane] : 0;
+                if (lane == 0) {
+                    vv.vn[i] = (unsigned char)n;
+                    vv.vg2[i] = __uint_as_float(g2_bits);
+                    vv.vacc[i] = 0.f;
+                    vv.vmask[i] = 0xFFFFFFFFu;
+                }
+                if (lane < n && mine > in_radius) s_d2[lane] = 0xFFFFFFFFu;  // (outside the radius: they sort last and are not counted)
+                unsigned tm1 = 0xFFFFFFFFu;
+                int n_ans = n_in;
+                if (n_in >= m) {
+                    unsigned t1 = 0;
+                    n_ans = wave_select_top_m<PER>(s_pos, s_d2, n, m, tgt, lane, t1);
+                    tm1 = t1;
+                } else if (n_in > 0) {
+                    // fewer than m inside the (fully covered) radius: those are the row — compact them to the front
+                    const unsigned long long keep = __ballot(lane < n && s_d2[lane] <= in_radius);
+                    const int at = __builtin_amdgcn_mbcnt_hi((unsigned)(keep >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)keep, 0u));
+                    const int p_l = lane < n ? s_pos[lane] : 0;
+                    const bool k_l = lane < n && s_d2[lane] <= in_radius;
+                    if (k_l) s_pos[at] = p_l;  // (at <= lane: a lane reads its own entry before anybody writes a later slot... same wave, lockstep)
+                }
+                if (lane < n_ans) nbr[(size_t)lane * ns + i] = s_pos[lane];
+                if (lane == 0) cnt[i] = n_ans, dm2[i] = tm1;
+                done = true;
+            }
+        }
+        if (done) continue;
         for (;;) {
             R2 = fminf(R2 * 2.25f, r2);
             // d2 >= +0 and r2 > 0: "d2 < r2" is "bits(d2) <= bits(r2) - 1"; an intermediate radius may include its sphere's surface
@@ -2198,6 +2249,7 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? 4 : C <= 16 ? (CAP * 13 + C *
         // (the casts go through uintptr_t so that the host pass, where every pointer is 64-bit, parses them too)
         const unsigned list0 = (unsigned)(__UINTPTR_TYPE__)(lds_u16p)(s_list + lcol), list_last = list0 + C * 512;
         const unsigned halo0 = (unsigned)(__UINTPTR_TYPE__)(lds_f32p)s_x;
+        bool no_room = false;
         for (int attempt = 0;; attempt++) {
             // the list's write cursor counts every accepted candidate (so n is exact), the store slot is clamped to
             // the spare slot C: an overflowing lane keeps its first C entries
@@ -2255,13 +2307,16 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? 4 : C <= 16 ? (CAP * 13 + C *
             // list overflow (dense neighbourhood, or no usable cut-off yet): the C entries that were kept are genuine
             // in-radius candidates, so the m-th smallest of them bounds the final m-th distance: scan again
             (void)select_top_m<M>(L, tgt, q, C, m, thr);
-            if constexpr (VERLET) thr = min(thr, thr_a);  // (the list of such a row ends at its cut-off: no margin, rebuilt next time)
+            if constexpr (VERLET) {
+                thr = min(thr, thr_a);  // (what is left of such a row's scan ends at its cut-off: nothing a list could live on)
+                no_room = true;
+            }
         }
         if constexpr (VERLET) {
             // The row's Verlet list: what the scan accepted (every target whose d2 bits are <= thr; the scan's lists are half
             // as long again as a Verlet list), cut back to the list's slots where there are more.
             constexpr int CVs = verlet_slots(M);
-            bool listed = scan_lists && n >= 0;
+            bool listed = scan_lists && n >= 0 && !no_room;  // (no_room: more targets in reach than the scan's list holds, twice: no list)
             if (listed && n > CVs) {
                 if constexpr (M <= 12) {
                     // the sixteen NEAREST stay; the list is complete below the farthest of them (for the typical row the 16th

@@ -20,7 +20,12 @@ if n in (8, 9, 10):      # (a config of synth.CONFIGS instead of a size: the com
     prm = (cfg["radius"], cfg["max_neighbours"], cfg["dof"], 3)
     inner = int(cfg.get("inner_steps", 1))
 else:
-    src, tgt, _, _ = synth.make_pair(n, cfg=3 if n >= 1_000_000 else 2)
+    scale = 1.0
+    for kv in list(opts):
+        if kv[0] == "traj":          # traj=3: bench.py's second trajectory (3 x motion, 3 x noise)
+            scale = float(kv[1])
+            opts.remove(kv)
+    src, tgt, _, _ = synth.make_pair(n, cfg=3 if n >= 1_000_000 else 2, motion_scale=scale, noise_scale=scale)
     prm = (1.0, 10, 5.0, 3)
 c = _lib.Context(0)
 for k, v in opts:
