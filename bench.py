@@ -126,7 +126,7 @@ def spawn_ranks(a):
     return subprocess.run(cmd, env=env).returncode
 
 
-def k1_instantiation(cfg, inner_steps, two_pass, fused=True, verlet=True):
+def k1_instantiation(cfg, inner_steps, two_pass, fused=True, verlet=True, n_rows=None):
     """Template string of the nn_fast_kernel instantiation a config's steady-state iterations launch (mirrors
     launch_tile<M> in csrc/ppcr_nn_tile.hip and k23_form in csrc/ppcr_hip_iteration.inc): list width M = the narrowest compiled
     width holding max_neighbours; widths <= 10 have the steady-state variant (16-slot lists, 1728-candidate halo), wider
@@ -148,9 +148,15 @@ def k1_instantiation(cfg, inner_steps, two_pass, fused=True, verlet=True):
     multi = "scene" in cfg   # (clouds with a dense tail: the multi-level instantiation)
     if steady and not two_pass and not multi and verlet:
         # the Verlet variant (csrc/ppcr_device.hip.h: VerletLists): 24-slot scan lists, 1920-candidate halo, four workgroups
-        # per CU; rows answered from their lists where the lists still hold
-        return f"nn_fast_kernel<{width}, 24, 1920, false, {ftm}, false, true>"
-    return f"nn_fast_kernel<{width}, {c}, {cap}, false, {ftm}, {'true' if multi else 'false'}, false>"
+        # per CU; rows answered from their lists where the lists still hold.  Last template argument: 1, or 2 where the grid is
+        # resident all at once (<= 1024 workgroups: a few failing rows are rebuilt inside the workgroup)
+        rows = n_rows if n_rows is not None else cfg["n"]
+        variant = 2 if (rows + 255) // 256 + 128 <= 1024 else 1
+        return f"nn_fast_kernel<{width}, 24, 1920, false, {ftm}, false, {variant}>"
+    if width in (16, 20) and not multi and verlet:
+        # the mid widths' Verlet variant (32-slot lists, 36-slot scan lists, 1600-candidate halo), one- or two-pass
+        return f"nn_fast_kernel<{width}, 36, 1600, false, -2, false, 1>"
+    return f"nn_fast_kernel<{width}, {c}, {cap}, false, {ftm}, {'true' if multi else 'false'}, 0>"
 
 
 def effective_cores():
@@ -589,8 +595,8 @@ def run_rank(a):
         two_pass = "nn_wide_kernel" in prof
         fused_on = not any(kv.split("=")[0] == "fuse_k23" and int(kv.split("=")[1]) == 0 for kv in a.opt)
         verlet_on = not any(kv.split("=")[0] == "verlet" and int(kv.split("=")[1]) != 1 for kv in a.opt)
-        kname = k1_instantiation(cfg, a.inner_steps, two_pass, fused_on, verlet_on)
-        kname_alone = k1_instantiation(cfg, a.inner_steps, two_pass, False, verlet_on)
+        kname = k1_instantiation(cfg, a.inner_steps, two_pass, fused_on, verlet_on, n)
+        kname_alone = k1_instantiation(cfg, a.inner_steps, two_pass, False, verlet_on, n)
         traffic, traffic_source, traffic_alone, pmc = None, None, None, {}
         tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
         if os.path.exists(tpath) and ns == nt == 1000000 and not two_pass:
@@ -608,7 +614,7 @@ def run_rank(a):
                                               (" and K23 (weights + 19 moments) folded in" if ", -2, " not in kname else "") +
                                               ("; Verlet variant: a workgroup whose rows' lists still provably hold every possible "
                                                "neighbour re-measures the lists (16 gathers per row), the others search the grid and "
-                                               "rebuild" if kname.endswith("true>") else "")),
+                                               "rebuild" if ", 24, 1920, " in kname else "")),
                            "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": traffic_source,
@@ -617,6 +623,13 @@ def run_rank(a):
         if traffic is not None:
             # what the kernel really pulled through the memory side, as a fraction of peak (the honest bandwidth figure)
             out["roofline"]["measured_traffic_frac"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            # ... and per regime, where the committed passes tell the Verlet variant's launches apart (tools/pmc_summary.py --split):
+            # answering launches re-measure lists, list-building ones search with a wider acceptance and write every row's list
+            regimes = {tag: (ent.get(kname + " " + tag) or {}).get("traffic_bytes_per_launch")
+                       for tag in ("[answering launches]", "[list-building launches]")}
+            if any(v is not None for v in regimes.values()):
+                out["roofline"]["traffic_by_regime"] = {k.strip("[]"): v for k, v in regimes.items()}
+                out["roofline"]["traffic_over_algorithmic_by_regime"] = {k.strip("[]"): (v / b_nn if v else None) for k, v in regimes.items()}
         if pmc.get("valu_per_wave"):
             # VALU issue: a wave64 VALU instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs at SIMD_CLOCK_GHZ
             simd_cycles = 1024 * avg_ms * 1e-3 * SIMD_CLOCK_GHZ * 1e9

@@ -1737,6 +1737,10 @@ def test_randomised_multi_level_soak():
         m = int(rng.choice([5, 10, 10, 16, 20, 20, 32]))
         with _lib.Context(0) as c:
             c.set_option("defer_moves", 1)
+            if trial % 2:      # every other trial with Verlet lists in the multi-level search (option verlet_levels), forced on
+                c.set_option("verlet_levels", 1)
+                c.set_option("verlet_engage", 100000)
+                c.set_option("verlet_dense", 1)
             c.set_params(radius, m, 5.0, 3)
             c.set_target(tgt)
             c.set_source(src)
