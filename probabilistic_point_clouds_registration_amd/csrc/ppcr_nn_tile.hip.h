@@ -1247,10 +1247,24 @@ __device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, c
             // Each entry is measured and — K23 folded in — its coordinates go to the lane's LDS cursor at once; only an entry
             // within the threshold moves the cursor (as in nn_fast_kernel's scan), so the coordinate registers are free again
             // entry by entry.  The cursor stops at the spare slot.
+            // (two entries per packed-f32 instruction — the same IEEE subtract / multiply / add per element as dist2_flann, no
+            //  FMA —, and every slot measured: a slot beyond the list's length holds a valid position and is masked out
+            //  afterwards, which is cheaper than a branch per entry)
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            unsigned d2_h[H];
+#pragma unroll
+            for (int u = 0; u + 1 < H; u += 2) {
+                const v2f ex = v2f{q.x, q.x} - v2f{cx[u], cx[u + 1]}, ey = v2f{q.y, q.y} - v2f{cy[u], cy[u + 1]}, ez = v2f{q.z, q.z} - v2f{cz[u], cz[u + 1]};
+                v2f d = ex * ex;
+                d = d + ey * ey;
+                d = d + ez * ez;
+                d2_h[u] = __float_as_uint(d.x), d2_h[u + 1] = __float_as_uint(d.y);
+            }
+            if constexpr (H % 2) d2_h[H - 1] = __float_as_uint(dist2_flann(q, make_float4(cx[H - 1], cy[H - 1], cz[H - 1], 0.f)));
 #pragma unroll
             for (int u = 0; u < H; u++) {
                 const int k = h0 + u;
-                d2b[k] = (k < nl) ? __float_as_uint(dist2_flann(q, make_float4(cx[u], cy[u], cz[u], 0.f))) : 0xFFFFFFFFu;
+                d2b[k] = (k < nl) ? d2_h[u] : 0xFFFFFFFFu;
                 const bool hit = d2b[k] <= thr;
                 in |= hit ? (1u << k) : 0u;
                 if constexpr (FTM != -2) {
