@@ -279,8 +279,23 @@ ppcr_comm *joinRanks(const Job &job, int device, std::int64_t started_unix_ms)
                 in.read(reinterpret_cast<char *>(&rec), sizeof rec);
                 have = in.gcount() == static_cast<std::streamsize>(sizeof rec) && std::memcmp(rec.magic, kRendezvousMagic, sizeof rec.magic) == 0;
                 rec.run_id[sizeof rec.run_id - 1] = 0;
-                if (have && !job.run_id.empty()) have = job.run_id.compare(0, sizeof rec.run_id - 1, rec.run_id) == 0;
-                else if (have) have = rec.written_unix_ms >= started_unix_ms - 60000;
+                if (have && !job.run_id.empty()) {
+                    have = job.run_id.compare(0, sizeof rec.run_id - 1, rec.run_id) == 0;
+                } else if (have) {
+                    // No --run-id: only a record written around this rank's own start can be this launch's (ranks of one
+                    // launch start within seconds of each other) — and only one that is still there, unchanged, half a second
+                    // later: rank 0 of THIS launch removes and rewrites the file first thing, so a valid record a crashed
+                    // launch left moments ago changes under a rank that read it too early.  (--run-id is the safe way.)
+                    have = rec.written_unix_ms >= started_unix_ms - 10000;
+                    if (have) {
+                        std::this_thread::sleep_for(std::chrono::milliseconds(500));
+                        RendezvousRecord again;
+                        std::memset(&again, 0, sizeof again);
+                        std::ifstream in2(job.rendezvous, std::ios::binary);
+                        in2.read(reinterpret_cast<char *>(&again), sizeof again);
+                        have = in2.gcount() == static_cast<std::streamsize>(sizeof again) && std::memcmp(&again, &rec, sizeof rec) == 0;
+                    }
+                }
             }
             if (!have) std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }

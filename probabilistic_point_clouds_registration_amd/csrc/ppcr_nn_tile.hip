@@ -289,7 +289,10 @@ void launch_tile(TileLaunch &t)
         return;
     }
     // persistent workgroups over the list: few when the last association this handle heard from handed nothing over
-    const int cleanup_grid = t.quiet ? std::min(nb, 32) : std::min(nb, 512);
+    // (a handful of hand-overs — a registration that still moves a few per cent of the radius per iteration leaves one to three
+    //  per launch — do not need 512 workgroups that read a counter and leave: four per workgroup the last launch handed over)
+    const int cleanup_grid = t.quiet ? std::min(nb, 32)
+                                     : std::min(nb, (t.handed_last != ~0u && t.handed_last < 128u) ? std::max(32, 4 * (int)t.handed_last) : 512);
     const int n_extra = steady ? (halves ? -1 : kMaxSplit) : 0;
     FoldSolve fs_none;
     std::memset(&fs_none, 0, sizeof(fs_none));

@@ -48,6 +48,7 @@ struct TileLaunch {
     int *ovf_list;                // workgroups handed to the cleanup kernel by this launch ...
     unsigned *ovf_now, *ovf_next; // ... counted here; the other counter of the ping-pong pair
     bool quiet;                   // the last association this handle heard from handed nothing over
+    unsigned handed_last;         // ... how many workgroups it handed over (~0u: not known)
     unsigned char *split_flag;    // the split table (see SplitTable)
     int *split_list;
     unsigned *split_state;        // {registrations, registrations visible to extra workgroups}

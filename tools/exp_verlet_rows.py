@@ -47,6 +47,6 @@ for it in range(iters):
     hist = [a - b for a, b in zip(v["failing_rows_hist"], prev["failing_rows_hist"])]
     print(f"it {it:2d} |t| {np.linalg.norm(T[:, 3]):.5f} trusted {int(v['trusted'])} searched {v['rebuilt'] - prev['rebuilt']:5d} "
           f"rows {v['rows_rebuilt'] - prev['rows_rebuilt']:6d} in {v['workgroups_rebuilding_rows'] - prev['workgroups_rebuilding_rows']:5d} wgs  "
-          f"failing-rows hist {hist}  no-list {v['rows_without_list']} short {c.debug_short_rows()}  " + "  ".join(f"{k.replace('_kernel', '')} {x:.1f}us" for k, x in dt.items()), flush=True)
+          f"failing-rows hist {hist}  no-list {v['rows_without_list']} short {c.debug_short_rows()} handed {int(c.debug_host_figures()[7])}  " + "  ".join(f"{k.replace('_kernel', '')} {x:.1f}us" for k, x in dt.items()), flush=True)
     prev = v
 c.close()
