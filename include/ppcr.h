@@ -321,11 +321,6 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *                  (default; a different summation order: results agree to rounding), 0 separate kernel;
  *   "merge_fold"   1 with "fuse_k23": the fold-and-solve step rides in the cleanup launch when the handle has the GPU
  *                  to itself (default), 0 always its own launch;
- *   "fold_tail"    1 with "merge_fold", inside ppcr_align's device-paced loop: while the associations hand no workgroup
- *                  over, the fold-and-solve step is a role of the association's last workgroups — ONE launch per
- *                  iteration (default); an association that does hand over is followed by the cleanup launch after all,
- *                  and the loop goes on with two launches; 0 always two launches; 2 (tests) one launch whatever the
- *                  hand-over history; results are identical bit for bit;
  *   "defer_moves"  1 ppcr_apply_transform leaves the move to the prologue of the next association (what ppcr_iterate
  *                  and ppcr_align always do; the temporal cut-off then survives the move), 0 moves at once (default);
  *   "inner_dev_steps"  IRLS steps beyond the first that ppcr_align enqueues for the device per outer iteration

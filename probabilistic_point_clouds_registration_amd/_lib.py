@@ -363,8 +363,7 @@ class Context:
 
     def debug_host_figures(self):
         """ppcr_debug_get_host_times (diagnostic, not part of ppcr.h): 8 doubles about the last ppcr_align on this
-        handle; [3] = iterations enqueued as one launch (option fold_tail), [4] = of which the host had to send the cleanup
-        launch after, [7] = workgroups its associations handed over to the cleanup kernel, summed over the iterations."""
+        handle; [7] = workgroups its associations handed over to the cleanup kernel, summed over the iterations."""
         out = (C.c_double * 8)()
         f = self._L.ppcr_debug_get_host_times
         f.argtypes = [C.c_void_p, C.c_void_p]

@@ -375,9 +375,6 @@ __device__ __forceinline__ void row_finish(RowAcc &acc, const Pose &P, float4 xf
 // consecutive 8-byte bank pairs.
 // The same two-round fold on scratch memory the caller provides (kernels that fold at their very end lend the buffers
 // they no longer need): sh holds 10 * 257 doubles, part 19 * 8.  All 256 threads must call it.
-// COHERENT: the sums leave with agent-scope atomic stores (a reader in the SAME launch, possibly on another XCD: the fold
-// role of a one-launch iteration, see FoldTail).
-template <bool COHERENT = false>
 __device__ __forceinline__ void block_reduce_scratch(const RowAcc &acc, double *sh, double *part, double *__restrict__ out,
                                                      size_t out_stride, bool write)
 {
@@ -409,8 +406,7 @@ __device__ __forceinline__ void block_reduce_scratch(const RowAcc &acc, double *
         double v = part[tid * 8];
 #pragma unroll
         for (int q = 1; q < 8; q++) v += part[tid * 8 + q];
-        if constexpr (COHERENT) __hip_atomic_store(&out[(size_t)tid * out_stride], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else out[(size_t)tid * out_stride] = v;
+        out[(size_t)tid * out_stride] = v;
     }
 }
 constexpr int kFoldScratchBytes = (10 * 257 + kNSums * 8) * 8;  // 21 776
@@ -630,7 +626,6 @@ struct VerletLists {
                           //     density varies a hundredfold have bounds from a twentieth of the radius to all of it, and a skin
                           //     sized for the finest level's rows is nothing to the coarsest's; 0 elsewhere)
     int build_all;        // no lists exist yet (or they are not trusted): every workgroup searches and builds
-    unsigned n_slots;     // workgroup slots of the launch (the grid, less the fold role's workgroups: FoldTail)
 };
 #ifndef PPCR_VERLET_SLOTS
 #define PPCR_VERLET_SLOTS 16
@@ -945,9 +940,6 @@ enum MailboxStatus : unsigned {
     kIterationDone = 1,  // the device finished the outer iteration's inner loop: T, cost_init, cost, steps are final
     kIterationPending = 2,  // the inner loop ran out of device steps before it converged: the host carries on from T
     kLaunchSkipped = 3,  // this launch stepped aside because an earlier one raised LoopState::abort
-    kIterationHandedOver = 4,  // a one-launch iteration (FoldTail) handed workgroups over: nothing was folded, LoopState::abort
-                               // is up and the host sends the cleanup launch — which folds and solves — after it
-    kTailTimedOut = 5,         // the fold role of a one-launch iteration gave up waiting (a defect, reported as an error)
 };
 struct HostMailbox {
     double sums[kNSums];
@@ -1018,31 +1010,6 @@ struct FoldSolve {  // everything the fold-and-solve step needs
     unsigned long long *dbg;  // diagnostic (nullable): wall-clock stamps of the solve lane
 };
 
-// ONE launch per outer iteration (nn_fast_kernel with a fold role: FoldTail).  With K23 folded into the association an
-// iteration is two dependent launches, the association and the cleanup launch that folds and solves — and on grids of a
-// few hundred workgroups the second one's dispatch (~4-5 us between two dependent kernels, plus its own start) is a
-// third of the iteration.  When the last associations handed no workgroup over, kNSums extra workgroups at the END of
-// the association's grid take the fold-and-solve role: they wait for every other workgroup's partial sums (one flag
-// word per workgroup, stamped with the launch's sequence number: nothing to clear, no shared counter — see
-// inner_steps_kernel, whose protocol this is), fold a row each and the last one solves and publishes.  Should the
-// association hand a workgroup over after all, nothing is folded: the fold role raises LoopState::abort, reports
-// kIterationHandedOver, and the host enqueues the ordinary cleanup launch for that iteration (AlignJob::redo_with_cleanup).
-// What the role reads from DEVICE memory (as kernel arguments FoldSolve's ~40 words would sit in the association's SGPRs):
-#ifndef PPCR_TAIL_SLEEP
-#define PPCR_TAIL_SLEEP 4
-#endif
-struct FoldTailConst {
-    FoldSolve fs;         // seq, mbox, handed_over, loop.first / last_dev: per launch (FoldTail, kernel arguments)
-    unsigned *flags;      // [slots of the association's grid]: == seq once that workgroup's partial sums are in place
-    HostMailbox *mbox_ring;
-    int mbox_slots;
-};
-struct FoldTail {
-    const FoldTailConst *k;  // nullptr: no fold role in this launch
-    unsigned seq;
-    int last_dev;
-};
-
 // a launch that steps aside still owes the host its mailbox slot (the host counts sequence numbers)
 __device__ __forceinline__ void publish_skipped(const FoldSolve &fs)
 {
@@ -1058,17 +1025,9 @@ __device__ __forceinline__ void solve_and_publish(const FoldSolve &fs, SumsPtr S
 // but whole (flag 1) — so that which blocks are split, the order of their partial-sum slots and with it every sum do not
 // depend on the order in which the registrations arrived (an atomic counter used to hand out the slots: with more than
 // kMaxSplit candidates two runs of one registration differed in their last bits).
-// (EXT: the caller lends kBlock words of LDS — a kernel whose LDS budget is spoken for: nn_fast_kernel's fold role)
-template <bool EXT = false>
-__device__ __forceinline__ void rebuild_split_list(const FoldSolve &fs, unsigned total, int *ext = nullptr)
+__device__ __forceinline__ void rebuild_split_list(const FoldSolve &fs, unsigned total)
 {
-    int *s_cnt;
-    if constexpr (EXT) {
-        s_cnt = ext;
-    } else {
-        __shared__ int s_cnt_own[kBlock];
-        s_cnt = s_cnt_own;
-    }
+    __shared__ int s_cnt[kBlock];
     const int nb = fs.split_nblocks, per = (nb + kBlock - 1) / kBlock;
     const int b0 = min((int)threadIdx.x * per, nb), b1 = min(b0 + per, nb);
     int mine = 0;
@@ -1103,18 +1062,10 @@ __device__ __forceinline__ void rebuild_split_list(const FoldSolve &fs, unsigned
 
 // one of the kNSums fold blocks (256 threads): fold row `sum_index` of the partials; the last block to finish solves.
 // Returns true on the ONE lane that solved (after everything it had to write is written).  LEAN: see solve_rigid_device.
-// EXT: the caller lends kFoldExtBytes of LDS (see rebuild_split_list).
-constexpr int kFoldExtBytes = 256 + kBlock * 4;  // {wave sums [4], moments [19]} in the first 256 bytes, then kBlock words
-template <bool LEAN = false, bool EXT = false>
-__device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int sum_index, unsigned char *ext = nullptr)
+template <bool LEAN = false>
+__device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int sum_index)
 {
-    double *sh;
-    if constexpr (EXT) {
-        sh = reinterpret_cast<double *>(ext);
-    } else {
-        __shared__ double sh_own[kBlock / 64];
-        sh = sh_own;
-    }
+    __shared__ double sh[kBlock / 64];
     const unsigned long long t_entry = fs.dbg ? wall_clock64() : 0ull;
     // (the first fold block also keeps the split table: the two words that say whether it has to are asked for here and
     //  looked at behind the row's loads)
@@ -1124,7 +1075,7 @@ __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int su
     double v = 0.0;
     // sixteen loads per lane in flight (4096 slots: ONE memory round trip at 1M points), added in slot order
     // (LEAN: eight — inner_steps_kernel has at most 2048 slots, and registers to save)
-    constexpr int kInFlight = (LEAN && !EXT) ? 8 : 16;
+    constexpr int kInFlight = LEAN ? 8 : 16;
     for (int b0 = 0; b0 < fs.nslots; b0 += kInFlight * kBlock) {
         double t[kInFlight];
 #pragma unroll
@@ -1138,10 +1089,7 @@ __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int su
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (split_total != split_rebuilt) {  // (uniform; a handful of launches per registration)
-        if constexpr (EXT) rebuild_split_list<true>(fs, split_total, reinterpret_cast<int *>(ext + 256));
-        else rebuild_split_list(fs, split_total);
-    }
+    if (split_total != split_rebuilt) rebuild_split_list(fs, split_total);  // (uniform; a handful of launches per registration)
     if (threadIdx.x != 0) return false;
     const unsigned long long t_folded = fs.dbg ? wall_clock64() : 0ull;
     double x = sh[0];
@@ -1157,13 +1105,7 @@ __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int su
     __hip_atomic_store(fs.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(fs.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every fold block is past its wait
     if constexpr (LEAN) {
-        double *s_S;  // the moments for the one lane that solves (see solve_rigid_device)
-        if constexpr (EXT) {
-            s_S = reinterpret_cast<double *>(ext) + kBlock / 64;
-        } else {
-            __shared__ double s_S_own[kNSums];
-            s_S = s_S_own;
-        }
+        __shared__ double s_S[kNSums];  // the moments for the one lane that solves (see solve_rigid_device)
 #pragma unroll
         for (int j = 0; j < kNSums; j++) s_S[j] = __hip_atomic_load(&fs.sums[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (fs.dbg) {
@@ -1260,75 +1202,6 @@ __device__ __forceinline__ void solve_and_publish(const FoldSolve &fs, SumsPtr S
     fs.mbox->degenerate = rs.degenerate ? 1u : 0u;
     fs.mbox->handed_over = handed;
     __hip_atomic_store(&fs.mbox->seq, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-__device__ __forceinline__ void publish_skipped_tail(const FoldTail &ft)
-{
-    HostMailbox *const mbox = ft.k->mbox_ring + (ft.seq % (unsigned)ft.k->mbox_slots);
-    mbox->status = kLaunchSkipped;
-    __hip_atomic_store(&mbox->seq, ft.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// The fold role of a one-launch iteration (FoldTail): workgroup `row` of the kNSums last workgroups of the association's
-// grid; n_real = the workgroups in front of them, handed = the launch's hand-over counter.  Every thread calls.
-// lds: kFoldExtBytes of the workgroup's LDS (it uses nothing else).
-__device__ __forceinline__ void fold_tail_role(const FoldTail &ft, const unsigned n_real, const int row, const unsigned *handed,
-                                               unsigned char *lds)
-{
-    const FoldTailConst *const k = ft.k;
-    // every other workgroup's partial sums must be in place (relaxed polls: see inner_steps_kernel); a bounded wait — a
-    // second of it — so that a defect ends as an error on the host and not as a hung device
-    bool gave_up = false;
-    volatile int *const s_word = reinterpret_cast<volatile int *>(lds);
-    if (threadIdx.x == 0) *s_word = 0;
-    __syncthreads();
-    // (sixteen flags per lane in flight: each poll is a round trip to the memory side, and 4000 workgroups' flags polled
-    //  one after the other were sixteen of them in a row even when every flag was up)
-    constexpr int kPoll = 16;
-    for (unsigned base = 0; base < n_real && !gave_up; base += kBlock * kPoll) {
-        unsigned spins = 0;
-        for (;;) {
-            unsigned f[kPoll];
-#pragma unroll
-            for (int u = 0; u < kPoll; u++) {
-                const unsigned j = base + (unsigned)u * kBlock + threadIdx.x;
-                f[u] = j < n_real ? __hip_atomic_load(&k->flags[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ft.seq;
-            }
-            bool all = true;
-#pragma unroll
-            for (int u = 0; u < kPoll; u++) all = all && f[u] == ft.seq;
-            if (all) break;
-            __builtin_amdgcn_s_sleep(PPCR_TAIL_SLEEP);
-            if (++spins > (1u << 21)) {
-                gave_up = true;
-                break;
-            }
-        }
-    }
-    if (gave_up) *s_word = 1;
-    __syncthreads();
-    const bool any_gave_up = *s_word != 0;
-    __syncthreads();  // (the fold reuses the word)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // kNSums of these per launch: the fold reads the partials plainly
-    const unsigned n_handed = __hip_atomic_load(handed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    HostMailbox *const mbox = k->mbox_ring + (ft.seq % (unsigned)k->mbox_slots);
-    if (any_gave_up || n_handed != 0u) {
-        if (row == 0 && threadIdx.x == 0) {
-            LoopState *const st = k->fs.loop.st;
-            __hip_atomic_store(&st->abort, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            mbox->status = any_gave_up ? kTailTimedOut : kIterationHandedOver;
-            mbox->handed_over = n_handed;
-            __hip_atomic_store(&mbox->seq, ft.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        return;
-    }
-    FoldSolve fs = k->fs;
-    fs.seq = ft.seq;
-    fs.mbox = mbox;
-    fs.handed_over = handed;
-    fs.loop.first = 1;
-    fs.loop.last_dev = ft.last_dev;
-    (void)fold_and_solve_block<true, true>(fs, row, lds);
 }
 
 }  // namespace dev

@@ -290,21 +290,6 @@ struct ppcr_ctx {
     DevBuf<InnerConst> d_inner_const;
     InnerConst h_inner_const{};
     bool inner_const_valid = false;
-    // one launch per outer iteration (FoldTail: the fold-and-solve step as a role of the association's last workgroups)
-    int opt_fold_tail = 1;
-    DevBuf<FoldTailConst> d_tail_const;  // what the role reads from device memory, and the host's copy
-    FoldTailConst h_tail_const{};
-    bool tail_const_valid = false;
-    DevBuf<unsigned> d_tail_flags;       // one word per workgroup slot, stamped with sequence numbers (cleared when allocated)
-    bool tail_blocked = false;           // this align loop met a hand-over in a one-launch iteration: two launches from here on
-    // the association launch of each iteration in flight (index: its mailbox sequence number % ring), should the host have
-    // to send the cleanup launch after it (kIterationHandedOver)
-    struct TailSaved {
-        TileLaunch tl;
-        FusedMoments fm;
-        int m = 0;
-        unsigned seq = 0;
-    } tail_saved[kMailboxRing];
     // per-iteration reports of the device-paced loop (track_kernel)
     HostReport *h_report = nullptr;    // pinned + device-mapped ring of kMailboxRing slots
     HostReport *d_report = nullptr;

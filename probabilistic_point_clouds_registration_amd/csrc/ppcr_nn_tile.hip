@@ -70,14 +70,7 @@ void check_fast_kernel_lds()
                    fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, -2, false, 2>() &&
                    fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, 8, false, 2>() &&
                    fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, 0, false, 2>() &&
-                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, -3, false, 2>() &&
-                   // (... with the fold role of a one-launch iteration, which borrows the same memory)
-                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, 8, false, 3>() &&
-                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, 0, false, 3>() &&
-                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, -3, false, 3>() &&
-                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, 8, false, 4>() &&
-                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, 0, false, 4>() &&
-                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, -3, false, 4>();
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, -3, false, 2>();
         // the diagnostic (option "stamps") instantiations launch_tile can reach
         if constexpr (M == 10)
             good = good && fast_kernel_lds_ok<M, 16, kCapSteady, true, -2, true>() && fast_kernel_lds_ok<M, 16, kCapSteady, true, -2, false>() &&
@@ -124,7 +117,6 @@ void launch_tile(TileLaunch &t)
     std::memset(&fm_none, 0, sizeof(fm_none));
     VerletLists vv_none;
     std::memset(&vv_none, 0, sizeof(vv_none));
-    const FoldTail ft_none{nullptr, 0u, 0};
     const LoopReset lr{t.loop_st};
     // (one-pass search: only rows marked unsearched are listed, its short rows are final)
     const bool multi = t.n_levels > 1 && t.levels != nullptr && t.short_count != nullptr;
@@ -138,34 +130,21 @@ void launch_tile(TileLaunch &t)
 #define PPCR_FAST(Cc, STAMPc, FTMc, FMc)                                                                               \
     nn_fast_kernel<M, Cc, (Cc <= 16 ? kCapSteady : CAP), STAMPc, FTMc><<<(Cc <= 16 ? grid_steady : nb), 256, 0, t.stream>>>( \
         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,  \
-        t.ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc, lr, un, vv_none, ft_none)
+        t.ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc, lr, un, vv_none)
     // steady state with Verlet lists: nn_fast_kernel<..., VERLET> answers from the lists where they still hold
-#define PPCR_FAST_V1(FTMc, FMc, Kc, GRIDc, FTc)                                                                         \
-    nn_fast_kernel<M, verlet_scan_slots(M), kCapVerlet, false, FTMc, false, Kc><<<GRIDc, 256, 0, t.stream>>>(               \
+#define PPCR_FAST_V1(FTMc, FMc, Kc)                                                                                     \
+    nn_fast_kernel<M, verlet_scan_slots(M), kCapVerlet, false, FTMc, false, Kc><<<grid_steady, 256, 0, t.stream>>>(         \
         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,    \
-        t.ovf_next, split_on_v, nullptr, FMc, lr, un, vv, FTc)
-    // (t.verlet_rows: the variant that rebuilds a few failing rows inside the workgroup — grids resident all at once;
-    //  tail: kNSums more workgroups, the fold role of a one-launch iteration — only where K23 is folded in)
+        t.ovf_next, split_on_v, nullptr, FMc, lr, un, vv)
+    // (t.verlet_rows: the variant that rebuilds a few failing rows inside the workgroup — grids resident all at once)
 #define PPCR_FAST_V(FTMc, FMc)                                                                                          \
     do {                                                                                                                \
-        if constexpr (FTMc != -2) {                                                                                     \
-            if (tail && t.verlet_rows) { PPCR_FAST_V1(FTMc, FMc, 4, grid_steady + kNSums, t.tail); break; }             \
-            if (tail) { PPCR_FAST_V1(FTMc, FMc, 3, grid_steady + kNSums, t.tail); break; }                              \
-        }                                                                                                               \
-        if (t.verlet_rows) PPCR_FAST_V1(FTMc, FMc, 2, grid_steady, ft_none);                                            \
-        else PPCR_FAST_V1(FTMc, FMc, 1, grid_steady, ft_none);                                                          \
+        if (t.verlet_rows) PPCR_FAST_V1(FTMc, FMc, 2);                                                                  \
+        else PPCR_FAST_V1(FTMc, FMc, 1);                                                                                \
     } while (0)
     t.fused = false;
-    t.tailed = false;
     int ftm = -2;  // model folded into this launch (-2: none)
     bool steady = false;
-    if (t.cleanup_only) {
-        // the association ran as a one-launch iteration and handed workgroups over (kIterationHandedOver): only the second
-        // launch — cleanup role, fold and solve — of the steady-state variant that folded K23 in
-        steady = true;
-        ftm = t.fuse_tm;
-        t.fused = true;
-    } else
     if (multi) {
         // multi-level search: every block picks its level of the grid in the kernel; no split table (a block whose halo
         // does not fit at its level leaves its rows to nn_wide_kernel), nothing folded in
@@ -177,7 +156,7 @@ void launch_tile(TileLaunch &t)
             if (st && t.dm2_in && t.short_lists) {
                 nn_fast_kernel<M, 16, kCapSteady, true, -2, true><<<grid_multi, 256, 0, t.stream>>>(
                     t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
-                    two_per_block, st, fm_none, lr, un, vv_none, ft_none);
+                    two_per_block, st, fm_none, lr, un, vv_none);
                 done = true;
             }
         }
@@ -185,7 +164,7 @@ void launch_tile(TileLaunch &t)
             if (st && !done) {
                 nn_fast_kernel<M, C, CAP, true, -2, true><<<grid_multi, 256, 0, t.stream>>>(
                     t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
-                    two_per_block, st, fm_none, lr, un, vv_none, ft_none);
+                    two_per_block, st, fm_none, lr, un, vv_none);
                 done = true;
             }
         }
@@ -201,11 +180,10 @@ void launch_tile(TileLaunch &t)
                 VerletLists vv = t.verlet;
                 vv.build_all = t.verlet_mode == 2 ? 0 : 1;
                 vv.order_now = nullptr, vv.order_next = nullptr, vv.count_now = nullptr, vv.count_next = nullptr, vv.count_clear = nullptr;
-                vv.n_slots = (unsigned)grid_multi;
                 constexpr int CAPV = M <= 12 ? kCapVerlet : CAP;
                 nn_fast_kernel<M, verlet_scan_slots(M), CAPV, false, -2, true, 1><<<grid_multi, 256, 0, t.stream>>>(
                     t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
-                    two_per_block, nullptr, fm_none, lr, un, vv, ft_none);
+                    two_per_block, nullptr, fm_none, lr, un, vv);
                 t.verlet_built = true;
                 done = true;
             }
@@ -214,7 +192,7 @@ void launch_tile(TileLaunch &t)
             if (!done && t.dm2_in && t.short_lists) {
                 nn_fast_kernel<M, 16, kCapSteady, false, -2, true><<<grid_multi, 256, 0, t.stream>>>(
                     t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
-                    two_per_block, nullptr, fm_none, lr, un, vv_none, ft_none);
+                    two_per_block, nullptr, fm_none, lr, un, vv_none);
                 done = true;
             }
         }
@@ -226,7 +204,7 @@ void launch_tile(TileLaunch &t)
         if (!done)
             nn_fast_kernel<M, C, CAPM, false, -2, true><<<grid_multi, 256, 0, t.stream>>>(t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr,
                                                                                          t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,
-                                                                                         t.ovf_next, two_per_block, nullptr, fm_none, lr, un, vv_none, ft_none);
+                                                                                         t.ovf_next, two_per_block, nullptr, fm_none, lr, un, vv_none);
         steady = true;  // (skips the single-level launches below)
     } else
     if constexpr (M <= 12) {
@@ -239,10 +217,6 @@ void launch_tile(TileLaunch &t)
             if (t.verlet_mode != 0 && !st && !halves) {
                 VerletLists vv = t.verlet;
                 vv.build_all = t.verlet_mode == 2 ? 0 : 1;
-                vv.n_slots = (unsigned)grid_steady;
-                // the fold-and-solve step inside THIS launch (FoldTail) instead of the cleanup launch below
-                const bool tail = t.tail.k != nullptr && ftm != -2 && t.fold != nullptr;
-                t.tailed = tail;
                 const SplitTable split_on_v{t.split_flag, t.split_list, t.split_state, t.split_state + 1, kMaxSplit, kCapVerlet * 15 / 16, 0};
                 if (ftm == 0) PPCR_FAST_V(0, *t.fuse);
                 else if (ftm == 8) PPCR_FAST_V(8, *t.fuse);
@@ -273,7 +247,6 @@ void launch_tile(TileLaunch &t)
                 // searched AND given fresh lists by nn_wide_kernel below
                 VerletLists vv = t.verlet;
                 vv.build_all = t.verlet_mode == 2 ? 0 : 1;
-                vv.n_slots = (unsigned)(nb + kMaxSplit);
                 const SplitTable split_mid_v{t.split_flag, t.split_list, t.split_state, t.split_state + 1, kMaxSplit, kCapVerletMid * 15 / 16, 0};
                 if (t.verlet_mode == 1) {
                     // the launch that BUILDS every list scans with the lists' reach in place of the rows' cut-offs: wider x
@@ -282,18 +255,18 @@ void launch_tile(TileLaunch &t)
                     // tile, three workgroups per CU.
                     nn_fast_kernel<M, verlet_scan_slots(M), CAP, false, -2, false, 1><<<nb + kMaxSplit, 256, 0, t.stream>>>(
                         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
-                        split_mid_v, nullptr, fm_none, lr, un, vv, ft_none);
+                        split_mid_v, nullptr, fm_none, lr, un, vv);
                 } else {
                     nn_fast_kernel<M, verlet_scan_slots(M), kCapVerletMid, false, -2, false, 1><<<nb + kMaxSplit, 256, 0, t.stream>>>(
                         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
-                        split_mid_v, nullptr, fm_none, lr, un, vv, ft_none);
+                        split_mid_v, nullptr, fm_none, lr, un, vv);
                 }
                 t.verlet_built = true;
             } else {
                 const SplitTable split_mid{t.split_flag, t.split_list, t.split_state, t.split_state + 1, kMaxSplit, CAP2 * 15 / 16, 0};
                 nn_fast_kernel<M, C2, CAP2, false, -2, false><<<nb + kMaxSplit, 256, 0, t.stream>>>(
                     t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now, t.ovf_next,
-                    split_mid, nullptr, fm_none, lr, un, vv_none, ft_none);
+                    split_mid, nullptr, fm_none, lr, un, vv_none);
             }
         }
     }
@@ -331,10 +304,6 @@ void launch_tile(TileLaunch &t)
     //  per launch — do not need 512 workgroups that read a counter and leave: four per workgroup the last launch handed over)
     const int cleanup_grid = t.quiet ? std::min(nb, 32)
                                      : std::min(nb, (t.handed_last != ~0u && t.handed_last < 128u) ? std::max(32, 4 * (int)t.handed_last) : 512);
-    if (t.tailed) {  // (the fold role rode in the association: no second launch)
-        t.merged = true;
-        return;
-    }
     const int n_extra = steady ? (halves ? -1 : kMaxSplit) : 0;
     FoldSolve fs_none;
     std::memset(&fs_none, 0, sizeof(fs_none));

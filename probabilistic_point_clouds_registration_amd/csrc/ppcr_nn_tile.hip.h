@@ -1149,7 +1149,7 @@ __device__ __forceinline__ unsigned verlet_slot(const VerletLists &vv, bool *fil
 {
     *filed_front = false;
     if (vv.order_now == nullptr) return blockIdx.x;
-    const unsigned c = blockIdx.x & 7u, j = blockIdx.x >> 3, per = (vv.n_slots + 7u) >> 3;
+    const unsigned c = blockIdx.x & 7u, j = blockIdx.x >> 3, per = (gridDim.x + 7u) >> 3;
     const unsigned nf = vv.count_now[2 * c];
     *filed_front = j < nf;
     return j < nf ? (unsigned)vv.order_now[c * per + j] : (unsigned)vv.order_now[8 * per + c * per + (j - nf)];
@@ -1157,7 +1157,7 @@ __device__ __forceinline__ unsigned verlet_slot(const VerletLists &vv, bool *fil
 __device__ __forceinline__ void verlet_file_slot(const VerletLists &vv, unsigned wg, bool front)
 {
     if (vv.order_next == nullptr) return;
-    const unsigned c = wg & 7u, per = (vv.n_slots + 7u) >> 3;
+    const unsigned c = wg & 7u, per = (gridDim.x + 7u) >> 3;
     const unsigned pos = atomicAdd(vv.count_next + 2 * c + (front ? 0u : 1u), 1u);
     vv.order_next[(front ? 0u : 8 * per) + c * per + pos] = (int)wg;
 }
@@ -1188,7 +1188,7 @@ struct VerletLds {
     static constexpr int kWinBytes = 3 * kSlots * 256 * 4;
     static constexpr int kBytes = kWinBytes > kFoldScratchBytes ? kWinBytes : kFoldScratchBytes;
 };
-template <int M, int FTM, bool TAIL = false>
+template <int M, int FTM>
 __device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, const bool valid, const float4 q, const int ns,
                                                    const float4 *__restrict__ tgt, const unsigned thr, const int m,
                                                    int *__restrict__ nbr, int *__restrict__ cnt, unsigned *__restrict__ dm2,
@@ -1395,7 +1395,7 @@ __device__ __forceinline__ void verlet_answer_rows(const int tid, const int i, c
         }
         __syncthreads();  // every lane is through with its winners: the fold borrows the memory
         double *const scratch = reinterpret_cast<double *>(s_mem);
-        block_reduce_scratch<TAIL>(sums, scratch, scratch + 10 * 257, fm.partials + wg, (size_t)fm.nslots, true);
+        block_reduce_scratch(sums, scratch, scratch + 10 * 257, fm.partials + wg, (size_t)fm.nslots, true);
         __syncthreads();  // (the forecast below borrows a word of the same memory)
     }
     // will this row's list still do after one more move like the last one?  (VerletLists' test with the new m-th distance)
@@ -1554,15 +1554,11 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? 4 : C <= 16 ? (CAP * 13 + C *
                                                          int *__restrict__ ovf_list, unsigned *__restrict__ ovf_count,
                                                          unsigned *__restrict__ ovf_count_next, SplitTable split,
                                                          unsigned long long *__restrict__ stamps, FusedMoments fm,
-                                                         LoopReset lr, UnansweredRows un, VerletLists vv, FoldTail ft)
+                                                         LoopReset lr, UnansweredRows un, VerletLists vv)
 {
     // VERLET_K: 0 no lists, 1 Verlet lists, 2 Verlet lists and a few failing rows rebuilt inside the workgroup (grids that are
-    // resident all at once: see verlet_rows_in_kernel); 3 / 4: as 1 / 2 with the fold role of a one-launch iteration compiled
-    // in (FoldTail: the last kNSums workgroups of the grid fold and solve when ft.k is given)
+    // resident all at once: see verlet_rows_in_kernel)
     constexpr bool VERLET = VERLET_K != 0;
-    constexpr bool TAIL = VERLET_K >= 3;
-    constexpr int VK = TAIL ? VERLET_K - 2 : VERLET_K;
-    static_assert(!TAIL || (FTM != -2 && !MULTI && !STAMPS), "the fold role folds what a K23-folding association wrote");
     // an earlier launch may have handed the iteration to the host (LoopState::abort, set before this kernel started):
     // then this one must touch nothing.  A uniform scalar load, tested below once the query load is in flight.
     const unsigned aborted = lr.st ? lr.st->abort : 0u;
@@ -1630,30 +1626,6 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? 4 : C <= 16 ? (CAP * 13 + C *
     // the workgroup's SLOT: its index in the launch, or (Verlet variant) the slot the previous launch filed for this place
     // in the dispatch order (verlet_slot).  The slot names the block, the partial sums' column, the hand-over entry.
     unsigned wg = blockIdx.x;
-    // workgroup slots of this launch: the grid — less the fold role's workgroups at its end (FoldTail), which leave here
-    unsigned n_slots = gridDim.x;
-    if constexpr (TAIL) {
-        if (ft.k != nullptr) {
-            n_slots = gridDim.x - kNSums;
-            if (blockIdx.x >= n_slots) {
-                if (aborted) {  // (the launch steps aside: its mailbox slot is still owed)
-                    if (blockIdx.x == gridDim.x - 1 && tid == 0) publish_skipped_tail(ft);
-                    return;
-                }
-                fold_tail_role(ft, n_slots, (int)(blockIdx.x - n_slots), ovf_count, reinterpret_cast<unsigned char *>(s_halo));
-                return;
-            }
-        }
-    }
-    // a workgroup in front of a fold role says when its partial sums (written with agent-scope stores) are in place
-    auto tail_done = [&]() {
-        if constexpr (TAIL) {
-            if (ft.k != nullptr) {
-                __syncthreads();  // (waits for the stores of threads 0 .. 18 as well)
-                if (tid == 0) __hip_atomic_store(&ft.k->flags[blockIdx.x], ft.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    };
     // (a launch that steps aside does not look at the order: the launch that should have filed it may have stepped aside too)
     bool filed_front = false;  // (Verlet dispatch order: the previous launch expected this workgroup to search again)
     if constexpr (VERLET)
@@ -1690,15 +1662,10 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? 4 : C <= 16 ? (CAP * 13 + C *
         }
     } else if ((int)wg < split.n_extra) {
         if (wg >= min(*split.visible, (unsigned)kMaxSplit)) {
-            if constexpr (FTM != -2) {  // an idle slot of the partials still has to read as zero
-                if (tid < kNSums) {
-                    if constexpr (TAIL) __hip_atomic_store(&fm.partials[(size_t)tid * fm.nslots + wg], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else fm.partials[(size_t)tid * fm.nslots + wg] = 0.0;
-                }
-            }
+            if constexpr (FTM != -2)  // an idle slot of the partials still has to read as zero
+                if (tid < kNSums) fm.partials[(size_t)tid * fm.nslots + wg] = 0.0;
             if constexpr (VERLET)
                 if (tid == 0 && !aborted) verlet_file_slot(vv, wg, false);
-            if (!aborted) tail_done();
             return;
         }
         bid = split.list[wg];
@@ -1758,7 +1725,7 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? 4 : C <= 16 ? (CAP * 13 + C *
     if (aborted) return;
     // the other counter of the ping-pong pair: idle during this launch  (the last workgroup is never an idle split slot;
     // with all_halves the first one never idles)
-    if (tid == 0 && wg == (split.all_halves ? 0u : n_slots - 1)) {
+    if (tid == 0 && wg == (split.all_halves ? 0u : gridDim.x - 1)) {
         *ovf_count_next = 0;
         if (un.next != nullptr) *un.next = 0;
         if constexpr (VERLET)
@@ -1851,7 +1818,7 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? 4 : C <= 16 ? (CAP * 13 + C *
             // (diagnostic: how many rows fail where any does — 1, 2-4, 5-16, more)
             if (tid == 0 && n_fail > 0 && vv.rebuilt != nullptr) atomicAdd(vv.rebuilt + 12 + (n_fail > 16 ? 3 : n_fail > 4 ? 2 : n_fail > 1 ? 1 : 0), 1u);
             bool answers = true;  // this lane's row is answered from its list
-            constexpr int kRows = verlet_rows_in_kernel(M, VK);
+            constexpr int kRows = verlet_rows_in_kernel(M, VERLET_K);
             // A FEW failing rows: the near ones are rebuilt here, one row per wave (verlet_rebuild_row), and answered with
             // the others; the far ones go to nn_wide_kernel's list (where there is one: two-pass and multi-level searches,
             // every launch that folds nothing in), which answers them and leaves them fresh lists.  More than a few: the
@@ -1919,9 +1886,8 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? 4 : C <= 16 ? (CAP * 13 + C *
                     }
                 // (the association's own threshold: the bound where there is one, strictly inside the full radius)
                 const unsigned thr_row = need2_full < r2_far ? __float_as_uint(need2_full) : __float_as_uint(r2_far) - 1u;
-                verlet_answer_rows<M, FTM, TAIL>(tid, i, valid && answers, q, ns, tgt0, thr_row, m, nbr, cnt, dm2, fm, vv, s_all, wg, g2, acc, moved,
-                                                 __builtin_amdgcn_sqrtf(r2_far));
-                tail_done();
+                verlet_answer_rows<M, FTM>(tid, i, valid && answers, q, ns, tgt0, thr_row, m, nbr, cnt, dm2, fm, vv, s_all, wg, g2, acc, moved,
+                                           __builtin_amdgcn_sqrtf(r2_far));
                 return;
             }
             if (tid == 0 && vv.rebuilt != nullptr) {  // (diagnostic: workgroups that searched again)
@@ -2137,9 +2103,7 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? 4 : C <= 16 ? (CAP * 13 + C *
         // once the fold-and-solve step has rebuilt the list from the flags (the kMaxSplit registered blocks with the
         // smallest ids are split, flag 2: which ones does not depend on the order the registrations arrived in) this
         // block is scanned in two halves
-        // (a fold role in this very launch reads the flags: written through)
-        if constexpr (TAIL) __hip_atomic_store(&split.flag[bid], (unsigned char)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else split.flag[bid] = 1;
+        split.flag[bid] = 1;
         atomicAdd(split.total, 1u);  // (only says that there is something new)
     }
     // the workgroup's unanswered rows go to the list in one piece: ONE atomic per workgroup that has any (every thread
@@ -2167,7 +2131,6 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? 4 : C <= 16 ? (CAP * 13 + C *
         if constexpr (FTM == -2)  // (a launch that folds K23 in never lists: the cleanup role redoes its hand-overs)
             if (un.list != nullptr) list_rows(valid, s_gbo);
         flush_stamps();
-        tail_done();  // (nothing to fold: the fold role sees the hand-over counter and leaves the iteration to the host)
         return;
     }
     // sorted-target position of a staged point = its LDS index + gbo[row slot]
@@ -2551,7 +2514,7 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? 4 : C <= 16 ? (CAP * 13 + C *
         __syncthreads();  // every wave is through with the halo: the fold borrows its memory
         double *const scratch = reinterpret_cast<double *>(s_halo);
         // a block that was handed to the cleanup kernel (s_bail) leaves its slot to that kernel
-        block_reduce_scratch<TAIL>(acc, scratch, scratch + 10 * 257, fm.partials + wg, (size_t)fm.nslots, s_bail == 0);
+        block_reduce_scratch(acc, scratch, scratch + 10 * 257, fm.partials + wg, (size_t)fm.nslots, s_bail == 0);
         stamp(6);
     }
     if constexpr (VERLET) {
@@ -2562,7 +2525,6 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? 4 : C <= 16 ? (CAP * 13 + C *
         verlet_forecast(vv, wg, valid && !(reach_next * reach_next < vg_new), s_need);
     }
     flush_stamps();
-    tail_done();
 }
 
 

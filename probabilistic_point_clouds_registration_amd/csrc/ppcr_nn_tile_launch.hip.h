@@ -60,16 +60,12 @@ struct TileLaunch {
     const dev::FusedMoments *fuse;  // fold K23 into K1 at this pose / model when the steady-state variant runs
     int fuse_tm;                    // ... in this compiled form: 0 Gaussian, 8 t with v + dim = 8, -3 t with another integer v + dim
     const dev::FoldSolve *fold;     // ... and the fold-and-solve step into the cleanup launch
-    dev::FoldTail tail;             // ... or (k != nullptr, with fold) into the association itself: one launch per iteration
-    int cleanup_only;               // the association has run (as a one-launch iteration that handed workgroups over): launch
-                                    //   only what follows it
     dev::LoopState *loop_st;        // device-paced loop: every launch steps aside while its abort flag is up (nullable)
     void (*between)(void *);        // called between the two launches (profiling scopes), may be null
     void (*between2)(void *);       // ... and before the second pass of a two-pass search
     void *between_arg;
     // out
     bool fused, merged;
-    bool tailed;                    // the fold role rode in the association (no second launch)
     bool verlet_built;              // the launch wrote / kept Verlet lists (the steady-state variant ran in Verlet mode)
 };
 

@@ -1800,52 +1800,6 @@ def test_no_lists_where_a_blocks_halo_would_outgrow_the_tile():
         assert np.linalg.norm(hist[-1][:, 3] - ora["history"][-1][:, 3]) < 1e-7
 
 
-def test_one_launch_iterations_equal_two_launch_iterations_bit_for_bit():
-    """Inside ppcr_align's loop the fold-and-solve step rides in the association itself while nothing is handed over
-    (FoldTail, option fold_tail): one launch per iteration.  Same partial sums, same fold, same solve: histories, costs and the
-    moved source are IDENTICAL to the two-launch form — on a calm pair (every iteration after the first few is one launch), on
-    a pair whose blocks are handed over in every iteration with the one-launch form forced (fold_tail = 2: the host sends the
-    cleanup launch after every single association, the trains behind it step aside and are taken back), with a
-    device-paced inner loop behind the association, and across chained calls."""
-    rng = np.random.default_rng(21)
-    n = 60000
-    for in_radius, dense, inner in ((16, 0, 1), (70, 1, 1), (16, 0, 4), (70, 1, 3)):
-        side = (n / (in_radius / 4.18879)) ** (1 / 3)
-        tgt = rng.uniform(0, side, size=(n, 3)).astype(np.float32)
-        src = (tgt[rng.permutation(n)] + rng.normal(0, 0.02, size=(n, 3)) + [0.03, -0.02, 0.01]).astype(np.float32)
-        runs = {}
-        for tail in (0, 2 if dense else 1):
-            with _lib.Context(0) as c:
-                c.set_option("fold_tail", tail)
-                c.set_option("verlet_dense", dense)
-                c.set_params(1.0, 10, 5.0, 3)
-                c.set_target(tgt)
-                c.set_source(src)
-                first = c.align(14, cost_drop_thresh=-1.0, inner_steps=inner)
-                fig_first = c.debug_host_figures()
-                second = c.align(9, cost_drop_thresh=-1.0, inner_steps=inner)
-                fig_second = c.debug_host_figures()
-                runs[tail] = (first, second, c.get_source())
-                if tail == 0:
-                    assert fig_first[3] == 0 and fig_second[3] == 0
-                elif not dense:
-                    # (only associations of the lists' variant, and none before a hand-over count is known)
-                    assert fig_first[3] >= 5 and fig_first[4] == 0, fig_first
-                    assert fig_second[3] >= 9 - 1 and fig_second[4] == 0, fig_second
-                else:
-                    assert fig_first[7] > 0 and fig_first[4] >= 5, fig_first          # redone in every iteration with lists
-                    assert fig_second[4] >= 6, fig_second
-        (a1, a2, sa), (b1, b2, sb) = runs[0], runs[2 if dense else 1]
-        for x, y in ((a1, b1), (a2, b2)):
-            np.testing.assert_array_equal(x["history"], y["history"])
-            np.testing.assert_array_equal(x["costs"], y["costs"])
-            np.testing.assert_array_equal(x["inner_steps"], y["inner_steps"])
-        np.testing.assert_array_equal(sa, sb)
-        ora = po.align(src, tgt, 1.0, 10, 5.0, 14, cost_drop_thresh=-1.0, inner_max_steps=inner)
-        assert synth.rotation_angle(a1["history"][-1][:, :3], ora["history"][-1][:, :3]) < 1e-8
-        assert np.linalg.norm(a1["history"][-1][:, 3] - ora["history"][-1][:, 3]) < 1e-7
-
-
 def test_sparse_source_against_a_dense_target():
     """Scan to map: a source ten times sparser than the target.  256 of its rows span a halo no LDS tile holds, so the tiled
     kernel hands every block over and the row-per-wave kernel answers every row; from the second such association on the
