@@ -28,6 +28,7 @@
 
 #include "ppcr_host_math.hpp"
 #include "ppcr_pool.hpp"
+#include "ppcr_batch_sched.hpp"
 #include "ppcr_kernels.hip.h"
 #include "ppcr_nn_tile_launch.hip.h"
 

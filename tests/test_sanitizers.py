@@ -177,3 +177,26 @@ def test_device_pool_suballocator_under_asan_ubsan_and_tsan(tmp_path):
         subprocess.check_call(common + ["-fsanitize=thread", "-DPOOL_TEST_SMALL_SLABS", "-o", exe])
         r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"), timeout=600)
         assert r.returncode == 0 and "pool test: 0 failed" in r.stdout and "ThreadSanitizer" not in r.stderr, (r.stdout + r.stderr)[-3000:]
+
+
+@needs_asan
+def test_batch_scheduler_threads_under_asan_and_tsan(tmp_path):
+    """csrc/ppcr_batch_sched.hpp — the threads, hand-over queues and error latch of ppcr_batch_run, the very template the
+    library instantiates with its handles — with a host stand-in for handles and registrations (tests/cpp/test_sched.cc):
+    every pair prepared / run / retired exactly once on a handle nobody else holds, bounded handles and lanes, every handle
+    released once, errors from each operation reported and the share wound down; four devices' shares side by side on one
+    error latch.  Under ASan + UBSan, then under TSan."""
+    src = os.path.join(ROOT, "tests", "cpp", "test_sched.cc")
+    common = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-I",
+              os.path.join(ROOT, "probabilistic_point_clouds_registration_amd", "csrc"), src, "-pthread"]
+    exe = str(tmp_path / "sched_asan")
+    subprocess.check_call(common + ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, **SAN_ENV), timeout=600)
+    assert r.returncode == 0 and "sched test: 0 failed" in r.stdout, (r.stdout + r.stderr)[-3000:]
+    if _tsan_ok():
+        exe = str(tmp_path / "sched_tsan")
+        subprocess.check_call(common + ["-fsanitize=thread", "-o", exe])
+        for _ in range(3):  # (thread interleavings differ from run to run)
+            r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"), timeout=600)
+            assert r.returncode == 0 and "sched test: 0 failed" in r.stdout and "ThreadSanitizer" not in r.stderr, (r.stdout + r.stderr)[-3000:]
+
