@@ -1062,7 +1062,7 @@ __device__ __forceinline__ void rebuild_split_list(const FoldSolve &fs, unsigned
 
 // one of the kNSums fold blocks (256 threads): fold row `sum_index` of the partials; the last block to finish solves.
 // Returns true on the ONE lane that solved (after everything it had to write is written).  LEAN: see solve_rigid_device.
-template <bool LEAN = false>
+template <bool LEAN = false, int IN_FLIGHT = 0>
 __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int sum_index)
 {
     __shared__ double sh[kBlock / 64];
@@ -1075,7 +1075,7 @@ __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int su
     double v = 0.0;
     // sixteen loads per lane in flight (4096 slots: ONE memory round trip at 1M points), added in slot order
     // (LEAN: eight — inner_steps_kernel has at most 2048 slots, and registers to save)
-    constexpr int kInFlight = LEAN ? 8 : 16;
+    constexpr int kInFlight = IN_FLIGHT > 0 ? IN_FLIGHT : (LEAN ? 8 : 16);
     for (int b0 = 0; b0 < fs.nslots; b0 += kInFlight * kBlock) {
         double t[kInFlight];
 #pragma unroll
@@ -1106,8 +1106,13 @@ __device__ __forceinline__ bool fold_and_solve_block(const FoldSolve &fs, int su
     __hip_atomic_store(fs.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every fold block is past its wait
     if constexpr (LEAN) {
         __shared__ double s_S[kNSums];  // the moments for the one lane that solves (see solve_rigid_device)
+        {   // (all nineteen loads in flight, then the LDS stores: load-store pairs were nineteen round trips in a row, 2.1 us)
+            double t[kNSums];
 #pragma unroll
-        for (int j = 0; j < kNSums; j++) s_S[j] = __hip_atomic_load(&fs.sums[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int j = 0; j < kNSums; j++) t[j] = __hip_atomic_load(&fs.sums[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < kNSums; j++) s_S[j] = t[j];
+        }
         if (fs.dbg) {
             __builtin_amdgcn_s_waitcnt(0);
             fs.dbg[0] = t_entry, fs.dbg[1] = t_folded, fs.dbg[2] = t_ticket, fs.dbg[3] = wall_clock64();
@@ -1185,8 +1190,13 @@ __device__ __forceinline__ void solve_and_publish(const FoldSolve &fs, SumsPtr S
     }
     // (an intermediate step sends nothing to the host: its 33 words over PCIe used to sit between two device steps)
     if (!publish) return;
+    {   // (S may be a volatile LDS pointer: read in one go, not one read per store)
+        double Sl[kNSums];
 #pragma unroll
-    for (int j = 0; j < kNSums; j++) fs.mbox->sums[j] = S[j];
+        for (int j = 0; j < kNSums; j++) Sl[j] = S[j];
+#pragma unroll
+        for (int j = 0; j < kNSums; j++) fs.mbox->sums[j] = Sl[j];
+    }
 #pragma unroll
     for (int a = 0; a < 3; a++) {
 #pragma unroll

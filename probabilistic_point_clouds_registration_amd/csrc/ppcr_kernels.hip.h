@@ -617,6 +617,14 @@ __global__ __launch_bounds__(BLOCK) void accumulate_ell_kernel(const int *__rest
 // solved (rows dealt G-strided in tiles of 256) and kNSums workgroups fold and solve.  When the loop is over (the common case at
 // its very first look) every remaining workgroup returns at once.
 // ---------------------------------------------------------------------------------------------
+#ifndef PPCR_INNER_LEAN
+#define PPCR_INNER_LEAN 1
+#endif
+#ifndef PPCR_INNER_PER_CU
+#define PPCR_INNER_PER_CU 5
+#endif
+// K23 workgroups of one device step that are resident together (with the step's fold slots): five per CU, or four
+constexpr int kInnerStepWgs = PPCR_INNER_PER_CU >= 5 ? 1200 : 1000;
 constexpr int kMaxDevSteps = 8;
 constexpr int kInnerMaxG = 2048;  // upper bound of the K23 workgroups per step (rows are dealt G-strided in tiles of 256)
 // workgroups a step carries behind its G K23 workgroups: kNSums fold workgroups + idle ones, so that a step is a multiple
@@ -660,7 +668,7 @@ __device__ __forceinline__ void inner_fold_role(const InnerConst *ic, unsigned s
     fs.handed_over = ic->ovf_state + ovf_index;
     fs.loop.first = 0;
     fs.loop.last_dev = (u == n_steps - 1) ? 1 : 0;
-    if (fold_and_solve_block<true>(fs, row)) {
+    if (fold_and_solve_block<PPCR_INNER_LEAN != 0, 8>(fs, row)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // one per step: pose, loop state
         __hip_atomic_store(ic->step_done, (unsigned long long)seq * kMaxDevSteps + (unsigned)(u + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -676,7 +684,7 @@ __device__ __forceinline__ void inner_fold_role(const InnerConst *ic, unsigned s
 // which K23's target gathers live in): waiting workgroups poll with relaxed loads — polling with acquire loads, tried
 // first, took a step from ~35 us to ~370 us.
 template <int W, int TM, bool ONEPASS>
-__global__ __launch_bounds__(kBlock, ONEPASS ? 5 : 3) void inner_steps_kernel(InnerArgs a)
+__global__ __launch_bounds__(kBlock, ONEPASS ? PPCR_INNER_PER_CU : 3) void inner_steps_kernel(InnerArgs a)
 {
     const InnerConst *const ic = a.ic;
     LoopState *const st = ic->fs.loop.st;

@@ -1545,7 +1545,7 @@ struct FastLds {
 // every iteration in which a single row of the cloud fails — inside the launch it hides behind the other workgroups' work.
 // Four workgroups per CU (the list path holds 48 coordinates in registers).
 template <int M, int C, int CAP, bool STAMPS, int FTM = -2, bool MULTI = false, int VERLET_K = 0>
-__global__ __launch_bounds__(256, (VERLET_K != 0 ? 4 : C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 4) : (CAP * 13 + C * 512 <= 39400 ? 4 : 3))) void nn_fast_kernel(float4 *__restrict__ src, int ns,
+__global__ __launch_bounds__(256, (VERLET_K != 0 ? (CAP * 13 + C * 512 > 40960 ? 3 : 4) : C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 4) : (CAP * 13 + C * 512 <= 39400 ? 4 : 3))) void nn_fast_kernel(float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt0,
                                                          const int *__restrict__ cell_start0, GridDesc g0,
                                                          float r2_0, int m, int *__restrict__ nbr,
