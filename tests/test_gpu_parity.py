@@ -1800,6 +1800,31 @@ def test_no_lists_where_a_blocks_halo_would_outgrow_the_tile():
         assert np.linalg.norm(hist[-1][:, 3] - ora["history"][-1][:, 3]) < 1e-7
 
 
+def test_skinned_grid_verdict_follows_the_source():
+    """Whether a grid's cells carry the Verlet lists' skin is decided from an estimate of a 256-row block's halo, which depends
+    on how dense the SOURCE is (its rows per target point).  A handle that keeps its target and gets sources of very different
+    sizes judges again at every ppcr_set_source and rebuilds the grid when the verdict flips: 42 target points in the radius —
+    no lists for a source as dense as the target, lists for one six times as dense, none again afterwards.  Results follow
+    the oracle every time."""
+    rng = np.random.default_rng(31)
+    n = 40000
+    side = (n / (42 / 4.18879)) ** (1 / 3)
+    tgt = rng.uniform(0, side, size=(n, 3)).astype(np.float32)
+    shift = np.array([0.03, -0.02, 0.01])
+    src_1 = (tgt[rng.permutation(n)] + rng.normal(0, 0.02, size=(n, 3)) + shift).astype(np.float32)
+    src_6 = (np.tile(tgt, (6, 1)) + rng.normal(0, 0.02, size=(6 * n, 3)) + shift).astype(np.float32)
+    with _lib.Context(0) as c:
+        c.set_params(1.0, 10, 5.0, 3)
+        c.set_target(tgt)
+        for src, want_lists in ((src_1, False), (src_6, True), (src_1, False)):
+            c.set_source(src)
+            res = c.align(16, cost_drop_thresh=-1.0, inner_steps=1)
+            assert c.debug_verlet()["trusted"] == want_lists, (len(src), c.debug_verlet())
+            ora = po.align(src, tgt, 1.0, 10, 5.0, 16, cost_drop_thresh=-1.0, inner_max_steps=1)
+            assert synth.rotation_angle(res["history"][-1][:, :3], ora["history"][-1][:, :3]) < 1e-8
+            assert np.linalg.norm(res["history"][-1][:, 3] - ora["history"][-1][:, 3]) < 1e-7
+
+
 def test_sparse_source_against_a_dense_target():
     """Scan to map: a source ten times sparser than the target.  256 of its rows span a halo no LDS tile holds, so the tiled
     kernel hands every block over and the row-per-wave kernel answers every row; from the second such association on the
