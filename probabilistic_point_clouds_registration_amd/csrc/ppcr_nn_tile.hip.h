@@ -779,12 +779,17 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
         // row (a workgroup whose halo outgrew the LDS tile, a row whose Verlet list ran out) takes its m-th distance of the
         // previous association where it has one — the source has hardly moved since — and the density of its own cell
         // where it has not.
+        // (the tiled kernel leaves a BOUND in dm2 for the rows it lists — the previous m-th distance + the row's move: the m
+        //  neighbours of the previous association lie inside, one sweep of that sphere is the whole search; the rows of a
+        //  workgroup that answered from lists and listed a few of its rows come with the previous m-th distance as it was)
         float R2;
-        if (found >= 0) {
+        if (found < 0 && prev_bits != 0xFFFFFFFFu && vv.vl != nullptr) {
+            R2 = fminf(__uint_as_float(prev_bits) * 1.05f + 1e-30f, r2);
+        } else if (prev_bits != 0xFFFFFFFFu) {
+            R2 = fminf(__uint_as_float(prev_bits), r2);
+        } else if (found >= 0) {
             const float k = cbrtf((float)m / fmaxf((float)found, 0.5f)) * 1.15f;
             R2 = r1_sq * k * k;
-        } else if (prev_bits != 0xFFFFFFFFu && vv.vl != nullptr) {
-            R2 = fminf(__uint_as_float(prev_bits) * 1.05f + 1e-30f, r2);
         } else {
             const bool inside = (unsigned)c.cx < (unsigned)g.n[0] && (unsigned)c.cy < (unsigned)g.n[1] && (unsigned)c.cz < (unsigned)g.n[2];
             const int cell = inside ? (c.cz * g.n[1] + c.cy) * g.n[0] + c.cx : 0;
@@ -908,7 +913,7 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
         // then holds the m nearest of the cloud: everything outside it is farther) or reaches the whole radius.  Half the
         // latency of search-then-list for the handful of rows a launch is left with once the lists answer.
         bool done = false;
-        if (vv.vl != nullptr && found < 0 && prev_bits != 0xFFFFFFFFu) {
+        if (vv.vl != nullptr && prev_bits != 0xFFFFFFFFu) {
             const float need0 = __builtin_amdgcn_sqrtf(__uint_as_float(prev_bits)) * 1.02f + 1e-30f;
             const float G1 = fminf(need0 + fmaxf(vv.skin2, vv.skin_rel * need0), (float)reach * g.h * 0.999f);
             const unsigned thr_g = __float_as_uint(G1 * G1);
@@ -1742,20 +1747,6 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? (CAP * 13 + C * 512 > 40960 ?
         const float ex = q.x - q0.x, ey = q.y - q0.y, ez = q.z - q0.z;
         moved = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez);  // 1 ulp: far inside the 1e-5 inflation below
     }
-    if constexpr (FTM == -2 && !VERLET) {
-        if (un.list_all && un.list != nullptr) {
-            // (uniform) every row to nn_wide_kernel, marked unsearched, every block counted as handed over.  The list is the
-            // identity and both counters are known: no atomics (4 000 waves drawing list positions from one counter at the
-            // same moment cost this path 20 us)
-            if (valid) cnt[i] = -1, un.list[i] = i;
-            if (tid == 0 && wg == 0) {
-                *un.count = (unsigned)ns;
-                *ovf_count = (unsigned)((ns + BLOCK - 1) / BLOCK);
-            }
-            flush_stamps();
-            return;
-        }
-    }
     // Temporal cut-off.  dm2[i] holds the float d2 of this query's m-th neighbour in the previous association
     // (all-ones when it had fewer than m).  Those m targets are now at most dm + |move| away, so the new m-th distance
     // is <= dm + |move|: a candidate farther than that cannot be among the m closest and is never appended.  The
@@ -1774,6 +1765,25 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? (CAP * 13 + C * 512 > 40960 ?
             const float t2 = bound * bound * 1.00001f + 1e-30f;
             thr0 = (t2 < (MULTI ? un.r2_full : r2_0)) ? __float_as_uint(t2) : 0xFFFFFFFFu;
             need2_full = fminf(t2, r2_far);
+        }
+    }
+    // What a row this kernel leaves to nn_wide_kernel finds in dm2: the BOUND just formed — the m neighbours of the previous
+    // association lie within it where the row is now, so one sweep of that sphere holds the row's answer (the kernel had
+    // the row's density to go by: an estimate, a sweep too wide or one too many) —, all-ones where there is none.
+    // (K23 folded in: nothing goes to that kernel)
+    const unsigned bound_bits = (FTM == -2 && need2_full < r2_far) ? __float_as_uint(need2_full) : 0xFFFFFFFFu;
+    if constexpr (FTM == -2 && !VERLET) {
+        if (un.list_all && un.list != nullptr) {
+            // (uniform) every row to nn_wide_kernel, marked unsearched, every block counted as handed over.  The list is the
+            // identity and both counters are known: no atomics (4 000 waves drawing list positions from one counter at the
+            // same moment cost this path 20 us)
+            if (valid) cnt[i] = -1, un.list[i] = i, dm2[i] = bound_bits;
+            if (tid == 0 && wg == 0) {
+                *un.count = (unsigned)ns;
+                *ovf_count = (unsigned)((ns + BLOCK - 1) / BLOCK);
+            }
+            flush_stamps();
+            return;
         }
     }
     // VERLET: the scan collects every target within G = bound + 2 skin (the bound on the m-th distance, or the radius for a
@@ -2128,6 +2138,8 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? (CAP * 13 + C * 512 > 40960 ?
             }
         }
         if (valid) cnt[i] = -1;
+        if constexpr (FTM == -2)
+            if (valid) dm2[i] = bound_bits;  // (see bound_bits: what nn_wide_kernel starts from)
         if constexpr (FTM == -2)  // (a launch that folds K23 in never lists: the cleanup role redoes its hand-overs)
             if (un.list != nullptr) list_rows(valid, s_gbo);
         flush_stamps();
@@ -2473,7 +2485,10 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? (CAP * 13 + C * 512 > 40960 ?
         // elsewhere it goes to nn_wide_kernel, marked unsearched (its count says nothing about the base level's radius)
         const bool short_here = MULTI && n < un.m_list && r2 < un.r2_full && to_base != nullptr;
         cnt[i] = (unanswered || short_here) ? -1 : n;
-        dm2[i] = tm;
+        // (a row that goes on to nn_wide_kernel takes the bound along, see bound_bits; that kernel writes the row's own)
+        bool listed = false;
+        if constexpr (FTM == -2) listed = un.list != nullptr && (unanswered || (n < un.m_list && (!MULTI || r2 < un.r2_full)));
+        dm2[i] = listed ? bound_bits : tm;
     }
     if constexpr (FTM == -2)
         if (un.list != nullptr) list_rows(valid && (unanswered || (n < un.m_list && (!MULTI || r2 < un.r2_full))), &s_box[0][0]);
