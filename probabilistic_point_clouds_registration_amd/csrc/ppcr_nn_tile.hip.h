@@ -737,7 +737,7 @@ __device__ __forceinline__ int wave_select_top_m(int *s_pos, unsigned *s_d2, int
 // every time (a cloud's fringe, its sparse parts: thousands of rows, 13-55 us of this kernel per iteration at the command
 // line's defaults) come here once per list lifetime instead of once per iteration.
 template <int M>
-__global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt,
+__global__ __launch_bounds__(256, 6) void nn_wide_kernel(const float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt,
                                                       const int *__restrict__ cell_start, GridDesc g, int reach, float r1_sq, float r2, int m,
                                                       int *__restrict__ nbr, int *__restrict__ cnt, unsigned *__restrict__ dm2,
                                                       const int *__restrict__ short_list, const unsigned *__restrict__ short_count,
@@ -761,14 +761,23 @@ __global__ __launch_bounds__(256) void nn_wide_kernel(const float4 *__restrict__
     unsigned char *const s_mark = s_mark_all[wave];
     unsigned *const s_mark4 = reinterpret_cast<unsigned *>(s_mark);
     const unsigned n_short = *short_count;
-    const unsigned entry0 = blockIdx.x * 4 + wave;
+    // A wave's rows one after the other, two deep: the row after next is looked up in the list and the next row's header —
+    // count, bound, coordinates: a round trip that depends on the list's — is asked for while this row is searched
+    // (a row is ~20 us of dependent round trips; the header's was the first of them).  Nobody but this wave writes its rows.
+    const unsigned entry0 = blockIdx.x * 4 + wave, stride = gridDim.x * 4;
     int i_next = entry0 < n_short ? short_list[entry0] : 0;
-    for (unsigned entry = entry0; entry < n_short; entry += gridDim.x * 4) {
+    int i_after = entry0 + stride < n_short ? short_list[entry0 + stride] : 0;
+    int found_next = cnt[i_next];
+    unsigned prev_next = dm2[i_next];
+    float4 q_next = src[i_next];
+    for (unsigned entry = entry0; entry < n_short; entry += stride) {
         const int i = __builtin_amdgcn_readfirstlane(i_next);
-        i_next = entry + gridDim.x * 4 < n_short ? short_list[entry + gridDim.x * 4] : 0;  // (travels under this row's search)
-        const int found = __builtin_amdgcn_readfirstlane(cnt[i]);  // < 0: its workgroup left the first pass to this one
-        const unsigned prev_bits = (unsigned)__builtin_amdgcn_readfirstlane((int)dm2[i]);
-        const float4 q = src[i];
+        const int found = __builtin_amdgcn_readfirstlane(found_next);  // < 0: its workgroup left the first pass to this one
+        const unsigned prev_bits = (unsigned)__builtin_amdgcn_readfirstlane((int)prev_next);
+        const float4 q = q_next;
+        i_next = i_after;
+        i_after = entry + 2 * stride < n_short ? short_list[entry + 2 * stride] : 0;
+        if (entry + stride < n_short) found_next = cnt[i_next], prev_next = dm2[i_next], q_next = src[i_next];  // (uniform)
         const QueryCells c = query_cells(q, g);
         const float fy = q.y - g.org[1], fz = q.z - g.org[2];
         // How far this row's m-th neighbour is, nobody knows; the search starts from an ESTIMATE and grows outwards (radius
