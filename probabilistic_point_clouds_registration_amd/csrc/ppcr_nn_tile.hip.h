@@ -1558,6 +1558,9 @@ struct FastLds {
 // for both: a rebuild is one workgroup's chain of dependent round trips (~25 us), which a launch of its own would add to
 // every iteration in which a single row of the cloud fails — inside the launch it hides behind the other workgroups' work.
 // Four workgroups per CU (the list path holds 48 coordinates in registers).
+#ifndef PPCR_LEVEL_Q16
+#define PPCR_LEVEL_Q16 15  // sixteenths of a block's rows whose cut-offs the block's level must cover (multi-level search)
+#endif
 template <int M, int C, int CAP, bool STAMPS, int FTM = -2, bool MULTI = false, int VERLET_K = 0>
 __global__ __launch_bounds__(256, (VERLET_K != 0 ? (CAP * 13 + C * 512 > 40960 ? 3 : 4) : C <= 16 ? (CAP * 13 + C * 512 <= 30900 ? 5 : 4) : (CAP * 13 + C * 512 <= 39400 ? 4 : 3))) void nn_fast_kernel(float4 *__restrict__ src, int ns,
                                                          const float4 *__restrict__ tgt0,
@@ -1934,7 +1937,9 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? (CAP * 13 + C * 512 > 40960 ?
     if constexpr (MULTI) {
         level = un.base_level;
         if (dm2_valid) {
-            // The finest level that covers the cut-offs of at least 7/8 of the block's rows (a row whose cut-off reaches
+            // The finest level that covers the cut-offs of at least 15/16 of the block's rows (7/8 until the rows left to
+            // nn_wide_kernel came with their bound: 12/16, 13/16, 14/16, 15/16 — LiDAR-like scene 4.85 / 4.94 / 5.08 / 5.14 k
+            // it/s, slab 5.09 / 5.17 / 5.29 / 5.34 k) (a row whose cut-off reaches
             // beyond the level searches the level's radius all the same: it is exact when it finds m there, and goes to
             // nn_wide_kernel when it does not).  Going by the block's LARGEST cut-off was measured first: one row at the
             // cloud's edge then drags its whole block to a level whose halo no tile holds (uniform 200k cloud at radius 3:
@@ -1957,7 +1962,7 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? (CAP * 13 + C * 512 > 40960 ?
             const int n_rows = s_need[un.n_levels - 1] + s_need[16 + un.n_levels - 1] + s_need[32 + un.n_levels - 1] + s_need[48 + un.n_levels - 1];
             level = un.n_levels - 1;
             for (int l = un.n_levels - 2; l >= 0; l--)
-                if (8 * (s_need[l] + s_need[16 + l] + s_need[32 + l] + s_need[48 + l]) >= 7 * n_rows) level = l;
+                if (16 * (s_need[l] + s_need[16 + l] + s_need[32 + l] + s_need[48 + l]) >= PPCR_LEVEL_Q16 * n_rows) level = l;
             // ... but never a level at which this block's halo has outgrown the tile before (the feedback word, see below)
             // cap | floor << 4 | split << 8 (a block that met both keeps the floor)
             level = max(min(level, (int)(level_fb & 15u)), (int)((level_fb >> 4) & 15u));
