@@ -1558,6 +1558,9 @@ struct FastLds {
 // for both: a rebuild is one workgroup's chain of dependent round trips (~25 us), which a launch of its own would add to
 // every iteration in which a single row of the cloud fails — inside the launch it hides behind the other workgroups' work.
 // Four workgroups per CU (the list path holds 48 coordinates in registers).
+#ifndef PPCR_CUT_TIES_BY_INDEX
+#define PPCR_CUT_TIES_BY_INDEX 1  // (0: the defect tests/test_gpu_parity.py::test_wide_lists_keep_the_tie_rule_on_a_lattice was written against)
+#endif
 #ifndef PPCR_LEVEL_Q16
 #define PPCR_LEVEL_Q16 15  // sixteenths of a block's rows whose cut-offs the block's level must cover (multi-level search)
 #endif
@@ -2377,11 +2380,26 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? (CAP * 13 + C * 512 > 40960 ?
                 while (__ballot(drop > 0) != 0ull) {
                     if (drop > 0) {
                         unsigned far = 0;
-                        int at = 0;
+                        int at = 0, ties = 0;
                         for_each_entry(L, q, n, [&](int t, int, unsigned b) {
+                            ties = b == far ? ties + 1 : (b > far ? 1 : ties);
                             at = b >= far ? t : at;
                             far = max(far, b);
                         });
+                        // (THE list is also what the association's row is selected from, by (d2, original index): of several
+                        //  entries at the farthest distance the one with the LARGEST original index leaves — whichever went,
+                        //  the Verlet list would be as good; the row would not: a lattice cloud's m-th neighbour ties with a
+                        //  dozen others, and the soak under another seed found rows that kept the wrong one)
+                        if (PPCR_CUT_TIES_BY_INDEX && ties > 1) {
+                            unsigned worst = 0;
+                            for_each_entry(L, q, n, [&](int t, int e, unsigned b) {
+                                if (b == far) {
+                                    const unsigned o = L.orig_of(e, tgt);
+                                    at = o >= worst ? t : at;
+                                    worst = max(worst, o);
+                                }
+                            });
+                        }
                         L.store(at, L.load(n - 1));
                         n -= 1;
                         gone = min(gone, far);
