@@ -253,6 +253,7 @@ struct ppcr_ctx {
     int opt_verlet_dense = 0;      // 1: keep the lists' cells whatever the halo estimate says (tests)
     unsigned assoc_counter = 0;    // associations that found (nearly) every block handed over (associate_impl: list_all)
     double halo_rho = 0, halo_h = 0;  // what that verdict was reached from (0: this grid was not judged): target density, skinned cell edge
+    bool verlet_big_tile = false;  // this grid: lists in the 2240-candidate tile (halo_outgrows_verlet_tile)
     bool verlet_grid_off = false;  // this grid: no skin — the halo of a block would outgrow the Verlet variant's tile (grid_finish)
     bool verlet_ok = false;      // the rows' lists were (re)built or verified by the previous association and nothing moved the source since but K1's own prologue
     DevBuf<int> vl;

@@ -70,7 +70,12 @@ void check_fast_kernel_lds()
                    fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, -2, false, 2>() &&
                    fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, 8, false, 2>() &&
                    fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, 0, false, 2>() &&
-                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, -3, false, 2>();
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), kCapVerlet, false, -3, false, 2>() &&
+                   // (... in the large tile: TileLaunch::verlet_big_tile)
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), CAP, false, -2, false, 1>() &&
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), CAP, false, 8, false, 1>() &&
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), CAP, false, 0, false, 1>() &&
+                   fast_kernel_lds_ok<M, verlet_scan_slots(M), CAP, false, -3, false, 1>();
         // the diagnostic (option "stamps") instantiations launch_tile can reach
         if constexpr (M == 10)
             good = good && fast_kernel_lds_ok<M, 16, kCapSteady, true, -2, true>() && fast_kernel_lds_ok<M, 16, kCapSteady, true, -2, false>() &&
@@ -132,15 +137,19 @@ void launch_tile(TileLaunch &t)
         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,  \
         t.ovf_next, (Cc <= 16 ? split_on : split_off), st, FMc, lr, un, vv_none)
     // steady state with Verlet lists: nn_fast_kernel<..., VERLET> answers from the lists where they still hold
-#define PPCR_FAST_V1(FTMc, FMc, Kc)                                                                                     \
-    nn_fast_kernel<M, verlet_scan_slots(M), kCapVerlet, false, FTMc, false, Kc><<<grid_steady, 256, 0, t.stream>>>(         \
+#define PPCR_FAST_V1(FTMc, FMc, Kc, CAPc)                                                                               \
+    nn_fast_kernel<M, verlet_scan_slots(M), CAPc, false, FTMc, false, Kc><<<grid_steady, 256, 0, t.stream>>>(               \
         t.src, t.ns, t.tgt, t.cell_start, t.grid, t.r2, t.m, t.nbr, t.cnt, t.pm, t.dm2, t.dm2_in, t.ovf_list, t.ovf_now,    \
         t.ovf_next, split_on_v, nullptr, FMc, lr, un, vv)
-    // (t.verlet_rows: the variant that rebuilds a few failing rows inside the workgroup — grids resident all at once)
+    // (t.verlet_rows: the variant that rebuilds a few failing rows inside the workgroup — grids resident all at once;
+    //  t.verlet_big_tile: denser clouds, whose blocks' halos outgrow the 1920-candidate tile but not the 2240-candidate
+    //  one — three workgroups per CU instead of four, which costs the timed windows 2-3 % where the small tile does:
+    //  kCapVerlet stays the default)
 #define PPCR_FAST_V(FTMc, FMc)                                                                                          \
     do {                                                                                                                \
-        if (t.verlet_rows) PPCR_FAST_V1(FTMc, FMc, 2);                                                                  \
-        else PPCR_FAST_V1(FTMc, FMc, 1);                                                                                \
+        if (t.verlet_big_tile) PPCR_FAST_V1(FTMc, FMc, 1, CAP);                                                         \
+        else if (t.verlet_rows) PPCR_FAST_V1(FTMc, FMc, 2, kCapVerlet);                                                 \
+        else PPCR_FAST_V1(FTMc, FMc, 1, kCapVerlet);                                                                    \
     } while (0)
     t.fused = false;
     int ftm = -2;  // model folded into this launch (-2: none)
@@ -217,7 +226,7 @@ void launch_tile(TileLaunch &t)
             if (t.verlet_mode != 0 && !st && !halves) {
                 VerletLists vv = t.verlet;
                 vv.build_all = t.verlet_mode == 2 ? 0 : 1;
-                const SplitTable split_on_v{t.split_flag, t.split_list, t.split_state, t.split_state + 1, kMaxSplit, kCapVerlet * 15 / 16, 0};
+                const SplitTable split_on_v{t.split_flag, t.split_list, t.split_state, t.split_state + 1, kMaxSplit, (t.verlet_big_tile ? CAP : kCapVerlet) * 15 / 16, 0};
                 if (ftm == 0) PPCR_FAST_V(0, *t.fuse);
                 else if (ftm == 8) PPCR_FAST_V(8, *t.fuse);
                 else if (ftm == -3) PPCR_FAST_V(-3, *t.fuse);

@@ -10,6 +10,9 @@ constexpr int kCapSteady = 1728;
 // ... of the Verlet variant (four workgroups per CU either way: its list path holds 48 coordinates in registers), whose
 // lists reach further than the plain search's cut-off: larger cells, larger halos
 constexpr int kCapVerlet = 1920;
+// ... and of that variant where the cloud is denser (a block's halo outgrows 1920 candidates for more blocks than can be split):
+// the first association's 2240-candidate tile, three workgroups per CU (TileLaunch::verlet_big_tile)
+constexpr int kCapVerletBig = 2240;
 // ... and of the Verlet variant of the mid-width lists (the command line's 20 neighbours: 32-slot Verlet lists, 36-slot scan
 // lists — 18.9 KB — beside the halo: 1600 candidates keep the kernel at four workgroups per CU)
 constexpr int kCapVerletMid = 1600;
@@ -57,6 +60,7 @@ struct TileLaunch {
     int verlet_mode;                //   0 off; 1 this association builds every row's list; 2 workgroups whose rows' lists still
                                     //   hold answer from them, the others search and rebuild
     int verlet_rows;                //   widths up to 10: the kernel variant that rebuilds a few failing rows inside the workgroup
+    int verlet_big_tile;            //   widths up to 10: the 2240-candidate tile (three workgroups per CU) — denser clouds
     const dev::FusedMoments *fuse;  // fold K23 into K1 at this pose / model when the steady-state variant runs
     int fuse_tm;                    // ... in this compiled form: 0 Gaussian, 8 t with v + dim = 8, -3 t with another integer v + dim
     const dev::FoldSolve *fold;     // ... and the fold-and-solve step into the cleanup launch

@@ -1812,12 +1812,12 @@ def test_no_lists_where_a_blocks_halo_would_outgrow_the_tile():
     """The Verlet variant's grid cells are a tenth wider than the radius; where the radius holds ~35 or more target points
     the halo of a 256-query block then outgrows that variant's LDS tile for more blocks than can be split, and everything
     beyond would be handed over in EVERY iteration (measured: 2.7 k against 7.4 k it/s at 1M points).  The library decides
-    per grid from the measured occupancy: lists at the benchmark's density, none at 42 points in the radius — where the
-    plain steady-state variant runs with hardly a hand-over; option verlet_dense overrides.  Results equal the oracle's
-    either way."""
+    per grid from the measured occupancy: lists at the benchmark's density, lists in the 2240-candidate tile (three workgroups
+    per CU) at 34 points in the radius, none at 42 — where the plain steady-state variant runs with hardly a hand-over;
+    option verlet_dense overrides.  Results equal the oracle's either way."""
     rng = np.random.default_rng(8)
     n = 60000
-    for in_radius, want_lists in ((16, True), (42, False)):
+    for in_radius, want_lists in ((16, True), (34, True), (42, False)):
         side = (n / (in_radius / 4.18879)) ** (1 / 3)
         tgt = rng.uniform(0, side, size=(n, 3)).astype(np.float32)
         src = (tgt[rng.permutation(n)] + rng.normal(0, 0.02, size=(n, 3)) + [0.03, -0.02, 0.01]).astype(np.float32)
