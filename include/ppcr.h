@@ -351,9 +351,11 @@ int ppcr_profile_get(ppcr_ctx *ctx, ppcr_kernel_stat *out, int capacity, int *n_
  *   "verlet_room"  -1 (default) the forecast must fit the whole skin (half of it on grids that are resident all at once, widths
  *                  up to 10), >= 0: this many per cent of it (experiments: tools/exp_verlet_sweep.py);
  *   "verlet_order" 1 workgroups that will probably search are dispatched first (default), 0 launch order;
- *   "verlet_dense" 0 no lists (and radius-sized grid cells) where the halo of a 256-query block would outgrow the list
- *                  variant's LDS tile — a radius that holds ~35 or more target points, a source much sparser than the target —
- *                  (default), 1 lists regardless (tests; set before the first association);
+ *   "verlet_dense" 0 the list variant's LDS tile by an estimate of a 256-query block's halo — the 1920-candidate tile, the
+ *                  2240-candidate one for denser clouds (three workgroups per CU), no lists (and radius-sized grid cells)
+ *                  where the halo would outgrow that too: a radius that holds ~38 or more target points, a source much
+ *                  sparser than the target — (default), 1 lists in the small tile regardless, 2 lists in the large tile
+ *                  regardless (tests; set before the first association);
  *   "two_pass"     1 a bounded search whose radius holds far more than max_neighbours target points runs in two passes
  *                  (default): the grid and the tiled kernel work with radius / k, chosen from the target's density, and
  *                  only the rows that find fewer than max_neighbours there are searched again with the full radius;

@@ -250,7 +250,7 @@ struct ppcr_ctx {
     int al_iterations = 0;
     int opt_verlet_order = 1;    // option "verlet_order": workgroups forecast to search again are dispatched first (default 1)
     double grid_skin2 = 0;       // 2 x skin the grid in use was built for (0: its cells do not cover a list's reach)
-    int opt_verlet_dense = 0;      // 1: keep the lists' cells whatever the halo estimate says (tests)
+    int opt_verlet_dense = 0;      // 1 / 2: keep the lists' cells whatever the halo estimate says, small / large tile (tests)
     unsigned assoc_counter = 0;    // associations that found (nearly) every block handed over (associate_impl: list_all)
     double halo_rho = 0, halo_h = 0;  // what that verdict was reached from (0: this grid was not judged): target density, skinned cell edge
     bool verlet_big_tile = false;  // this grid: lists in the 2240-candidate tile (halo_outgrows_verlet_tile)

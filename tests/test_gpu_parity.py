@@ -831,7 +831,9 @@ def test_verlet_lists_randomised_soak():
             c.set_option("two_pass", 0)          # lists belong to the one-pass, single-level search: keep every trial there
             c.set_option("levels", 0)            # (radius 1.5 then scans ~140 candidates per row: lists with hardly any room)
             c.set_option("verlet_engage", 100000)
-            c.set_option("verlet_dense", 1)      # (... also where the library would not keep lists: blocks whose halo outgrows the tile)
+            # (... also where the library would not keep lists: blocks whose halo outgrows the tile; every third trial in the
+            #  large tile — the same kernel at three workgroups per CU, which denser clouds get: halo_outgrows_verlet_tile)
+            c.set_option("verlet_dense", 2 if trial % 3 == 1 else 1)
             c.set_option("verlet_skin", skin)
             c.set_option("verlet_order", int(rng.integers(0, 2)))
             c.set_params(radius, m, 5.0, 3)
