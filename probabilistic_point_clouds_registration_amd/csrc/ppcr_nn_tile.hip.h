@@ -1793,7 +1793,10 @@ __global__ __launch_bounds__(256, (VERLET_K != 0 ? (CAP * 13 + C * 512 > 40960 ?
             // identity and both counters are known: no atomics (4 000 waves drawing list positions from one counter at the
             // same moment cost this path 20 us)
             if (valid) cnt[i] = -1, un.list[i] = i, dm2[i] = bound_bits;
-            if (tid == 0 && wg == 0) {
+            // (written by a workgroup that always gets here: slot 0 of the steady-state grids is a split slot and leaves
+            //  above when no block is registered — every row stayed marked unsearched and nn_wide_kernel saw an empty list:
+            //  found by the association soak under another seed)
+            if (tid == 0 && wg == (split.all_halves ? 0u : gridDim.x - 1)) {
                 *un.count = (unsigned)ns;
                 *ovf_count = (unsigned)((ns + BLOCK - 1) / BLOCK);
             }

@@ -1430,6 +1430,49 @@ def test_randomised_association_soak(ctx):
                 po.transform_cloud(cur, T)
 
 
+def test_every_row_listed_when_every_block_was_handed_over():
+    """A nearly flat slab searched in two passes with a stencil five cells wide: no 256-row block's halo has a shape the tile
+    takes, every block is handed over, and from the second such association on the tiled kernel lists EVERY row for the
+    row-per-wave kernel without trying (UnansweredRows::list_all).  The list's length used to be written by workgroup slot 0
+    — a split slot that leaves at once while no block is registered for splitting: the row-per-wave kernel then saw an empty
+    list and every row stayed marked unsearched (found by the association soak under a seed the suite does not use).  Six
+    associations under moves equal the oracle's, and the path is asserted to have run."""
+    rng = np.random.default_rng(9)
+    nt, ns = 27840, 11763
+    tgt = (rng.uniform(0, 1, size=(nt, 3)) * [18.28, 0.61, 5.24]).astype(np.float32)
+    src = (tgt[rng.integers(0, nt, size=ns)] + rng.normal(0, 0.02, size=(ns, 3))).astype(np.float32)
+    radius, m = 1.289, 20
+    listed_all = 0
+    with _lib.Context(0) as c:
+        c.set_option("grid_xf", 8)
+        c.set_option("defer_moves", 1)
+        c.set_params(radius, m, 5.0, 3)
+        c.set_target(tgt)
+        c.set_source(src)
+        cur = src.copy()
+        for step in range(6):
+            c.associate()
+            rows, nnz = c.association_size()
+            assert 0 <= nnz <= rows * m, (step, nnz)
+            rp, col, d2 = c.get_association()
+            orp, ocol, od2 = po.radius_search(cur, tgt, radius, m, method=1)
+            np.testing.assert_array_equal(rp, orp, err_msg=f"step {step}")
+            np.testing.assert_array_equal(col, ocol, err_msg=f"step {step}")
+            np.testing.assert_array_equal(d2, od2, err_msg=f"step {step}")
+            listed_all += int(c.debug_short_rows() == ns)
+            # (a fold-and-solve step tells the handle how many blocks the association handed over — without one, bare
+            #  associations never learn it and never list every row; and nothing here rebuilds the split list, as a
+            #  registration's own fold would: slot 0 stays idle, which is what hid the defect from the align loops)
+            c.accumulate(np.array([0.999, 0.01, -0.02, 0.015]), np.array([0.01, 0.02, -0.015]))
+            T = np.eye(4)
+            T[:3, :3] = synth.rodrigues(rng.normal(size=3), 0.003)
+            T[:3, 3] = rng.normal(0, 0.01 * radius, size=3)
+            c.apply_transform(T)
+            po.transform_cloud(cur, T)
+        assert c.search_reach() > 1
+    assert listed_all >= 3, listed_all
+
+
 def test_randomised_row_per_wave_soak():
     """Seeded random sweep aimed at the row-per-wave search (K1's list of unanswered rows + nn_wide_kernel): radii that hold many
     times max_neighbours points (two-pass searches with automatic and forced reach), clouds with blobs hundreds of times
